@@ -1,0 +1,101 @@
+/*
+ * s3g_raster.h -- C ABI of the MI355X-native differentiable Gaussian rasterizer (libs3g.so).
+ *
+ * Drop-in boundary for the reference's native rasterizer interface.  Each entry point replaces one
+ * member of CudaRasterizer::Rasterizer (RAST = /root/reference/submodules/depth-diff-gaussian-rasterization):
+ *
+ *   s3g_raster_forward   <- Rasterizer::forward    RAST/cuda_rasterizer/rasterizer.h:36-59
+ *                           (called by RasterizeGaussiansCUDA, RAST/rasterize_points.cu:35-117)
+ *   s3g_raster_backward  <- Rasterizer::backward   RAST/cuda_rasterizer/rasterizer.h:61-87
+ *                           (called by RasterizeGaussiansBackwardCUDA, RAST/rasterize_points.cu:119-202)
+ *   s3g_mark_visible     <- Rasterizer::markVisible RAST/cuda_rasterizer/rasterizer.h:24-29
+ *
+ * Same argument meaning as the reference: all array arguments are DEVICE pointers to fp32 (unless
+ * noted), a NULL pointer means "not provided" exactly like the reference's nullptr / numel()==0
+ * tensors, and the three scratch arenas are obtained through resize callbacks (the reference's
+ * std::function<char*(size_t)> geometryBuffer/binningBuffer/imageBuffer, rasterizer.h:37-39).  The
+ * byte layout of the arenas is private to this library (forward writes them, backward of the SAME
+ * build reads them); they must stay alive and unmodified between the two calls.
+ *
+ * Differences from the reference, on purpose:
+ *   - every kernel is launched on the caller's `stream` (the reference uses the legacy default stream);
+ *   - errors are returned as int codes (0 = ok) with a thread-local message, never thrown/trapped;
+ *   - plain C: no torch, glm or std types cross the boundary.
+ */
+#ifndef S3G_RASTER_H
+#define S3G_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3G_OK 0
+#define S3G_ERR_INVALID_ARG 1   /* bad argument combination (reference: Python Exception / AT_ERROR) */
+#define S3G_ERR_HIP 2           /* a HIP runtime call failed; see s3g_last_error() */
+#define S3G_ERR_ALLOC 3         /* a resize callback returned NULL */
+#define S3G_ERR_PREFILTERED 4   /* a Gaussian was culled although prefiltered=1 (reference: __trap, auxiliary.h:156-160) */
+
+/* Resize callback: return a device pointer to at least `bytes` bytes, 128-byte aligned, owned by the caller. */
+typedef void* (*s3g_resize_fn)(void* user, size_t bytes);
+
+typedef struct s3g_raster_inputs {
+  int P;                      /* number of Gaussians */
+  int D;                      /* active SH degree 0..3 */
+  int M;                      /* SH coefficients stored per Gaussian (0 when shs == NULL) */
+  int width, height;          /* image size in pixels */
+  const float* background;    /* [3] */
+  const float* means3D;       /* [P,3] */
+  const float* shs;           /* [P,M,3] or NULL (then colors_precomp != NULL) */
+  const float* colors_precomp;/* [P,3]   or NULL */
+  const float* opacities;     /* [P] */
+  const float* scales;        /* [P,3] or NULL (then cov3D_precomp != NULL) */
+  float scale_modifier;
+  const float* rotations;     /* [P,4] (r,x,y,z), used un-normalised like the reference */
+  const float* cov3D_precomp; /* [P,6] or NULL */
+  const float* viewmatrix;    /* [16] world->view, row-vector convention (scene/cameras.py:59) */
+  const float* projmatrix;    /* [16] full projection, row-vector convention (scene/cameras.py:63) */
+  const float* cam_pos;       /* [3] */
+  float tan_fovx, tan_fovy;
+  int prefiltered;
+  int debug;                  /* 1: synchronise + check after every kernel (reference CHECK_CUDA) */
+} s3g_raster_inputs;
+
+/* Forward.  out_color [3,H,W], out_depth [1,H,W], radii [P] int32: device, caller allocated (contents are
+ * fully overwritten for P > 0).  *num_rendered receives the number of (Gaussian, tile) instances.
+ * One host synchronisation on `stream` (to size the binning arena), like the reference (rasterizer_impl.cu:282). */
+int s3g_raster_forward(const s3g_raster_inputs* in,
+                       s3g_resize_fn geometry_buffer, void* geometry_user,
+                       s3g_resize_fn binning_buffer, void* binning_user,
+                       s3g_resize_fn image_buffer, void* image_user,
+                       float* out_color, float* out_depth, int* radii,
+                       int* num_rendered, void* stream /* hipStream_t */);
+
+/* Backward.  `R` is the num_rendered returned by the matching forward; radii / arenas are the ones it filled.
+ * dL_dpix [3,H,W], dL_dpix_depth [1,H,W].  All dL_d* outputs are device arrays that the CALLER HAS ZEROED
+ * (rasterize_points.cu:154-163): dL_dmean2D [P,3], dL_dconic [P,2,2], dL_dopacity [P], dL_dcolor [P,3],
+ * dL_ddepth [P], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3] (may be NULL when M==0), dL_dscale [P,3],
+ * dL_drot [P,4]. */
+int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int* radii,
+                        const void* geometry_arena, const void* binning_arena, const void* image_arena,
+                        const float* dL_dpix, const float* dL_dpix_depth,
+                        float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                        float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                        float* dL_dscale, float* dL_drot, void* stream);
+
+/* present[P] (uint8 0/1) = in_frustum (auxiliary.h:139-164: view-space z > 0.2). */
+int s3g_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char* s3g_last_error(void);
+
+/* Library/ABI version: bumped whenever the private arena layout or a signature changes. */
+int s3g_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S3G_RASTER_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of libs3g.so (the C ABI declared in include/*.h).
+
+The product path has NO fallback: if the shared library is missing or was not built for this tree, importing
+an op raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C s3gaussian_amd/csrc` (hipcc cross-compiles gfx950 without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libs3g.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+ABI_VERSION = 1
+
+RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class RasterInputs(C.Structure):
+    """struct s3g_raster_inputs (include/s3g_raster.h)."""
+    _fields_ = [
+        ("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("width", C.c_int), ("height", C.c_int),
+        ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("opacities", C.c_void_p), ("scales", C.c_void_p), ("scale_modifier", C.c_float), ("rotations", C.c_void_p),
+        ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p),
+        ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int), ("debug", C.c_int),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into s3gaussian_amd/lib/libs3g.so (in-tree, travels with gpurun)."""
+    cmd = ["make", "-s", "-C", CSRC_DIR, "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the MI355X HIP library has not been built. "
+            "Run `make -C s3gaussian_amd/csrc` (or __graft_entry__.build()). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.s3g_last_error.restype = C.c_char_p
+    L.s3g_abi_version.restype = C.c_int
+    if L.s3g_abi_version() != ABI_VERSION:
+        raise ImportError(f"libs3g.so ABI {L.s3g_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    vp = C.c_void_p
+    L.s3g_raster_forward.restype = C.c_int
+    L.s3g_raster_forward.argtypes = [C.POINTER(RasterInputs), RESIZE_FN, vp, RESIZE_FN, vp, RESIZE_FN, vp, vp, vp, vp,
+                                     C.POINTER(C.c_int), vp]
+    L.s3g_raster_backward.restype = C.c_int
+    L.s3g_raster_backward.argtypes = [C.POINTER(RasterInputs), C.c_int] + [vp] * 17
+    L.s3g_mark_visible.restype = C.c_int
+    L.s3g_mark_visible.argtypes = [C.c_int, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(code: int) -> None:
+    if code != 0:
+        msg = lib().s3g_last_error().decode("utf-8", "replace")
+        if code == 1:
+            raise Exception(msg)  # reference raises plain Exception for bad argument combos
+        raise RuntimeError(f"libs3g error {code}: {msg}")
+
+
+EXPORTED_SYMBOLS = ["s3g_raster_forward", "s3g_raster_backward", "s3g_mark_visible", "s3g_last_error", "s3g_abi_version"]

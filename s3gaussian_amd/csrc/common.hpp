@@ -1,0 +1,131 @@
+// Shared helpers for the gfx950 kernels of libs3g.so (private; not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/s3g_raster.h"
+
+namespace s3g {
+
+constexpr int TILE_X = 16;  // reference BLOCK_X/BLOCK_Y, RAST/cuda_rasterizer/config.h:16-17
+constexpr int TILE_Y = 16;
+constexpr int TILE_PIX = TILE_X * TILE_Y;
+constexpr int WAVE = 64;
+
+// ---- error plumbing ------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define S3G_HIP_CHECK(expr)                                                                     \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      s3g::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return S3G_ERR_HIP;                                                                       \
+    }                                                                                           \
+  } while (0)
+// After a kernel launch: always catch launch errors; in debug also synchronise (reference CHECK_CUDA, auxiliary.h:166-173).
+#define S3G_KERNEL_CHECK(stream, debug)                          \
+  do {                                                           \
+    S3G_HIP_CHECK(hipGetLastError());                            \
+    if (debug) S3G_HIP_CHECK(hipStreamSynchronize(stream));      \
+  } while (0)
+
+// ---- arena carving (128-byte aligned sub-arrays, like the reference's obtain<>(), rasterizer_impl.h) ----
+struct Carver {
+  char* base;
+  size_t off;
+  explicit Carver(void* p) : base(reinterpret_cast<char*>(p)), off(0) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = (off + 127) & ~size_t(127);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+  size_t bytes() const { return (off + 127) & ~size_t(127); }
+};
+
+// Per-Gaussian forward state ("GeometryState").
+struct GeomState {
+  float* depths;          // [P]   view-space z
+  float2* means2D;        // [P]   pixel coordinates
+  float4* conic_opacity;  // [P]   (conic a, b, c, opacity)
+  float* cov3D;           // [P,6]
+  float* rgb;             // [P,3] SH->RGB result (only when shs given)
+  uint8_t* clamped;       // [P,3]
+  ushort4* rect;          // [P]   tile rect (min.x, min.y, max.x, max.y), zero area when culled
+  static GeomState carve(void* p, size_t P, size_t* bytes) {
+    Carver c(p);
+    GeomState g;
+    g.depths = c.take<float>(P);
+    g.means2D = c.take<float2>(P);
+    g.conic_opacity = c.take<float4>(P);
+    g.cov3D = c.take<float>(P * 6);
+    g.rgb = c.take<float>(P * 3);
+    g.clamped = c.take<uint8_t>(P * 3);
+    g.rect = c.take<ushort4>(P);
+    if (bytes) *bytes = c.bytes();
+    return g;
+  }
+};
+
+// Per-image state ("ImageState") + the per-tile bucket bookkeeping.
+struct ImageState {
+  float* final_T;        // [H*W]
+  uint32_t* n_contrib;   // [H*W]
+  uint2* ranges;         // [tiles]  [start,end) into the sorted instance list
+  uint32_t* tile_count;  // [tiles]  instances per tile (histogram, then reused as scatter cursor)
+  uint32_t* ctrl;        // [8]      ctrl[0]=R (total instances), ctrl[1]=max instances in one tile, ctrl[2]=error flags
+  static ImageState carve(void* p, size_t N, size_t tiles, size_t* bytes) {
+    Carver c(p);
+    ImageState s;
+    s.final_T = c.take<float>(N);
+    s.n_contrib = c.take<uint32_t>(N);
+    s.ranges = c.take<uint2>(tiles);
+    s.tile_count = c.take<uint32_t>(tiles);
+    s.ctrl = c.take<uint32_t>(8);
+    if (bytes) *bytes = c.bytes();
+    return s;
+  }
+};
+
+// Per-instance state ("BinningState").
+struct BinningState {
+  uint64_t* keys;        // [R]  (depth bits << 32 | gaussian index), sorted ascending inside each tile range
+  uint32_t* point_list;  // [R]  gaussian index, tile-major, front-to-back
+  static BinningState carve(void* p, size_t R, size_t* bytes) {
+    Carver c(p);
+    BinningState b;
+    b.keys = c.take<uint64_t>(R);
+    b.point_list = c.take<uint32_t>(R);
+    if (bytes) *bytes = c.bytes();
+    return b;
+  }
+};
+
+// ---- small device helpers -------------------------------------------------------------------------------
+// Row-vector 4x4 matrices are indexed column-major like the reference (auxiliary.h:58-77).
+struct Mat16 {
+  float m[16];
+};
+
+__device__ __forceinline__ float3 xform_4x3(const float3 p, const float* __restrict__ M) {
+  return make_float3(M[0] * p.x + M[4] * p.y + M[8] * p.z + M[12], M[1] * p.x + M[5] * p.y + M[9] * p.z + M[13],
+                     M[2] * p.x + M[6] * p.y + M[10] * p.z + M[14]);
+}
+__device__ __forceinline__ float4 xform_4x4(const float3 p, const float* __restrict__ M) {
+  return make_float4(M[0] * p.x + M[4] * p.y + M[8] * p.z + M[12], M[1] * p.x + M[5] * p.y + M[9] * p.z + M[13],
+                     M[2] * p.x + M[6] * p.y + M[10] * p.z + M[14], M[3] * p.x + M[7] * p.y + M[11] * p.z + M[15]);
+}
+
+// XCD-aware tile order: hardware places workgroup b on XCD (b % 8); give each XCD a contiguous band of
+// tiles so neighbouring tiles (which share most of their Gaussians) hit the same 4 MiB L2.
+__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t bid, uint32_t nblocks) {
+  constexpr uint32_t XCDS = 8;
+  const uint32_t per = (nblocks + XCDS - 1) / XCDS;
+  const uint32_t t = (bid % XCDS) * per + bid / XCDS;
+  return t;  // may be >= nblocks for the tail: caller must bounds-check
+}
+
+}  // namespace s3g

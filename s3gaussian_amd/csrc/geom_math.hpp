@@ -1,0 +1,103 @@
+// Per-Gaussian geometry math shared by the forward and backward per-Gaussian kernels (private header).
+// All of it is compiled with -ffp-contract=off: one rounding per fp32 op, in the order the reference source
+// writes it (glm 0.9.9.9 mat3 products expanded in glm's own summation order, type_mat3x3.inl:486-518), so the
+// per-Gaussian integer outputs (radii, tile rectangles, instance counts) are bit-identical to the fp32 oracle.
+#pragma once
+#include "common.hpp"
+
+namespace s3g {
+
+struct M3 {
+  float m[3][3];  // glm layout: m[column][row]
+};
+__device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B) {
+  M3 R;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) R.m[c][r] = A.m[0][r] * B.m[c][0] + A.m[1][r] * B.m[c][1] + A.m[2][r] * B.m[c][2];
+  return R;
+}
+__device__ __forceinline__ M3 m3_T(const M3& A) {
+  M3 R;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) R.m[c][r] = A.m[r][c];
+  return R;
+}
+
+// Rotation matrix of an (un-normalised, like the reference) quaternion (r,x,y,z): forward.cu:127-138
+__device__ __forceinline__ M3 quat_to_R(const float4 rot) {
+  const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
+  M3 R = {{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+           {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+           {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}}};
+  return R;
+}
+
+// forward.cu:118-152
+__device__ __forceinline__ void cov3d_from_scale_rot(const float3 scale, float mod, const float4 rot, float* cov3D) {
+  M3 S = {{{mod * scale.x, 0.f, 0.f}, {0.f, mod * scale.y, 0.f}, {0.f, 0.f, mod * scale.z}}};
+  M3 Mm = m3_mul(S, quat_to_R(rot));
+  M3 Sigma = m3_mul(m3_T(Mm), Mm);
+  cov3D[0] = Sigma.m[0][0];
+  cov3D[1] = Sigma.m[0][1];
+  cov3D[2] = Sigma.m[0][2];
+  cov3D[3] = Sigma.m[1][1];
+  cov3D[4] = Sigma.m[1][2];
+  cov3D[5] = Sigma.m[2][2];
+}
+
+// Everything computeCov2D needs in both directions (forward.cu:74-113, backward.cu:166-199).
+struct Cov2DCtx {
+  float3 t;  // view-space mean with x,y clamped to 1.3*tan(fov)
+  float txtz, tytz, limx, limy;
+  M3 W, T, Vrk, cov;  // cov is BEFORE the +0.3 low-pass
+};
+__device__ __forceinline__ Cov2DCtx cov2d_common(const float3 mean, float fx, float fy, float tan_fovx, float tan_fovy,
+                                                 const float* cov3D, const float* __restrict__ V) {
+  Cov2DCtx c;
+  c.t = xform_4x3(mean, V);
+  c.limx = 1.3f * tan_fovx;
+  c.limy = 1.3f * tan_fovy;
+  c.txtz = c.t.x / c.t.z;
+  c.tytz = c.t.y / c.t.z;
+  c.t.x = fminf(c.limx, fmaxf(-c.limx, c.txtz)) * c.t.z;
+  c.t.y = fminf(c.limy, fmaxf(-c.limy, c.tytz)) * c.t.z;
+  const float tz = c.t.z;
+  M3 J = {{{fx / tz, 0.f, -(fx * c.t.x) / (tz * tz)}, {0.f, fy / tz, -(fy * c.t.y) / (tz * tz)}, {0.f, 0.f, 0.f}}};
+  M3 W = {{{V[0], V[4], V[8]}, {V[1], V[5], V[9]}, {V[2], V[6], V[10]}}};
+  M3 Vrk = {{{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]}, {cov3D[2], cov3D[4], cov3D[5]}}};
+  c.W = W;
+  c.Vrk = Vrk;
+  c.T = m3_mul(W, J);
+  c.cov = m3_mul(m3_mul(m3_T(c.T), m3_T(Vrk)), c.T);
+  return c;
+}
+
+// auxiliary.h:22-39
+__device__ const float SH_C0 = 0.28209479177387814f;
+__device__ const float SH_C1 = 0.4886025119029199f;
+__device__ const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                   -1.0925484305920792f, 0.5462742152960396f};
+__device__ const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                   -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+// Blend-kernel helpers shared by forward and backward so both take identical skip decisions.
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct StagedGaussian {  // 48 B, three ds_read_b128
+  float4 a;              // mean.x, mean.y, qa, qb       (q* = conic pre-scaled by -0.5*log2e / -log2e)
+  float4 b;              // qc, opacity, depth, r
+  float4 c;              // g, b, conic.x, conic.y       (un-scaled conic only used by the backward epilogue)
+};
+
+__device__ __forceinline__ float gaussian_exponent2(float dx, float dy, float qa, float qb, float qc) {
+  float q = (qb * dx) * dy;
+  q = __builtin_fmaf(qc * dy, dy, q);
+  q = __builtin_fmaf(qa * dx, dx, q);
+  return q;
+}
+
+}  // namespace s3g

@@ -1,0 +1,424 @@
+// Backward half of the MI355X-native differentiable Gaussian rasterizer (gfx950, wave64).
+//
+// Computes what CudaRasterizer::Rasterizer::backward computes (RAST/cuda_rasterizer/rasterizer_impl.cu:343-444):
+//   blend_backward_kernel      <- BACKWARD::render / renderCUDA       (backward.cu:415-590)
+//   geometry_backward_kernel   <- computeCov2DCUDA + preprocessCUDA   (backward.cu:144-274, 346-412) fused into one pass
+//
+// The reference issues 10 global float atomicAdd per contributing (pixel, Gaussian) pair (backward.cu:550-587).
+// Here a pair costs no memory traffic at all:
+//   1. the six geometry sums are re-associated so that everything depending only on the Gaussian (conic, opacity,
+//      0.5*W) is factored out of the pixel sum: with v = dL/dalpha * G the kernel accumulates
+//      S0=sum v, Sx=sum v*dx, Sy=sum v*dy, Sxx=sum v*dx*dx, Sxy=sum v*dx*dy, Syy=sum v*dy*dy (+3 colour, +1 depth);
+//   2. each of the 10 sums is reduced across the 64 lanes of a wave with DPP row-shift/broadcast adds (no LDS, no
+//      shuffles through memory), skipped outright when no lane of the wave is touched by the Gaussian;
+//   3. the 4 waves of the tile combine in an LDS accumulator (ds_add_f32 from one lane);
+//   4. once per 256-Gaussian batch each lane owns one Gaussian and applies the factored-out coefficients, then
+//      issues its 10 global atomics -- i.e. 10 atomics per (tile, Gaussian) instance instead of per pixel pair.
+#include "geom_math.hpp"
+
+namespace s3g {
+
+// ---- wave64 reduction: inclusive scan with DPP, total lands in lane 63 (LLVM's gfx9 atomic-optimizer sequence) ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row total
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
+  return v;
+}
+
+constexpr int NSUM = 10;  // dcolor r,g,b | ddepth | S0 | Sx | Sy | Sxx | Sxy | Syy
+
+__global__ void __launch_bounds__(256)
+blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ ranges,
+                      const uint32_t* __restrict__ point_list, const float* __restrict__ bg,
+                      const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity,
+                      const float* __restrict__ colors, const float* __restrict__ depths,
+                      const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
+                      const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixel_depths,
+                      float* __restrict__ dL_dmean2D /*[P,3]*/, float* __restrict__ dL_dconic /*[P,4]*/,
+                      float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_ddepths) {
+  __shared__ StagedGaussian sg[256];
+  __shared__ float acc[NSUM][256];
+  __shared__ uint32_t sid[256];
+  __shared__ uint32_t touched[256];
+  __shared__ uint32_t wave_last[4];
+
+  const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile >= (uint32_t)tiles) return;
+  const int tx = tile % gx, ty = tile / gx;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = tx * TILE_X + (tid & 15), py = ty * TILE_Y + (tid >> 4);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const uint2 rg = ranges[tile];
+  const size_t pix = (size_t)py * W + px, N = (size_t)H * W;
+
+  const float T_final = inside ? final_Ts[pix] : 0.f;
+  const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;
+  float gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f;
+  if (inside) {
+    gr = dL_dpixels[pix];
+    gg = dL_dpixels[N + pix];
+    gb = dL_dpixels[2 * N + pix];
+    gd = dL_dpixel_depths[pix];
+  }
+  const float bg_dot = bg[0] * gr + bg[1] * gg + bg[2] * gb;
+
+  // Nothing behind the deepest contributor of the tile can receive gradient: start there instead of at range end.
+  uint32_t m = last_contributor;
+  for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+  if (lane == 0) wave_last[wave] = m;
+  __syncthreads();
+  const uint32_t hi = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));  // 1-based count
+
+  float T = T_final;
+  float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;          // accum_rec (colour, depth)
+  float last_alpha = 0.f, lr = 0.f, lg = 0.f, lb = 0.f, ld = 0.f;
+
+  for (uint32_t done_cnt = 0; done_cnt < hi; done_cnt += 256) {
+    const uint32_t cnt = min(256u, hi - done_cnt);
+    __syncthreads();  // previous batch fully consumed (sg, acc, sid, touched)
+    if ((uint32_t)tid < cnt) {
+      const uint32_t pos = hi - 1 - (done_cnt + tid);  // back to front
+      const uint32_t id = point_list[rg.x + pos];
+      const float2 mm = means2D[id];
+      const float4 co = conic_opacity[id];
+      StagedGaussian s;
+      s.a = make_float4(mm.x, mm.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
+      s.b = make_float4(-0.5f * LOG2E * co.z, co.w, depths[id], colors[3 * (size_t)id]);
+      s.c = make_float4(colors[3 * (size_t)id + 1], colors[3 * (size_t)id + 2], co.x, co.y);
+      sg[tid] = s;
+      sid[tid] = id;
+      touched[tid] = 0u;
+#pragma unroll
+      for (int k = 0; k < NSUM; k++) acc[k][tid] = 0.f;
+    }
+    __syncthreads();
+
+    for (uint32_t j = 0; j < cnt; j++) {
+      const uint32_t pos = hi - 1 - (done_cnt + j);  // 0-based position in the tile list
+      // contributor index in the reference is pos (after its decrement); it skips when contributor >= last_contributor
+      bool valid = pos < last_contributor;
+      const float4 A = sg[j].a;
+      const float4 B = sg[j].b;
+      const float dx = A.x - pxf, dy = A.y - pyf;
+      const float q = gaussian_exponent2(dx, dy, A.z, A.w, B.x);
+      const float G = __builtin_amdgcn_exp2f(q);
+      const float alpha = fminf(0.99f, B.y * G);
+      valid = valid && !(q > 0.f) && !(alpha < 1.0f / 255.0f);
+      if (__ballot(valid) == 0ull) continue;  // wave-uniform: this Gaussian misses all 64 pixels of the wave
+
+      float p_r = 0.f, p_g = 0.f, p_b = 0.f, p_d = 0.f, s0 = 0.f, sx = 0.f, sy = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f;
+      if (valid) {
+        const float4 Cc = sg[j].c;
+        const float cr = B.w, cg = Cc.x, cb = Cc.y, cd = B.z;
+        const float rcp = __builtin_amdgcn_rcpf(1.f - alpha);
+        T = T * rcp;
+        const float w = alpha * T;  // dchannel_dcolor
+        const float one_m_la = 1.f - last_alpha;
+        ar = last_alpha * lr + one_m_la * ar;
+        ag = last_alpha * lg + one_m_la * ag;
+        ab = last_alpha * lb + one_m_la * ab;
+        ad = last_alpha * ld + one_m_la * ad;
+        lr = cr; lg = cg; lb = cb; ld = cd;
+        float dL_dalpha = (cr - ar) * gr + (cg - ag) * gg + (cb - ab) * gb + (cd - ad) * gd;
+        dL_dalpha *= T;
+        last_alpha = alpha;
+        dL_dalpha += (-T_final * rcp) * bg_dot;
+        p_r = w * gr; p_g = w * gg; p_b = w * gb; p_d = w * gd;
+        const float v = dL_dalpha * G;
+        const float vx = v * dx, vy = v * dy;
+        s0 = v; sx = vx; sy = vy; sxx = vx * dx; sxy = vx * dy; syy = vy * dy;
+      }
+      // wave-uniform from here: all 64 lanes take part in the DPP reductions
+      p_r = wave_sum_lane63(p_r); p_g = wave_sum_lane63(p_g); p_b = wave_sum_lane63(p_b); p_d = wave_sum_lane63(p_d);
+      s0 = wave_sum_lane63(s0); sx = wave_sum_lane63(sx); sy = wave_sum_lane63(sy);
+      sxx = wave_sum_lane63(sxx); sxy = wave_sum_lane63(sxy); syy = wave_sum_lane63(syy);
+      if (lane == 63) {
+        atomicAdd(&acc[0][j], p_r); atomicAdd(&acc[1][j], p_g); atomicAdd(&acc[2][j], p_b); atomicAdd(&acc[3][j], p_d);
+        atomicAdd(&acc[4][j], s0); atomicAdd(&acc[5][j], sx); atomicAdd(&acc[6][j], sy);
+        atomicAdd(&acc[7][j], sxx); atomicAdd(&acc[8][j], sxy); atomicAdd(&acc[9][j], syy);
+        touched[j] = 1u;
+      }
+    }
+    __syncthreads();
+    // Epilogue of the batch: lane t owns Gaussian t of the batch.
+    if ((uint32_t)tid < cnt && touched[tid]) {
+      const uint32_t id = sid[tid];
+      const float4 co = conic_opacity[id];              // exact (un-scaled) conic + opacity, L2 resident
+      const float ca = co.x, cb = co.y, cc = co.z, o = co.w;
+      const float S0 = acc[4][tid], Sx = acc[5][tid], Sy = acc[6][tid], Sxx = acc[7][tid], Sxy = acc[8][tid],
+                  Syy = acc[9][tid];
+      atomicAdd(&dL_dcolors[3 * (size_t)id + 0], acc[0][tid]);
+      atomicAdd(&dL_dcolors[3 * (size_t)id + 1], acc[1][tid]);
+      atomicAdd(&dL_dcolors[3 * (size_t)id + 2], acc[2][tid]);
+      atomicAdd(&dL_ddepths[id], acc[3][tid]);
+      atomicAdd(&dL_dopacity[id], S0);
+      // dL_dG = o * dL_dalpha ; dG_ddelx = -G*dx*conic.x - G*dy*conic.y ; times 0.5*W (backward.cu:571-579)
+      atomicAdd(&dL_dmean2D[3 * (size_t)id + 0], (0.5f * W) * o * (-(ca * Sx) - cb * Sy));
+      atomicAdd(&dL_dmean2D[3 * (size_t)id + 1], (0.5f * H) * o * (-(cc * Sy) - cb * Sx));
+      atomicAdd(&dL_dconic[4 * (size_t)id + 0], -0.5f * o * Sxx);
+      atomicAdd(&dL_dconic[4 * (size_t)id + 1], -0.5f * o * Sxy);
+      atomicAdd(&dL_dconic[4 * (size_t)id + 3], -0.5f * o * Syy);
+    }
+  }
+}
+
+// =========================================================================================================
+// Per-Gaussian geometry backward: conic -> cov2D -> (cov3D, mean) ; mean2D, depth -> mean ; SH ; cov3D -> scale, rot.
+// One pass over the Gaussians, HBM-bound.  Formulae follow backward.cu:144-412 term by term (fp32, no contraction).
+// =========================================================================================================
+struct GeomBwdArgs {
+  int P, D, M;
+  const float* means3D;
+  const int* radii;
+  const float* shs;
+  const uint8_t* clamped;
+  const float* scales;
+  const float* rotations;
+  float scale_modifier;
+  const float* cov3Ds;  // precomputed or the forward's own
+  const float* view;
+  const float* proj;
+  const float* campos;
+  float fx, fy, tan_fovx, tan_fovy;
+  const float* dL_dmean2D;  // [P,3]
+  const float* dL_dconic;   // [P,4]
+  const float* dL_dcolor;   // [P,3]
+  const float* dL_ddepth;   // [P]
+  float* dL_dmean3D;        // [P,3]
+  float* dL_dcov3D;         // [P,6]
+  float* dL_dsh;            // [P,M,3]
+  float* dL_dscale;         // [P,3]
+  float* dL_drot;           // [P,4]
+};
+
+__global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.P || !(a.radii[idx] > 0)) return;
+  const float3 mean = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+  const float* V = a.view;
+  const float* proj = a.proj;
+
+  // ---- computeCov2DCUDA (backward.cu:144-274) ----
+  float cov3D[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) cov3D[k] = a.cov3Ds[6 * (size_t)idx + k];
+  const Cov2DCtx c = cov2d_common(mean, a.fx, a.fy, a.tan_fovx, a.tan_fovy, cov3D, V);
+  const float x_grad_mul = (c.txtz < -c.limx || c.txtz > c.limx) ? 0.f : 1.f;
+  const float y_grad_mul = (c.tytz < -c.limy || c.tytz > c.limy) ? 0.f : 1.f;
+  const float dcx = a.dL_dconic[4 * (size_t)idx], dcy = a.dL_dconic[4 * (size_t)idx + 1],
+              dcz = a.dL_dconic[4 * (size_t)idx + 3];
+  const float ca = c.cov.m[0][0] + 0.3f, cb = c.cov.m[0][1], cc = c.cov.m[1][1] + 0.3f;
+  const float denom = ca * cc - cb * cb;
+  float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+  const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+  float dcov[6];
+#define TM(c_, r_) c.T.m[c_][r_]
+#define VM(c_, r_) c.Vrk.m[c_][r_]
+  if (denom2inv != 0.f) {
+    dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
+    dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
+    dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+    dcov[0] = (TM(0, 0) * TM(0, 0) * dL_da + TM(0, 0) * TM(1, 0) * dL_db + TM(1, 0) * TM(1, 0) * dL_dc);
+    dcov[3] = (TM(0, 1) * TM(0, 1) * dL_da + TM(0, 1) * TM(1, 1) * dL_db + TM(1, 1) * TM(1, 1) * dL_dc);
+    dcov[5] = (TM(0, 2) * TM(0, 2) * dL_da + TM(0, 2) * TM(1, 2) * dL_db + TM(1, 2) * TM(1, 2) * dL_dc);
+    dcov[1] = 2 * TM(0, 0) * TM(0, 1) * dL_da + (TM(0, 0) * TM(1, 1) + TM(0, 1) * TM(1, 0)) * dL_db + 2 * TM(1, 0) * TM(1, 1) * dL_dc;
+    dcov[2] = 2 * TM(0, 0) * TM(0, 2) * dL_da + (TM(0, 0) * TM(1, 2) + TM(0, 2) * TM(1, 0)) * dL_db + 2 * TM(1, 0) * TM(1, 2) * dL_dc;
+    dcov[4] = 2 * TM(0, 2) * TM(0, 1) * dL_da + (TM(0, 1) * TM(1, 2) + TM(0, 2) * TM(1, 1)) * dL_db + 2 * TM(1, 1) * TM(1, 2) * dL_dc;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; k++) dcov[k] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+
+  const float dL_dT00 = 2 * (TM(0, 0) * VM(0, 0) + TM(0, 1) * VM(0, 1) + TM(0, 2) * VM(0, 2)) * dL_da + (TM(1, 0) * VM(0, 0) + TM(1, 1) * VM(0, 1) + TM(1, 2) * VM(0, 2)) * dL_db;
+  const float dL_dT01 = 2 * (TM(0, 0) * VM(1, 0) + TM(0, 1) * VM(1, 1) + TM(0, 2) * VM(1, 2)) * dL_da + (TM(1, 0) * VM(1, 0) + TM(1, 1) * VM(1, 1) + TM(1, 2) * VM(1, 2)) * dL_db;
+  const float dL_dT02 = 2 * (TM(0, 0) * VM(2, 0) + TM(0, 1) * VM(2, 1) + TM(0, 2) * VM(2, 2)) * dL_da + (TM(1, 0) * VM(2, 0) + TM(1, 1) * VM(2, 1) + TM(1, 2) * VM(2, 2)) * dL_db;
+  const float dL_dT10 = 2 * (TM(1, 0) * VM(0, 0) + TM(1, 1) * VM(0, 1) + TM(1, 2) * VM(0, 2)) * dL_dc + (TM(0, 0) * VM(0, 0) + TM(0, 1) * VM(0, 1) + TM(0, 2) * VM(0, 2)) * dL_db;
+  const float dL_dT11 = 2 * (TM(1, 0) * VM(1, 0) + TM(1, 1) * VM(1, 1) + TM(1, 2) * VM(1, 2)) * dL_dc + (TM(0, 0) * VM(1, 0) + TM(0, 1) * VM(1, 1) + TM(0, 2) * VM(1, 2)) * dL_db;
+  const float dL_dT12 = 2 * (TM(1, 0) * VM(2, 0) + TM(1, 1) * VM(2, 1) + TM(1, 2) * VM(2, 2)) * dL_dc + (TM(0, 0) * VM(2, 0) + TM(0, 1) * VM(2, 1) + TM(0, 2) * VM(2, 2)) * dL_db;
+#undef TM
+#undef VM
+  const float dL_dJ00 = c.W.m[0][0] * dL_dT00 + c.W.m[0][1] * dL_dT01 + c.W.m[0][2] * dL_dT02;
+  const float dL_dJ02 = c.W.m[2][0] * dL_dT00 + c.W.m[2][1] * dL_dT01 + c.W.m[2][2] * dL_dT02;
+  const float dL_dJ11 = c.W.m[1][0] * dL_dT10 + c.W.m[1][1] * dL_dT11 + c.W.m[1][2] * dL_dT12;
+  const float dL_dJ12 = c.W.m[2][0] * dL_dT10 + c.W.m[2][1] * dL_dT11 + c.W.m[2][2] * dL_dT12;
+  const float tz = 1.f / c.t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+  const float dL_dtx = x_grad_mul * -a.fx * tz2 * dL_dJ02;
+  const float dL_dty = y_grad_mul * -a.fy * tz2 * dL_dJ12;
+  const float dL_dtz = -a.fx * tz2 * dL_dJ00 - a.fy * tz2 * dL_dJ11 + (2 * a.fx * c.t.x) * tz3 * dL_dJ02 +
+                       (2 * a.fy * c.t.y) * tz3 * dL_dJ12;
+  // transformVec4x3Transpose (auxiliary.h:89-97); the reference ASSIGNS here (backward.cu:273)
+  float dmx = V[0] * dL_dtx + V[1] * dL_dty + V[2] * dL_dtz;
+  float dmy = V[4] * dL_dtx + V[5] * dL_dty + V[6] * dL_dtz;
+  float dmz = V[8] * dL_dtx + V[9] * dL_dty + V[10] * dL_dtz;
+
+  // ---- preprocessCUDA backward (backward.cu:346-412) ----
+  const float4 m_hom = xform_4x4(mean, proj);
+  const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+  const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+  const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+  const float g2x = a.dL_dmean2D[3 * (size_t)idx], g2y = a.dL_dmean2D[3 * (size_t)idx + 1];
+  dmx += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+  dmy += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+  dmz += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+  const float mul3 = V[2] * mean.x + V[6] * mean.y + V[10] * mean.z + V[14];
+  const float gdep = a.dL_ddepth[idx];
+  dmx += (V[2] - V[3] * mul3) * gdep;
+  dmy += (V[6] - V[7] * mul3) * gdep;
+  dmz += (V[10] - V[11] * mul3) * gdep;
+
+  // ---- SH backward (backward.cu:20-139) ----
+  if (a.shs != nullptr) {
+    const int deg = a.D;
+    const float3 dir_orig = make_float3(mean.x - a.campos[0], mean.y - a.campos[1], mean.z - a.campos[2]);
+    const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+    const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+    const float* sh = a.shs + (size_t)idx * a.M * 3;
+    float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+    float dRGB[3], dRdx[3] = {0.f, 0.f, 0.f}, dRdy[3] = {0.f, 0.f, 0.f}, dRdz[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) dRGB[ch] = a.dL_dcolor[3 * (size_t)idx + ch] * (a.clamped[3 * (size_t)idx + ch] ? 0.f : 1.f);
+#define SH(k) sh[(k)*3 + ch]
+#define DSH(k, v) dsh[(k)*3 + ch] = (v)*dRGB[ch]
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      DSH(0, SH_C0);
+      if (deg > 0) {
+        DSH(1, -SH_C1 * y); DSH(2, SH_C1 * z); DSH(3, -SH_C1 * x);
+        dRdx[ch] = -SH_C1 * SH(3); dRdy[ch] = -SH_C1 * SH(1); dRdz[ch] = SH_C1 * SH(2);
+        if (deg > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          DSH(4, SH_C2[0] * xy); DSH(5, SH_C2[1] * yz); DSH(6, SH_C2[2] * (2.f * zz - xx - yy));
+          DSH(7, SH_C2[3] * xz); DSH(8, SH_C2[4] * (xx - yy));
+          dRdx[ch] += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
+          dRdy[ch] += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
+          dRdz[ch] += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
+          if (deg > 2) {
+            DSH(9, SH_C3[0] * y * (3.f * xx - yy)); DSH(10, SH_C3[1] * xy * z); DSH(11, SH_C3[2] * y * (4.f * zz - xx - yy));
+            DSH(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)); DSH(13, SH_C3[4] * x * (4.f * zz - xx - yy));
+            DSH(14, SH_C3[5] * z * (xx - yy)); DSH(15, SH_C3[6] * x * (xx - 3.f * yy));
+            dRdx[ch] += (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
+                         SH_C3[3] * SH(12) * -3.f * 2.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                         SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy));
+            dRdy[ch] += (SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz + SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) +
+                         SH_C3[3] * SH(12) * -3.f * 2.f * yz + SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz +
+                         SH_C3[6] * SH(15) * -3.f * 2.f * xy);
+            dRdz[ch] += (SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz + SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                         SH_C3[4] * SH(13) * 4.f * 2.f * xz + SH_C3[5] * SH(14) * (xx - yy));
+          }
+        }
+      }
+    }
+#undef SH
+#undef DSH
+    const float ddx = dRdx[0] * dRGB[0] + dRdx[1] * dRGB[1] + dRdx[2] * dRGB[2];
+    const float ddy = dRdy[0] * dRGB[0] + dRdy[1] * dRGB[1] + dRdy[2] * dRGB[2];
+    const float ddz = dRdz[0] * dRGB[0] + dRdz[1] * dRGB[1] + dRdz[2] * dRGB[2];
+    // dnormvdv (auxiliary.h:107-117)
+    const float3 v = dir_orig;
+    const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    dmx += ((+sum2 - v.x * v.x) * ddx - v.y * v.x * ddy - v.z * v.x * ddz) * invsum32;
+    dmy += (-v.x * v.y * ddx + (sum2 - v.y * v.y) * ddy - v.z * v.y * ddz) * invsum32;
+    dmz += (-v.x * v.z * ddx - v.y * v.z * ddy + (sum2 - v.z * v.z) * ddz) * invsum32;
+  }
+  a.dL_dmean3D[3 * (size_t)idx + 0] = dmx;
+  a.dL_dmean3D[3 * (size_t)idx + 1] = dmy;
+  a.dL_dmean3D[3 * (size_t)idx + 2] = dmz;
+
+  // ---- computeCov3D backward (backward.cu:278-341) ----
+  if (a.scales != nullptr) {
+    const float4 rot = reinterpret_cast<const float4*>(a.rotations)[idx];
+    const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
+    const M3 R = quat_to_R(rot);
+    const float3 s = make_float3(a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
+                                 a.scale_modifier * a.scales[3 * idx + 2]);
+    M3 S = {{{s.x, 0.f, 0.f}, {0.f, s.y, 0.f}, {0.f, 0.f, s.z}}};
+    M3 Mm = m3_mul(S, R);
+    M3 dSigma = {{{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]}, {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}}};
+    M3 M2;
+#pragma unroll
+    for (int cc_ = 0; cc_ < 3; cc_++)
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++) M2.m[cc_][rr] = 2.0f * Mm.m[cc_][rr];
+    M3 dM = m3_mul(M2, dSigma);
+    M3 Rt = m3_T(R), dMt = m3_T(dM);
+    a.dL_dscale[3 * (size_t)idx + 0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
+    a.dL_dscale[3 * (size_t)idx + 1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
+    a.dL_dscale[3 * (size_t)idx + 2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
+    const float sv[3] = {s.x, s.y, s.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++) dMt.m[k][rr] *= sv[k];
+#define Dm(c_, r_) dMt.m[c_][r_]
+    float4 dq;
+    dq.x = 2 * z * (Dm(0, 1) - Dm(1, 0)) + 2 * y * (Dm(2, 0) - Dm(0, 2)) + 2 * x * (Dm(1, 2) - Dm(2, 1));
+    dq.y = 2 * y * (Dm(1, 0) + Dm(0, 1)) + 2 * z * (Dm(2, 0) + Dm(0, 2)) + 2 * r * (Dm(1, 2) - Dm(2, 1)) - 4 * x * (Dm(2, 2) + Dm(1, 1));
+    dq.z = 2 * x * (Dm(1, 0) + Dm(0, 1)) + 2 * r * (Dm(2, 0) - Dm(0, 2)) + 2 * z * (Dm(1, 2) + Dm(2, 1)) - 4 * y * (Dm(2, 2) + Dm(0, 0));
+    dq.w = 2 * r * (Dm(0, 1) - Dm(1, 0)) + 2 * x * (Dm(2, 0) + Dm(0, 2)) + 2 * y * (Dm(1, 2) + Dm(2, 1)) - 4 * z * (Dm(1, 1) + Dm(0, 0));
+#undef Dm
+    reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
+  }
+}
+
+}  // namespace s3g
+
+using namespace s3g;
+
+extern "C" int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int* radii, const void* geometry_arena,
+                                   const void* binning_arena, const void* image_arena, const float* dL_dpix,
+                                   const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                   float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                                   float* dL_dscale, float* dL_drot, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!in) {
+    set_error("s3g_raster_backward: NULL inputs");
+    return S3G_ERR_INVALID_ARG;
+  }
+  const int P = in->P, W = in->width, H = in->height;
+  if (P == 0) return S3G_OK;
+  if (!radii || !geometry_arena || !image_arena || (R > 0 && !binning_arena) || !dL_dpix || !dL_dpix_depth ||
+      !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_ddepth || !dL_dmean3D || !dL_dcov3D ||
+      !dL_dscale || !dL_drot || (in->shs && !dL_dsh)) {
+    set_error("s3g_raster_backward: NULL array argument");
+    return S3G_ERR_INVALID_ARG;
+  }
+  const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y, tiles = gx * gy;
+  const bool debug = in->debug != 0;
+  GeomState g = GeomState::carve(const_cast<void*>(geometry_arena), P, nullptr);
+  ImageState im = ImageState::carve(const_cast<void*>(image_arena), (size_t)W * H, tiles, nullptr);
+  BinningState b = BinningState::carve(const_cast<void*>(binning_arena), (size_t)(R > 0 ? R : 0), nullptr);
+
+  const float* color_ptr = in->colors_precomp ? in->colors_precomp : g.rgb;
+  if (R > 0) {
+    const uint32_t tile_blocks = ((uint32_t)tiles + 7u) & ~7u;
+    hipLaunchKernelGGL(blend_backward_kernel, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
+                       b.point_list, in->background, g.means2D, g.conic_opacity, color_ptr, g.depths, im.final_T,
+                       im.n_contrib, dL_dpix, dL_dpix_depth, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth);
+    S3G_KERNEL_CHECK(stream, debug);
+  }
+  GeomBwdArgs ga;
+  ga.P = P; ga.D = in->D; ga.M = in->M; ga.means3D = in->means3D; ga.radii = radii; ga.shs = in->shs;
+  ga.clamped = g.clamped; ga.scales = in->scales; ga.rotations = in->rotations; ga.scale_modifier = in->scale_modifier;
+  ga.cov3Ds = in->cov3D_precomp ? in->cov3D_precomp : g.cov3D;
+  ga.view = in->viewmatrix; ga.proj = in->projmatrix; ga.campos = in->cam_pos;
+  ga.fy = H / (2.0f * in->tan_fovy); ga.fx = W / (2.0f * in->tan_fovx);
+  ga.tan_fovx = in->tan_fovx; ga.tan_fovy = in->tan_fovy;
+  ga.dL_dmean2D = dL_dmean2D; ga.dL_dconic = dL_dconic; ga.dL_dcolor = dL_dcolor; ga.dL_ddepth = dL_ddepth;
+  ga.dL_dmean3D = dL_dmean3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dsh = dL_dsh; ga.dL_dscale = dL_dscale; ga.dL_drot = dL_drot;
+  hipLaunchKernelGGL(geometry_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, ga);
+  S3G_KERNEL_CHECK(stream, debug);
+  return S3G_OK;
+}

@@ -1,0 +1,519 @@
+// Forward half of the MI355X-native differentiable Gaussian rasterizer (gfx950, wave64).
+//
+// What it computes is the reference's CudaRasterizer::Rasterizer::forward
+// (RAST/cuda_rasterizer/rasterizer_impl.cu:198-339); how it computes it is not:
+//
+//   reference (CUDA)                                   this file (CDNA4)
+//   -------------------------------------------------  ------------------------------------------------------
+//   preprocessCUDA  (forward.cu:155-256)               preprocess_kernel: same per-Gaussian math (bit-exact fp32,
+//                                                      contraction off) + per-tile instance histogram
+//   InclusiveSum over P + duplicateWithKeys + global   scan over TILES (6.7k, not 1.2M) -> tile ranges directly;
+//   64-bit radix sort of all R instances + range scan   scatter into per-tile buckets; per-tile bitonic sort of
+//   (rasterizer_impl.cu:278-319)                        (depth bits, index) keys staged in LDS.  Resulting order is
+//                                                      identical to the stable (tile, depth) radix sort: ties in
+//                                                      depth resolve by ascending Gaussian index.
+//   renderCUDA (forward.cu:261-379)                    blend_forward_kernel: 16x16 tile = 4 wave64, Gaussian
+//                                                      attributes (incl. colour+depth) staged in LDS, conic
+//                                                      pre-scaled so alpha = o * exp2(q) is one v_exp_f32
+#include "geom_math.hpp"
+
+#include <stdarg.h>
+
+namespace s3g {
+
+static thread_local char g_err[512] = {0};
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+// =========================================================================================================
+// 1. Per-Gaussian preprocess (EWA projection).  HBM-bound: 56 B read + ~68 B written per Gaussian.
+//    Bit-exact with the fp32 oracle: contraction is disabled so every op rounds once, in source order
+//    (glm mat3 products expanded in glm's summation order, type_mat3x3.inl:486-518).
+// =========================================================================================================
+// forward.cu:20-71
+__device__ __forceinline__ float3 sh_to_rgb(int idx, int deg, int M, const float3 pos, const float3 campos,
+                                            const float* __restrict__ shs, uint8_t* __restrict__ clamped) {
+  float3 dir = make_float3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
+  const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+  const float x = dir.x / len, y = dir.y / len, z = dir.z / len;
+  const float* sh = shs + (size_t)idx * M * 3;
+  float res[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+#define SH(k) sh[(k)*3 + c]
+    float v = SH_C0 * SH(0);
+    if (deg > 0) {
+      v = v - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+      if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        v = v + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) + SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
+            SH_C2[3] * xz * SH(7) + SH_C2[4] * (xx - yy) * SH(8);
+        if (deg > 2) {
+          v = v + SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
+              SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) + SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+              SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3[5] * z * (xx - yy) * SH(14) +
+              SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+        }
+      }
+    }
+#undef SH
+    v += 0.5f;
+    clamped[3 * idx + c] = (v < 0.f);
+    res[c] = fmaxf(v, 0.f);
+  }
+  return make_float3(res[0], res[1], res[2]);
+}
+
+struct PreprocessArgs {
+  int P, D, M, W, H, gx, gy;
+  const float* means3D;
+  const float* scales;
+  float scale_modifier;
+  const float* rotations;
+  const float* opacities;
+  const float* shs;
+  const float* cov3D_precomp;
+  const float* colors_precomp;
+  const float* viewmatrix;
+  const float* projmatrix;
+  const float* cam_pos;
+  float tan_fovx, tan_fovy, focal_x, focal_y;
+  int prefiltered;
+  int* radii;
+  GeomState g;
+  uint32_t* tile_count;
+  uint32_t* ctrl;
+};
+
+__global__ void __launch_bounds__(256) preprocess_kernel(const PreprocessArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.P) return;
+  a.radii[idx] = 0;
+  a.g.rect[idx] = make_ushort4(0, 0, 0, 0);
+
+  const float3 p = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+  const float3 p_view = xform_4x3(p, a.viewmatrix);
+  if (p_view.z <= 0.2f) {  // in_frustum, auxiliary.h:154
+    if (a.prefiltered) atomicOr(&a.ctrl[2], 1u);
+    return;
+  }
+  const float4 p_hom = xform_4x4(p, a.projmatrix);
+  const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+  const float2 p_proj = make_float2(p_hom.x * p_w, p_hom.y * p_w);
+
+  float cov3D[6];
+  if (a.cov3D_precomp != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) cov3D[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+  } else {
+    const float3 s = make_float3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
+    const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+    cov3d_from_scale_rot(s, a.scale_modifier, q, cov3D);
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.g.cov3D[6 * (size_t)idx + k] = cov3D[k];
+  }
+  const Cov2DCtx cc = cov2d_common(p, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.viewmatrix);
+  const float3 cov = make_float3(cc.cov.m[0][0] + 0.3f, cc.cov.m[0][1], cc.cov.m[1][1] + 0.3f);
+  const float det = cov.x * cov.z - cov.y * cov.y;
+  if (det == 0.0f) return;
+  const float det_inv = 1.f / det;
+  const float3 conic = make_float3(cov.z * det_inv, -cov.y * det_inv, cov.x * det_inv);
+  const float mid = 0.5f * (cov.x + cov.z);
+  const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+  const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+  const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+  // ndc2Pix (auxiliary.h:41-44) is double arithmetic in the reference (double literals)
+  const float px = (float)((((double)p_proj.x + 1.0) * a.W - 1.0) * 0.5);
+  const float py = (float)((((double)p_proj.y + 1.0) * a.H - 1.0) * 0.5);
+  // getRect (auxiliary.h:46-56)
+  const int r = (int)my_radius;
+  const int rx0 = min(a.gx, max(0, (int)((px - r) / TILE_X)));
+  const int ry0 = min(a.gy, max(0, (int)((py - r) / TILE_Y)));
+  const int rx1 = min(a.gx, max(0, (int)((px + r + TILE_X - 1) / TILE_X)));
+  const int ry1 = min(a.gy, max(0, (int)((py + r + TILE_Y - 1) / TILE_Y)));
+  if ((rx1 - rx0) * (ry1 - ry0) == 0) return;
+
+  if (a.colors_precomp == nullptr) {
+    const float3 cp = make_float3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]);
+    const float3 c = sh_to_rgb(idx, a.D, a.M, p, cp, a.shs, a.g.clamped);
+    a.g.rgb[3 * (size_t)idx + 0] = c.x;
+    a.g.rgb[3 * (size_t)idx + 1] = c.y;
+    a.g.rgb[3 * (size_t)idx + 2] = c.z;
+  }
+  a.g.depths[idx] = p_view.z;
+  a.radii[idx] = r;
+  a.g.means2D[idx] = make_float2(px, py);
+  a.g.conic_opacity[idx] = make_float4(conic.x, conic.y, conic.z, a.opacities[idx]);
+  a.g.rect[idx] = make_ushort4((unsigned short)rx0, (unsigned short)ry0, (unsigned short)rx1, (unsigned short)ry1);
+  // per-tile instance histogram (fire-and-forget L2 atomics)
+  for (int y = ry0; y < ry1; y++)
+    for (int x = rx0; x < rx1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+}
+
+// =========================================================================================================
+// 2. Exclusive scan over tiles: ranges[t] = [start, end), tile_count[t] <- start (becomes the scatter cursor),
+//    ctrl[0] = R, ctrl[1] = longest tile list.  One 1024-thread workgroup; tiles is O(10^3..10^4).
+// =========================================================================================================
+__global__ void __launch_bounds__(1024) scan_tiles_kernel(int tiles, uint32_t* __restrict__ tile_count,
+                                                          uint2* __restrict__ ranges, uint32_t* __restrict__ ctrl) {
+  __shared__ uint32_t buf[2][1024];
+  __shared__ uint32_t wmax[16];
+  const int tid = threadIdx.x;
+  uint32_t carry = 0, vmax = 0;
+  for (int base = 0; base < tiles; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = i < tiles ? tile_count[i] : 0u;
+    vmax = max(vmax, v);
+    int cur = 0;
+    buf[0][tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+      uint32_t x = buf[cur][tid];
+      if (tid >= off) x += buf[cur][tid - off];
+      buf[cur ^ 1][tid] = x;
+      cur ^= 1;
+      __syncthreads();
+    }
+    const uint32_t incl = buf[cur][tid];
+    const uint32_t total = buf[cur][1023];
+    if (i < tiles) {
+      const uint32_t start = carry + incl - v;
+      ranges[i] = make_uint2(start, start + v);
+      tile_count[i] = start;
+    }
+    carry += total;
+    __syncthreads();
+  }
+  // block max
+  for (int off = 32; off >= 1; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off));
+  if ((tid & 63) == 0) wmax[tid >> 6] = vmax;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t m = 0;
+    for (int w = 0; w < 16; w++) m = max(m, wmax[w]);
+    ctrl[0] = carry;
+    ctrl[1] = m;
+  }
+}
+
+// =========================================================================================================
+// 3. Scatter instances into their tile bucket (order inside a bucket is arbitrary here; the sort fixes it).
+// =========================================================================================================
+__global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, const ushort4* __restrict__ rect,
+                                                      const float* __restrict__ depths, uint32_t* __restrict__ cursor,
+                                                      uint64_t* __restrict__ keys) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  const ushort4 r = rect[idx];
+  if (r.z <= r.x || r.w <= r.y) return;
+  const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx;
+  for (int y = r.y; y < r.w; y++)
+    for (int x = r.x; x < r.z; x++) {
+      const uint32_t pos = atomicAdd(&cursor[y * gx + x], 1u);
+      keys[pos] = key;
+    }
+}
+
+// =========================================================================================================
+// 4. Per-tile sort of 64-bit (depth bits | index) keys: bitonic network with all comparators ascending
+//    (first sub-step of each stage mirrors, i ^ (k-1)), so a non-power-of-two list is handled by skipping
+//    comparators whose upper element is past the end (virtual +inf padding never moves).
+//    Lists that fit stay in LDS; longer ones run the same network in place in global memory.
+// =========================================================================================================
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_network(KeyPtr a, uint32_t n, uint32_t tid, uint32_t nthreads) {
+  uint32_t lN = 0;
+  while ((1u << lN) < n) lN++;
+  const uint32_t half = (1u << lN) >> 1;  // comparators per step
+  for (uint32_t lk = 1; lk <= lN; lk++) {
+    {  // mirror step: element o of block b against element k-1-o
+      const uint32_t k = 1u << lk, lhk = lk - 1, hk = 1u << lhk;
+      for (uint32_t c = tid; c < half; c += nthreads) {
+        const uint32_t b = c >> lhk, o = c & (hk - 1);
+        const uint32_t i = (b << lk) + o, l = (b << lk) + (k - 1 - o);
+        if (l < n) {
+          const uint64_t x = a[i], y = a[l];
+          if (x > y) { a[i] = y; a[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+    for (int lj = (int)lk - 2; lj >= 0; lj--) {  // half-cleaners, distance j = 2^lj
+      const uint32_t j = 1u << lj;
+      for (uint32_t c = tid; c < half; c += nthreads) {
+        const uint32_t b = c >> lj, o = c & (j - 1);
+        const uint32_t i = (b << (lj + 1)) + o, l = i + j;
+        if (l < n) {
+          const uint64_t x = a[i], y = a[l];
+          if (x > y) { a[i] = y; a[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Tiles with lo < n <= hi are handled by this launch; lds_keys = capacity of the dynamic LDS buffer in keys.
+__global__ void __launch_bounds__(256) sort_tiles_kernel(int tiles, const uint2* __restrict__ ranges,
+                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list,
+                                                         uint32_t lo, uint32_t hi, uint32_t lds_keys) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
+  const uint32_t t = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (t >= (uint32_t)tiles) return;
+  const uint2 rg = ranges[t];
+  const uint32_t n = rg.y - rg.x;
+  if (n <= lo || n > hi) return;
+  uint64_t* gk = keys + rg.x;
+  const uint32_t tid = threadIdx.x;
+  if (n <= lds_keys) {
+    for (uint32_t i = tid; i < n; i += 256) skeys[i] = gk[i];
+    __syncthreads();
+    if (n > 1) bitonic_network(skeys, n, tid, 256u);
+    for (uint32_t i = tid; i < n; i += 256) {
+      const uint64_t k = skeys[i];
+      gk[i] = k;
+      point_list[rg.x + i] = (uint32_t)k;
+    }
+  } else {
+    bitonic_network((volatile uint64_t*)gk, n, tid, 256u);  // same workgroup: coherent through its own L1 after barriers
+    for (uint32_t i = tid; i < n; i += 256) point_list[rg.x + i] = (uint32_t)gk[i];
+  }
+}
+
+// =========================================================================================================
+// 5. Front-to-back alpha/depth blending, one 16x16 tile per workgroup (4 wave64), one pixel per lane.
+//    Per batch of 256 Gaussians the workgroup gathers (mean2D, conic, opacity, rgb, depth) into LDS with one
+//    coalesced index read + L2-resident attribute gathers; the inner loop then reads wave-uniform LDS
+//    addresses (broadcast).  The conic is pre-scaled by -0.5*log2(e) / -log2(e) while staging so the
+//    Gaussian weight is a bare v_exp_f32:  alpha = min(0.99, o * exp2(qa*dx*dx + qc*dy*dy + qb*dx*dy)).
+// =========================================================================================================
+__global__ void __launch_bounds__(256)
+blend_forward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ ranges,
+                     const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
+                     const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
+                     const float* __restrict__ depths, const float* __restrict__ bg, float* __restrict__ final_T,
+                     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth) {
+  __shared__ StagedGaussian sg[256];
+  const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile >= (uint32_t)tiles) return;
+  const int tx = tile % gx, ty = tile / gx;
+  const int tid = threadIdx.x;
+  const int px = tx * TILE_X + (tid & 15), py = ty * TILE_Y + (tid >> 4);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const uint2 rg = ranges[tile];
+  int todo = (int)(rg.y - rg.x);
+
+  bool done = !inside;
+  float T = 1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f;
+  uint32_t contributor = 0, last_contributor = 0;
+
+  for (uint32_t base = rg.x; base < rg.y; base += 256, todo -= 256) {
+    if (__syncthreads_count(done) == 256) break;  // also protects sg[] reuse
+    if (base + tid < rg.y) {
+      const uint32_t id = point_list[base + tid];
+      const float2 m = means2D[id];
+      const float4 co = conic_opacity[id];
+      StagedGaussian s;
+      s.a = make_float4(m.x, m.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
+      s.b = make_float4(-0.5f * LOG2E * co.z, co.w, depths[id], colors[3 * (size_t)id]);
+      s.c = make_float4(colors[3 * (size_t)id + 1], colors[3 * (size_t)id + 2], co.x, co.y);
+      sg[tid] = s;
+    }
+    __syncthreads();
+    const int cnt = min(256, todo);
+    for (int j = 0; !done && j < cnt; j++) {
+      contributor++;
+      const float4 A = sg[j].a;
+      const float dx = A.x - pxf, dy = A.y - pyf;
+      const float4 B = sg[j].b;
+      const float q = gaussian_exponent2(dx, dy, A.z, A.w, B.x);
+      if (q > 0.f) continue;
+      const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(q));
+      if (alpha < 1.0f / 255.0f) continue;
+      const float test_T = T * (1.f - alpha);
+      if (test_T < 0.0001f) {
+        done = true;
+        continue;
+      }
+      const float w = alpha * T;
+      const float4 Cc = sg[j].c;
+      Cr = __builtin_fmaf(B.w, w, Cr);
+      Cg = __builtin_fmaf(Cc.x, w, Cg);
+      Cb = __builtin_fmaf(Cc.y, w, Cb);
+      D = __builtin_fmaf(B.z, w, D);
+      T = test_T;
+      last_contributor = contributor;
+    }
+  }
+  if (inside) {
+    const size_t pix = (size_t)py * W + px, N = (size_t)H * W;
+    final_T[pix] = T;
+    n_contrib[pix] = last_contributor;
+    out_color[pix] = Cr + T * bg[0];
+    out_color[N + pix] = Cg + T * bg[1];
+    out_color[2 * N + pix] = Cb + T * bg[2];
+    out_depth[pix] = D;
+  }
+}
+
+__global__ void __launch_bounds__(256) check_frustum_kernel(int P, const float* __restrict__ means3D,
+                                                            const float* __restrict__ viewmatrix,
+                                                            uint8_t* __restrict__ present) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+  present[idx] = xform_4x3(p, viewmatrix).z > 0.2f ? 1 : 0;
+}
+
+static inline uint32_t round_up8(uint32_t v) { return (v + 7u) & ~7u; }
+
+}  // namespace s3g
+
+using namespace s3g;
+
+extern "C" const char* s3g_last_error(void) { return g_err; }
+extern "C" int s3g_abi_version(void) { return 1; }
+
+extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geometry_buffer, void* geometry_user,
+                                  s3g_resize_fn binning_buffer, void* binning_user, s3g_resize_fn image_buffer,
+                                  void* image_user, float* out_color, float* out_depth, int* radii, int* num_rendered,
+                                  void* stream_) {
+  g_err[0] = 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!in || !geometry_buffer || !binning_buffer || !image_buffer || !num_rendered) {
+    set_error("s3g_raster_forward: NULL argument");
+    return S3G_ERR_INVALID_ARG;
+  }
+  *num_rendered = 0;
+  const int P = in->P, W = in->width, H = in->height;
+  if (P < 0 || W <= 0 || H <= 0) {
+    set_error("s3g_raster_forward: bad sizes P=%d W=%d H=%d", P, W, H);
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (P == 0) return S3G_OK;  // rasterize_points.cu:82: outputs keep the caller's zero fill
+  if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) {
+    set_error("Please provide excatly one of either SHs or precomputed colors!");
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (((in->scales == nullptr || in->rotations == nullptr) && in->cov3D_precomp == nullptr) ||
+      ((in->scales != nullptr || in->rotations != nullptr) && in->cov3D_precomp != nullptr)) {
+    set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (!in->means3D || !in->opacities || !in->viewmatrix || !in->projmatrix || !in->cam_pos || !in->background ||
+      !out_color || !out_depth || !radii) {
+    set_error("s3g_raster_forward: NULL array argument");
+    return S3G_ERR_INVALID_ARG;
+  }
+  const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y, tiles = gx * gy;
+  if (gx > 65535 || gy > 65535) {
+    set_error("image too large for 16-bit tile coordinates");
+    return S3G_ERR_INVALID_ARG;
+  }
+  const bool debug = in->debug != 0;
+
+  size_t geom_bytes = 0, img_bytes = 0;
+  GeomState::carve(nullptr, P, &geom_bytes);
+  ImageState::carve(nullptr, (size_t)W * H, tiles, &img_bytes);
+  void* geom_p = geometry_buffer(geometry_user, geom_bytes);
+  void* img_p = image_buffer(image_user, img_bytes);
+  if (!geom_p || !img_p) {
+    set_error("resize callback returned NULL");
+    return S3G_ERR_ALLOC;
+  }
+  GeomState g = GeomState::carve(geom_p, P, nullptr);
+  ImageState im = ImageState::carve(img_p, (size_t)W * H, tiles, nullptr);
+
+  // tile_count[tiles] and ctrl[8] are adjacent up to alignment: clear both
+  S3G_HIP_CHECK(hipMemsetAsync(im.tile_count, 0, (char*)(im.ctrl + 8) - (char*)im.tile_count, stream));
+
+  PreprocessArgs pa;
+  pa.P = P; pa.D = in->D; pa.M = in->M; pa.W = W; pa.H = H; pa.gx = gx; pa.gy = gy;
+  pa.means3D = in->means3D; pa.scales = in->scales; pa.scale_modifier = in->scale_modifier;
+  pa.rotations = in->rotations; pa.opacities = in->opacities; pa.shs = in->shs;
+  pa.cov3D_precomp = in->cov3D_precomp; pa.colors_precomp = in->colors_precomp;
+  pa.viewmatrix = in->viewmatrix; pa.projmatrix = in->projmatrix; pa.cam_pos = in->cam_pos;
+  pa.tan_fovx = in->tan_fovx; pa.tan_fovy = in->tan_fovy;
+  pa.focal_y = H / (2.0f * in->tan_fovy); pa.focal_x = W / (2.0f * in->tan_fovx);
+  pa.prefiltered = in->prefiltered; pa.radii = radii; pa.g = g; pa.tile_count = im.tile_count; pa.ctrl = im.ctrl;
+  hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, pa);
+  S3G_KERNEL_CHECK(stream, debug);
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, tiles, im.tile_count, im.ranges, im.ctrl);
+  S3G_KERNEL_CHECK(stream, debug);
+
+  // the one host sync of the forward (reference: rasterizer_impl.cu:282): R sizes the binning arena
+  static thread_local uint32_t* h_ctrl = nullptr;
+  if (!h_ctrl) S3G_HIP_CHECK(hipHostMalloc((void**)&h_ctrl, 8 * sizeof(uint32_t), hipHostMallocDefault));
+  S3G_HIP_CHECK(hipMemcpyAsync(h_ctrl, im.ctrl, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  S3G_HIP_CHECK(hipStreamSynchronize(stream));
+  const uint32_t R = h_ctrl[0], max_tile = h_ctrl[1];
+  if (h_ctrl[2] & 1u) {
+    set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
+    return S3G_ERR_PREFILTERED;
+  }
+  if (R > 0x7fffffffu) {
+    set_error("too many Gaussian/tile instances (%u)", R);
+    return S3G_ERR_INVALID_ARG;
+  }
+  *num_rendered = (int)R;
+
+  size_t bin_bytes = 0;
+  BinningState::carve(nullptr, R, &bin_bytes);
+  void* bin_p = binning_buffer(binning_user, bin_bytes);
+  if (!bin_p && R > 0) {
+    set_error("resize callback returned NULL");
+    return S3G_ERR_ALLOC;
+  }
+  BinningState b = BinningState::carve(bin_p, R, nullptr);
+
+  const uint32_t tile_blocks = round_up8((uint32_t)tiles);
+  if (R > 0) {
+    hipLaunchKernelGGL(scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, g.rect, g.depths,
+                       im.tile_count, b.keys);
+    S3G_KERNEL_CHECK(stream, debug);
+    // short lists: 32 KiB of LDS per workgroup (5 workgroups/CU); long lists: up to 128 KiB, beyond that in global
+    constexpr uint32_t SMALL = 4096, LARGE = 16384;
+    const uint32_t small_cap = max_tile < SMALL ? max_tile : SMALL;
+    hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)small_cap * 8, stream, tiles, im.ranges,
+                       b.keys, b.point_list, 0u, SMALL, small_cap);
+    S3G_KERNEL_CHECK(stream, debug);
+    if (max_tile > SMALL) {
+      const uint32_t large_cap = max_tile < LARGE ? max_tile : LARGE;
+      static bool attr_set = false;
+      if (!attr_set) {
+        S3G_HIP_CHECK(hipFuncSetAttribute((const void*)sort_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          LARGE * 8));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)large_cap * 8, stream, tiles,
+                         im.ranges, b.keys, b.point_list, SMALL, 0xffffffffu, large_cap);
+      S3G_KERNEL_CHECK(stream, debug);
+    }
+  }
+  const float* feat = in->colors_precomp ? in->colors_precomp : g.rgb;
+  hipLaunchKernelGGL(blend_forward_kernel, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
+                     b.point_list, g.means2D, g.conic_opacity, feat, g.depths, in->background, im.final_T, im.n_contrib,
+                     out_color, out_depth);
+  S3G_KERNEL_CHECK(stream, debug);
+  return S3G_OK;
+}
+
+extern "C" int s3g_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                                uint8_t* present, void* stream_) {
+  g_err[0] = 0;
+  (void)projmatrix;
+  if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) {
+    set_error("s3g_mark_visible: bad argument");
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (P == 0) return S3G_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(check_frustum_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, viewmatrix, present);
+  S3G_HIP_CHECK(hipGetLastError());
+  return S3G_OK;
+}

@@ -1,0 +1,158 @@
+"""Tensor-level entry points with the signatures of the reference's native module
+`diff_gaussian_rasterization._C` (RAST/ext.cpp:15-19, RAST/rasterize_points.h:18-68), implemented on top of the
+C ABI of libs3g.so.  `diff_gaussian_rasterization._C` in this repo re-exports this module.
+
+torch is used here for device memory and the current HIP stream only; no torch type crosses into libs3g.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Tuple
+
+import torch
+
+from . import _lib
+
+NUM_CHANNELS = 3  # RAST/cuda_rasterizer/config.h:15
+
+
+def _require_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the MI355X rasterizer has no CPU fallback")
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    """contiguous float32 view/copy (reference: .contiguous().data<float>()); empty tensors stay empty."""
+    if t.numel() == 0:
+        return t
+    _require_gpu(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t) -> int:
+    return 0 if (t is None or t.numel() == 0) else t.data_ptr()
+
+
+class _Arena:
+    """Resize callback target: a torch uint8 tensor on the device (caching allocator), like resizeFunctional
+    (RAST/rasterize_points.cu:27-33)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.error = None
+
+        def _resize(_user, nbytes):
+            try:
+                self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+                return self.tensor.data_ptr() if nbytes else 0
+            except Exception as ex:  # must not propagate through the C frame
+                self.error = ex
+                return 0
+
+        self.cb = _lib.RESIZE_FN(_resize)
+
+
+def _inputs(P, D, M, W, H, bg, means3D, sh, colors, opacity, scales, scale_modifier, rotations, cov3D, view, proj,
+            tanx, tany, campos, prefiltered, debug) -> _lib.RasterInputs:
+    return _lib.RasterInputs(P, int(D), int(M), int(W), int(H), _ptr(bg), _ptr(means3D), _ptr(sh), _ptr(colors),
+                             _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D),
+                             _ptr(view), _ptr(proj), _ptr(campos), float(tanx), float(tany), int(bool(prefiltered)),
+                             int(bool(debug)))
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """-> (num_rendered, color[3,H,W], depth[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer)."""
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _require_gpu(means3D, "means3D")
+    L = _lib.lib()
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    geom, binning, img = _Arena(dev), _Arena(dev), _Arena(dev)
+    rendered = C.c_int(0)
+    if P != 0:
+        M = sh.size(1) if sh.numel() != 0 else 0
+        keep = [_f32(background, "bg"), _f32(means3D, "means3D"), _f32(sh, "sh"), _f32(colors, "colors_precomp"),
+                _f32(opacity, "opacities"), _f32(scales, "scales"), _f32(rotations, "rotations"),
+                _f32(cov3D_precomp, "cov3D_precomp"), _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"),
+                _f32(campos, "campos")]
+        bg_, m3_, sh_, col_, op_, sc_, rot_, cov_, view_, proj_, cam_ = keep
+        inp = _inputs(P, degree, M, W, H, bg_, m3_, sh_, col_, op_, sc_, scale_modifier, rot_, cov_, view_, proj_,
+                      tan_fovx, tan_fovy, cam_, prefiltered, debug)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            code = L.s3g_raster_forward(C.byref(inp), geom.cb, None, binning.cb, None, img.cb, None,
+                                        out_color.data_ptr(), out_depth.data_ptr(), radii.data_ptr(),
+                                        C.byref(rendered), stream)
+        for a in (geom, binning, img):
+            if a.error is not None:
+                raise a.error
+        _lib.check(code)
+    return rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor
+
+
+# float offsets (per Gaussian) inside the single zero-filled gradient slab of the backward
+def _grad_slab(P: int, M: int, dev) -> Tuple[torch.Tensor, dict]:
+    widths = [("rot", 4), ("conic", 4), ("means3D", 3), ("means2D", 3), ("colors", 3), ("scales", 3), ("cov3D", 6),
+              ("opacity", 1), ("depths", 1), ("sh", 3 * M)]
+    total = sum(w for _, w in widths) * P
+    slab = torch.zeros(max(total, 1), dtype=torch.float32, device=dev)  # one memset (reference: 10 torch::zeros)
+    views, off = {}, 0
+    for name, w in widths:
+        views[name] = slab[off:off + w * P]
+        off += w * P
+    return slab, views
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, sh, degree,
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
+           dL_dscales[P,3], dL_drotations[P,4])   (RAST/rasterize_points.cu:201)."""
+    L = _lib.lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    _, v = _grad_slab(P, M, dev)
+    if P != 0:
+        keep = [_f32(background, "bg"), _f32(means3D, "means3D"), _f32(sh, "sh"), _f32(colors, "colors_precomp"),
+                _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp"),
+                _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos"),
+                _f32(dL_dout_color, "dL_dout_color"), _f32(dL_dout_depth, "dL_dout_depth"), radii.contiguous()]
+        bg_, m3_, sh_, col_, sc_, rot_, cov_, view_, proj_, cam_, gcol_, gdep_, radii_ = keep
+        inp = _inputs(P, degree, M, W, H, bg_, m3_, sh_, col_, None, sc_, scale_modifier, rot_, cov_, view_, proj_,
+                      tan_fovx, tan_fovy, cam_, False, debug)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            code = L.s3g_raster_backward(C.byref(inp), int(R), radii_.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer),
+                                         _ptr(imageBuffer), gcol_.data_ptr(), gdep_.data_ptr(), v["means2D"].data_ptr(),
+                                         v["conic"].data_ptr(), v["opacity"].data_ptr(), v["colors"].data_ptr(),
+                                         v["depths"].data_ptr(), v["means3D"].data_ptr(), v["cov3D"].data_ptr(),
+                                         _ptr(v["sh"]), v["scales"].data_ptr(), v["rot"].data_ptr(), stream)
+        _lib.check(code)
+    return (v["means2D"].view(P, 3), v["colors"].view(P, NUM_CHANNELS), v["opacity"].view(P, 1), v["means3D"].view(P, 3),
+            v["cov3D"].view(P, 6), v["sh"].view(P, M, 3), v["scales"].view(P, 3), v["rot"].view(P, 4))
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """-> bool[P]  (RAST/rasterize_points.cu:204-223)."""
+    L = _lib.lib()
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        _require_gpu(means3D, "means3D")
+        m3, view, proj = _f32(means3D, "means3D"), _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix")
+        with torch.cuda.device(means3D.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            code = L.s3g_mark_visible(P, m3.data_ptr(), view.data_ptr(), proj.data_ptr(), present.data_ptr(), stream)
+        _lib.check(code)
+    return present

@@ -1,0 +1,118 @@
+"""Python surface of the rasterizer: same public names, fields, call signatures and error behaviour as
+RAST/diff_gaussian_rasterization/__init__.py:158-221 so that the reference's gaussian_renderer/__init__.py:18,44-57,
+127-135 imports and calls it unchanged.  The top-level package `diff_gaussian_rasterization` re-exports these.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple
+
+import torch
+from torch import nn
+
+from . import raster_C as _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """12 fields, keyword-constructed by the caller (gaussian_renderer/__init__.py:44-57)."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _snapshot(args):
+    """debug=True: keep a host copy of every argument so a failing call can be dumped (reference :17-19, :83-90)."""
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """autograd node; forward keeps the three private arenas alive for backward (reference :44-156)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        native_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                       rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                       rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        if rs.debug:
+            saved = _snapshot(native_args)
+            try:
+                out = _C.rasterize_gaussians(*native_args)
+            except Exception:
+                torch.save(saved, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+        else:
+            out = _C.rasterize_gaussians(*native_args)
+        num_rendered, color, depth, radii, geom, binning, img = out
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii, grad_out_depth):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), device=means3D.device)
+        if grad_out_depth is None:
+            grad_out_depth = torch.zeros((1, rs.image_height, rs.image_width), device=means3D.device)
+        native_args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                       rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_depth, sh,
+                       rs.sh_degree, rs.campos, geom, ctx.num_rendered, binning, img, rs.debug)
+        if rs.debug:
+            saved = _snapshot(native_args)
+            try:
+                grads = _C.rasterize_gaussians_backward(*native_args)
+            except Exception:
+                torch.save(saved, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
+        else:
+            grads = _C.rasterize_gaussians_backward(*native_args)
+        g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot = grads
+        # order of forward's inputs: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
+        return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rot, g_cov3D, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """bool[P]: Gaussians in front of the near cull plane (view z > 0.2)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])  # the reference's "not provided" sentinel: numel()==0 -> NULL at the C ABI
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)

@@ -1,0 +1,65 @@
+"""Shared scene builders / comparison helpers for the tests."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from s3gaussian_amd import synth
+
+
+def tiny_scene(P=300, W=48, H=40, seed=0, scale=0.15, sigma=0.4, spread=2.2, bg=(0.2, 0.5, 0.7), zmin=3.0, zmax=6.0):
+    """Small pinhole scene; camera at the origin looking along +z (OpenCV).  Returns CPU float32 tensors."""
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(P, 3, generator=g) * 2 - 1
+    xyz[:, 2] = zmin + (zmax - zmin) * torch.rand(P, generator=g)
+    xyz[:, :2] *= spread
+    scales = torch.exp(math.log(scale) + sigma * torch.randn(P, 3, generator=g))
+    q = torch.randn(P, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    op = torch.sigmoid(1.5 * torch.randn(P, 1, generator=g))
+    shs = torch.cat([torch.randn(P, 1, 3, generator=g), 0.3 * torch.randn(P, 15, 3, generator=g)], 1)
+    col = torch.rand(P, 3, generator=g)
+    fov = math.radians(60)
+    cam = synth.make_camera(np.eye(3), np.zeros(3), fov, 2 * math.atan(math.tan(fov / 2) * H / W), W, H)
+    return dict(means3D=xyz.contiguous(), scales=scales, rotations=q, opacities=op, shs=shs.contiguous(),
+                colors_precomp=col, cam=cam, bg=torch.tensor(bg, dtype=torch.float32))
+
+
+def cam_kwargs(s):
+    cam = s["cam"]
+    return dict(bg=s["bg"], viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"],
+                tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], image_height=cam["image_height"],
+                image_width=cam["image_width"])
+
+
+def to_np(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+def oracle_forward(oracle, s, mode="precomp", sh_degree=3, **over):
+    kw = to_np(cam_kwargs(s))
+    args = dict(means3D=s["means3D"].numpy(), opacities=s["opacities"].numpy(), scales=s["scales"].numpy(),
+                rotations=s["rotations"].numpy())
+    if mode == "precomp":
+        args.update(colors_precomp=s["colors_precomp"].numpy(), sh_degree=0)
+    else:
+        args.update(shs=s["shs"].numpy(), sh_degree=sh_degree)
+    args.update(over)
+    return oracle.forward(**kw, **args)
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def settings_from(s, device, sh_degree=0, debug=False):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    cam = s["cam"]
+    return GaussianRasterizationSettings(
+        image_height=cam["image_height"], image_width=cam["image_width"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+        bg=s["bg"].to(device), scale_modifier=1.0, viewmatrix=cam["viewmatrix"].to(device),
+        projmatrix=cam["projmatrix"].to(device), sh_degree=sh_degree, campos=cam["campos"].to(device),
+        prefiltered=False, debug=debug)
