@@ -74,12 +74,18 @@ int s3g_raster_forward(const s3g_raster_inputs* in,
                        int* num_rendered, void* stream /* hipStream_t */);
 
 /* Backward.  `R` is the num_rendered returned by the matching forward; radii / arenas are the ones it filled.
- * dL_dpix [3,H,W], dL_dpix_depth [1,H,W].  All dL_d* outputs are device arrays that the CALLER HAS ZEROED
- * (rasterize_points.cu:154-163): dL_dmean2D [P,3], dL_dconic [P,2,2], dL_dopacity [P], dL_dcolor [P,3],
- * dL_ddepth [P], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3] (may be NULL when M==0), dL_dscale [P,3],
- * dL_drot [P,4]. */
+ * `workspace`: device scratch of s3g_raster_backward_workspace_bytes(P, R) bytes (per-instance gradient records;
+ * contents need no initialisation and are dead after the call).
+ * dL_dpix [3,H,W], dL_dpix_depth [1,H,W].  Outputs (device): dL_dmean2D [P,3], dL_dopacity [P], dL_dcolor [P,3],
+ * dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3] (may be NULL when M==0), dL_dscale [P,3], dL_drot [P,4]
+ * (16-byte aligned); dL_dconic [P,2,2] (16-byte aligned) and dL_ddepth [P] are the reference's internal
+ * intermediates and MAY BE NULL.  Unlike the reference (which accumulates with atomics into caller-zeroed arrays,
+ * rasterize_points.cu:154-163) every element of every output is WRITTEN (zeros for culled Gaussians), so the
+ * caller does not have to clear them, and the result is bit-reproducible run to run (no atomics). */
+size_t s3g_raster_backward_workspace_bytes(int P, int R);
 int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int* radii,
                         const void* geometry_arena, const void* binning_arena, const void* image_arena,
+                        void* workspace,
                         const float* dL_dpix, const float* dL_dpix_depth,
                         float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                         float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,

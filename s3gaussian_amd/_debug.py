@@ -25,7 +25,7 @@ def decode_geometry(buf: torch.Tensor, P: int) -> dict:
     return dict(depths=c.take(P, torch.float32), means2D=c.take(2 * P, torch.float32).view(P, 2),
                 conic_opacity=c.take(4 * P, torch.float32).view(P, 4), cov3D=c.take(6 * P, torch.float32).view(P, 6),
                 rgb=c.take(3 * P, torch.float32).view(P, 3), clamped=c.take(3 * P, torch.uint8).view(P, 3),
-                rect=c.take(4 * P, torch.int16).view(P, 4))
+                rect=c.take(4 * P, torch.int16).view(P, 4), gauss_off=c.take(P, torch.int32))
 
 
 def decode_image(buf: torch.Tensor, W: int, H: int) -> dict:
@@ -33,9 +33,9 @@ def decode_image(buf: torch.Tensor, W: int, H: int) -> dict:
     c = _Carver(buf)
     return dict(final_T=c.take(W * H, torch.float32).view(H, W), n_contrib=c.take(W * H, torch.int32).view(H, W),
                 ranges=c.take(2 * tiles, torch.int32).view(tiles, 2), tile_count=c.take(tiles, torch.int32),
-                ctrl=c.take(8, torch.int32))
+                tile_hi=c.take(tiles, torch.int32), ctrl=c.take(8, torch.int32))
 
 
 def decode_binning(buf: torch.Tensor, R: int) -> dict:
     c = _Carver(buf)
-    return dict(keys=c.take(R, torch.int64), point_list=c.take(R, torch.int32))
+    return dict(keys=c.take(R, torch.int64), point_list=c.take(R, torch.int32), slot_pos=c.take(R, torch.int32))

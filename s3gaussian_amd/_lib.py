@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libs3g.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -58,7 +58,9 @@ def lib() -> C.CDLL:
     L.s3g_raster_forward.argtypes = [C.POINTER(RasterInputs), RESIZE_FN, vp, RESIZE_FN, vp, RESIZE_FN, vp, vp, vp, vp,
                                      C.POINTER(C.c_int), vp]
     L.s3g_raster_backward.restype = C.c_int
-    L.s3g_raster_backward.argtypes = [C.POINTER(RasterInputs), C.c_int] + [vp] * 17
+    L.s3g_raster_backward.argtypes = [C.POINTER(RasterInputs), C.c_int] + [vp] * 18
+    L.s3g_raster_backward_workspace_bytes.restype = C.c_size_t
+    L.s3g_raster_backward_workspace_bytes.argtypes = [C.c_int, C.c_int]
     L.s3g_mark_visible.restype = C.c_int
     L.s3g_mark_visible.argtypes = [C.c_int, vp, vp, vp, vp, vp]
     _lib = L
@@ -73,4 +75,4 @@ def check(code: int) -> None:
         raise RuntimeError(f"libs3g error {code}: {msg}")
 
 
-EXPORTED_SYMBOLS = ["s3g_raster_forward", "s3g_raster_backward", "s3g_mark_visible", "s3g_last_error", "s3g_abi_version"]
+EXPORTED_SYMBOLS = ["s3g_raster_forward", "s3g_raster_backward", "s3g_raster_backward_workspace_bytes", "s3g_mark_visible", "s3g_last_error", "s3g_abi_version"]

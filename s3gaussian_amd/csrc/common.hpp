@@ -13,6 +13,20 @@ constexpr int TILE_X = 16;  // reference BLOCK_X/BLOCK_Y, RAST/cuda_rasterizer/c
 constexpr int TILE_Y = 16;
 constexpr int TILE_PIX = TILE_X * TILE_Y;
 constexpr int WAVE = 64;
+constexpr int MAX_BIN_BLOCKS = 512;   // binning workgroups (2 per CU); each keeps a histogram of ALL tiles in LDS
+constexpr int MAX_TILES_LDS = 38000;  // (160 KiB - slack) / 4 B: largest tile grid the single-pass multisplit handles
+constexpr int NREC = 10;              // floats per instance gradient record written by the blend backward
+
+// number of binning workgroups / Gaussians per workgroup for a scene of P Gaussians
+inline int bin_blocks(int P) {
+  int nb = (P + 255) / 256;
+  return nb < 1 ? 1 : (nb > MAX_BIN_BLOCKS ? MAX_BIN_BLOCKS : nb);
+}
+inline int bin_chunk(int P) {
+  const int nb = bin_blocks(P);
+  const int per = (P + nb - 1) / nb;
+  return ((per + 255) / 256) * 256;
+}
 
 // ---- error plumbing ------------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
@@ -55,6 +69,7 @@ struct GeomState {
   float* rgb;             // [P,3] SH->RGB result (only when shs given)
   uint8_t* clamped;       // [P,3]
   ushort4* rect;          // [P]   tile rect (min.x, min.y, max.x, max.y), zero area when culled
+  uint32_t* gauss_off;    // [P]   exclusive scan of tiles_touched: first slot of the Gaussian in slot_pos[]
   static GeomState carve(void* p, size_t P, size_t* bytes) {
     Carver c(p);
     GeomState g;
@@ -65,6 +80,7 @@ struct GeomState {
     g.rgb = c.take<float>(P * 3);
     g.clamped = c.take<uint8_t>(P * 3);
     g.rect = c.take<ushort4>(P);
+    g.gauss_off = c.take<uint32_t>(P);
     if (bytes) *bytes = c.bytes();
     return g;
   }
@@ -75,16 +91,22 @@ struct ImageState {
   float* final_T;        // [H*W]
   uint32_t* n_contrib;   // [H*W]
   uint2* ranges;         // [tiles]  [start,end) into the sorted instance list
-  uint32_t* tile_count;  // [tiles]  instances per tile (histogram, then reused as scatter cursor)
+  uint32_t* tile_count;  // [tiles]  instances per tile
+  uint32_t* tile_hi;     // [tiles]  ranges[t].x + deepest contributing list position (1-based) over the tile's pixels
   uint32_t* ctrl;        // [8]      ctrl[0]=R (total instances), ctrl[1]=max instances in one tile, ctrl[2]=error flags
-  static ImageState carve(void* p, size_t N, size_t tiles, size_t* bytes) {
+  uint32_t* chunk_total; // [MAX_BIN_BLOCKS] instances emitted per binning workgroup (then its exclusive prefix)
+  uint32_t* table;       // [nb][tiles] per-workgroup, per-tile instance counts (then exclusive prefix over workgroups)
+  static ImageState carve(void* p, size_t N, size_t tiles, size_t nb, size_t* bytes) {
     Carver c(p);
     ImageState s;
     s.final_T = c.take<float>(N);
     s.n_contrib = c.take<uint32_t>(N);
     s.ranges = c.take<uint2>(tiles);
     s.tile_count = c.take<uint32_t>(tiles);
+    s.tile_hi = c.take<uint32_t>(tiles);
     s.ctrl = c.take<uint32_t>(8);
+    s.chunk_total = c.take<uint32_t>(MAX_BIN_BLOCKS);
+    s.table = c.take<uint32_t>(nb * tiles);
     if (bytes) *bytes = c.bytes();
     return s;
   }
@@ -94,11 +116,13 @@ struct ImageState {
 struct BinningState {
   uint64_t* keys;        // [R]  (depth bits << 32 | gaussian index), sorted ascending inside each tile range
   uint32_t* point_list;  // [R]  gaussian index, tile-major, front-to-back
+  uint32_t* slot_pos;    // [R]  slot_pos[gauss_off[g] + k] = position in point_list of g's k-th tile (row-major in its rect)
   static BinningState carve(void* p, size_t R, size_t* bytes) {
     Carver c(p);
     BinningState b;
     b.keys = c.take<uint64_t>(R);
     b.point_list = c.take<uint32_t>(R);
+    b.slot_pos = c.take<uint32_t>(R);
     if (bytes) *bytes = c.bytes();
     return b;
   }

@@ -5,15 +5,18 @@
 //   geometry_backward_kernel   <- computeCov2DCUDA + preprocessCUDA   (backward.cu:144-274, 346-412) fused into one pass
 //
 // The reference issues 10 global float atomicAdd per contributing (pixel, Gaussian) pair (backward.cu:550-587).
-// Here a pair costs no memory traffic at all:
+// Device-scope atomics execute memory-side on MI355X (a few G/s), so this backward has NO global atomics at all and
+// is bit-reproducible run to run:
 //   1. the six geometry sums are re-associated so that everything depending only on the Gaussian (conic, opacity,
 //      0.5*W) is factored out of the pixel sum: with v = dL/dalpha * G the kernel accumulates
 //      S0=sum v, Sx=sum v*dx, Sy=sum v*dy, Sxx=sum v*dx*dx, Sxy=sum v*dx*dy, Syy=sum v*dy*dy (+3 colour, +1 depth);
 //   2. each of the 10 sums is reduced across the 64 lanes of a wave with DPP row-shift/broadcast adds (no LDS, no
 //      shuffles through memory), skipped outright when no lane of the wave is touched by the Gaussian;
 //   3. the 4 waves of the tile combine in an LDS accumulator (ds_add_f32 from one lane);
-//   4. once per 256-Gaussian batch each lane owns one Gaussian and applies the factored-out coefficients, then
-//      issues its 10 global atomics -- i.e. 10 atomics per (tile, Gaussian) instance instead of per pixel pair.
+//   4. once per 256-Gaussian batch each lane owns one Gaussian and stores its 10 sums as one 40-byte record at the
+//      instance's position in the sorted list (coalesced: consecutive lanes -> consecutive records);
+//   5. geometry_backward_kernel gathers each Gaussian's records through slot_pos[] (the instance -> position map
+//      the forward's sort emitted), applies the factored-out coefficients and runs the per-Gaussian chain.
 #include "geom_math.hpp"
 
 namespace s3g {
@@ -34,31 +37,29 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
-constexpr int NSUM = 10;  // dcolor r,g,b | ddepth | S0 | Sx | Sy | Sxx | Sxy | Syy
+// record layout (NREC floats): dcolor r,g,b | ddepth | S0 | Sx | Sy | Sxx | Sxy | Syy
 
 __global__ void __launch_bounds__(256)
 blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ ranges,
-                      const uint32_t* __restrict__ point_list, const float* __restrict__ bg,
-                      const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity,
-                      const float* __restrict__ colors, const float* __restrict__ depths,
-                      const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib,
-                      const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixel_depths,
-                      float* __restrict__ dL_dmean2D /*[P,3]*/, float* __restrict__ dL_dconic /*[P,4]*/,
-                      float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_ddepths) {
+                      const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ point_list,
+                      const float* __restrict__ bg, const float2* __restrict__ means2D,
+                      const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
+                      const float* __restrict__ depths, const float* __restrict__ final_Ts,
+                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+                      const float* __restrict__ dL_dpixel_depths, float* __restrict__ records /*[R][NREC]*/) {
   __shared__ StagedGaussian sg[256];
-  __shared__ float acc[NSUM][256];
-  __shared__ uint32_t sid[256];
-  __shared__ uint32_t touched[256];
-  __shared__ uint32_t wave_last[4];
+  __shared__ float acc[NREC][256];
 
   const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= (uint32_t)tiles) return;
+  const uint2 rg = ranges[tile];
+  const uint32_t hi = tile_hi[tile] - rg.x;  // deepest contributor of the tile (1-based); nothing behind it gets gradient
+  if (hi == 0) return;
   const int tx = tile % gx, ty = tile / gx;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int px = tx * TILE_X + (tid & 15), py = ty * TILE_Y + (tid >> 4);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
-  const uint2 rg = ranges[tile];
   const size_t pix = (size_t)py * W + px, N = (size_t)H * W;
 
   const float T_final = inside ? final_Ts[pix] : 0.f;
@@ -72,20 +73,13 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
   }
   const float bg_dot = bg[0] * gr + bg[1] * gg + bg[2] * gb;
 
-  // Nothing behind the deepest contributor of the tile can receive gradient: start there instead of at range end.
-  uint32_t m = last_contributor;
-  for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-  if (lane == 0) wave_last[wave] = m;
-  __syncthreads();
-  const uint32_t hi = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));  // 1-based count
-
   float T = T_final;
-  float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;          // accum_rec (colour, depth)
+  float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;  // accum_rec (colour, depth)
   float last_alpha = 0.f, lr = 0.f, lg = 0.f, lb = 0.f, ld = 0.f;
 
   for (uint32_t done_cnt = 0; done_cnt < hi; done_cnt += 256) {
     const uint32_t cnt = min(256u, hi - done_cnt);
-    __syncthreads();  // previous batch fully consumed (sg, acc, sid, touched)
+    __syncthreads();  // previous batch fully consumed (sg, acc)
     if ((uint32_t)tid < cnt) {
       const uint32_t pos = hi - 1 - (done_cnt + tid);  // back to front
       const uint32_t id = point_list[rg.x + pos];
@@ -94,18 +88,16 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
       StagedGaussian s;
       s.a = make_float4(mm.x, mm.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
       s.b = make_float4(-0.5f * LOG2E * co.z, co.w, depths[id], colors[3 * (size_t)id]);
-      s.c = make_float4(colors[3 * (size_t)id + 1], colors[3 * (size_t)id + 2], co.x, co.y);
+      s.c = make_float4(colors[3 * (size_t)id + 1], colors[3 * (size_t)id + 2], 0.f, 0.f);
       sg[tid] = s;
-      sid[tid] = id;
-      touched[tid] = 0u;
 #pragma unroll
-      for (int k = 0; k < NSUM; k++) acc[k][tid] = 0.f;
+      for (int k = 0; k < NREC; k++) acc[k][tid] = 0.f;
     }
     __syncthreads();
 
     for (uint32_t j = 0; j < cnt; j++) {
       const uint32_t pos = hi - 1 - (done_cnt + j);  // 0-based position in the tile list
-      // contributor index in the reference is pos (after its decrement); it skips when contributor >= last_contributor
+      // the reference's `contributor` equals pos after its decrement; it skips when contributor >= last_contributor
       bool valid = pos < last_contributor;
       const float4 A = sg[j].a;
       const float4 B = sg[j].b;
@@ -146,28 +138,15 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
         atomicAdd(&acc[0][j], p_r); atomicAdd(&acc[1][j], p_g); atomicAdd(&acc[2][j], p_b); atomicAdd(&acc[3][j], p_d);
         atomicAdd(&acc[4][j], s0); atomicAdd(&acc[5][j], sx); atomicAdd(&acc[6][j], sy);
         atomicAdd(&acc[7][j], sxx); atomicAdd(&acc[8][j], sxy); atomicAdd(&acc[9][j], syy);
-        touched[j] = 1u;
       }
     }
     __syncthreads();
-    // Epilogue of the batch: lane t owns Gaussian t of the batch.
-    if ((uint32_t)tid < cnt && touched[tid]) {
-      const uint32_t id = sid[tid];
-      const float4 co = conic_opacity[id];              // exact (un-scaled) conic + opacity, L2 resident
-      const float ca = co.x, cb = co.y, cc = co.z, o = co.w;
-      const float S0 = acc[4][tid], Sx = acc[5][tid], Sy = acc[6][tid], Sxx = acc[7][tid], Sxy = acc[8][tid],
-                  Syy = acc[9][tid];
-      atomicAdd(&dL_dcolors[3 * (size_t)id + 0], acc[0][tid]);
-      atomicAdd(&dL_dcolors[3 * (size_t)id + 1], acc[1][tid]);
-      atomicAdd(&dL_dcolors[3 * (size_t)id + 2], acc[2][tid]);
-      atomicAdd(&dL_ddepths[id], acc[3][tid]);
-      atomicAdd(&dL_dopacity[id], S0);
-      // dL_dG = o * dL_dalpha ; dG_ddelx = -G*dx*conic.x - G*dy*conic.y ; times 0.5*W (backward.cu:571-579)
-      atomicAdd(&dL_dmean2D[3 * (size_t)id + 0], (0.5f * W) * o * (-(ca * Sx) - cb * Sy));
-      atomicAdd(&dL_dmean2D[3 * (size_t)id + 1], (0.5f * H) * o * (-(cc * Sy) - cb * Sx));
-      atomicAdd(&dL_dconic[4 * (size_t)id + 0], -0.5f * o * Sxx);
-      atomicAdd(&dL_dconic[4 * (size_t)id + 1], -0.5f * o * Sxy);
-      atomicAdd(&dL_dconic[4 * (size_t)id + 3], -0.5f * o * Syy);
+    // Epilogue of the batch: lane t owns Gaussian t of the batch and stores its record (zeros if untouched).
+    if ((uint32_t)tid < cnt) {
+      const uint32_t pos = hi - 1 - (done_cnt + tid);
+      float2* rec = reinterpret_cast<float2*>(records + (size_t)(rg.x + pos) * NREC);
+#pragma unroll
+      for (int k = 0; k < NREC / 2; k++) rec[k] = make_float2(acc[2 * k][tid], acc[2 * k + 1][tid]);
     }
   }
 }
@@ -190,10 +169,20 @@ struct GeomBwdArgs {
   const float* proj;
   const float* campos;
   float fx, fy, tan_fovx, tan_fovy;
-  const float* dL_dmean2D;  // [P,3]
-  const float* dL_dconic;   // [P,4]
-  const float* dL_dcolor;   // [P,3]
-  const float* dL_ddepth;   // [P]
+  int W, H, gx;
+  // gather side
+  const ushort4* rect;
+  const uint32_t* gauss_off;
+  const uint32_t* slot_pos;
+  const uint32_t* tile_hi;        // absolute end of the written records of each tile
+  const float* records;           // [R][NREC]
+  const float4* conic_opacity;
+  // outputs (every element of every output is written, zeros for culled Gaussians)
+  float* dL_dmean2D;        // [P,3]
+  float* dL_dconic;         // [P,4]  optional (may be NULL)
+  float* dL_dopacity;       // [P]
+  float* dL_dcolor;         // [P,3]
+  float* dL_ddepth;         // [P]    optional (may be NULL)
   float* dL_dmean3D;        // [P,3]
   float* dL_dcov3D;         // [P,6]
   float* dL_dsh;            // [P,M,3]
@@ -201,9 +190,90 @@ struct GeomBwdArgs {
   float* dL_drot;           // [P,4]
 };
 
+// Sum the records of the tiles k = k0, k0+stride, ... of one Gaussian's rect (row-major inside the rect).
+__device__ __forceinline__ void gather_records(const GeomBwdArgs& a, const ushort4 r, uint32_t o, int k0, int stride,
+                                               float* acc) {
+  const int w = (int)r.z - (int)r.x, n = w * ((int)r.w - (int)r.y);
+  for (int k = k0; k < n; k += stride) {
+    const int ty = (int)r.y + k / w, tx = (int)r.x + k % w;
+    const int t = ty * a.gx + tx;
+    const uint32_t pos = a.slot_pos[o + k];
+    if (pos < a.tile_hi[t]) {  // tile_hi = absolute end of the positions the blend backward wrote
+      const float2* rec = reinterpret_cast<const float2*>(a.records + (size_t)pos * NREC);
+#pragma unroll
+      for (int q = 0; q < NREC / 2; q++) {
+        const float2 v = rec[q];
+        acc[2 * q] += v.x;
+        acc[2 * q + 1] += v.y;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArgs a) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.P || !(a.radii[idx] > 0)) return;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const bool live = gid < a.P;
+  const int idx = live ? gid : a.P - 1;  // keep every lane alive for the wave-cooperative gather below
+  const size_t i3 = 3 * (size_t)idx;
+  const bool vis = live && a.radii[idx] > 0;
+
+  // ---- gather the per-instance records of this Gaussian (one per tile of its rect) ----
+  float acc[NREC];
+#pragma unroll
+  for (int k = 0; k < NREC; k++) acc[k] = 0.f;
+  const ushort4 r = vis ? a.rect[idx] : make_ushort4(0, 0, 0, 0);
+  const uint32_t o = vis ? a.gauss_off[idx] : 0u;
+  const int n = ((int)r.z - (int)r.x) * ((int)r.w - (int)r.y);
+  constexpr int BIG = 24;
+  if (n > 0 && n <= BIG) gather_records(a, r, o, 0, 1, acc);
+  uint64_t big = __ballot(n > BIG);
+  const int lane = threadIdx.x & 63;
+  while (big) {  // wave-uniform: all 64 lanes gather one large rect together, then reduce with DPP
+    const int src = __ffsll((unsigned long long)big) - 1;
+    big &= big - 1;
+    ushort4 br;
+    br.x = (unsigned short)__shfl((int)r.x, src); br.y = (unsigned short)__shfl((int)r.y, src);
+    br.z = (unsigned short)__shfl((int)r.z, src); br.w = (unsigned short)__shfl((int)r.w, src);
+    const uint32_t bo = (uint32_t)__shfl((int)o, src);
+    float part[NREC];
+#pragma unroll
+    for (int k = 0; k < NREC; k++) part[k] = 0.f;
+    gather_records(a, br, bo, lane, 64, part);
+#pragma unroll
+    for (int k = 0; k < NREC; k++) {
+      const float tot = __shfl(wave_sum_lane63(part[k]), 63);
+      if (lane == src) acc[k] = tot;
+    }
+  }
+  if (!live) return;
+  if (!vis) {  // culled: the reference leaves its zero-initialised outputs untouched
+    a.dL_dmean2D[i3] = a.dL_dmean2D[i3 + 1] = a.dL_dmean2D[i3 + 2] = 0.f;
+    a.dL_dcolor[i3] = a.dL_dcolor[i3 + 1] = a.dL_dcolor[i3 + 2] = 0.f;
+    a.dL_dmean3D[i3] = a.dL_dmean3D[i3 + 1] = a.dL_dmean3D[i3 + 2] = 0.f;
+    a.dL_dscale[i3] = a.dL_dscale[i3 + 1] = a.dL_dscale[i3 + 2] = 0.f;
+    a.dL_dopacity[idx] = 0.f;
+    reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = 0.f;
+    if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.dL_ddepth) a.dL_ddepth[idx] = 0.f;
+    if (a.shs != nullptr)
+      for (int k = 0; k < a.M * 3; k++) a.dL_dsh[(size_t)idx * a.M * 3 + k] = 0.f;
+    return;
+  }
+  const float4 co = a.conic_opacity[idx];
+  const float S0 = acc[4], Sx = acc[5], Sy = acc[6], Sxx = acc[7], Sxy = acc[8], Syy = acc[9];
+  // dL_dG = o * dL_dalpha ; dG_ddelx = -G*dx*conic.x - G*dy*conic.y ; times 0.5*W (backward.cu:571-584)
+  const float g2x = (0.5f * a.W) * co.w * (-(co.x * Sx) - co.y * Sy);
+  const float g2y = (0.5f * a.H) * co.w * (-(co.z * Sy) - co.y * Sx);
+  const float dcx = -0.5f * co.w * Sxx, dcy = -0.5f * co.w * Sxy, dcz = -0.5f * co.w * Syy;
+  const float gdep = acc[3];
+  a.dL_dmean2D[i3] = g2x; a.dL_dmean2D[i3 + 1] = g2y; a.dL_dmean2D[i3 + 2] = 0.f;
+  a.dL_dcolor[i3] = acc[0]; a.dL_dcolor[i3 + 1] = acc[1]; a.dL_dcolor[i3 + 2] = acc[2];
+  a.dL_dopacity[idx] = S0;
+  if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(dcx, dcy, 0.f, dcz);
+  if (a.dL_ddepth) a.dL_ddepth[idx] = gdep;
+
   const float3 mean = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
   const float* V = a.view;
   const float* proj = a.proj;
@@ -215,8 +285,6 @@ __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArg
   const Cov2DCtx c = cov2d_common(mean, a.fx, a.fy, a.tan_fovx, a.tan_fovy, cov3D, V);
   const float x_grad_mul = (c.txtz < -c.limx || c.txtz > c.limx) ? 0.f : 1.f;
   const float y_grad_mul = (c.tytz < -c.limy || c.tytz > c.limy) ? 0.f : 1.f;
-  const float dcx = a.dL_dconic[4 * (size_t)idx], dcy = a.dL_dconic[4 * (size_t)idx + 1],
-              dcz = a.dL_dconic[4 * (size_t)idx + 3];
   const float ca = c.cov.m[0][0] + 0.3f, cb = c.cov.m[0][1], cc = c.cov.m[1][1] + 0.3f;
   const float denom = ca * cc - cb * cb;
   float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
@@ -268,12 +336,10 @@ __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArg
   const float m_w = 1.0f / (m_hom.w + 0.0000001f);
   const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
   const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-  const float g2x = a.dL_dmean2D[3 * (size_t)idx], g2y = a.dL_dmean2D[3 * (size_t)idx + 1];
   dmx += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
   dmy += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
   dmz += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
   const float mul3 = V[2] * mean.x + V[6] * mean.y + V[10] * mean.z + V[14];
-  const float gdep = a.dL_ddepth[idx];
   dmx += (V[2] - V[3] * mul3) * gdep;
   dmy += (V[6] - V[7] * mul3) * gdep;
   dmz += (V[10] - V[11] * mul3) * gdep;
@@ -288,7 +354,8 @@ __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArg
     float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
     float dRGB[3], dRdx[3] = {0.f, 0.f, 0.f}, dRdy[3] = {0.f, 0.f, 0.f}, dRdz[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) dRGB[ch] = a.dL_dcolor[3 * (size_t)idx + ch] * (a.clamped[3 * (size_t)idx + ch] ? 0.f : 1.f);
+    for (int ch = 0; ch < 3; ch++) dRGB[ch] = acc[ch] * (a.clamped[3 * (size_t)idx + ch] ? 0.f : 1.f);
+    for (int k = (deg + 1) * (deg + 1) * 3; k < a.M * 3; k++) dsh[k] = 0.f;  // coefficients above the active degree
 #define SH(k) sh[(k)*3 + ch]
 #define DSH(k, v) dsh[(k)*3 + ch] = (v)*dRGB[ch]
 #pragma unroll
@@ -370,6 +437,9 @@ __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArg
     dq.w = 2 * r * (Dm(0, 1) - Dm(1, 0)) + 2 * x * (Dm(2, 0) + Dm(0, 2)) + 2 * y * (Dm(1, 2) + Dm(2, 1)) - 4 * z * (Dm(1, 1) + Dm(0, 0));
 #undef Dm
     reinterpret_cast<float4*>(a.dL_drot)[idx] = dq;
+  } else {
+    a.dL_dscale[i3] = a.dL_dscale[i3 + 1] = a.dL_dscale[i3 + 2] = 0.f;
+    reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -377,11 +447,16 @@ __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArg
 
 using namespace s3g;
 
+extern "C" size_t s3g_raster_backward_workspace_bytes(int P, int R) {
+  (void)P;
+  return ((size_t)(R > 0 ? R : 0) * NREC * sizeof(float) + 127) & ~size_t(127);
+}
+
 extern "C" int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int* radii, const void* geometry_arena,
-                                   const void* binning_arena, const void* image_arena, const float* dL_dpix,
-                                   const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                   float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                                   float* dL_dscale, float* dL_drot, void* stream_) {
+                                   const void* binning_arena, const void* image_arena, void* workspace,
+                                   const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
+                                   float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+                                   float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!in) {
     set_error("s3g_raster_backward: NULL inputs");
@@ -389,24 +464,25 @@ extern "C" int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int
   }
   const int P = in->P, W = in->width, H = in->height;
   if (P == 0) return S3G_OK;
-  if (!radii || !geometry_arena || !image_arena || (R > 0 && !binning_arena) || !dL_dpix || !dL_dpix_depth ||
-      !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_ddepth || !dL_dmean3D || !dL_dcov3D ||
-      !dL_dscale || !dL_drot || (in->shs && !dL_dsh)) {
+  if (!radii || !geometry_arena || !image_arena || (R > 0 && (!binning_arena || !workspace)) || !dL_dpix ||
+      !dL_dpix_depth || !dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale ||
+      !dL_drot || (in->shs && !dL_dsh)) {
     set_error("s3g_raster_backward: NULL array argument");
     return S3G_ERR_INVALID_ARG;
   }
   const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y, tiles = gx * gy;
   const bool debug = in->debug != 0;
   GeomState g = GeomState::carve(const_cast<void*>(geometry_arena), P, nullptr);
-  ImageState im = ImageState::carve(const_cast<void*>(image_arena), (size_t)W * H, tiles, nullptr);
+  ImageState im = ImageState::carve(const_cast<void*>(image_arena), (size_t)W * H, tiles, bin_blocks(P), nullptr);
   BinningState b = BinningState::carve(const_cast<void*>(binning_arena), (size_t)(R > 0 ? R : 0), nullptr);
+  float* records = reinterpret_cast<float*>(workspace);
 
   const float* color_ptr = in->colors_precomp ? in->colors_precomp : g.rgb;
   if (R > 0) {
     const uint32_t tile_blocks = ((uint32_t)tiles + 7u) & ~7u;
     hipLaunchKernelGGL(blend_backward_kernel, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
-                       b.point_list, in->background, g.means2D, g.conic_opacity, color_ptr, g.depths, im.final_T,
-                       im.n_contrib, dL_dpix, dL_dpix_depth, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth);
+                       im.tile_hi, b.point_list, in->background, g.means2D, g.conic_opacity, color_ptr, g.depths,
+                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, records);
     S3G_KERNEL_CHECK(stream, debug);
   }
   GeomBwdArgs ga;
@@ -416,7 +492,11 @@ extern "C" int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int
   ga.view = in->viewmatrix; ga.proj = in->projmatrix; ga.campos = in->cam_pos;
   ga.fy = H / (2.0f * in->tan_fovy); ga.fx = W / (2.0f * in->tan_fovx);
   ga.tan_fovx = in->tan_fovx; ga.tan_fovy = in->tan_fovy;
-  ga.dL_dmean2D = dL_dmean2D; ga.dL_dconic = dL_dconic; ga.dL_dcolor = dL_dcolor; ga.dL_ddepth = dL_ddepth;
+  ga.W = W; ga.H = H; ga.gx = gx;
+  ga.rect = g.rect; ga.gauss_off = g.gauss_off; ga.slot_pos = b.slot_pos; ga.tile_hi = im.tile_hi;
+  ga.records = records; ga.conic_opacity = g.conic_opacity;
+  ga.dL_dmean2D = dL_dmean2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolor = dL_dcolor;
+  ga.dL_ddepth = dL_ddepth;
   ga.dL_dmean3D = dL_dmean3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dsh = dL_dsh; ga.dL_dscale = dL_dscale; ga.dL_drot = dL_drot;
   hipLaunchKernelGGL(geometry_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, ga);
   S3G_KERNEL_CHECK(stream, debug);

@@ -7,11 +7,14 @@
 //   -------------------------------------------------  ------------------------------------------------------
 //   preprocessCUDA  (forward.cu:155-256)               preprocess_kernel: same per-Gaussian math (bit-exact fp32,
 //                                                      contraction off) + per-tile instance histogram
-//   InclusiveSum over P + duplicateWithKeys + global   scan over TILES (6.7k, not 1.2M) -> tile ranges directly;
-//   64-bit radix sort of all R instances + range scan   scatter into per-tile buckets; per-tile bitonic sort of
-//   (rasterizer_impl.cu:278-319)                        (depth bits, index) keys staged in LDS.  Resulting order is
-//                                                      identical to the stable (tile, depth) radix sort: ties in
-//                                                      depth resolve by ascending Gaussian index.
+//   InclusiveSum over P + duplicateWithKeys + global   ATOMIC-FREE single-pass multisplit: device-scope atomics on
+//   64-bit radix sort of all R instances + range scan   MI355X execute memory-side (~2-6 G/s measured), so instances are
+//   (rasterizer_impl.cu:278-319)                        binned with per-workgroup histograms of ALL tiles held in LDS
+//                                                      (27 KB for 6.7k tiles; 160 KB LDS allows ~38k tiles), a
+//                                                      [workgroup][tile] offset table and LDS cursors; then a per-tile
+//                                                      bitonic sort of (depth bits, index) keys staged in LDS.  Final
+//                                                      order == the reference's stable (tile, depth) radix sort: ties
+//                                                      in depth resolve by ascending Gaussian index.
 //   renderCUDA (forward.cu:261-379)                    blend_forward_kernel: 16x16 tile = 4 wave64, Gaussian
 //                                                      attributes (incl. colour+depth) staged in LDS, conic
 //                                                      pre-scaled so alpha = o * exp2(q) is one v_exp_f32
@@ -85,7 +88,6 @@ struct PreprocessArgs {
   int prefiltered;
   int* radii;
   GeomState g;
-  uint32_t* tile_count;
   uint32_t* ctrl;
 };
 
@@ -149,46 +151,170 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreprocessArgs a)
   a.g.means2D[idx] = make_float2(px, py);
   a.g.conic_opacity[idx] = make_float4(conic.x, conic.y, conic.z, a.opacities[idx]);
   a.g.rect[idx] = make_ushort4((unsigned short)rx0, (unsigned short)ry0, (unsigned short)rx1, (unsigned short)ry1);
-  // per-tile instance histogram (fire-and-forget L2 atomics)
-  for (int y = ry0; y < ry1; y++)
-    for (int x = rx0; x < rx1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
 }
 
 // =========================================================================================================
-// 2. Exclusive scan over tiles: ranges[t] = [start, end), tile_count[t] <- start (becomes the scatter cursor),
-//    ctrl[0] = R, ctrl[1] = longest tile list.  One 1024-thread workgroup; tiles is O(10^3..10^4).
+// 2. Atomic-free binning ("multisplit" of the R instances into tiles*).
+//    bin_count : NB fat workgroups, each owns a contiguous chunk of Gaussians and histograms its instances over
+//                ALL tiles in LDS (ds_add_u32), then stores its row of table[NB][tiles] + its chunk total.
+//    bin_scan  : per tile, exclusive prefix over the NB workgroups (in place) and the tile total.
+//    scan_tiles: exclusive scan over tiles -> ranges, R, longest list; exclusive scan of chunk totals.
+//    bin_write : same walk as bin_count; LDS cursors start at ranges[t].x + table[wg][t]; every instance key is
+//                stored at a private slot.  Also emits gauss_off[g] = exclusive scan of tiles_touched (Gaussian order),
+//                the address of g's slots in the instance->position map used by the backward gather.
+//    Rects wider than BIG_RECT tiles are walked by the whole wave instead of one lane.
+//    (*) order inside a tile is arbitrary here; the per-tile sort fixes it.
 // =========================================================================================================
-__global__ void __launch_bounds__(1024) scan_tiles_kernel(int tiles, uint32_t* __restrict__ tile_count,
-                                                          uint2* __restrict__ ranges, uint32_t* __restrict__ ctrl) {
+constexpr int BIN_THREADS = 256;
+constexpr int BIG_RECT = 32;
+
+struct BinArgs {
+  int P, gx, tiles, chunk;         // chunk = Gaussians per workgroup (multiple of BIN_THREADS)
+  const ushort4* rect;
+  const float* depths;
+  uint32_t* table;                 // [NB][tiles]
+  uint32_t* chunk_total;           // [NB] instances emitted by each workgroup; after scan_tiles: exclusive prefix
+  const uint2* ranges;             // bin_write only
+  uint64_t* keys;                  // bin_write only
+  uint32_t* gauss_off;             // bin_write only
+};
+
+template <bool WRITE>
+__global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [tiles] histogram / cursors, then 8 words of scratch
+  uint32_t* cell = lds;
+  uint32_t* wsum = lds + a.tiles;  // [4] wave totals + [1] carry
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t* trow = a.table + (size_t)blockIdx.x * a.tiles;
+  for (int i = tid; i < a.tiles; i += BIN_THREADS) cell[i] = WRITE ? a.ranges[i].x + trow[i] : 0u;
+  uint32_t carry = WRITE ? a.chunk_total[blockIdx.x] : 0u;  // exclusive prefix of previous workgroups' instances
+  uint32_t my_total = 0;
+  __syncthreads();
+  const int g0 = blockIdx.x * a.chunk, g1 = min(a.P, g0 + a.chunk);
+  for (int base = g0; base < g1; base += BIN_THREADS) {
+    const int g = base + tid;
+    ushort4 r = make_ushort4(0, 0, 0, 0);
+    if (g < g1) r = a.rect[g];
+    const int w = (int)r.z - (int)r.x, h = (int)r.w - (int)r.y;
+    const uint32_t area = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
+    uint64_t key = 0;
+    if (WRITE) {
+      // block-wide exclusive scan of area -> gauss_off
+      uint32_t incl = area;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += t;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      uint32_t wbase = 0, tot = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t v = wsum[k];
+        if (k < wave) wbase += v;
+        tot += v;
+      }
+      if (g < g1) a.gauss_off[g] = carry + wbase + incl - area;
+      carry += tot;
+      __syncthreads();  // wsum reused next iteration
+      if (area) key = ((uint64_t)__float_as_uint(a.depths[g]) << 32) | (uint32_t)g;
+    } else {
+      my_total += area;
+    }
+    if (area != 0 && area <= BIG_RECT) {
+      for (int y = r.y; y < r.w; y++)
+        for (int x = r.x; x < r.z; x++) {
+          const uint32_t pos = atomicAdd(&cell[y * a.gx + x], 1u);
+          if (WRITE) a.keys[pos] = key;
+        }
+    }
+    uint64_t big = __ballot(area > BIG_RECT);
+    while (big) {  // wave-uniform loop: all 64 lanes walk one large rect together
+      const int src = __ffsll((unsigned long long)big) - 1;
+      big &= big - 1;
+      const int bx = __shfl((int)r.x, src), by = __shfl((int)r.y, src), bw = __shfl(w, src);
+      const uint32_t barea = (uint32_t)__shfl((int)area, src);
+      const uint32_t klo = (uint32_t)__shfl((int)(uint32_t)key, src), khi = (uint32_t)__shfl((int)(uint32_t)(key >> 32), src);
+      for (uint32_t k = lane; k < barea; k += 64) {
+        const int ty = by + (int)(k / (uint32_t)bw), tx = bx + (int)(k % (uint32_t)bw);
+        const uint32_t pos = atomicAdd(&cell[ty * a.gx + tx], 1u);
+        if (WRITE) a.keys[pos] = ((uint64_t)khi << 32) | klo;
+      }
+    }
+  }
+  if (!WRITE) {
+    __syncthreads();
+    uint32_t* row = a.table + (size_t)blockIdx.x * a.tiles;
+    for (int i = tid; i < a.tiles; i += BIN_THREADS) row[i] = cell[i];
+    for (int off = 32; off >= 1; off >>= 1) my_total += (uint32_t)__shfl_xor((int)my_total, off);
+    if (lane == 0) wsum[wave] = my_total;
+    __syncthreads();
+    if (tid == 0) a.chunk_total[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+}
+
+// One thread per tile: exclusive prefix over workgroups (coalesced across tiles), 8 independent loads in flight.
+__global__ void __launch_bounds__(256) bin_scan_kernel(int tiles, int nb, uint32_t* __restrict__ table,
+                                                       uint32_t* __restrict__ tile_count) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= tiles) return;
+  uint32_t run = 0;
+  for (int b = 0; b < nb; b += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = (b + k < nb) ? table[(size_t)(b + k) * tiles + t] : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (b + k < nb) table[(size_t)(b + k) * tiles + t] = run;
+      run += v[k];
+    }
+  }
+  tile_count[t] = run;
+}
+
+// Exclusive scan over tiles: ranges[t] = [start, end); ctrl[0] = R, ctrl[1] = longest tile list; also turns
+// chunk_total[nb] into its exclusive prefix.  One 1024-thread workgroup; tiles is O(10^3..10^4), nb <= 1024.
+__device__ __forceinline__ uint32_t block_inclusive_scan_1024(uint32_t v, uint32_t (*buf)[1024], int tid, uint32_t* total) {
+  int cur = 0;
+  buf[0][tid] = v;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele
+    uint32_t x = buf[cur][tid];
+    if (tid >= off) x += buf[cur][tid - off];
+    buf[cur ^ 1][tid] = x;
+    cur ^= 1;
+    __syncthreads();
+  }
+  const uint32_t incl = buf[cur][tid];
+  *total = buf[cur][1023];
+  __syncthreads();
+  return incl;
+}
+
+__global__ void __launch_bounds__(1024) scan_tiles_kernel(int tiles, const uint32_t* __restrict__ tile_count,
+                                                          uint2* __restrict__ ranges, uint32_t* __restrict__ ctrl,
+                                                          int nb, uint32_t* __restrict__ chunk_total) {
   __shared__ uint32_t buf[2][1024];
   __shared__ uint32_t wmax[16];
   const int tid = threadIdx.x;
-  uint32_t carry = 0, vmax = 0;
+  uint32_t carry = 0, vmax = 0, total;
   for (int base = 0; base < tiles; base += 1024) {
     const int i = base + tid;
     const uint32_t v = i < tiles ? tile_count[i] : 0u;
     vmax = max(vmax, v);
-    int cur = 0;
-    buf[0][tid] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-      uint32_t x = buf[cur][tid];
-      if (tid >= off) x += buf[cur][tid - off];
-      buf[cur ^ 1][tid] = x;
-      cur ^= 1;
-      __syncthreads();
-    }
-    const uint32_t incl = buf[cur][tid];
-    const uint32_t total = buf[cur][1023];
+    const uint32_t incl = block_inclusive_scan_1024(v, buf, tid, &total);
     if (i < tiles) {
       const uint32_t start = carry + incl - v;
       ranges[i] = make_uint2(start, start + v);
-      tile_count[i] = start;
     }
     carry += total;
-    __syncthreads();
   }
-  // block max
+  {
+    const uint32_t v = tid < nb ? chunk_total[tid] : 0u;
+    const uint32_t incl = block_inclusive_scan_1024(v, buf, tid, &total);
+    if (tid < nb) chunk_total[tid] = incl - v;
+  }
   for (int off = 32; off >= 1; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off));
   if ((tid & 63) == 0) wmax[tid >> 6] = vmax;
   __syncthreads();
@@ -198,24 +324,6 @@ __global__ void __launch_bounds__(1024) scan_tiles_kernel(int tiles, uint32_t* _
     ctrl[0] = carry;
     ctrl[1] = m;
   }
-}
-
-// =========================================================================================================
-// 3. Scatter instances into their tile bucket (order inside a bucket is arbitrary here; the sort fixes it).
-// =========================================================================================================
-__global__ void __launch_bounds__(256) scatter_kernel(int P, int gx, const ushort4* __restrict__ rect,
-                                                      const float* __restrict__ depths, uint32_t* __restrict__ cursor,
-                                                      uint64_t* __restrict__ keys) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= P) return;
-  const ushort4 r = rect[idx];
-  if (r.z <= r.x || r.w <= r.y) return;
-  const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx;
-  for (int y = r.y; y < r.w; y++)
-    for (int x = r.x; x < r.z; x++) {
-      const uint32_t pos = atomicAdd(&cursor[y * gx + x], 1u);
-      keys[pos] = key;
-    }
 }
 
 // =========================================================================================================
@@ -258,8 +366,22 @@ __device__ __forceinline__ void bitonic_network(KeyPtr a, uint32_t n, uint32_t t
 }
 
 // Tiles with lo < n <= hi are handled by this launch; lds_keys = capacity of the dynamic LDS buffer in keys.
-__global__ void __launch_bounds__(256) sort_tiles_kernel(int tiles, const uint2* __restrict__ ranges,
+// After sorting, slot_pos[gauss_off[g] + (tile's index inside g's rect)] = position of the instance in point_list:
+// the instance -> position map that lets the backward gather per-instance gradients without atomics.
+__device__ __forceinline__ void emit_instance(uint32_t pos, uint32_t g, int tx, int ty, const ushort4* __restrict__ rect,
+                                              const uint32_t* __restrict__ gauss_off, uint32_t* __restrict__ point_list,
+                                              uint32_t* __restrict__ slot_pos) {
+  point_list[pos] = g;
+  const ushort4 r = rect[g];
+  const uint32_t local = (uint32_t)(ty - (int)r.y) * (uint32_t)((int)r.z - (int)r.x) + (uint32_t)(tx - (int)r.x);
+  slot_pos[gauss_off[g] + local] = pos;
+}
+
+__global__ void __launch_bounds__(256) sort_tiles_kernel(int tiles, int gx, const uint2* __restrict__ ranges,
                                                          uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list,
+                                                         const ushort4* __restrict__ rect,
+                                                         const uint32_t* __restrict__ gauss_off,
+                                                         uint32_t* __restrict__ slot_pos,
                                                          uint32_t lo, uint32_t hi, uint32_t lds_keys) {
   extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
   const uint32_t t = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -269,18 +391,17 @@ __global__ void __launch_bounds__(256) sort_tiles_kernel(int tiles, const uint2*
   if (n <= lo || n > hi) return;
   uint64_t* gk = keys + rg.x;
   const uint32_t tid = threadIdx.x;
+  const int tx = (int)(t % (uint32_t)gx), ty = (int)(t / (uint32_t)gx);
   if (n <= lds_keys) {
     for (uint32_t i = tid; i < n; i += 256) skeys[i] = gk[i];
     __syncthreads();
     if (n > 1) bitonic_network(skeys, n, tid, 256u);
-    for (uint32_t i = tid; i < n; i += 256) {
-      const uint64_t k = skeys[i];
-      gk[i] = k;
-      point_list[rg.x + i] = (uint32_t)k;
-    }
+    for (uint32_t i = tid; i < n; i += 256)
+      emit_instance(rg.x + i, (uint32_t)skeys[i], tx, ty, rect, gauss_off, point_list, slot_pos);
   } else {
     bitonic_network((volatile uint64_t*)gk, n, tid, 256u);  // same workgroup: coherent through its own L1 after barriers
-    for (uint32_t i = tid; i < n; i += 256) point_list[rg.x + i] = (uint32_t)gk[i];
+    for (uint32_t i = tid; i < n; i += 256)
+      emit_instance(rg.x + i, (uint32_t)gk[i], tx, ty, rect, gauss_off, point_list, slot_pos);
   }
 }
 
@@ -296,8 +417,10 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ 
                      const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
                      const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
                      const float* __restrict__ depths, const float* __restrict__ bg, float* __restrict__ final_T,
-                     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth) {
+                     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_hi, float* __restrict__ out_color,
+                     float* __restrict__ out_depth) {
   __shared__ StagedGaussian sg[256];
+  __shared__ uint32_t wave_hi[4];
   const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= (uint32_t)tiles) return;
   const int tx = tile % gx, ty = tile / gx;
@@ -359,6 +482,12 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ 
     out_color[2 * N + pix] = Cb + T * bg[2];
     out_depth[pix] = D;
   }
+  // end (absolute list position) of the deepest contributor of the tile: the backward never looks behind it
+  uint32_t m = inside ? last_contributor : 0u;
+  for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+  if ((tid & 63) == 0) wave_hi[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) tile_hi[tile] = rg.x + max(max(wave_hi[0], wave_hi[1]), max(wave_hi[2], wave_hi[3]));
 }
 
 __global__ void __launch_bounds__(256) check_frustum_kernel(int P, const float* __restrict__ means3D,
@@ -377,7 +506,7 @@ static inline uint32_t round_up8(uint32_t v) { return (v + 7u) & ~7u; }
 using namespace s3g;
 
 extern "C" const char* s3g_last_error(void) { return g_err; }
-extern "C" int s3g_abi_version(void) { return 1; }
+extern "C" int s3g_abi_version(void) { return 2; }
 
 extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geometry_buffer, void* geometry_user,
                                   s3g_resize_fn binning_buffer, void* binning_user, s3g_resize_fn image_buffer,
@@ -417,9 +546,15 @@ extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geo
   }
   const bool debug = in->debug != 0;
 
+  if (tiles > MAX_TILES_LDS) {
+    set_error("image of %d tiles exceeds the %d tiles the LDS multisplit handles", tiles, MAX_TILES_LDS);
+    return S3G_ERR_INVALID_ARG;
+  }
+  const int nb = bin_blocks(P), chunk = bin_chunk(P);
+
   size_t geom_bytes = 0, img_bytes = 0;
   GeomState::carve(nullptr, P, &geom_bytes);
-  ImageState::carve(nullptr, (size_t)W * H, tiles, &img_bytes);
+  ImageState::carve(nullptr, (size_t)W * H, tiles, nb, &img_bytes);
   void* geom_p = geometry_buffer(geometry_user, geom_bytes);
   void* img_p = image_buffer(image_user, img_bytes);
   if (!geom_p || !img_p) {
@@ -427,10 +562,9 @@ extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geo
     return S3G_ERR_ALLOC;
   }
   GeomState g = GeomState::carve(geom_p, P, nullptr);
-  ImageState im = ImageState::carve(img_p, (size_t)W * H, tiles, nullptr);
+  ImageState im = ImageState::carve(img_p, (size_t)W * H, tiles, nb, nullptr);
 
-  // tile_count[tiles] and ctrl[8] are adjacent up to alignment: clear both
-  S3G_HIP_CHECK(hipMemsetAsync(im.tile_count, 0, (char*)(im.ctrl + 8) - (char*)im.tile_count, stream));
+  S3G_HIP_CHECK(hipMemsetAsync(im.ctrl, 0, 8 * sizeof(uint32_t), stream));
 
   PreprocessArgs pa;
   pa.P = P; pa.D = in->D; pa.M = in->M; pa.W = W; pa.H = H; pa.gx = gx; pa.gy = gy;
@@ -440,10 +574,29 @@ extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geo
   pa.viewmatrix = in->viewmatrix; pa.projmatrix = in->projmatrix; pa.cam_pos = in->cam_pos;
   pa.tan_fovx = in->tan_fovx; pa.tan_fovy = in->tan_fovy;
   pa.focal_y = H / (2.0f * in->tan_fovy); pa.focal_x = W / (2.0f * in->tan_fovx);
-  pa.prefiltered = in->prefiltered; pa.radii = radii; pa.g = g; pa.tile_count = im.tile_count; pa.ctrl = im.ctrl;
+  pa.prefiltered = in->prefiltered; pa.radii = radii; pa.g = g; pa.ctrl = im.ctrl;
   hipLaunchKernelGGL(preprocess_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, pa);
   S3G_KERNEL_CHECK(stream, debug);
-  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, tiles, im.tile_count, im.ranges, im.ctrl);
+
+  // atomic-free binning, counting half
+  const size_t bin_lds = ((size_t)tiles + 8) * sizeof(uint32_t);
+  static bool bin_attr_set = false;
+  if (!bin_attr_set) {
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)bin_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (MAX_TILES_LDS + 8) * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)bin_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (MAX_TILES_LDS + 8) * 4));
+    bin_attr_set = true;
+  }
+  BinArgs ba;
+  ba.P = P; ba.gx = gx; ba.tiles = tiles; ba.chunk = chunk; ba.rect = g.rect; ba.depths = g.depths;
+  ba.table = im.table; ba.chunk_total = im.chunk_total; ba.ranges = im.ranges; ba.keys = nullptr; ba.gauss_off = g.gauss_off;
+  hipLaunchKernelGGL(bin_kernel<false>, dim3(nb), dim3(BIN_THREADS), bin_lds, stream, ba);
+  S3G_KERNEL_CHECK(stream, debug);
+  hipLaunchKernelGGL(bin_scan_kernel, dim3((tiles + 255) / 256), dim3(256), 0, stream, tiles, nb, im.table, im.tile_count);
+  S3G_KERNEL_CHECK(stream, debug);
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, tiles, im.tile_count, im.ranges, im.ctrl, nb,
+                     im.chunk_total);
   S3G_KERNEL_CHECK(stream, debug);
 
   // the one host sync of the forward (reference: rasterizer_impl.cu:282): R sizes the binning arena
@@ -473,14 +626,14 @@ extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geo
 
   const uint32_t tile_blocks = round_up8((uint32_t)tiles);
   if (R > 0) {
-    hipLaunchKernelGGL(scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, gx, g.rect, g.depths,
-                       im.tile_count, b.keys);
+    ba.keys = b.keys;
+    hipLaunchKernelGGL(bin_kernel<true>, dim3(nb), dim3(BIN_THREADS), bin_lds, stream, ba);
     S3G_KERNEL_CHECK(stream, debug);
-    // short lists: 32 KiB of LDS per workgroup (5 workgroups/CU); long lists: up to 128 KiB, beyond that in global
+    // short lists: <= 32 KiB of LDS per workgroup (5 workgroups/CU); long lists: up to 128 KiB, beyond that in global
     constexpr uint32_t SMALL = 4096, LARGE = 16384;
     const uint32_t small_cap = max_tile < SMALL ? max_tile : SMALL;
-    hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)small_cap * 8, stream, tiles, im.ranges,
-                       b.keys, b.point_list, 0u, SMALL, small_cap);
+    hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)small_cap * 8, stream, tiles, gx,
+                       im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, b.slot_pos, 0u, SMALL, small_cap);
     S3G_KERNEL_CHECK(stream, debug);
     if (max_tile > SMALL) {
       const uint32_t large_cap = max_tile < LARGE ? max_tile : LARGE;
@@ -490,15 +643,15 @@ extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geo
                                           LARGE * 8));
         attr_set = true;
       }
-      hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)large_cap * 8, stream, tiles,
-                         im.ranges, b.keys, b.point_list, SMALL, 0xffffffffu, large_cap);
+      hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)large_cap * 8, stream, tiles, gx,
+                         im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, b.slot_pos, SMALL, 0xffffffffu, large_cap);
       S3G_KERNEL_CHECK(stream, debug);
     }
   }
   const float* feat = in->colors_precomp ? in->colors_precomp : g.rgb;
   hipLaunchKernelGGL(blend_forward_kernel, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
                      b.point_list, g.means2D, g.conic_opacity, feat, g.depths, in->background, im.final_T, im.n_contrib,
-                     out_color, out_depth);
+                     im.tile_hi, out_color, out_depth);
   S3G_KERNEL_CHECK(stream, debug);
   return S3G_OK;
 }

@@ -7,8 +7,6 @@ torch is used here for device memory and the current HIP stream only; no torch t
 from __future__ import annotations
 
 import ctypes as C
-from typing import Tuple
-
 import torch
 
 from . import _lib
@@ -99,30 +97,31 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor
 
 
-# float offsets (per Gaussian) inside the single zero-filled gradient slab of the backward
-def _grad_slab(P: int, M: int, dev) -> Tuple[torch.Tensor, dict]:
-    widths = [("rot", 4), ("conic", 4), ("means3D", 3), ("means2D", 3), ("colors", 3), ("scales", 3), ("cov3D", 6),
-              ("opacity", 1), ("depths", 1), ("sh", 3 * M)]
+def _grad_slab(P: int, M: int, dev, internals: bool) -> dict:
+    """One uninitialised slab carved into the gradient arrays (the library writes every element)."""
+    widths = [("rot", 4), ("conic", 4 if internals else 0), ("means3D", 3), ("means2D", 3), ("colors", 3), ("scales", 3),
+              ("cov3D", 6), ("opacity", 1), ("depths", 1 if internals else 0), ("sh", 3 * M)]
     total = sum(w for _, w in widths) * P
-    slab = torch.zeros(max(total, 1), dtype=torch.float32, device=dev)  # one memset (reference: 10 torch::zeros)
+    slab = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
     views, off = {}, 0
     for name, w in widths:
         views[name] = slab[off:off + w * P]
         off += w * P
-    return slab, views
+    return views
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, sh, degree,
-                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, return_internals=False):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
-           dL_dscales[P,3], dL_drotations[P,4])   (RAST/rasterize_points.cu:201)."""
+           dL_dscales[P,3], dL_drotations[P,4])   (RAST/rasterize_points.cu:201).
+    return_internals=True appends (dL_dconic[P,2,2], dL_ddepths[P,1]), the reference's internal intermediates."""
     L = _lib.lib()
     dev = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
-    _, v = _grad_slab(P, M, dev)
+    v = _grad_slab(P, M, dev, return_internals)
     if P != 0:
         keep = [_f32(background, "bg"), _f32(means3D, "means3D"), _f32(sh, "sh"), _f32(colors, "colors_precomp"),
                 _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp"),
@@ -131,16 +130,21 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         bg_, m3_, sh_, col_, sc_, rot_, cov_, view_, proj_, cam_, gcol_, gdep_, radii_ = keep
         inp = _inputs(P, degree, M, W, H, bg_, m3_, sh_, col_, None, sc_, scale_modifier, rot_, cov_, view_, proj_,
                       tan_fovx, tan_fovy, cam_, False, debug)
+        work = torch.empty(L.s3g_raster_backward_workspace_bytes(P, int(R)), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
             code = L.s3g_raster_backward(C.byref(inp), int(R), radii_.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer),
-                                         _ptr(imageBuffer), gcol_.data_ptr(), gdep_.data_ptr(), v["means2D"].data_ptr(),
-                                         v["conic"].data_ptr(), v["opacity"].data_ptr(), v["colors"].data_ptr(),
-                                         v["depths"].data_ptr(), v["means3D"].data_ptr(), v["cov3D"].data_ptr(),
-                                         _ptr(v["sh"]), v["scales"].data_ptr(), v["rot"].data_ptr(), stream)
+                                         _ptr(imageBuffer), _ptr(work), gcol_.data_ptr(), gdep_.data_ptr(),
+                                         v["means2D"].data_ptr(), _ptr(v["conic"]), v["opacity"].data_ptr(),
+                                         v["colors"].data_ptr(), _ptr(v["depths"]), v["means3D"].data_ptr(),
+                                         v["cov3D"].data_ptr(), _ptr(v["sh"]), v["scales"].data_ptr(),
+                                         v["rot"].data_ptr(), stream)
         _lib.check(code)
-    return (v["means2D"].view(P, 3), v["colors"].view(P, NUM_CHANNELS), v["opacity"].view(P, 1), v["means3D"].view(P, 3),
-            v["cov3D"].view(P, 6), v["sh"].view(P, M, 3), v["scales"].view(P, 3), v["rot"].view(P, 4))
+    out = (v["means2D"].view(P, 3), v["colors"].view(P, NUM_CHANNELS), v["opacity"].view(P, 1), v["means3D"].view(P, 3),
+           v["cov3D"].view(P, 6), v["sh"].view(P, M, 3), v["scales"].view(P, 3), v["rot"].view(P, 4))
+    if return_internals:
+        out = out + (v["conic"].view(P, 2, 2), v["depths"].view(P, 1))
+    return out
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
