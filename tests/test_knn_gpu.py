@@ -1,0 +1,50 @@
+"""distCUDA2 (HIP) vs the CPU restatement of simple-knn and brute force.  Distances are sums of three fp32 products,
+identical on both sides up to fma contraction (off on both): compared with rtol 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("P", [1, 3, 4, 7, 1000, 1024, 1025, 30_000])
+def test_distcuda2_matches_oracle(gpu_device, P):
+    from oracle.oracle import knn_mean_dist2
+    from simple_knn._C import distCUDA2
+    g = np.random.default_rng(P)
+    pts = (g.normal(size=(P, 3)) * np.array([30, 10, 2])).astype(np.float32)
+    got = distCUDA2(torch.from_numpy(pts).to(gpu_device)).cpu().numpy()
+    want = knn_mean_dist2(pts)
+    # fewer than 4 points: missing neighbours are FLT_MAX, the mean is +inf or ~FLT_MAX/3 exactly like the reference
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
+
+
+def test_distcuda2_duplicates_and_clusters(gpu_device):
+    from oracle.oracle import knn_mean_dist2
+    from simple_knn._C import distCUDA2
+    g = np.random.default_rng(0)
+    base = g.normal(size=(2000, 3)).astype(np.float32)
+    pts = np.concatenate([base, base[:500], base[:100] + 1e-4, np.zeros((5, 3), np.float32)]).astype(np.float32)
+    got = distCUDA2(torch.from_numpy(pts).to(gpu_device)).cpu().numpy()
+    np.testing.assert_allclose(got, knn_mean_dist2(pts), rtol=1e-6, atol=1e-12)
+
+
+def test_distcuda2_full_size_properties(gpu_device):
+    """1.5 M points (reference num_pts, arguments/__init__.py:67): finite, positive, permutation-equivariant, and a
+    random sample equals brute force."""
+    from simple_knn._C import distCUDA2
+    g = torch.Generator().manual_seed(0)
+    P = 1_500_000
+    pts = (torch.rand(P, 3, generator=g) * torch.tensor([100.0, 40.0, 10.0])).to(gpu_device)
+    d = distCUDA2(pts)
+    assert torch.isfinite(d).all() and (d > 0).all()
+    perm = torch.randperm(P, generator=g).to(gpu_device)
+    d2 = distCUDA2(pts[perm])
+    assert torch.equal(d2, d[perm])
+    idx = torch.randint(0, P, (64,), generator=g).to(gpu_device)
+    diff = pts[idx][:, None, :] - pts[None, :, :]
+    dd = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    dd[torch.arange(64, device=gpu_device), idx] = float("inf")
+    best = torch.topk(dd, 3, dim=1, largest=False).values
+    want = (best[:, 0] + best[:, 1] + best[:, 2]) / 3.0
+    torch.testing.assert_close(d[idx], want, rtol=1e-5, atol=0)

@@ -228,7 +228,7 @@ def test_all_culled_gives_background(gpu_device, oracle):
     assert ref["num_rendered"] == 0
     assert int(gpu["radii"].abs().sum()) == 0
     np.testing.assert_allclose(gpu["color"].detach().cpu().numpy(), ref["color"], atol=0)
-    assert float(gpu["depth"].abs().max()) == 0.0
+    assert float(gpu["depth"].detach().abs().max()) == 0.0
 
 
 def test_single_huge_gaussian(gpu_device, oracle):
