@@ -1,0 +1,50 @@
+/*
+ * s3g_hexplane.h -- C ABI of the MI355X-native multi-resolution HexPlane sampler (libs3g.so).
+ *
+ *   s3g_hexplane_forward   <- HexPlaneField.forward / get_density -> interpolate_ms_features -> 24x grid_sample_wrapper
+ *                             (/root/reference/scene/hexplane.py:177-183, :151-175, :73-106, :21-46)
+ *   s3g_hexplane_backward  <- the autograd backward of the same (torch grid_sampler_2d_backward x24 + product rule)
+ *
+ * One fused pass per direction instead of 24 grid_sample launches that each materialise a [P,32] tensor.
+ *
+ * Semantics (identical to the reference): pts = (xyz - aabb[0]) * (2 / (aabb[1] - aabb[0])) - 1 with aabb[0] the MAX
+ * corner and aabb[1] the MIN corner (scene/hexplane.py:19-20,113-114); the time coordinate is used as given (NOT
+ * normalised, scene/hexplane.py:164); each of the 6 planes of a level -- coordinate pairs (x,y) (x,z) (x,t) (y,z)
+ * (y,t) (z,t) in itertools.combinations order -- is sampled bilinearly with align_corners=True and border padding;
+ * the 6 samples are multiplied, the levels concatenated: features [P, levels*C].
+ *
+ * Plane memory layout: the reference parameter of plane (c0,c1) is a [1, C, res[c1], res[c0]] tensor; this library
+ * reads it CHANNEL-LAST, i.e. as [res[c1]][res[c0]][C] floats -- exactly the bytes of the same tensor in
+ * torch.channels_last memory format, so one texel (C = 32 floats = 128 B) is one cache line and one half-wave load.
+ */
+#ifndef S3G_HEXPLANE_H
+#define S3G_HEXPLANE_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3G_HEX_MAX_LEVELS 8
+#define S3G_HEX_CHANNELS 32 /* output_coordinate_dim of the reference config (arguments/__init__.py:219) */
+
+typedef struct s3g_hexplane_desc {
+  int levels;                                /* len(multires) */
+  int res[S3G_HEX_MAX_LEVELS][4];            /* per level: resolution along x, y, z, t */
+  const float* planes[S3G_HEX_MAX_LEVELS][6];/* device, channel-last [res[c1]][res[c0]][32] */
+  float aabb_max[3], aabb_min[3];            /* aabb[0], aabb[1] */
+} s3g_hexplane_desc;
+
+/* features [P, levels*32].  xyz [P,3], time [P] (device fp32). */
+int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time, float* features,
+                         void* stream);
+
+/* dL_dfeatures [P, levels*32] -> dL_dxyz [P,3] (written) and dL_dplanes[l][i] (same layout as planes; ACCUMULATED,
+ * the caller zero-fills them; a NULL entry skips that plane). */
+int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
+                          const float* dL_dfeatures, float* dL_dxyz, float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6],
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,180 @@
+"""HexPlane field on the MI355X: same module surface as the reference's scene/hexplane.py::HexPlaneField
+(:109-183) -- `aabb`, `grids` (ModuleList of ParameterList, names `grids.{level}.{plane}`, shapes [1,32,H,W]),
+`feat_dim`, `get_aabb`, `set_aabb`, `get_density`, `forward` -- so state_dicts / checkpoints interchange
+(SURVEY.md 5.4).  The 24 grid_sample launches are replaced by one fused HIP kernel per direction
+(include/s3g_hexplane.h).
+
+Plane parameters are held in torch.channels_last memory format: logical shape stays [1,32,H,W] (what the
+reference's optimizer groups, regularisers and checkpoints see) while the bytes are [H][W][32], which is the layout
+the kernels read -- no shadow copy, no transposes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+MAX_LEVELS, CHANNELS = 8, 32
+
+
+class _HexDesc(C.Structure):
+    """struct s3g_hexplane_desc (include/s3g_hexplane.h)."""
+    _fields_ = [("levels", C.c_int), ("res", (C.c_int * 4) * MAX_LEVELS), ("planes", (C.c_void_p * 6) * MAX_LEVELS),
+                ("aabb_max", C.c_float * 3), ("aabb_min", C.c_float * 3)]
+
+
+_PlanePtrs = (C.c_void_p * 6) * MAX_LEVELS
+_bound = False
+
+
+def _bind():
+    global _bound
+    L = _lib.lib()
+    if not _bound:
+        vp = C.c_void_p
+        L.s3g_hexplane_forward.restype = C.c_int
+        L.s3g_hexplane_forward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp]
+        L.s3g_hexplane_backward.restype = C.c_int
+        L.s3g_hexplane_backward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, C.POINTER(_PlanePtrs), vp]
+        _bound = True
+    return L
+
+
+def _channels_last_ptr(p: torch.Tensor) -> int:
+    if not p.is_contiguous(memory_format=torch.channels_last):
+        raise RuntimeError("hexplane planes must be in torch.channels_last memory format (see HexPlaneField)")
+    return p.data_ptr()
+
+
+def _make_desc(planes, resolutions, aabb_host) -> _HexDesc:
+    d = _HexDesc()
+    d.levels = len(resolutions)
+    for l, res in enumerate(resolutions):
+        for k in range(4):
+            d.res[l][k] = int(res[k])
+        for i in range(6):
+            d.planes[l][i] = _channels_last_ptr(planes[l * 6 + i])
+    for k in range(3):
+        d.aabb_max[k] = aabb_host[0][k]
+        d.aabb_min[k] = aabb_host[1][k]
+    return d
+
+
+class _HexPlaneSample(torch.autograd.Function):
+    """features[P, levels*32] = prod over the 6 planes of bilinear samples, concatenated over levels."""
+
+    @staticmethod
+    def forward(ctx, xyz, time, meta, *planes):
+        resolutions, aabb_host = meta
+        if not xyz.is_cuda:
+            raise RuntimeError(f"xyz must live on the GPU (got {xyz.device}); the HexPlane sampler has no CPU fallback")
+        L = _bind()
+        P = xyz.shape[0]
+        xyz_c = xyz.detach().contiguous().float()
+        t_c = time.detach().reshape(-1).contiguous().float()
+        if t_c.numel() != P:
+            raise RuntimeError("time must have one value per point")
+        feat = torch.empty((P, len(resolutions) * CHANNELS), dtype=torch.float32, device=xyz.device)
+        d = _make_desc(planes, resolutions, aabb_host)
+        with torch.cuda.device(xyz.device):
+            _lib.check(L.s3g_hexplane_forward(C.byref(d), P, xyz_c.data_ptr(), t_c.data_ptr(), feat.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream))
+        ctx.meta = meta
+        ctx.save_for_backward(xyz_c, t_c, *planes)
+        return feat
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        xyz_c, t_c, *planes = ctx.saved_tensors
+        resolutions, aabb_host = ctx.meta
+        L = _bind()
+        P = xyz_c.shape[0]
+        gfeat = gfeat.contiguous()
+        gxyz = torch.empty_like(xyz_c)
+        gplanes = [torch.zeros_like(p) if ctx.needs_input_grad[3 + i] else None for i, p in enumerate(planes)]
+        ptrs = _PlanePtrs()
+        for l in range(len(resolutions)):
+            for i in range(6):
+                g = gplanes[l * 6 + i]
+                ptrs[l][i] = _channels_last_ptr(g) if g is not None else None
+        d = _make_desc(planes, resolutions, aabb_host)
+        with torch.cuda.device(xyz_c.device):
+            _lib.check(L.s3g_hexplane_backward(C.byref(d), P, xyz_c.data_ptr(), t_c.data_ptr(), gfeat.data_ptr(),
+                                               gxyz.data_ptr(), C.byref(ptrs), torch.cuda.current_stream().cuda_stream))
+        return (gxyz if ctx.needs_input_grad[0] else None, None, None, *gplanes)
+
+
+def hexplane_sample(xyz, time, planes, resolutions, aabb_host):
+    return _HexPlaneSample.apply(xyz, time, (tuple(tuple(r) for r in resolutions), aabb_host), *planes)
+
+
+class HexPlaneField(nn.Module):
+    def __init__(self, bounds, planeconfig, multires) -> None:
+        super().__init__()
+        self.aabb = nn.Parameter(torch.tensor([[bounds] * 3, [-bounds] * 3], dtype=torch.float32), requires_grad=False)
+        self.grid_config = [planeconfig]
+        self.multiscale_res_multipliers = multires
+        self.concat_features = True
+        if planeconfig["grid_dimensions"] != 2 or planeconfig["input_coordinate_dim"] != 4:
+            raise NotImplementedError("only the 4D/2D-plane (HexPlane) configuration of the reference is supported")
+        if planeconfig["output_coordinate_dim"] != CHANNELS:
+            raise NotImplementedError(f"output_coordinate_dim must be {CHANNELS}")
+        if len(multires) > MAX_LEVELS:
+            raise NotImplementedError(f"at most {MAX_LEVELS} resolution levels")
+        self.grids = nn.ModuleList()
+        self.resolutions = []
+        self.feat_dim = 0
+        for res in multires:
+            reso = [r * res for r in planeconfig["resolution"][:3]] + list(planeconfig["resolution"][3:])
+            self.resolutions.append(tuple(reso))
+            planes = nn.ParameterList()
+            for comb in itertools.combinations(range(4), 2):
+                p = torch.empty([1, CHANNELS] + [reso[c] for c in comb[::-1]])
+                if 3 in comb:
+                    nn.init.ones_(p)                  # time planes start at 1 (scene/hexplane.py:64-65)
+                else:
+                    nn.init.uniform_(p, a=0.1, b=0.5)
+                planes.append(nn.Parameter(p.contiguous(memory_format=torch.channels_last)))
+            self.grids.append(planes)
+            self.feat_dim += CHANNELS
+        self._aabb_host = None
+
+    @property
+    def get_aabb(self):
+        return self.aabb[0], self.aabb[1]
+
+    def set_aabb(self, xyz_max, xyz_min):
+        self.aabb = nn.Parameter(torch.tensor([xyz_max, xyz_min], dtype=torch.float32, device=self.aabb.device),
+                                 requires_grad=False)
+        self._aabb_host = None
+
+    def _apply(self, fn, *args, **kwargs):  # .to()/.cuda(): keep the planes channel-last on the new device
+        out = super()._apply(fn, *args, **kwargs)
+        for planes in self.grids:
+            for p in planes:
+                if not p.data.is_contiguous(memory_format=torch.channels_last):
+                    p.data = p.data.contiguous(memory_format=torch.channels_last)
+        self._aabb_host = None
+        return out
+
+    def _host_aabb(self):
+        key = (self.aabb.data_ptr(), self.aabb._version)
+        if self._aabb_host is None or self._aabb_host[0] != key:
+            a = self.aabb.detach().cpu().tolist()   # one tiny D2H, only when the aabb changed
+            self._aabb_host = (key, (tuple(a[0]), tuple(a[1])))
+        return self._aabb_host[1]
+
+    def _planes(self):
+        return [p for planes in self.grids for p in planes]
+
+    def get_density(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None):
+        pts = pts.reshape(-1, pts.shape[-1])
+        return hexplane_sample(pts, timestamps, self._planes(), self.resolutions, self._host_aabb())
+
+    def forward(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None):
+        return self.get_density(pts, timestamps)
