@@ -95,6 +95,12 @@ int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int* radii,
 int s3g_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);
 
+/* Optional in-library timing of the two blend kernels with hipEvent pairs recorded on the launch stream
+ * (bench.py's roofline leg).  id 0 = blend forward, 1 = blend backward.  s3g_profile_read sums and clears the
+ * recorded launches (synchronising on their events) and returns how many there were. */
+void s3g_profile_enable(int on);
+int s3g_profile_read(int id, double* total_ms, double* total_instances, double* total_pixels);
+
 /* Thread-local description of the last error returned on this thread ("" if none). */
 const char* s3g_last_error(void);
 

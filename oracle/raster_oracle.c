@@ -29,8 +29,9 @@
  *
  * Gradient accumulation: the reference sums per-(pixel,Gaussian) terms with
  * float atomicAdd in non-deterministic order (backward.cu:550-587).  The oracle
- * accumulates those sums in double and rounds once, i.e. the order-independent
- * limit of what the reference computes.
+ * accumulates those sums in double (OpenMP atomics over tiles; double sums of
+ * fp32 terms are order-independent to ~1e-16 relative) and rounds once, i.e. the
+ * order-independent limit of what the reference computes.
  */
 #include <math.h>
 #include <stdint.h>
@@ -445,12 +446,14 @@ static void render_tile_bw(const orc_inputs* in, const orc_state* st, const real
           last_color[ch] = c;
           real dL_dchannel = dL_dpixel[ch];
           dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
+#pragma omp atomic
           acc->dcolors[id * NUM_CHANNELS + ch] += (double)(dchannel_dcolor * dL_dchannel);
         }
         real c_d = st->depths[id];
         accum_depth_rec = last_alpha * last_depth + (1 - last_alpha) * accum_depth_rec;
         last_depth = c_d;
         dL_dalpha += (c_d - accum_depth_rec) * dL_dpixel_depth;
+#pragma omp atomic
         acc->ddepths[id] += (double)(dchannel_dcolor * dL_dpixel_depth);
         dL_dalpha *= T;
         last_alpha = alpha;
@@ -461,11 +464,17 @@ static void render_tile_bw(const orc_inputs* in, const orc_state* st, const real
         real gdx = G * dx, gdy = G * dy;
         real dG_ddelx = -gdx * co[0] - gdy * co[1];
         real dG_ddely = -gdy * co[2] - gdx * co[1];
+#pragma omp atomic
         acc->dmean2D[2 * id + 0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+#pragma omp atomic
         acc->dmean2D[2 * id + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
+#pragma omp atomic
         acc->dconic[3 * id + 0] += (double)((real)-0.5 * gdx * dx * dL_dG);
+#pragma omp atomic
         acc->dconic[3 * id + 1] += (double)((real)-0.5 * gdx * dy * dL_dG);
+#pragma omp atomic
         acc->dconic[3 * id + 2] += (double)((real)-0.5 * gdy * dy * dL_dG);
+#pragma omp atomic
         acc->dopacity[id] += (double)(G * dL_dalpha);
       }
     }
@@ -625,6 +634,7 @@ void orc_backward(const orc_inputs* in, const orc_state* st, const int* radii, c
   acc.dopacity = (double*)calloc((size_t)P, sizeof(double));
   acc.dcolors = (double*)calloc((size_t)P * 3, sizeof(double));
   acc.ddepths = (double*)calloc((size_t)P, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
   for (int ty = 0; ty < gy; ty++)
     for (int tx = 0; tx < gx; tx++) render_tile_bw(in, st, colors, tx, ty, gx, dL_dpix, dL_dpix_depth, &acc);
   for (int i = 0; i < P; i++) {

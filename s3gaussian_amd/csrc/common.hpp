@@ -45,6 +45,11 @@ void set_error(const char* fmt, ...);
     if (debug) S3G_HIP_CHECK(hipStreamSynchronize(stream));      \
   } while (0)
 
+// ---- optional in-library kernel timing (bench.py's roofline leg): hipEvent pairs on the launch stream ----------
+// id 0 = blend_forward_kernel, id 1 = blend_backward_kernel
+void profile_begin(int id, hipStream_t stream);
+void profile_end(int id, hipStream_t stream, double instances, double pixels);
+
 // ---- arena carving (128-byte aligned sub-arrays, like the reference's obtain<>(), rasterizer_impl.h) ----
 struct Carver {
   char* base;

@@ -22,6 +22,8 @@
 
 #include <stdarg.h>
 
+#include <vector>
+
 namespace s3g {
 
 static thread_local char g_err[512] = {0};
@@ -30,6 +32,26 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof g_err, fmt, ap);
   va_end(ap);
+}
+
+// ---- in-library kernel timing -----------------------------------------------------------------------------
+struct ProfRec { hipEvent_t a, b; double instances, pixels; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof[2];
+static hipEvent_t g_prof_pending[2];
+void profile_begin(int id, hipStream_t stream) {
+  if (!g_prof_on) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, stream);
+  g_prof_pending[id] = e;
+}
+void profile_end(int id, hipStream_t stream, double instances, double pixels) {
+  if (!g_prof_on) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, stream);
+  g_prof[id].push_back(ProfRec{g_prof_pending[id], e, instances, pixels});
 }
 
 // =========================================================================================================
@@ -649,11 +671,36 @@ extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geo
     }
   }
   const float* feat = in->colors_precomp ? in->colors_precomp : g.rgb;
+  profile_begin(0, stream);
   hipLaunchKernelGGL(blend_forward_kernel, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
                      b.point_list, g.means2D, g.conic_opacity, feat, g.depths, in->background, im.final_T, im.n_contrib,
                      im.tile_hi, out_color, out_depth);
+  profile_end(0, stream, (double)R, (double)W * H);
   S3G_KERNEL_CHECK(stream, debug);
   return S3G_OK;
+}
+
+extern "C" void s3g_profile_enable(int on) { g_prof_on = on != 0; }
+
+// Sums the recorded launches of kernel `id` (0 blend forward, 1 blend backward), synchronising on their events, then
+// forgets them.  Returns the number of launches.
+extern "C" int s3g_profile_read(int id, double* total_ms, double* total_instances, double* total_pixels) {
+  if (id < 0 || id > 1) return 0;
+  double ms = 0, inst = 0, pix = 0;
+  int n = 0;
+  for (ProfRec& r : g_prof[id]) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+      ms += t; inst += r.instances; pix += r.pixels; n++;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof[id].clear();
+  if (total_ms) *total_ms = ms;
+  if (total_instances) *total_instances = inst;
+  if (total_pixels) *total_pixels = pix;
+  return n;
 }
 
 extern "C" int s3g_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -1,0 +1,300 @@
+"""Host-side mirror of the reference's hot path around the accelerated operators (GPU only):
+
+  GaussianParams      <- the tensors/optimizer groups of scene/gaussian_model.py:30-201 that the path touches
+  render()            <- gaussian_renderer/__init__.py:23-210 (same arguments, same result-dict keys)
+  training_loss()     <- train.py:395-425 loss assembly (L1 + dx/dshs reg + depth L2 + plane regulation + DSSIM + feat L2)
+  training_step()     <- train.py:372-437,521-522 for one view (batch_size = 1)
+
+Everything outside that path (data readers, densification, checkpoints, evaluation, logging) stays with the
+reference and is NOT rebuilt here (DESIGN.md "out of scope").  The losses are plain PyTorch on the
+GPU exactly like the reference's utils/loss_utils.py; the operators underneath are the HIP library.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .deformation import deform_network
+from .knn import distCUDA2
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def default_hyper(**over) -> SimpleNamespace:
+    """ModelHiddenParams defaults (arguments/__init__.py:204-233)."""
+    h = dict(net_width=64, timebase_pe=4, defor_depth=1, posebase_pe=10, scale_rotation_pe=2, opacity_pe=2,
+             timenet_width=64, timenet_output=32, bounds=1.6, plane_tv_weight=0.0001, time_smoothness_weight=0.01,
+             l1_time_planes=0.0001,
+             kplanes_config=dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32,
+                                 resolution=[64, 64, 64, 25]),
+             multires=[1, 2, 4, 8], no_dx=False, no_grid=False, no_ds=True, no_dr=True, no_do=True, no_dshs=False,
+             feat_head=True, empty_voxel=False, grid_pe=0, static_mlp=False, apply_rotation=False)
+    h.update(over)
+    return SimpleNamespace(**h)
+
+
+def default_opt(**over) -> SimpleNamespace:
+    """The OptimizationParams the path reads (arguments/__init__.py:100-158)."""
+    o = dict(position_lr_init=0.00016, deformation_lr_init=0.000016, grid_lr_init=0.00016, feature_lr=0.0025,
+             opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, lambda_dssim=0.2, lambda_depth=0.5,
+             lambda_feat=0.001, lambda_dx=0.001, lambda_dshs=0.001)
+    o.update(over)
+    return SimpleNamespace(**o)
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+class GaussianParams(nn.Module):
+    """Parameter store with the reference's attribute names (`_xyz`, `_features_dc`, ..., `_deformation`)."""
+
+    def __init__(self, sh_degree: int, hyper: SimpleNamespace):
+        super().__init__()
+        self.max_sh_degree = sh_degree
+        self.active_sh_degree = sh_degree
+        self._deformation = deform_network(hyper)
+        self.spatial_lr_scale = 1.0
+        self.scaling_activation = torch.exp
+        self.opacity_activation = torch.sigmoid
+        self.rotation_activation = F.normalize
+
+    @torch.no_grad()
+    def init_from_tensors(self, xyz, log_scales, rotations, opacity_logit, shs, device):
+        self._xyz = nn.Parameter(xyz.float().to(device).contiguous())
+        shs = shs.float().to(device)
+        self._features_dc = nn.Parameter(shs[:, :1].contiguous())
+        self._features_rest = nn.Parameter(shs[:, 1:].contiguous())
+        self._scaling = nn.Parameter(log_scales.float().to(device).contiguous())
+        self._rotation = nn.Parameter(rotations.float().to(device).contiguous())
+        self._opacity = nn.Parameter(opacity_logit.float().to(device).contiguous())
+        self._deformation = self._deformation.to(device)
+        self._deformation_table = torch.ones(xyz.shape[0], dtype=torch.bool, device=device)
+        self.max_radii2D = torch.zeros(xyz.shape[0], device=device)
+        return self
+
+    @torch.no_grad()
+    def create_from_points(self, points: torch.Tensor, colors: torch.Tensor, device):
+        """scene/gaussian_model.py:142-169: scales from the 3-NN distance (distCUDA2), identity rotations, opacity 0.1."""
+        pts = points.float().to(device)
+        dist2 = torch.clamp_min(distCUDA2(pts), 0.0000001)
+        log_scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
+        rots = torch.zeros((pts.shape[0], 4), device=device)
+        rots[:, 0] = 1
+        op = inverse_sigmoid(0.1 * torch.ones((pts.shape[0], 1), device=device))
+        shs = torch.zeros((pts.shape[0], (self.max_sh_degree + 1) ** 2, 3), device=device)
+        shs[:, 0] = (colors.float().to(device) - 0.5) / 0.28209479177387814
+        return self.init_from_tensors(pts, log_scales, rots, op, shs, device)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    def training_setup(self, opt: SimpleNamespace):
+        """Adam groups of scene/gaussian_model.py:177-189 (eps 1e-15)."""
+        s = self.spatial_lr_scale
+        groups = [
+            {"params": [self._xyz], "lr": opt.position_lr_init * s, "name": "xyz"},
+            {"params": list(self._deformation.get_mlp_parameters()), "lr": opt.deformation_lr_init * s, "name": "deformation"},
+            {"params": list(self._deformation.get_grid_parameters()), "lr": opt.grid_lr_init * s, "name": "grid"},
+            {"params": [self._features_dc], "lr": opt.feature_lr, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": opt.feature_lr / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": opt.opacity_lr, "name": "opacity"},
+            {"params": [self._scaling], "lr": opt.scaling_lr, "name": "scaling"},
+            {"params": [self._rotation], "lr": opt.rotation_lr, "name": "rotation"},
+        ]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        return self.optimizer
+
+    def compute_regulation(self, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight):
+        """scene/gaussian_model.py:710-749."""
+        grids = self._deformation.deformation_net.grid.grids
+        sp = sum(_plane_smoothness(g[i]) for g in grids for i in (0, 1, 3))
+        tm = sum(_plane_smoothness(g[i]) for g in grids for i in (2, 4, 5))
+        l1 = sum(torch.abs(1 - g[i]).mean() for g in grids for i in (2, 4, 5))
+        return plane_tv_weight * sp + time_smoothness_weight * tm + l1_time_planes_weight * l1
+
+
+# ---- SH evaluation (utils/sh_utils.py:57-112), used on the default convert_SHs_python=True path ----------------
+_C0 = 0.28209479177387814
+_C1 = 0.4886025119029199
+_C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+_C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+       1.445305721320277, -0.5900435899266435]
+
+
+def eval_sh(deg, sh, dirs):
+    result = _C0 * sh[..., 0]
+    if deg > 0:
+        x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+        result = result - _C1 * y * sh[..., 1] + _C1 * z * sh[..., 2] - _C1 * x * sh[..., 3]
+        if deg > 1:
+            xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+            result = (result + _C2[0] * xy * sh[..., 4] + _C2[1] * yz * sh[..., 5] + _C2[2] * (2.0 * zz - xx - yy) * sh[..., 6]
+                      + _C2[3] * xz * sh[..., 7] + _C2[4] * (xx - yy) * sh[..., 8])
+            if deg > 2:
+                result = (result + _C3[0] * y * (3 * xx - yy) * sh[..., 9] + _C3[1] * xy * z * sh[..., 10]
+                          + _C3[2] * y * (4 * zz - xx - yy) * sh[..., 11] + _C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12]
+                          + _C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + _C3[5] * z * (xx - yy) * sh[..., 14]
+                          + _C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+    return result
+
+
+def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg_color: torch.Tensor,
+           scaling_modifier=1.0, override_color=None, stage="fine", return_decomposition=False, return_dx=False,
+           render_feat=False):
+    """Mirror of gaussian_renderer/__init__.py::render.  `viewpoint_camera` is a dict with the fields the reference
+    reads from a Camera (image_height/width, FoVx/FoVy or tanfovx/tanfovy, world_view_transform=viewmatrix,
+    full_proj_transform=projmatrix, camera_center=campos, time)."""
+    dev = pc.get_xyz.device
+    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    means3D = pc.get_xyz
+    cam = viewpoint_camera
+    rs = GaussianRasterizationSettings(
+        image_height=int(cam["image_height"]), image_width=int(cam["image_width"]), tanfovx=cam["tanfovx"],
+        tanfovy=cam["tanfovy"], bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=cam["viewmatrix"],
+        projmatrix=cam["projmatrix"], sh_degree=pc.active_sh_degree, campos=cam["campos"], prefiltered=False,
+        debug=getattr(pipe, "debug", False))
+    rasterizer = GaussianRasterizer(raster_settings=rs)
+    time = torch.full((means3D.shape[0], 1), float(cam["time"]), device=dev)
+    means2D = screenspace_points
+    opacity, shs = pc._opacity, pc.get_features
+    scales, rotations, cov3D_precomp = pc._scaling, pc._rotation, None
+    dx = feat = dshs = None
+    if "coarse" in stage:
+        means3D_final, scales_final, rotations_final, opacity_final, shs_final = means3D, scales, rotations, opacity, shs
+    elif "fine" in stage:
+        (means3D_final, scales_final, rotations_final, opacity_final, shs_final, dx, feat, dshs) = pc._deformation(
+            means3D, scales, rotations, opacity, shs, time)
+    else:
+        raise NotImplementedError
+    scales_final = pc.scaling_activation(scales_final)
+    rotations_final = pc.rotation_activation(rotations_final)
+    opacity = pc.opacity_activation(opacity_final)
+    colors_precomp = None
+    if override_color is None:
+        if getattr(pipe, "convert_SHs_python", True):
+            shs_view = shs_final.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - cam["campos"].repeat(pc.get_features.shape[0], 1)  # NB: un-deformed xyz (reference :110)
+            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized) + 0.5, 0.0)
+    else:
+        colors_precomp = override_color
+    if colors_precomp is not None:
+        shs_final = None
+    rendered_image, radii, depth = rasterizer(means3D=means3D_final, means2D=means2D, shs=shs_final,
+                                              colors_precomp=colors_precomp, opacities=opacity, scales=scales_final,
+                                              rotations=rotations_final, cov3D_precomp=cov3D_precomp)
+    out = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+           "radii": radii, "depth": depth}
+    if render_feat and "fine" in stage:
+        rendered_image2, _, _ = rasterizer(means3D=means3D_final, means2D=means2D, shs=None, colors_precomp=feat,
+                                           opacities=opacity, scales=scales_final, rotations=rotations_final,
+                                           cov3D_precomp=cov3D_precomp)
+        out["feat"] = rendered_image2
+    if return_decomposition and dx is not None:
+        max_values = torch.max(torch.abs(dx), dim=1)[0]
+        dynamic_mask = max_values > torch.mean(max_values)
+        for tag, m in (("d", dynamic_mask), ("s", ~dynamic_mask)):
+            img, rad, dep = rasterizer(means3D=means3D_final[m], means2D=means2D[m],
+                                       shs=shs_final[m] if shs_final is not None else None,
+                                       colors_precomp=colors_precomp[m] if colors_precomp is not None else None,
+                                       opacities=opacity[m], scales=scales_final[m], rotations=rotations_final[m],
+                                       cov3D_precomp=None)
+            out.update({f"render_{tag}": img, f"depth_{tag}": dep, f"visibility_filter_{tag}": rad > 0})
+    if return_dx and "fine" in stage:
+        out.update({"dx": dx, "dshs": dshs})
+    return out
+
+
+# ---- losses (utils/loss_utils.py, scene/regulation.py) -----------------------------------------------------------
+def l1_loss(a, b):
+    return torch.abs(a - b).mean()
+
+
+def l2_loss(a, b):
+    return ((a - b) ** 2).mean()
+
+
+def compute_depth_l2(pred, gt, max_depth: float = 80.0):
+    pred, gt = pred.squeeze(), gt.squeeze()
+    m = (gt > 0.01) & (gt < max_depth)
+    return F.mse_loss(torch.clamp(pred[m] / max_depth, 0.0, 1.0), torch.clamp(gt[m] / max_depth, 0.0, 1.0))
+
+
+_ssim_windows = {}
+
+
+def ssim(img1, img2, window_size=11):
+    ch = img1.size(-3)
+    key = (ch, window_size, img1.device, img1.dtype)
+    if key not in _ssim_windows:
+        g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)])
+        g = (g / g.sum()).unsqueeze(1)
+        _ssim_windows[key] = g.mm(g.t()).float()[None, None].expand(ch, 1, window_size, window_size).contiguous().to(img1)
+    w, pad = _ssim_windows[key], window_size // 2
+    mu1, mu2 = F.conv2d(img1, w, padding=pad, groups=ch), F.conv2d(img2, w, padding=pad, groups=ch)
+    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1 = F.conv2d(img1 * img1, w, padding=pad, groups=ch) - mu1_sq
+    s2 = F.conv2d(img2 * img2, w, padding=pad, groups=ch) - mu2_sq
+    s12 = F.conv2d(img1 * img2, w, padding=pad, groups=ch) - mu12
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu12 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))).mean()
+
+
+def _plane_smoothness(t):
+    d1 = t[..., 1:, :] - t[..., :-1, :]
+    d2 = d1[..., 1:, :] - d1[..., :-1, :]
+    return torch.square(d2).mean()
+
+
+def psnr(img1, img2):
+    mse = ((img1 - img2) ** 2).reshape(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+def training_loss(pc: GaussianParams, pkg: Dict, gt_image, gt_depth, gt_feat, hyper, opt, stage="fine"):
+    """train.py:395-425 for a batch of one view."""
+    image = pkg["render"].unsqueeze(0)
+    gt = gt_image.unsqueeze(0)
+    loss = l1_loss(image, gt[:, :3])
+    if "fine" in stage and not hyper.no_dx and opt.lambda_dx != 0:
+        loss = loss + torch.mean(torch.abs(pkg["dx"])) * opt.lambda_dx
+    if "fine" in stage and not hyper.no_dshs and opt.lambda_dshs != 0:
+        loss = loss + torch.mean(torch.abs(pkg["dshs"])) * opt.lambda_dshs
+    if opt.lambda_depth != 0:
+        loss = loss + compute_depth_l2(pkg["depth"].unsqueeze(0), gt_depth.unsqueeze(0)) * opt.lambda_depth
+    if stage == "fine" and hyper.time_smoothness_weight != 0:
+        loss = loss + pc.compute_regulation(hyper.time_smoothness_weight, hyper.l1_time_planes, hyper.plane_tv_weight)
+    if opt.lambda_dssim != 0:
+        loss = loss + opt.lambda_dssim * (1.0 - ssim(image, gt))
+    if stage == "fine" and hyper.feat_head:
+        loss = loss + l2_loss(pkg["feat"], gt_feat) * opt.lambda_feat
+    return loss
+
+
+def training_step(pc: GaussianParams, cam: Dict, gt_image, gt_depth, gt_feat, hyper, opt, bg, stage="fine",
+                  pipe: Optional[SimpleNamespace] = None, grad_hook=None):
+    """One iteration of train.py for one view: render -> loss -> backward -> Adam step.  `grad_hook(pc, pkg)` runs
+    between backward and the optimizer step (used by the data-parallel wrapper for the RCCL all-reduce)."""
+    pipe = pipe or SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
+    pkg = render(cam, pc, pipe, bg, stage=stage, return_dx=True, render_feat=(stage == "fine" and hyper.feat_head))
+    loss = training_loss(pc, pkg, gt_image, gt_depth, gt_feat, hyper, opt, stage)
+    loss.backward()
+    if grad_hook is not None:
+        grad_hook(pc, pkg)
+    pc.optimizer.step()
+    pc.optimizer.zero_grad(set_to_none=True)
+    return loss.detach(), pkg
