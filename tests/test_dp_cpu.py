@@ -1,0 +1,84 @@
+"""World-size-2 gloo tests (CPU) of the view-parallel data-parallel helpers (s3gaussian_amd/dp.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from s3gaussian_amd import dp
+    r, w, _ = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    # a parameter set shaped like the real one: row-major tensors, a channels_last plane, and an unused (grad None) head
+    params = [torch.nn.Parameter(torch.zeros(1000, 3)), torch.nn.Parameter(torch.zeros(1000, 15, 3)),
+              torch.nn.Parameter(torch.zeros(1, 32, 8, 16).contiguous(memory_format=torch.channels_last)),
+              torch.nn.Parameter(torch.zeros(64, 64)), torch.nn.Parameter(torch.zeros(7))]
+    g = torch.Generator().manual_seed(100 + rank)
+    for p in params[:-1]:
+        grad = torch.randn(p.shape, generator=g)
+        p.grad = grad.contiguous(memory_format=torch.channels_last) if p.dim() == 4 else grad
+    red = dp.GradAllReducer(params, bucket_mb=0.02)  # tiny buckets: exercise the bucket boundaries
+    n = red()
+    expect = []
+    for p in params[:-1]:
+        acc = torch.zeros(p.shape)
+        for rr in range(world):
+            gg = torch.Generator().manual_seed(100 + rr)
+            for q_ in params[:-1]:
+                t = torch.randn(q_.shape, generator=gg)
+                if q_ is p:
+                    acc += t
+        expect.append(acc / world)
+    ok = all(torch.allclose(p.grad, e, atol=1e-6) for p, e in zip(params[:-1], expect)) and params[-1].grad is None
+    ok = ok and params[2].grad.is_contiguous(memory_format=torch.channels_last)
+    ok = ok and n == sum(p.numel() for p in params[:-1])
+    # densification statistics
+    vg = torch.full((10, 3), float(rank + 1))
+    vis = torch.arange(10) % (rank + 2) == 0
+    radii = torch.arange(10, dtype=torch.int32) * (rank + 1)
+    gn, cnt, rmax = dp.reduce_densification_stats(vg, vis, radii)
+    exp_gn = sum((torch.full((10,), (rr + 1) * 2 ** 0.5) * (torch.arange(10) % (rr + 2) == 0)) for rr in range(world))
+    exp_cnt = sum((torch.arange(10) % (rr + 2) == 0).float() for rr in range(world))
+    ok = ok and torch.allclose(gn[:, 0], exp_gn, atol=1e-5) and torch.allclose(cnt[:, 0], exp_cnt)
+    ok = ok and torch.equal(rmax, torch.arange(10, dtype=torch.int32) * world)
+    # view sharding: disjoint, covering, same permutation on every rank
+    mine = dp.shard_views(150, rank, world, seed=0)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    flat = sorted(v for g_ in gathered for v in g_)
+    ok = ok and flat == list(range(150))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_view_parallel_helpers_world_size_2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert results == {0: True, 1: True}
+
+
+def test_single_process_is_a_noop():
+    from s3gaussian_amd import dp
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    assert dp.GradAllReducer([p])() == 0
+    assert torch.equal(p.grad, torch.ones(4))
+    assert dp.shard_views(10, 0, 1) == dp.shard_views(10, 0, 1)
