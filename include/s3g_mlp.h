@@ -1,0 +1,52 @@
+/*
+ * s3g_mlp.h -- C ABI of the fused deformation-MLP kernels (fp32 MFMA on gfx950, libs3g.so).
+ *
+ *   s3g_deform_mlp_forward   <- Deformation.query_time's feature_out + the pos_deform / shs_deform / dino_head
+ *                               Sequentials of forward_dynamic   (/root/reference/scene/deformation.py:53-76,78-94,108-166)
+ *   s3g_deform_mlp_backward  <- their autograd (10 nn.Linear backward GEMM pairs + ReLU masks)
+ *
+ * Network (reference defaults, arguments/__init__.py:204-233: net_width 64, defor_depth 1, feat_head on):
+ *   hidden = W0 x + b0                                   x: HexPlane features [P,128]
+ *   dx     = P2 relu(P1 relu(hidden) + pb1) + pb2        [P,3]
+ *   dshs   = S2 relu(S1 relu(hidden) + sb1) + sb2        [P,48]
+ *   feat   = D2 relu(D1 relu(D0 hidden + db0) + db1) + db2   [P,3]   (dino_head has NO leading ReLU, deformation.py:70-76)
+ * Weights are torch nn.Linear tensors as they are: weight [out,in] row-major, bias [out], device fp32.
+ * Arithmetic: v_mfma_f32_32x32x2_f32 = exact fp32 fma chains (no reduced precision).
+ */
+#ifndef S3G_MLP_H
+#define S3G_MLP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct s3g_mlp_params {  /* the same struct describes weights (const use) and their gradients */
+  float *W0, *b0;   /* feature_out.0  [64,128], [64] */
+  float *P1, *pb1;  /* pos_deform.1   [64,64],  [64] */
+  float *P2, *pb2;  /* pos_deform.3   [3,64],   [3]  */
+  float *S1, *sb1;  /* shs_deform.1   [64,64],  [64] */
+  float *S2, *sb2;  /* shs_deform.3   [48,64],  [48] */
+  float *D0, *db0;  /* dino_head.0    [64,64],  [64] */
+  float *D1, *db1;  /* dino_head.2    [64,64],  [64] */
+  float *D2, *db2;  /* dino_head.4    [3,64],   [3]  */
+} s3g_mlp_params;
+
+/* bytes of the activation stash written by forward and read by backward: 5 x [P,64] fp32
+ * (hidden, pos1, shs1, dino1, dino2); the backward workspace (5 gradient signals) has the same size. */
+size_t s3g_deform_mlp_stash_bytes(int P);
+
+/* features [P,128] -> dx [P,3], dshs [P,48], feat [P,3]; `stash` may be NULL when no backward will follow. */
+int s3g_deform_mlp_forward(const s3g_mlp_params* w, int P, const float* features, float* dx, float* dshs, float* feat,
+                           float* stash, void* stream);
+
+/* g_dx [P,3], g_dshs [P,48], g_feat [P,3] (upstream gradients) -> g_features [P,128] (written) and the parameter
+ * gradients in `gw` (ACCUMULATED: the caller zero-fills them).  `stash` from the matching forward; `workspace` of
+ * s3g_deform_mlp_stash_bytes(P) bytes, uninitialised. */
+int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* features, const float* stash, const float* g_dx,
+                            const float* g_dshs, const float* g_feat, float* g_features, const s3g_mlp_params* gw,
+                            float* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from .hexplane import HexPlaneField
+from .mlp import deform_mlp
 
 
 def _head(W, out):
@@ -63,8 +64,21 @@ class Deformation(nn.Module):
             raise NotImplementedError("forward_static needs static_mlp, which the reference defaults disable")
         return self.forward_dynamic(rays_pts_emb, scales_emb, rotations_emb, opacity, shs_emb, time_feature, time_emb)
 
+    def _fused_ok(self):
+        a = self.args
+        return (self.D == 1 and self.W == 64 and self.grid.feat_dim == 128 and not a.no_dx and not a.no_dshs and a.no_ds
+                and a.no_dr and a.no_do and a.feat_head)
+
     def forward_dynamic(self, rays_pts_emb, scales_emb, rotations_emb, opacity_emb, shs_emb, time_feature, time_emb):
         a = self.args
+        if self._fused_ok() and rays_pts_emb.is_cuda:
+            # reference default configuration: HexPlane sampler -> one fused MFMA MLP kernel (include/s3g_mlp.h)
+            feats = self.grid(rays_pts_emb[:, :3], time_emb[:, :1])
+            dx, dshs, feat = deform_mlp(feats, self.feature_out, self.pos_deform, self.shs_deform, self.dino_head)
+            dshs = dshs.reshape([shs_emb.shape[0], 16, 3])
+            return (rays_pts_emb[:, :3] + dx, scales_emb[:, :3], rotations_emb[:, :4], opacity_emb[:, :1], shs_emb + dshs,
+                    dx, feat, dshs)
+        # other switch combinations: HexPlane sampler + library GEMMs
         hidden = self.query_time(rays_pts_emb, scales_emb, rotations_emb, time_feature, time_emb)
         dx = dshs = feat = None
         pts = rays_pts_emb[:, :3]

@@ -1,0 +1,95 @@
+"""Fused deformation MLP (feature_out + pos/shs/dino heads) on the MI355X matrix cores; see include/s3g_mlp.h."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_NAMES = ["W0", "b0", "P1", "pb1", "P2", "pb2", "S1", "sb1", "S2", "sb2", "D0", "db0", "D1", "db1", "D2", "db2"]
+_SHAPES = [(64, 128), (64,), (64, 64), (64,), (3, 64), (3,), (64, 64), (64,), (48, 64), (48,), (64, 64), (64,), (64, 64),
+           (64,), (3, 64), (3,)]
+
+
+class _Params(C.Structure):
+    """struct s3g_mlp_params (include/s3g_mlp.h)."""
+    _fields_ = [(n, C.c_void_p) for n in _NAMES]
+
+
+_bound = False
+
+
+def _bind():
+    global _bound
+    L = _lib.lib()
+    if not _bound:
+        vp = C.c_void_p
+        L.s3g_deform_mlp_stash_bytes.restype = C.c_size_t
+        L.s3g_deform_mlp_stash_bytes.argtypes = [C.c_int]
+        L.s3g_deform_mlp_forward.restype = C.c_int
+        L.s3g_deform_mlp_forward.argtypes = [C.POINTER(_Params), C.c_int, vp, vp, vp, vp, vp, vp]
+        L.s3g_deform_mlp_backward.restype = C.c_int
+        L.s3g_deform_mlp_backward.argtypes = [C.POINTER(_Params), C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(_Params), vp, vp]
+        _bound = True
+    return L
+
+
+def _pack(tensors) -> _Params:
+    p = _Params()
+    for n, shape, t in zip(_NAMES, _SHAPES, tensors):
+        if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError(f"deform MLP: parameter {n} must be contiguous float32 {shape}, got {tuple(t.shape)} {t.dtype}")
+        setattr(p, n, t.data_ptr())
+    return p
+
+
+class _DeformMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, *params):
+        if not features.is_cuda:
+            raise RuntimeError(f"deform MLP: features must live on the GPU (got {features.device}); no CPU fallback")
+        L = _bind()
+        x = features.contiguous().float()
+        P, dev = x.shape[0], x.device
+        dx = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        dshs = torch.empty((P, 48), dtype=torch.float32, device=dev)
+        feat = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        need_bwd = any(ctx.needs_input_grad)
+        stash = torch.empty((5, P, 64), dtype=torch.float32, device=dev) if need_bwd else None
+        w = _pack([p.detach() for p in params])
+        with torch.cuda.device(dev):
+            _lib.check(L.s3g_deform_mlp_forward(C.byref(w), P, x.data_ptr(), dx.data_ptr(), dshs.data_ptr(), feat.data_ptr(),
+                                                stash.data_ptr() if stash is not None else None,
+                                                torch.cuda.current_stream().cuda_stream))
+        if need_bwd:
+            ctx.save_for_backward(x, stash, *params)
+        return dx, dshs, feat
+
+    @staticmethod
+    def backward(ctx, g_dx, g_dshs, g_feat):
+        x, stash, *params = ctx.saved_tensors
+        L = _bind()
+        P, dev = x.shape[0], x.device
+        z = lambda g, n: (torch.zeros((P, n), dtype=torch.float32, device=dev) if g is None else g.contiguous().float())
+        g_dx, g_dshs, g_feat = z(g_dx, 3), z(g_dshs, 48), z(g_feat, 3)
+        gx = torch.empty_like(x)
+        grads = [torch.zeros_like(p) for p in params]
+        ws = torch.empty((5, P, 64), dtype=torch.float32, device=dev)
+        w, gw = _pack([p.detach() for p in params]), _pack(grads)
+        with torch.cuda.device(dev):
+            _lib.check(L.s3g_deform_mlp_backward(C.byref(w), P, x.data_ptr(), stash.data_ptr(), g_dx.data_ptr(),
+                                                 g_dshs.data_ptr(), g_feat.data_ptr(), gx.data_ptr(), C.byref(gw),
+                                                 ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return (gx, *grads)
+
+
+def deform_mlp(features, feature_out, pos_deform, shs_deform, dino_head):
+    """features [P,128] -> (dx [P,3], dshs [P,48], feat [P,3]) with the reference's Sequential modules as parameter
+    holders (feature_out = Sequential(Linear); heads = Sequential(ReLU, Linear, ReLU, Linear); dino = Sequential(Linear,
+    ReLU, Linear, ReLU, Linear))."""
+    ps = [feature_out[0].weight, feature_out[0].bias, pos_deform[1].weight, pos_deform[1].bias, pos_deform[3].weight,
+          pos_deform[3].bias, shs_deform[1].weight, shs_deform[1].bias, shs_deform[3].weight, shs_deform[3].bias,
+          dino_head[0].weight, dino_head[0].bias, dino_head[2].weight, dino_head[2].bias, dino_head[4].weight,
+          dino_head[4].bias]
+    return _DeformMLP.apply(features, *ps)
