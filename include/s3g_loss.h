@@ -16,9 +16,9 @@
 extern "C" {
 #endif
 
-/* img1, img2: [C,H,W] fp32 device.  ssim_sum: device float, ACCUMULATED (caller zeroes): sum of the SSIM map, the loss
+/* img1, img2: [C,H,W] fp32 device.  ssim_sum: device DOUBLE, ACCUMULATED (caller zeroes): sum of the SSIM map, the loss
  * value is ssim_sum / (C*H*W).  dm_dmu1, dm_dsigma1_sq, dm_dsigma12: [C,H,W] scratch kept for the backward. */
-int s3g_ssim_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_sum, float* dm_dmu1,
+int s3g_ssim_forward(int C, int H, int W, const float* img1, const float* img2, double* ssim_sum, float* dm_dmu1,
                      float* dm_dsigma1_sq, float* dm_dsigma12, void* stream);
 
 /* dL_dimg1[C,H,W] = (*dL_dmean / (C*H*W)) * d(sum of SSIM map)/d img1.  dL_dmean: device float (upstream gradient of
@@ -26,6 +26,28 @@ int s3g_ssim_forward(int C, int H, int W, const float* img1, const float* img2, 
 int s3g_ssim_backward(int C, int H, int W, const float* img1, const float* img2, const float* dm_dmu1,
                       const float* dm_dsigma1_sq, const float* dm_dsigma12, const float* dL_dmean, float* dL_dimg1,
                       void* stream);
+
+/*
+ *   s3g_plane_regulation  <- GaussianModel.compute_regulation = _plane_regulation + _time_regulation + _l1_regulation
+ *                            (/root/reference/scene/gaussian_model.py:710-749) over compute_plane_smoothness
+ *                            (/root/reference/scene/regulation.py:22-28), forward value AND gradient in one pass.
+ * The reference launches ~25 elementwise/reduction kernels per plane and direction (24 planes -> ~600 launches per
+ * iteration, several full sweeps over the 143 MB of planes); here every plane element is read once.
+ *
+ * Per plane (logical [1,C,H,W], channel-last bytes [H][W][C], C = 32):
+ *   value += w_smooth * mean_{c,h<H-2,w} (p[h+2]-2p[h+1]+p[h])^2  +  w_l1 * mean |1 - p|
+ *   grad   = d value / d p      (written, not accumulated)
+ */
+typedef struct s3g_plane_reg_desc {
+  const float* plane;   /* device, channel-last */
+  float* grad;          /* device, same layout, written */
+  int H, W;
+  float w_smooth, w_l1; /* plane_tv_weight or time_smoothness_weight ; l1_time_planes or 0 */
+} s3g_plane_reg_desc;
+
+#define S3G_MAX_REG_PLANES 48
+/* value: device DOUBLE, ACCUMULATED (caller zeroes). */
+int s3g_plane_regulation(int nplanes, const s3g_plane_reg_desc* planes, double* value, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ static SsimWindow make_window() {  // gaussian(11, 1.5), loss_utils.py:56-58, co
 
 __global__ void __launch_bounds__(256) ssim_forward_kernel(int C, int H, int W, const float* __restrict__ img1,
                                                            const float* __restrict__ img2, const SsimWindow win,
-                                                           float* __restrict__ ssim_sum, float* __restrict__ m_mu1,
+                                                           double* __restrict__ ssim_sum, float* __restrict__ m_mu1,
                                                            float* __restrict__ m_s11, float* __restrict__ m_s12) {
   __shared__ float t1[SS_H][SS_H + 1], t2[SS_H][SS_H + 1];
   __shared__ float hb[5][SS_H][SS_T + 1];
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(int C, int H, int W, 
   for (int off = 32; off >= 1; off >>= 1) val += __shfl_xor(val, off);
   if ((tid & 63) == 0) red[tid >> 6] = val;
   __syncthreads();
-  if (tid == 0) atomicAdd(ssim_sum, red[0] + red[1] + red[2] + red[3]);
+  if (tid == 0) atomicAdd(ssim_sum, (double)(red[0] + red[1] + red[2] + red[3]));
 }
 
 __global__ void __launch_bounds__(256) ssim_backward_kernel(int C, int H, int W, const float* __restrict__ img1,
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(int C, int H, int W,
 
 using namespace s3g;
 
-extern "C" int s3g_ssim_forward(int C, int H, int W, const float* img1, const float* img2, float* ssim_sum, float* dm_dmu1,
+extern "C" int s3g_ssim_forward(int C, int H, int W, const float* img1, const float* img2, double* ssim_sum, float* dm_dmu1,
                                 float* dm_dsigma1_sq, float* dm_dsigma12, void* stream_) {
   if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !ssim_sum || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12) {
     set_error("s3g_ssim_forward: bad argument");
@@ -155,6 +155,87 @@ extern "C" int s3g_ssim_backward(int C, int H, int W, const float* img1, const f
   dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C);
   hipLaunchKernelGGL(ssim_backward_kernel, grid, dim3(256), 0, (hipStream_t)stream_, C, H, W, img1, img2, win, dm_dmu1,
                      dm_dsigma1_sq, dm_dsigma12, dL_dmean, dL_dimg1);
+  S3G_HIP_CHECK(hipGetLastError());
+  return S3G_OK;
+}
+
+// =========================================================================================================
+// Fused HexPlane regulariser: value + gradient of scene/gaussian_model.py:710-749 in one pass over the planes.
+// =========================================================================================================
+namespace s3g {
+
+struct PlaneRegArgs {
+  s3g_plane_reg_desc pl[S3G_MAX_REG_PLANES];
+  int first_block[S3G_MAX_REG_PLANES + 1];
+  int nplanes;
+  double* value;
+};
+constexpr int PR_ROWS = 16;  // rows of one (w, c) column handled per thread
+
+__global__ void __launch_bounds__(256) plane_reg_kernel(const PlaneRegArgs a) {
+  __shared__ float red[4];
+  int pi = 0;
+  while (pi + 1 < a.nplanes && (int)blockIdx.x >= a.first_block[pi + 1]) pi++;
+  const s3g_plane_reg_desc d = a.pl[pi];
+  const int cols = d.W * 32;                       // (w, c) columns, contiguous in memory
+  const int col_blocks = (cols + 255) / 256;
+  const int b = blockIdx.x - a.first_block[pi];
+  const int col = (b % col_blocks) * 256 + threadIdx.x;
+  const int h0 = (b / col_blocks) * PR_ROWS;
+  float local = 0.f;
+  if (col < cols) {
+    const int H = d.H;
+    const float cs = H > 2 ? d.w_smooth / ((float)(H - 2) * (float)cols) : 0.f;  // mean over C*(H-2)*W
+    const float cl = d.w_l1 / ((float)H * (float)cols);
+    const float* p = d.plane + col;
+    auto at = [&](int h) { return (h >= 0 && h < H) ? p[(size_t)h * cols] : 0.f; };
+    // second differences d2[j] = p[j+2] - 2 p[j+1] + p[j], valid for 0 <= j <= H-3
+    auto d2 = [&](int j, float pj, float pj1, float pj2) { return (j >= 0 && j <= H - 3) ? (pj2 - 2.f * pj1 + pj) : 0.f; };
+    float w[5];  // p[h-2 .. h+2]
+    w[0] = at(h0 - 2); w[1] = at(h0 - 1); w[2] = at(h0); w[3] = at(h0 + 1); w[4] = at(h0 + 2);
+    for (int h = h0; h < min(h0 + PR_ROWS, H); h++) {
+      const float dm2 = d2(h - 2, w[0], w[1], w[2]), dm1 = d2(h - 1, w[1], w[2], w[3]), d0 = d2(h, w[2], w[3], w[4]);
+      local += cs * d0 * d0;                       // each d2[h] is owned by row h
+      float g = 2.f * cs * (dm2 - 2.f * dm1 + d0);
+      if (d.w_l1 != 0.f) {
+        const float x = 1.f - w[2];
+        local += cl * fabsf(x);
+        g += cl * (x > 0.f ? -1.f : (x < 0.f ? 1.f : 0.f));
+      }
+      d.grad[(size_t)h * cols + col] = g;
+      w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = w[4]; w[4] = at(h + 3);
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(a.value, (double)(red[0] + red[1] + red[2] + red[3]));
+}
+
+}  // namespace s3g
+
+extern "C" int s3g_plane_regulation(int nplanes, const s3g_plane_reg_desc* planes, double* value, void* stream_) {
+  using namespace s3g;
+  if (nplanes < 0 || nplanes > S3G_MAX_REG_PLANES || (nplanes > 0 && (!planes || !value))) {
+    set_error("s3g_plane_regulation: bad argument");
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (nplanes == 0) return S3G_OK;
+  PlaneRegArgs a;
+  a.nplanes = nplanes;
+  a.value = value;
+  int blocks = 0;
+  for (int i = 0; i < nplanes; i++) {
+    if (!planes[i].plane || !planes[i].grad || planes[i].H < 1 || planes[i].W < 1) {
+      set_error("s3g_plane_regulation: bad plane descriptor %d", i);
+      return S3G_ERR_INVALID_ARG;
+    }
+    a.pl[i] = planes[i];
+    a.first_block[i] = blocks;
+    blocks += ((planes[i].W * 32 + 255) / 256) * ((planes[i].H + PR_ROWS - 1) / PR_ROWS);
+  }
+  a.first_block[nplanes] = blocks;
+  hipLaunchKernelGGL(plane_reg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }

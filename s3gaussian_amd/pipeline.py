@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from .deformation import deform_network
 from .knn import distCUDA2
+from .losses import plane_regulation as fused_plane_regulation
 from .losses import ssim as fused_ssim
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
@@ -120,6 +121,8 @@ class GaussianParams(nn.Module):
     def compute_regulation(self, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight):
         """scene/gaussian_model.py:710-749."""
         grids = self._deformation.deformation_net.grid.grids
+        if self._xyz.is_cuda:
+            return fused_plane_regulation(grids, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight)
         sp = sum(_plane_smoothness(g[i]) for g in grids for i in (0, 1, 3))
         tm = sum(_plane_smoothness(g[i]) for g in grids for i in (2, 4, 5))
         l1 = sum(torch.abs(1 - g[i]).mean() for g in grids for i in (2, 4, 5))
