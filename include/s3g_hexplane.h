@@ -39,10 +39,13 @@ int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, co
                          void* stream);
 
 /* dL_dfeatures [P, levels*32] -> dL_dxyz [P,3] (written) and dL_dplanes[l][i] (same layout as planes; ACCUMULATED,
- * the caller zero-fills them; a NULL entry skips that plane). */
+ * the caller zero-fills them; a NULL entry skips that plane).  `workspace`: device scratch of
+ * s3g_hexplane_backward_workspace_bytes(levels, P) bytes (3 KB per point: per-plane sample gradients + sort buffers),
+ * uninitialised. */
+size_t s3g_hexplane_backward_workspace_bytes(int levels, int P);
 int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
                           const float* dL_dfeatures, float* dL_dxyz, float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6],
-                          void* stream);
+                          void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

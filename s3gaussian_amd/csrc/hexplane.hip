@@ -6,6 +6,17 @@
 // Here 32 consecutive lanes own the 32 channels of ONE point (a wave64 handles two points), so with the planes stored
 // channel-last every texel fetch is one coalesced 128-byte line and the product over planes never leaves registers.
 // Arithmetic follows torch's grid_sampler_2d (bilinear, border, align_corners=True) op for op; contraction is off.
+//
+// Backward without an atomic storm.  A direct scatter is 96 line-coalesced float atomics per point; MI355X retires
+// ~10 G such line-ops/s whatever the contention (tools/ubench/atomic_lines.hip), i.e. 11.5 ms at 1.2 M points.  So:
+//   pass A  (point order)   re-gathers the taps, applies the product rule, writes dL/ds for all 24 plane-levels to a
+//                           scratch slab G[24][P][32] (3 KB per point -- HBM is 288 GB) and finishes dL/dxyz;
+//   sort    three 2-level counting sorts of the point indices by (major, minor) 512x512 cell, one per plane
+//           orientation, with LDS histograms (no global atomics, no library sort);
+//   pass B  (sorted order, one launch per orientation = 2 plane kinds x all levels): a half-wave walks a run of
+//           spatially consecutive points keeping (texel id, partial sum) per bilinear corner in registers and only
+//           issues an atomic when the texel changes -- consecutive points share texels, so the 96 line-ops per point
+//           drop to ~4.
 #include "common.hpp"
 
 #include "../../include/s3g_hexplane.h"
@@ -96,9 +107,11 @@ __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) 
   }
 }
 
-__global__ void __launch_bounds__(256) hexplane_backward_kernel(const HexArgs a) {
+// ---- pass A: per point, dL/ds for every plane-level -> G, and dL/dxyz ----
+__global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexArgs a, float* __restrict__ G) {
   const int c = threadIdx.x & 31, slot = threadIdx.x >> 5;
   const int F = a.d.levels * HEXC;
+  const size_t PL = (size_t)a.P * HEXC;  // one plane-level slab of G
   for (int p0 = blockIdx.x * 8; p0 < a.P; p0 += gridDim.x * 8) {  // uniform trip count: shuffles below need all lanes
     const int p = p0 + slot;
     const bool live = p < a.P;
@@ -135,13 +148,7 @@ __global__ void __launch_bounds__(256) hexplane_backward_kernel(const HexArgs a)
         const float gi = gs * pre[i];  // dL/ds_i
         gs = gs * s[i];
         if (live) {
-          float* gp = a.gplanes[l][i];
-          if (gp != nullptr) {
-            if (t[i].o00 >= 0) atomicAdd(&gp[(size_t)t[i].o00 * HEXC + c], gi * t[i].w00);
-            if (t[i].o01 >= 0) atomicAdd(&gp[(size_t)t[i].o01 * HEXC + c], gi * t[i].w01);
-            if (t[i].o10 >= 0) atomicAdd(&gp[(size_t)t[i].o10 * HEXC + c], gi * t[i].w10);
-            if (t[i].o11 >= 0) atomicAdd(&gp[(size_t)t[i].o11 * HEXC + c], gi * t[i].w11);
-          }
+          G[(size_t)(l * 6 + i) * PL + (size_t)p * HEXC + c] = gi;
           // torch grid_sampler_2d_backward: gix = -nw*(iy_se-iy) + ne*(iy_sw-iy) - sw*(iy-iy_ne) + se*(iy-iy_nw), ...
           const float gix = (-v00[i] * (t[i].y1f - t[i].iy) + v01[i] * (t[i].y1f - t[i].iy) - v10[i] * (t[i].iy - t[i].y0f) +
                              v11[i] * (t[i].iy - t[i].y0f)) * gi;
@@ -160,6 +167,163 @@ __global__ void __launch_bounds__(256) hexplane_backward_kernel(const HexArgs a)
       du[k] = v;
     }
     if (live && c < 3) a.gxyz[3 * (size_t)p + c] = du[c] * (2.0f / (a.d.aabb_min[c] - a.d.aabb_max[c]));
+  }
+}
+
+// ---- sort: point indices ordered by (major cell, minor cell) on a 512 x 512 grid, per orientation ----
+// orientation o: major axis MAJ[o], minor axis MIN_[o]; handles planes PLA[o] (spatial) and PLT[o] (the major axis vs time)
+constexpr int SORT_BINS = 512, SORT_NB = 256;
+__device__ constexpr int MAJ[3] = {0, 1, 2};
+__device__ constexpr int MIN_[3] = {1, 2, 0};
+__device__ constexpr int PLA[3] = {0, 3, 1};  // (x,y) (y,z) (x,z)
+__device__ constexpr int PLT[3] = {2, 4, 5};  // (x,t) (y,t) (z,t)
+
+__device__ __forceinline__ int sort_cell(const HexArgs& a, int p, int axis) {
+  const float u = (a.xyz[3 * (size_t)p + axis] - a.d.aabb_max[axis]) * (2.0f / (a.d.aabb_min[axis] - a.d.aabb_max[axis])) - 1.0f;
+  const int cidx = (int)floorf((u + 1.f) * 0.5f * (float)SORT_BINS);
+  return min(SORT_BINS - 1, max(0, cidx));
+}
+
+struct SortWork {
+  uint32_t* table;      // [3][SORT_NB][SORT_BINS]
+  uint32_t* seg_start;  // [3][SORT_BINS + 1]
+  uint32_t* tmp;        // [3][P]  indices grouped by major cell
+  uint32_t* order;      // [3][P]  final order
+};
+
+template <bool WRITE>
+__global__ void __launch_bounds__(256) hexsort_major_kernel(const HexArgs a, const SortWork w, int chunk) {
+  __shared__ uint32_t cell[SORT_BINS];
+  const int o = blockIdx.y;
+  uint32_t* row = w.table + ((size_t)o * SORT_NB + blockIdx.x) * SORT_BINS;
+  for (int i = threadIdx.x; i < SORT_BINS; i += 256) cell[i] = WRITE ? w.seg_start[o * (SORT_BINS + 1) + i] + row[i] : 0u;
+  __syncthreads();
+  const int g0 = blockIdx.x * chunk, g1 = min(a.P, g0 + chunk);
+  for (int g = g0 + threadIdx.x; g < g1; g += 256) {
+    const uint32_t pos = atomicAdd(&cell[sort_cell(a, g, MAJ[o])], 1u);
+    if (WRITE) w.tmp[(size_t)o * a.P + pos] = (uint32_t)g;
+  }
+  if (!WRITE) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < SORT_BINS; i += 256) row[i] = cell[i];
+  }
+}
+
+// one workgroup per orientation: per-bin prefix over the SORT_NB workgroups, then exclusive scan of the bin totals
+__global__ void __launch_bounds__(512) hexsort_scan_kernel(const SortWork w, int P) {
+  __shared__ uint32_t tot[SORT_BINS];
+  const int o = blockIdx.x, b = threadIdx.x;
+  uint32_t* tab = w.table + (size_t)o * SORT_NB * SORT_BINS;
+  uint32_t run = 0;
+  for (int k = 0; k < SORT_NB; k++) {
+    const uint32_t v = tab[(size_t)k * SORT_BINS + b];
+    tab[(size_t)k * SORT_BINS + b] = run;
+    run += v;
+  }
+  tot[b] = run;
+  __syncthreads();
+  if (b == 0) {
+    uint32_t acc = 0;
+    for (int i = 0; i < SORT_BINS; i++) {
+      w.seg_start[o * (SORT_BINS + 1) + i] = acc;
+      acc += tot[i];
+    }
+    w.seg_start[o * (SORT_BINS + 1) + SORT_BINS] = acc;
+  }
+}
+
+// one workgroup per (major bin, orientation): counting sort of the segment by minor cell
+__global__ void __launch_bounds__(256) hexsort_minor_kernel(const HexArgs a, const SortWork w) {
+  __shared__ uint32_t cnt[SORT_BINS];
+  __shared__ uint32_t wsum[4];
+  const int o = blockIdx.y, bin = blockIdx.x, tid = threadIdx.x;
+  const uint32_t s0 = w.seg_start[o * (SORT_BINS + 1) + bin], s1 = w.seg_start[o * (SORT_BINS + 1) + bin + 1];
+  if (s1 == s0) return;
+  const uint32_t* tmp = w.tmp + (size_t)o * a.P;
+  uint32_t* order = w.order + (size_t)o * a.P;
+  for (int i = tid; i < SORT_BINS; i += 256) cnt[i] = 0u;
+  __syncthreads();
+  for (uint32_t k = s0 + tid; k < s1; k += 256) atomicAdd(&cnt[sort_cell(a, (int)tmp[k], MIN_[o])], 1u);
+  __syncthreads();
+  // exclusive scan of 512 counters: each thread owns two consecutive bins
+  const uint32_t c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
+  uint32_t incl = c0 + c1;
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t base = s0;
+  for (int k = 0; k < wave; k++) base += wsum[k];
+  const uint32_t excl = base + incl - (c0 + c1);
+  __syncthreads();
+  cnt[2 * tid] = excl;
+  cnt[2 * tid + 1] = excl + c0;
+  __syncthreads();
+  for (uint32_t k = s0 + tid; k < s1; k += 256) {
+    const uint32_t g = tmp[k];
+    order[atomicAdd(&cnt[sort_cell(a, (int)g, MIN_[o])], 1u)] = g;
+  }
+}
+
+// ---- pass B: scatter in sorted order with register run-length combining ----
+constexpr int SEG = 128;  // sorted points walked by one half-wave
+
+struct Slot {
+  int id;
+  float acc;
+};
+__device__ __forceinline__ void slot_add(Slot& sl, int id, float v, float* __restrict__ gp, int c) {
+  if (id != sl.id) {
+    if (sl.id >= 0) atomicAdd(&gp[(size_t)sl.id * HEXC + c], sl.acc);
+    sl.id = id;
+    sl.acc = 0.f;
+  }
+  sl.acc += v;
+}
+
+__global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
+                                                               const uint32_t* __restrict__ order_all) {
+  const int o = blockIdx.y;
+  const int c = threadIdx.x & 31;
+  const int seg = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int k0 = seg * SEG, k1 = min(a.P, k0 + SEG);
+  if (k0 >= a.P) return;
+  const uint32_t* order = order_all + (size_t)o * a.P;
+  const size_t PL = (size_t)a.P * HEXC;
+  const int planes2[2] = {PLA[o], PLT[o]};
+  for (int l = 0; l < a.d.levels; l++) {
+    Slot sl[2][4];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) sl[q][r] = Slot{-1, 0.f};
+    float* gp[2] = {a.gplanes[l][planes2[0]], a.gplanes[l][planes2[1]]};
+    for (int k = k0; k < k1; k++) {
+      const int p = (int)order[k];
+      float u[4];
+      point_coords(a, p, u);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        if (gp[q] == nullptr) continue;
+        const int i = planes2[q];
+        const int ax0 = i == 0 ? 0 : i == 1 ? 0 : i == 2 ? 0 : i == 3 ? 1 : i == 4 ? 1 : 2;
+        const int ax1 = i == 0 ? 1 : i == 1 ? 2 : i == 2 ? 3 : i == 3 ? 2 : i == 4 ? 3 : 3;
+        const Tap t = make_tap(u[ax0], u[ax1], a.d.res[l][ax0], a.d.res[l][ax1]);
+        const float g = G[(size_t)(l * 6 + i) * PL + (size_t)p * HEXC + c];
+        if (t.o00 >= 0) slot_add(sl[q][0], t.o00, g * t.w00, gp[q], c);
+        if (t.o01 >= 0) slot_add(sl[q][1], t.o01, g * t.w01, gp[q], c);
+        if (t.o10 >= 0) slot_add(sl[q][2], t.o10, g * t.w10, gp[q], c);
+        if (t.o11 >= 0) slot_add(sl[q][3], t.o11, g * t.w11, gp[q], c);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (sl[q][r].id >= 0 && gp[q] != nullptr) atomicAdd(&gp[q][(size_t)sl[q][r].id * HEXC + c], sl[q][r].acc);
   }
 }
 
@@ -204,22 +368,51 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
   return S3G_OK;
 }
 
+extern "C" size_t s3g_hexplane_backward_workspace_bytes(int levels, int P) {
+  if (levels < 1 || P < 0) return 0;
+  Carver c(nullptr);
+  c.take<float>((size_t)levels * 6 * P * HEXC);
+  c.take<uint32_t>((size_t)3 * SORT_NB * SORT_BINS);
+  c.take<uint32_t>((size_t)3 * (SORT_BINS + 1));
+  c.take<uint32_t>((size_t)3 * P);
+  c.take<uint32_t>((size_t)3 * P);
+  return c.bytes();
+}
+
 extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
                                      const float* dL_dfeatures, float* dL_dxyz,
-                                     float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* stream_) {
+                                     float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* workspace, void* stream_) {
   if (int e = check_desc(d)) return e;
-  if (P < 0 || (P > 0 && (!xyz || !time || !dL_dfeatures || !dL_dxyz || !dL_dplanes))) {
+  if (P < 0 || (P > 0 && (!xyz || !time || !dL_dfeatures || !dL_dxyz || !dL_dplanes || !workspace))) {
     set_error("s3g_hexplane_backward: bad argument");
     return S3G_ERR_INVALID_ARG;
   }
   if (P == 0) return S3G_OK;
+  hipStream_t stream = (hipStream_t)stream_;
   HexArgs a;
   memset(&a, 0, sizeof a);
   a.d = *d; a.P = P; a.xyz = xyz; a.time = time; a.gfeat = dL_dfeatures; a.gxyz = dL_dxyz;
   for (int l = 0; l < d->levels; l++)
     for (int i = 0; i < 6; i++) a.gplanes[l][i] = dL_dplanes[l][i];
+  Carver c(workspace);
+  float* G = c.take<float>((size_t)d->levels * 6 * P * HEXC);
+  SortWork w;
+  w.table = c.take<uint32_t>((size_t)3 * SORT_NB * SORT_BINS);
+  w.seg_start = c.take<uint32_t>((size_t)3 * (SORT_BINS + 1));
+  w.tmp = c.take<uint32_t>((size_t)3 * P);
+  w.order = c.take<uint32_t>((size_t)3 * P);
+
   const int blocks = min((P + 7) / 8, 256 * 16);
-  hipLaunchKernelGGL(hexplane_backward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
+  hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3(blocks), dim3(256), 0, stream, a, G);
+  S3G_HIP_CHECK(hipGetLastError());
+  const int chunk = (((P + SORT_NB - 1) / SORT_NB + 255) / 256) * 256;
+  hipLaunchKernelGGL(hexsort_major_kernel<false>, dim3(SORT_NB, 3), dim3(256), 0, stream, a, w, chunk);
+  hipLaunchKernelGGL(hexsort_scan_kernel, dim3(3), dim3(512), 0, stream, w, P);
+  hipLaunchKernelGGL(hexsort_major_kernel<true>, dim3(SORT_NB, 3), dim3(256), 0, stream, a, w, chunk);
+  hipLaunchKernelGGL(hexsort_minor_kernel, dim3(SORT_BINS, 3), dim3(256), 0, stream, a, w);
+  S3G_HIP_CHECK(hipGetLastError());
+  const int nseg = (P + SEG - 1) / SEG;
+  hipLaunchKernelGGL(hexplane_scatter_kernel, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, G, w.order);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }

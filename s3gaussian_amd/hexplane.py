@@ -40,7 +40,9 @@ def _bind():
         L.s3g_hexplane_forward.restype = C.c_int
         L.s3g_hexplane_forward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp]
         L.s3g_hexplane_backward.restype = C.c_int
-        L.s3g_hexplane_backward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, C.POINTER(_PlanePtrs), vp]
+        L.s3g_hexplane_backward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, C.POINTER(_PlanePtrs), vp, vp]
+        L.s3g_hexplane_backward_workspace_bytes.restype = C.c_size_t
+        L.s3g_hexplane_backward_workspace_bytes.argtypes = [C.c_int, C.c_int]
         _bound = True
     return L
 
@@ -103,9 +105,12 @@ class _HexPlaneSample(torch.autograd.Function):
                 g = gplanes[l * 6 + i]
                 ptrs[l][i] = _channels_last_ptr(g) if g is not None else None
         d = _make_desc(planes, resolutions, aabb_host)
+        work = torch.empty(L.s3g_hexplane_backward_workspace_bytes(len(resolutions), P), dtype=torch.uint8,
+                           device=xyz_c.device)
         with torch.cuda.device(xyz_c.device):
             _lib.check(L.s3g_hexplane_backward(C.byref(d), P, xyz_c.data_ptr(), t_c.data_ptr(), gfeat.data_ptr(),
-                                               gxyz.data_ptr(), C.byref(ptrs), torch.cuda.current_stream().cuda_stream))
+                                               gxyz.data_ptr(), C.byref(ptrs), work.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream))
         return (gxyz if ctx.needs_input_grad[0] else None, None, None, *gplanes)
 
 
