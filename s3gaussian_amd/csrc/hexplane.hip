@@ -293,37 +293,59 @@ __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, 
   if (k0 >= a.P) return;
   const uint32_t* order = order_all + (size_t)o * a.P;
   const size_t PL = (size_t)a.P * HEXC;
-  const int planes2[2] = {PLA[o], PLT[o]};
-  for (int l = 0; l < a.d.levels; l++) {
-    Slot sl[2][4];
+  const int i0 = PLA[o], i1 = PLT[o];
+  const int ax00 = PAIR0[i0], ax01 = PAIR1[i0], ax10 = PAIR0[i1], ax11 = PAIR1[i1];
+  constexpr int LG = 4;  // levels handled together: (2 planes x 4 corners) x 4 levels = 32 run-length slots in registers
+  for (int l0 = 0; l0 < a.d.levels; l0 += LG) {
+    Slot sl[LG][2][4];
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int l = 0; l < LG; l++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) sl[q][r] = Slot{-1, 0.f};
-    float* gp[2] = {a.gplanes[l][planes2[0]], a.gplanes[l][planes2[1]]};
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) sl[l][q][r] = Slot{-1, 0.f};
     for (int k = k0; k < k1; k++) {
       const int p = (int)order[k];
       float u[4];
       point_coords(a, p, u);
+      float g[LG][2];
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
-        if (gp[q] == nullptr) continue;
-        const int i = planes2[q];
-        const int ax0 = i == 0 ? 0 : i == 1 ? 0 : i == 2 ? 0 : i == 3 ? 1 : i == 4 ? 1 : 2;
-        const int ax1 = i == 0 ? 1 : i == 1 ? 2 : i == 2 ? 3 : i == 3 ? 2 : i == 4 ? 3 : 3;
-        const Tap t = make_tap(u[ax0], u[ax1], a.d.res[l][ax0], a.d.res[l][ax1]);
-        const float g = G[(size_t)(l * 6 + i) * PL + (size_t)p * HEXC + c];
-        if (t.o00 >= 0) slot_add(sl[q][0], t.o00, g * t.w00, gp[q], c);
-        if (t.o01 >= 0) slot_add(sl[q][1], t.o01, g * t.w01, gp[q], c);
-        if (t.o10 >= 0) slot_add(sl[q][2], t.o10, g * t.w10, gp[q], c);
-        if (t.o11 >= 0) slot_add(sl[q][3], t.o11, g * t.w11, gp[q], c);
+      for (int l = 0; l < LG; l++) {  // all G rows of this point are requested before the first is consumed
+        const bool on = l0 + l < a.d.levels;
+        g[l][0] = (on && a.gplanes[l0 + l][i0]) ? G[(size_t)((l0 + l) * 6 + i0) * PL + (size_t)p * HEXC + c] : 0.f;
+        g[l][1] = (on && a.gplanes[l0 + l][i1]) ? G[(size_t)((l0 + l) * 6 + i1) * PL + (size_t)p * HEXC + c] : 0.f;
+      }
+#pragma unroll
+      for (int l = 0; l < LG; l++) {
+        if (l0 + l >= a.d.levels) break;
+        float* gp0 = a.gplanes[l0 + l][i0];
+        float* gp1 = a.gplanes[l0 + l][i1];
+        if (gp0 != nullptr) {
+          const Tap t = make_tap(u[ax00], u[ax01], a.d.res[l0 + l][ax00], a.d.res[l0 + l][ax01]);
+          if (t.o00 >= 0) slot_add(sl[l][0][0], t.o00, g[l][0] * t.w00, gp0, c);
+          if (t.o01 >= 0) slot_add(sl[l][0][1], t.o01, g[l][0] * t.w01, gp0, c);
+          if (t.o10 >= 0) slot_add(sl[l][0][2], t.o10, g[l][0] * t.w10, gp0, c);
+          if (t.o11 >= 0) slot_add(sl[l][0][3], t.o11, g[l][0] * t.w11, gp0, c);
+        }
+        if (gp1 != nullptr) {
+          const Tap t = make_tap(u[ax10], u[ax11], a.d.res[l0 + l][ax10], a.d.res[l0 + l][ax11]);
+          if (t.o00 >= 0) slot_add(sl[l][1][0], t.o00, g[l][1] * t.w00, gp1, c);
+          if (t.o01 >= 0) slot_add(sl[l][1][1], t.o01, g[l][1] * t.w01, gp1, c);
+          if (t.o10 >= 0) slot_add(sl[l][1][2], t.o10, g[l][1] * t.w10, gp1, c);
+          if (t.o11 >= 0) slot_add(sl[l][1][3], t.o11, g[l][1] * t.w11, gp1, c);
+        }
       }
     }
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int l = 0; l < LG; l++) {
+      if (l0 + l >= a.d.levels) break;
+      float* gpq[2] = {a.gplanes[l0 + l][i0], a.gplanes[l0 + l][i1]};
 #pragma unroll
-      for (int r = 0; r < 4; r++)
-        if (sl[q][r].id >= 0 && gp[q] != nullptr) atomicAdd(&gp[q][(size_t)sl[q][r].id * HEXC + c], sl[q][r].acc);
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (sl[l][q][r].id >= 0 && gpq[q] != nullptr) atomicAdd(&gpq[q][(size_t)sl[l][q][r].id * HEXC + c], sl[l][q][r].acc);
+    }
   }
 }
 
