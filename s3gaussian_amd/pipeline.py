@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .deformation import deform_network
+from .glue import activations_and_colors
 from .knn import distCUDA2
 from .losses import plane_regulation as fused_plane_regulation
 from .losses import ssim as fused_ssim
@@ -176,28 +177,46 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
     rasterizer = GaussianRasterizer(raster_settings=rs)
     time = torch.full((means3D.shape[0], 1), float(cam["time"]), device=dev)
     means2D = screenspace_points
-    opacity, shs = pc._opacity, pc.get_features
+    opacity = pc._opacity
     scales, rotations, cov3D_precomp = pc._scaling, pc._rotation, None
-    dx = feat = dshs = None
+    dx = feat = dshs = shs_final = None
+    net = pc._deformation.deformation_net
+    hy = net.args
+    glue_ok = (means3D.is_cuda and override_color is None and getattr(pipe, "convert_SHs_python", True)
+               and pc.max_sh_degree == 3)
+    fused_glue = glue_ok and ("coarse" in stage or net._fused_ok())
     if "coarse" in stage:
-        means3D_final, scales_final, rotations_final, opacity_final, shs_final = means3D, scales, rotations, opacity, shs
+        means3D_final, scales_final, rotations_final, opacity_final = means3D, scales, rotations, opacity
+        if not fused_glue:
+            shs_final = pc.get_features
     elif "fine" in stage:
-        (means3D_final, scales_final, rotations_final, opacity_final, shs_final, dx, feat, dshs) = pc._deformation(
-            means3D, scales, rotations, opacity, shs, time)
+        if fused_glue:
+            # default configuration: only dx / dshs / feat are produced by the network (scales, rotations, opacity pass
+            # through, deformation.py:126-152); `shs + dshs` is folded into the glue kernel below
+            dx, dshs, feat = net.deform_heads(means3D, time)
+            means3D_final, scales_final, rotations_final, opacity_final = means3D + dx, scales, rotations, opacity
+        else:
+            (means3D_final, scales_final, rotations_final, opacity_final, shs_final, dx, feat, dshs) = pc._deformation(
+                means3D, scales, rotations, opacity, pc.get_features, time)
     else:
         raise NotImplementedError
-    scales_final = pc.scaling_activation(scales_final)
-    rotations_final = pc.rotation_activation(rotations_final)
-    opacity = pc.opacity_activation(opacity_final)
     colors_precomp = None
-    if override_color is None:
-        if getattr(pipe, "convert_SHs_python", True):
-            shs_view = shs_final.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
-            dir_pp = pc.get_xyz - cam["campos"].repeat(pc.get_features.shape[0], 1)  # NB: un-deformed xyz (reference :110)
-            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
-            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized) + 0.5, 0.0)
+    if fused_glue:
+        # one kernel per direction for exp / normalize / sigmoid / (shs + dshs) / eval_sh / clamp (include/s3g_glue.h)
+        colors_precomp, scales_final, rotations_final, opacity = activations_and_colors(
+            pc.active_sh_degree, pc._features_dc, pc._features_rest, dshs, pc.get_xyz, cam["campos"], scales, rotations, opacity)
     else:
-        colors_precomp = override_color
+        scales_final = pc.scaling_activation(scales_final)
+        rotations_final = pc.rotation_activation(rotations_final)
+        opacity = pc.opacity_activation(opacity_final)
+        if override_color is None:
+            if getattr(pipe, "convert_SHs_python", True):
+                shs_view = shs_final.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+                dir_pp = pc.get_xyz - cam["campos"].repeat(pc.get_features.shape[0], 1)  # NB: un-deformed xyz (reference :110)
+                dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+                colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized) + 0.5, 0.0)
+        else:
+            colors_precomp = override_color
     if colors_precomp is not None:
         shs_final = None
     rendered_image, radii, depth = rasterizer(means3D=means3D_final, means2D=means2D, shs=shs_final,
