@@ -200,6 +200,21 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    # render ms/frame (the second half of BASELINE's metric): one render(stage="fine") under no_grad, SURVEY.md 3.5
+    from types import SimpleNamespace
+    from s3gaussian_amd.pipeline import render as render_fn
+    pipe = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
+    with torch.no_grad():
+        for i in range(3):
+            render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_frames = 20
+        for i in range(n_frames):
+            render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
+        torch.cuda.synchronize()
+        render_ms = 1000.0 * (time.perf_counter() - t1) / n_frames
+
     if rank == 0:
         ms, inst, pix = C.c_double(), C.c_double(), C.c_double()
         n_bwd = L.s3g_profile_read(1, C.byref(ms), C.byref(inst), C.byref(pix))
@@ -232,7 +247,8 @@ def main():
                                    "(hexplane+deformation ON), RGB+depth render + feature render, L1+DSSIM+depthL2+featL2+regs, Adam",
                        "gaussians": a.P, "image": [a.height, a.width], "views_per_step_per_rank": 1,
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
-                       "blend_forward_avg_ms": round(ms_f.value / n_fwd, 4) if n_fwd else None},
+                       "blend_forward_avg_ms": round(ms_f.value / n_fwd, 4) if n_fwd else None,
+                       "render_ms_per_frame": round(render_ms, 3)},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

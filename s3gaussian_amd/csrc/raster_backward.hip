@@ -12,8 +12,8 @@
 //      S0=sum v, Sx=sum v*dx, Sy=sum v*dy, Sxx=sum v*dx*dx, Sxy=sum v*dx*dy, Syy=sum v*dy*dy (+3 colour, +1 depth);
 //   2. each of the 10 sums is reduced across the 64 lanes of a wave with DPP row-shift/broadcast adds (no LDS, no
 //      shuffles through memory), skipped outright when no lane of the wave is touched by the Gaussian;
-//   3. the 4 waves of the tile combine in an LDS accumulator (ds_add_f32 from one lane);
-//   4. once per 256-Gaussian batch each lane owns one Gaussian and stores its 10 sums as one 40-byte record at the
+//   3. the 4 waves of the tile park their sums in per-wave LDS slots, added in fixed order (no float atomics anywhere);
+//   4. once per 128-Gaussian batch each lane owns one Gaussian and stores its 10 sums as one 40-byte record at the
 //      instance's position in the sorted list (coalesced: consecutive lanes -> consecutive records);
 //   5. geometry_backward_kernel gathers each Gaussian's records through slot_pos[] (the instance -> position map
 //      the forward's sort emitted), applies the factored-out coefficients and runs the per-Gaussian chain.
@@ -47,8 +47,9 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
                       const float* __restrict__ depths, const float* __restrict__ final_Ts,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                       const float* __restrict__ dL_dpixel_depths, float* __restrict__ records /*[R][NREC]*/) {
-  __shared__ StagedGaussian sg[256];
-  __shared__ float acc[NREC][256];
+  constexpr uint32_t BATCH = 128;  // Gaussians staged per round
+  __shared__ StagedGaussian sg[BATCH];
+  __shared__ float acc[4][NREC][BATCH];  // one slot per wave: combined in fixed order -> bit-reproducible sums
 
   const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= (uint32_t)tiles) return;
@@ -56,7 +57,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
   const uint32_t hi = tile_hi[tile] - rg.x;  // deepest contributor of the tile (1-based); nothing behind it gets gradient
   if (hi == 0) return;
   const int tx = tile % gx, ty = tile / gx;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = tx * TILE_X + (tid & 15), py = ty * TILE_Y + (tid >> 4);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
@@ -77,9 +78,10 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
   float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;  // accum_rec (colour, depth)
   float last_alpha = 0.f, lr = 0.f, lg = 0.f, lb = 0.f, ld = 0.f;
 
-  for (uint32_t done_cnt = 0; done_cnt < hi; done_cnt += 256) {
-    const uint32_t cnt = min(256u, hi - done_cnt);
+  for (uint32_t done_cnt = 0; done_cnt < hi; done_cnt += BATCH) {
+    const uint32_t cnt = min(BATCH, hi - done_cnt);
     __syncthreads();  // previous batch fully consumed (sg, acc)
+    for (uint32_t e = tid; e < 4 * NREC * BATCH; e += 256) (&acc[0][0][0])[e] = 0.f;
     if ((uint32_t)tid < cnt) {
       const uint32_t pos = hi - 1 - (done_cnt + tid);  // back to front
       const uint32_t id = point_list[rg.x + pos];
@@ -90,8 +92,6 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
       s.b = make_float4(-0.5f * LOG2E * co.z, co.w, depths[id], colors[3 * (size_t)id]);
       s.c = make_float4(colors[3 * (size_t)id + 1], colors[3 * (size_t)id + 2], 0.f, 0.f);
       sg[tid] = s;
-#pragma unroll
-      for (int k = 0; k < NREC; k++) acc[k][tid] = 0.f;
     }
     __syncthreads();
 
@@ -135,9 +135,9 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
       s0 = wave_sum_lane63(s0); sx = wave_sum_lane63(sx); sy = wave_sum_lane63(sy);
       sxx = wave_sum_lane63(sxx); sxy = wave_sum_lane63(sxy); syy = wave_sum_lane63(syy);
       if (lane == 63) {
-        atomicAdd(&acc[0][j], p_r); atomicAdd(&acc[1][j], p_g); atomicAdd(&acc[2][j], p_b); atomicAdd(&acc[3][j], p_d);
-        atomicAdd(&acc[4][j], s0); atomicAdd(&acc[5][j], sx); atomicAdd(&acc[6][j], sy);
-        atomicAdd(&acc[7][j], sxx); atomicAdd(&acc[8][j], sxy); atomicAdd(&acc[9][j], syy);
+        float* aw = &acc[wave][0][j];
+        aw[0 * BATCH] = p_r; aw[1 * BATCH] = p_g; aw[2 * BATCH] = p_b; aw[3 * BATCH] = p_d; aw[4 * BATCH] = s0;
+        aw[5 * BATCH] = sx; aw[6 * BATCH] = sy; aw[7 * BATCH] = sxx; aw[8 * BATCH] = sxy; aw[9 * BATCH] = syy;
       }
     }
     __syncthreads();
@@ -146,7 +146,11 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
       const uint32_t pos = hi - 1 - (done_cnt + tid);
       float2* rec = reinterpret_cast<float2*>(records + (size_t)(rg.x + pos) * NREC);
 #pragma unroll
-      for (int k = 0; k < NREC / 2; k++) rec[k] = make_float2(acc[2 * k][tid], acc[2 * k + 1][tid]);
+      for (int k = 0; k < NREC / 2; k++) {
+        const float lo = ((acc[0][2 * k][tid] + acc[1][2 * k][tid]) + acc[2][2 * k][tid]) + acc[3][2 * k][tid];
+        const float hi2 = ((acc[0][2 * k + 1][tid] + acc[1][2 * k + 1][tid]) + acc[2][2 * k + 1][tid]) + acc[3][2 * k + 1][tid];
+        rec[k] = make_float2(lo, hi2);
+      }
     }
   }
 }
