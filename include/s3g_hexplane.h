@@ -34,9 +34,11 @@ typedef struct s3g_hexplane_desc {
   float aabb_max[3], aabb_min[3];            /* aabb[0], aabb[1] */
 } s3g_hexplane_desc;
 
-/* features [P, levels*32].  xyz [P,3], time [P] (device fp32). */
+/* features [P, levels*32].  xyz [P,3], time [P] (device fp32).  proc_order: optional (may be NULL) permutation of
+ * [0,P) giving the order in which points are PROCESSED (results do not depend on it); passing the spatial order a
+ * previous s3g_hexplane_backward returned makes neighbouring lanes fetch the same texels (L1/L2 hits). */
 int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time, float* features,
-                         void* stream);
+                         const unsigned int* proc_order, void* stream);
 
 /* dL_dfeatures [P, levels*32] -> dL_dxyz [P,3] (written) and dL_dplanes[l][i] (same layout as planes; ACCUMULATED,
  * the caller zero-fills them; a NULL entry skips that plane).  `workspace`: device scratch of
@@ -45,7 +47,8 @@ int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, co
 size_t s3g_hexplane_backward_workspace_bytes(int levels, int P);
 int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
                           const float* dL_dfeatures, float* dL_dxyz, float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6],
-                          void* workspace, void* stream);
+                          void* workspace, unsigned int* order_out /* [P] or NULL: the (x,y) spatial order, reusable as
+                          proc_order of later forwards */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,7 @@ struct HexArgs {
   const float* gfeat;
   float* feat;
   float* gxyz;
+  const uint32_t* proc_order;  // optional: process point proc_order[i] at step i (spatially sorted -> texel reuse in L1/L2)
 };
 
 struct Tap {         // one bilinear footprint
@@ -86,7 +87,8 @@ __device__ constexpr int PAIR1[6] = {1, 2, 3, 2, 3, 3};
 __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) {
   const int c = threadIdx.x & 31, slot = threadIdx.x >> 5;
   const int F = a.d.levels * HEXC;
-  for (int p = blockIdx.x * 8 + slot; p < a.P; p += gridDim.x * 8) {
+  for (int pi = blockIdx.x * 8 + slot; pi < a.P; pi += gridDim.x * 8) {
+    const int p = a.proc_order ? (int)a.proc_order[pi] : pi;
     float u[4];
     point_coords(a, p, u);
     for (int l = 0; l < a.d.levels; l++) {
@@ -108,13 +110,24 @@ __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) 
 }
 
 // ---- pass A: per point, dL/ds for every plane-level -> G, and dL/dxyz ----
-__global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexArgs a, float* __restrict__ G) {
+// G layout: slab (orientation o, level l, kind q) = G + (((o * levels + l) * 2 + q) * P + rank_o[p]) * 32, i.e. every
+// orientation's rows are stored in THAT orientation's sorted order, so pass B streams them sequentially.
+__device__ constexpr int ORI_OF[6] = {0, 2, 0, 1, 1, 2};   // plane i -> orientation pass that scatters it
+__device__ constexpr int KIND_OF[6] = {0, 0, 1, 0, 1, 1};  // 0 = spatial plane of the pass, 1 = its time plane
+
+__global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexArgs a, float* __restrict__ G,
+                                                                      const uint32_t* __restrict__ rank_all) {
   const int c = threadIdx.x & 31, slot = threadIdx.x >> 5;
   const int F = a.d.levels * HEXC;
-  const size_t PL = (size_t)a.P * HEXC;  // one plane-level slab of G
+  const size_t PL = (size_t)a.P * HEXC;  // one slab of G
   for (int p0 = blockIdx.x * 8; p0 < a.P; p0 += gridDim.x * 8) {  // uniform trip count: shuffles below need all lanes
-    const int p = p0 + slot;
-    const bool live = p < a.P;
+    const int pi = p0 + slot;
+    const bool live = pi < a.P;
+    const int p = live ? (a.proc_order ? (int)a.proc_order[pi] : pi) : 0;
+    uint32_t rk[3] = {0u, 0u, 0u};
+    if (live)
+#pragma unroll
+      for (int o = 0; o < 3; o++) rk[o] = rank_all[(size_t)o * a.P + p];
     float u[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) point_coords(a, p, u);
     float du[3] = {0.f, 0.f, 0.f};
@@ -148,7 +161,7 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
         const float gi = gs * pre[i];  // dL/ds_i
         gs = gs * s[i];
         if (live) {
-          G[(size_t)(l * 6 + i) * PL + (size_t)p * HEXC + c] = gi;
+          G[(size_t)((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * PL + (size_t)rk[ORI_OF[i]] * HEXC + c] = gi;
           // torch grid_sampler_2d_backward: gix = -nw*(iy_se-iy) + ne*(iy_sw-iy) - sw*(iy-iy_ne) + se*(iy-iy_nw), ...
           const float gix = (-v00[i] * (t[i].y1f - t[i].iy) + v01[i] * (t[i].y1f - t[i].iy) - v10[i] * (t[i].iy - t[i].y0f) +
                              v11[i] * (t[i].iy - t[i].y0f)) * gi;
@@ -178,9 +191,16 @@ __device__ constexpr int MIN_[3] = {1, 2, 0};
 __device__ constexpr int PLA[3] = {0, 3, 1};  // (x,y) (y,z) (x,z)
 __device__ constexpr int PLT[3] = {2, 4, 5};  // (x,t) (y,t) (z,t)
 
+// Sort cell of a point along `axis` = its texel column at the FINEST level, computed exactly like make_tap does, so
+// all points of one cell share their four finest-level corner texels (a coarser cell grid would cut cells with texel
+// boundaries -- align_corners grids of different levels do not nest -- and break the register run-length combining).
 __device__ __forceinline__ int sort_cell(const HexArgs& a, int p, int axis) {
   const float u = (a.xyz[3 * (size_t)p + axis] - a.d.aabb_max[axis]) * (2.0f / (a.d.aabb_min[axis] - a.d.aabb_max[axis])) - 1.0f;
-  const int cidx = (int)floorf((u + 1.f) * 0.5f * (float)SORT_BINS);
+  const int W = a.d.res[a.d.levels - 1][axis];
+  float ix = ((u + 1.f) / 2.f) * (float)(W - 1);
+  ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
+  int cidx = (int)floorf(ix);
+  if (W > SORT_BINS) cidx = (int)(((long long)cidx * SORT_BINS) / W);
   return min(SORT_BINS - 1, max(0, cidx));
 }
 
@@ -189,6 +209,7 @@ struct SortWork {
   uint32_t* seg_start;  // [3][SORT_BINS + 1]
   uint32_t* tmp;        // [3][P]  indices grouped by major cell
   uint32_t* order;      // [3][P]  final order
+  uint32_t* rank;       // [3][P]  inverse permutation: rank[o][order[o][k]] = k
 };
 
 template <bool WRITE>
@@ -268,6 +289,11 @@ __global__ void __launch_bounds__(256) hexsort_minor_kernel(const HexArgs a, con
   }
 }
 
+__global__ void __launch_bounds__(256) hexsort_rank_kernel(int P, const uint32_t* __restrict__ order, uint32_t* __restrict__ rank) {
+  const int k = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
+  if (k < P) rank[(size_t)o * P + order[(size_t)o * P + k]] = (uint32_t)k;
+}
+
 // ---- pass B: scatter in sorted order with register run-length combining ----
 constexpr int SEG = 128;  // sorted points walked by one half-wave
 
@@ -312,8 +338,8 @@ __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, 
 #pragma unroll
       for (int l = 0; l < LG; l++) {  // all G rows of this point are requested before the first is consumed
         const bool on = l0 + l < a.d.levels;
-        g[l][0] = (on && a.gplanes[l0 + l][i0]) ? G[(size_t)((l0 + l) * 6 + i0) * PL + (size_t)p * HEXC + c] : 0.f;
-        g[l][1] = (on && a.gplanes[l0 + l][i1]) ? G[(size_t)((l0 + l) * 6 + i1) * PL + (size_t)p * HEXC + c] : 0.f;
+        g[l][0] = (on && a.gplanes[l0 + l][i0]) ? G[(size_t)((o * a.d.levels + l0 + l) * 2 + 0) * PL + (size_t)k * HEXC + c] : 0.f;
+        g[l][1] = (on && a.gplanes[l0 + l][i1]) ? G[(size_t)((o * a.d.levels + l0 + l) * 2 + 1) * PL + (size_t)k * HEXC + c] : 0.f;
       }
 #pragma unroll
       for (int l = 0; l < LG; l++) {
@@ -374,7 +400,7 @@ static int check_desc(const s3g_hexplane_desc* d) {
 using namespace s3g;
 
 extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
-                                    float* features, void* stream_) {
+                                    float* features, const uint32_t* proc_order, void* stream_) {
   if (int e = check_desc(d)) return e;
   if (P < 0 || (P > 0 && (!xyz || !time || !features))) {
     set_error("s3g_hexplane_forward: bad argument");
@@ -383,7 +409,7 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
   if (P == 0) return S3G_OK;
   HexArgs a;
   memset(&a, 0, sizeof a);
-  a.d = *d; a.P = P; a.xyz = xyz; a.time = time; a.feat = features;
+  a.d = *d; a.P = P; a.xyz = xyz; a.time = time; a.feat = features; a.proc_order = proc_order;
   const int blocks = min((P + 7) / 8, 256 * 16);
   hipLaunchKernelGGL(hexplane_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
   S3G_HIP_CHECK(hipGetLastError());
@@ -398,12 +424,14 @@ extern "C" size_t s3g_hexplane_backward_workspace_bytes(int levels, int P) {
   c.take<uint32_t>((size_t)3 * (SORT_BINS + 1));
   c.take<uint32_t>((size_t)3 * P);
   c.take<uint32_t>((size_t)3 * P);
+  c.take<uint32_t>((size_t)3 * P);
   return c.bytes();
 }
 
 extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
                                      const float* dL_dfeatures, float* dL_dxyz,
-                                     float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* workspace, void* stream_) {
+                                     float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* workspace,
+                                     uint32_t* order_out, void* stream_) {
   if (int e = check_desc(d)) return e;
   if (P < 0 || (P > 0 && (!xyz || !time || !dL_dfeatures || !dL_dxyz || !dL_dplanes || !workspace))) {
     set_error("s3g_hexplane_backward: bad argument");
@@ -423,16 +451,22 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
   w.seg_start = c.take<uint32_t>((size_t)3 * (SORT_BINS + 1));
   w.tmp = c.take<uint32_t>((size_t)3 * P);
   w.order = c.take<uint32_t>((size_t)3 * P);
+  w.rank = c.take<uint32_t>((size_t)3 * P);
 
-  const int blocks = min((P + 7) / 8, 256 * 16);
-  hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3(blocks), dim3(256), 0, stream, a, G);
-  S3G_HIP_CHECK(hipGetLastError());
+  // 1. three spatial orders (2-level LDS counting sorts) and their inverse permutations
   const int chunk = (((P + SORT_NB - 1) / SORT_NB + 255) / 256) * 256;
   hipLaunchKernelGGL(hexsort_major_kernel<false>, dim3(SORT_NB, 3), dim3(256), 0, stream, a, w, chunk);
   hipLaunchKernelGGL(hexsort_scan_kernel, dim3(3), dim3(512), 0, stream, w, P);
   hipLaunchKernelGGL(hexsort_major_kernel<true>, dim3(SORT_NB, 3), dim3(256), 0, stream, a, w, chunk);
   hipLaunchKernelGGL(hexsort_minor_kernel, dim3(SORT_BINS, 3), dim3(256), 0, stream, a, w);
+  hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.rank);
   S3G_HIP_CHECK(hipGetLastError());
+  // 2. per-point pass, walking the points in (x,y) order so neighbouring half-waves share texels
+  a.proc_order = w.order;
+  const int blocks = min((P + 7) / 8, 256 * 16);
+  hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3(blocks), dim3(256), 0, stream, a, G, w.rank);
+  S3G_HIP_CHECK(hipGetLastError());
+  if (order_out) S3G_HIP_CHECK(hipMemcpyAsync(order_out, w.order, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
   const int nseg = (P + SEG - 1) / SEG;
   hipLaunchKernelGGL(hexplane_scatter_kernel, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, G, w.order);
   S3G_HIP_CHECK(hipGetLastError());

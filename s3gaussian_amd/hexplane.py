@@ -38,9 +38,9 @@ def _bind():
     if not _bound:
         vp = C.c_void_p
         L.s3g_hexplane_forward.restype = C.c_int
-        L.s3g_hexplane_forward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp]
+        L.s3g_hexplane_forward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, vp]
         L.s3g_hexplane_backward.restype = C.c_int
-        L.s3g_hexplane_backward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, C.POINTER(_PlanePtrs), vp, vp]
+        L.s3g_hexplane_backward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, C.POINTER(_PlanePtrs), vp, vp, vp]
         L.s3g_hexplane_backward_workspace_bytes.restype = C.c_size_t
         L.s3g_hexplane_backward_workspace_bytes.argtypes = [C.c_int, C.c_int]
         _bound = True
@@ -72,7 +72,7 @@ class _HexPlaneSample(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, time, meta, *planes):
-        resolutions, aabb_host = meta
+        resolutions, aabb_host, cache = meta
         if not xyz.is_cuda:
             raise RuntimeError(f"xyz must live on the GPU (got {xyz.device}); the HexPlane sampler has no CPU fallback")
         L = _bind()
@@ -83,8 +83,12 @@ class _HexPlaneSample(torch.autograd.Function):
             raise RuntimeError("time must have one value per point")
         feat = torch.empty((P, len(resolutions) * CHANNELS), dtype=torch.float32, device=xyz.device)
         d = _make_desc(planes, resolutions, aabb_host)
+        order = cache.get("order") if cache is not None else None
+        if order is not None and (order.numel() != P or order.device != xyz.device):
+            order = None  # stale (densification changed P): fall back to identity order
         with torch.cuda.device(xyz.device):
             _lib.check(L.s3g_hexplane_forward(C.byref(d), P, xyz_c.data_ptr(), t_c.data_ptr(), feat.data_ptr(),
+                                              order.data_ptr() if order is not None else None,
                                               torch.cuda.current_stream().cuda_stream))
         ctx.meta = meta
         ctx.save_for_backward(xyz_c, t_c, *planes)
@@ -93,7 +97,7 @@ class _HexPlaneSample(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gfeat):
         xyz_c, t_c, *planes = ctx.saved_tensors
-        resolutions, aabb_host = ctx.meta
+        resolutions, aabb_host, cache = ctx.meta
         L = _bind()
         P = xyz_c.shape[0]
         gfeat = gfeat.contiguous()
@@ -107,15 +111,19 @@ class _HexPlaneSample(torch.autograd.Function):
         d = _make_desc(planes, resolutions, aabb_host)
         work = torch.empty(L.s3g_hexplane_backward_workspace_bytes(len(resolutions), P), dtype=torch.uint8,
                            device=xyz_c.device)
+        order_out = torch.empty(P, dtype=torch.int32, device=xyz_c.device) if cache is not None else None
         with torch.cuda.device(xyz_c.device):
             _lib.check(L.s3g_hexplane_backward(C.byref(d), P, xyz_c.data_ptr(), t_c.data_ptr(), gfeat.data_ptr(),
                                                gxyz.data_ptr(), C.byref(ptrs), work.data_ptr(),
+                                               order_out.data_ptr() if order_out is not None else None,
                                                torch.cuda.current_stream().cuda_stream))
+        if cache is not None:
+            cache["order"] = order_out  # spatial processing order for the next forward (positions move slowly)
         return (gxyz if ctx.needs_input_grad[0] else None, None, None, *gplanes)
 
 
-def hexplane_sample(xyz, time, planes, resolutions, aabb_host):
-    return _HexPlaneSample.apply(xyz, time, (tuple(tuple(r) for r in resolutions), aabb_host), *planes)
+def hexplane_sample(xyz, time, planes, resolutions, aabb_host, cache=None):
+    return _HexPlaneSample.apply(xyz, time, (tuple(tuple(r) for r in resolutions), aabb_host, cache), *planes)
 
 
 class HexPlaneField(nn.Module):
@@ -148,6 +156,7 @@ class HexPlaneField(nn.Module):
             self.grids.append(planes)
             self.feat_dim += CHANNELS
         self._aabb_host = None
+        self._order_cache = {}  # {"order": int32 [P]} spatial processing order left behind by the last backward
 
     @property
     def get_aabb(self):
@@ -179,7 +188,7 @@ class HexPlaneField(nn.Module):
 
     def get_density(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None):
         pts = pts.reshape(-1, pts.shape[-1])
-        return hexplane_sample(pts, timestamps, self._planes(), self.resolutions, self._host_aabb())
+        return hexplane_sample(pts, timestamps, self._planes(), self.resolutions, self._host_aabb(), self._order_cache)
 
     def forward(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None):
         return self.get_density(pts, timestamps)

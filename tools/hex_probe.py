@@ -1,0 +1,31 @@
+"""HexPlane sampler-only probe at 1.2 M points (cfg3 aabb): forward + backward timings."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from s3gaussian_amd import synth  # noqa: E402
+from s3gaussian_amd.hexplane import HexPlaneField  # noqa: E402
+
+dev = torch.device("cuda:0")
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 1_200_000
+sc = synth.street_scene(P=P, n_frames=2)
+cfg = dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32, resolution=[64, 64, 64, 25])
+f = HexPlaneField(1.6, cfg, [1, 2, 4, 8])
+f.set_aabb(*sc["aabb"])
+f = f.to(dev)
+xyz = sc["gaussians"]["xyz"].to(dev).requires_grad_(True)
+t = torch.full((P, 1), 0.37, device=dev)
+w = torch.randn(P, 128, device=dev)
+for it in range(4):
+    for p in f.parameters():
+        p.grad = None
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    out = f(xyz, t)
+    e[1].record()
+    (out * w).sum().backward()
+    e[2].record()
+    torch.cuda.synchronize()
+    print(f"iter {it}: forward {e[0].elapsed_time(e[1]):.3f} ms  backward(+loss) {e[1].elapsed_time(e[2]):.3f} ms")
