@@ -25,6 +25,15 @@ constexpr int HID = 64;   // net_width
 constexpr int FEAT = 128; // HexPlane feature width
 constexpr int WREGION = 64 * 65;  // floats: largest weight slab staged at once ([64 in][64 out + 1])
 
+// Workgroup barrier that only orders LDS traffic.  __syncthreads() also drains every outstanding GLOBAL store
+// (s_waitcnt vmcnt(0)): the stash/output stores of a phase nobody in this kernel reads would stall all 4 waves at
+// every one of the 9 phase boundaries.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // rows of the 32x32 accumulator held by (lane, reg): row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); col = lane & 31
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
@@ -168,33 +177,33 @@ __global__ void __launch_bounds__(256) mlp_forward_kernel(const MlpFwdArgs a) {
     // ---- hidden = W0 x + b0 (two K halves of W0 staged in turn) ----
     acc_init_bias<2>(acc, a.w.b0, HID, lane);
     for (int half = 0; half < 2; half++) {
-      __syncthreads();
+      lds_barrier();
       stage_weight<HID, FEAT, HID, 64>(wl, a.w.W0, half * 64, tid);
-      __syncthreads();
+      lds_barrier();
       gemm_straight<2, false>(wl, 65, X + half * 64 * LDA, 64, acc, lane);
     }
     acc_store<2, false>(acc, H, lane);
     if (a.stash) tile_store<HID>(H, a.stash + 0 * PS, p0, npts, lane);
     // ---- pos1 = relu(P1 relu(hidden) + pb1) -> X[0:64] ----
-    __syncthreads();
+    lds_barrier();
     stage_weight<HID, HID, HID, HID>(wl, a.w.P1, 0, tid);
-    __syncthreads();
+    lds_barrier();
     acc_init_bias<2>(acc, a.w.pb1, HID, lane);
     gemm_straight<2, true>(wl, 65, H, HID, acc, lane);
     acc_store<2, true>(acc, X, lane);
     if (a.stash) tile_store<HID>(X, a.stash + 1 * PS, p0, npts, lane);
     // ---- shs1 = relu(S1 relu(hidden) + sb1) -> X[64:128] ----
-    __syncthreads();
+    lds_barrier();
     stage_weight<HID, HID, HID, HID>(wl, a.w.S1, 0, tid);
-    __syncthreads();
+    lds_barrier();
     acc_init_bias<2>(acc, a.w.sb1, HID, lane);
     gemm_straight<2, true>(wl, 65, H, HID, acc, lane);
     acc_store<2, true>(acc, X + 64 * LDA, lane);
     if (a.stash) tile_store<HID>(X + 64 * LDA, a.stash + 2 * PS, p0, npts, lane);
     // ---- dx = P2 pos1 + pb2 ----
-    __syncthreads();
+    lds_barrier();
     stage_weight<3, HID, 32, HID>(wl, a.w.P2, 0, tid);
-    __syncthreads();
+    lds_barrier();
     {
       f32x16 o[1];
       acc_init_bias<1>(o, a.w.pb2, 3, lane);
@@ -203,33 +212,33 @@ __global__ void __launch_bounds__(256) mlp_forward_kernel(const MlpFwdArgs a) {
       tile_store<3>(T, a.dx, p0, npts, lane);
     }
     // ---- dshs = S2 shs1 + sb2 ----
-    __syncthreads();
+    lds_barrier();
     stage_weight<48, HID, 64, HID>(wl, a.w.S2, 0, tid);
-    __syncthreads();
+    lds_barrier();
     acc_init_bias<2>(acc, a.w.sb2, 48, lane);
     gemm_straight<2, false>(wl, 65, X + 64 * LDA, HID, acc, lane);
     acc_store<2, false>(acc, T, lane);
     tile_store<48>(T, a.dshs, p0, npts, lane);
     // ---- dino1 = relu(D0 hidden + db0) -> X[0:64] ----
-    __syncthreads();
+    lds_barrier();
     stage_weight<HID, HID, HID, HID>(wl, a.w.D0, 0, tid);
-    __syncthreads();
+    lds_barrier();
     acc_init_bias<2>(acc, a.w.db0, HID, lane);
     gemm_straight<2, false>(wl, 65, H, HID, acc, lane);
     acc_store<2, true>(acc, X, lane);
     if (a.stash) tile_store<HID>(X, a.stash + 3 * PS, p0, npts, lane);
     // ---- dino2 = relu(D1 dino1 + db1) -> X[64:128] ----
-    __syncthreads();
+    lds_barrier();
     stage_weight<HID, HID, HID, HID>(wl, a.w.D1, 0, tid);
-    __syncthreads();
+    lds_barrier();
     acc_init_bias<2>(acc, a.w.db1, HID, lane);
     gemm_straight<2, false>(wl, 65, X, HID, acc, lane);
     acc_store<2, true>(acc, X + 64 * LDA, lane);
     if (a.stash) tile_store<HID>(X + 64 * LDA, a.stash + 4 * PS, p0, npts, lane);
     // ---- feat = D2 dino2 + db2 ----
-    __syncthreads();
+    lds_barrier();
     stage_weight<3, HID, 32, HID>(wl, a.w.D2, 0, tid);
-    __syncthreads();
+    lds_barrier();
     {
       f32x16 o[1];
       acc_init_bias<1>(o, a.w.db2, 3, lane);
@@ -268,38 +277,38 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const MlpBwdArgs a) {
     // ================= dino head =================
     tile_load<HID, HID>(U1, a.stash + 4 * PS, p0, npts, lane);           // dino2
     tile_load<3, 32>(T, a.g_feat, p0, npts, lane);                        // g_feat, rows 3..31 zero
-    __syncthreads();
+    lds_barrier();
     stage_weight<3, HID, 32, HID>(wl, a.w.D2, 0, tid);
-    __syncthreads();
+    lds_barrier();
     acc_init_bias<2>(acc, nullptr, 0, lane);
     gemm_transposed<2>(wl, 33, T, 32, acc, lane);                         // D2^T g_feat
     acc_store_masked<2>(acc, U1, U1, lane);                               // (.) * [dino2 > 0]  -> g wrt dino2 pre-activation
     tile_store<HID>(U1, a.ws + 0 * PS, p0, npts, lane);
     tile_load<HID, HID>(U0, a.stash + 3 * PS, p0, npts, lane);           // dino1
-    __syncthreads();
+    lds_barrier();
     stage_weight<HID, HID, HID, HID>(wl, a.w.D1, 0, tid);
-    __syncthreads();
+    lds_barrier();
     acc_init_bias<2>(acc, nullptr, 0, lane);
     gemm_transposed<2>(wl, 65, U1, HID, acc, lane);                       // D1^T g_d2
     acc_store_masked<2>(acc, U0, U0, lane);                               // * [dino1 > 0]
     tile_store<HID>(U0, a.ws + 1 * PS, p0, npts, lane);
-    __syncthreads();
+    lds_barrier();
     stage_weight<HID, HID, HID, HID>(wl, a.w.D0, 0, tid);
-    __syncthreads();
+    lds_barrier();
     gemm_transposed<2>(wl, 65, U0, HID, ghid, lane);                      // ghid += D0^T g_d1   (no mask: dino input is raw hidden)
     // ================= pos head =================
     tile_load<HID, HID>(U1, a.stash + 1 * PS, p0, npts, lane);           // pos1
     tile_load<3, 32>(T, a.g_dx, p0, npts, lane);
-    __syncthreads();
+    lds_barrier();
     stage_weight<3, HID, 32, HID>(wl, a.w.P2, 0, tid);
-    __syncthreads();
+    lds_barrier();
     acc_init_bias<2>(acc, nullptr, 0, lane);
     gemm_transposed<2>(wl, 33, T, 32, acc, lane);
     acc_store_masked<2>(acc, U1, U1, lane);                               // g wrt pos1 pre-activation
     tile_store<HID>(U1, a.ws + 2 * PS, p0, npts, lane);
-    __syncthreads();
+    lds_barrier();
     stage_weight<HID, HID, HID, HID>(wl, a.w.P1, 0, tid);
-    __syncthreads();
+    lds_barrier();
     acc_init_bias<2>(acc, nullptr, 0, lane);
     gemm_transposed<2>(wl, 65, U1, HID, acc, lane);                       // P1^T g_pos1  (gradient wrt relu(hidden))
 #pragma unroll
@@ -310,16 +319,16 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const MlpBwdArgs a) {
     // ================= shs head =================
     tile_load<HID, HID>(U1, a.stash + 2 * PS, p0, npts, lane);           // shs1
     tile_load<48, 64>(U0, a.g_dshs, p0, npts, lane);                      // g_dshs, rows 48..63 zero
-    __syncthreads();
+    lds_barrier();
     stage_weight<48, HID, 64, HID>(wl, a.w.S2, 0, tid);
-    __syncthreads();
+    lds_barrier();
     acc_init_bias<2>(acc, nullptr, 0, lane);
     gemm_transposed<2>(wl, 65, U0, 64, acc, lane);
     acc_store_masked<2>(acc, U1, U1, lane);
     tile_store<HID>(U1, a.ws + 3 * PS, p0, npts, lane);
-    __syncthreads();
+    lds_barrier();
     stage_weight<HID, HID, HID, HID>(wl, a.w.S1, 0, tid);
-    __syncthreads();
+    lds_barrier();
     acc_init_bias<2>(acc, nullptr, 0, lane);
     gemm_transposed<2>(wl, 65, U1, HID, acc, lane);
 #pragma unroll
@@ -331,9 +340,9 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const MlpBwdArgs a) {
     acc_store<2, false>(ghid, T, lane);
     tile_store<HID>(T, a.ws + 4 * PS, p0, npts, lane);
     for (int half = 0; half < 2; half++) {                                // g_x[:, half*64 : half*64+64] = W0[:, half]^T ghid
-      __syncthreads();
+      lds_barrier();
       stage_weight<HID, FEAT, HID, 64>(wl, a.w.W0, half * 64, tid);
-      __syncthreads();
+      lds_barrier();
       acc_init_bias<2>(acc, nullptr, 0, lane);
       gemm_transposed<2>(wl, 65, T, HID, acc, lane);
       acc_store<2, false>(acc, U0, lane);
