@@ -31,9 +31,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            backend = os.environ.get("S3G_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -58,9 +58,10 @@ class GradAllReducer:
     """Bucketed average of .grad over all ranks.  Parameters whose grad is None on this rank (unused heads) are
     skipped; they are None on every rank because all replicas run the same graph."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, inplace_mb: float = 16.0):
         self.params = [p for p in params]
         self.bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
+        self.inplace_elems = int(inplace_mb * 1024 * 1024 / 4)  # gradients at least this big are reduced where they live
         self._buf = None
 
     def _buckets(self, grads: Sequence[torch.Tensor]):
@@ -81,7 +82,16 @@ class GradAllReducer:
         world = dist.get_world_size()
         grads = [p.grad for p in self.params if p.grad is not None]
         total = 0
-        for bucket in self._buckets(grads):
+        small = []
+        for g in grads:  # big tensors (xyz/f_rest/planes: ~95 % of the bytes): no pack/unpack copies at all
+            v = _flat_view(g) if g.numel() >= self.inplace_elems else None
+            if v is None:
+                small.append(g)
+                continue
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            v.mul_(1.0 / world)
+            total += g.numel()
+        for bucket in self._buckets(small):
             n = sum(g.numel() for g in bucket)
             if self._buf is None or self._buf.numel() < n or self._buf.device != bucket[0].device:
                 self._buf = torch.empty(max(n, 1), dtype=torch.float32, device=bucket[0].device)

@@ -24,10 +24,16 @@ def _worker(rank, world, port, q):
     params = [torch.nn.Parameter(torch.zeros(1000, 3)), torch.nn.Parameter(torch.zeros(1000, 15, 3)),
               torch.nn.Parameter(torch.zeros(1, 32, 8, 16).contiguous(memory_format=torch.channels_last)),
               torch.nn.Parameter(torch.zeros(64, 64)), torch.nn.Parameter(torch.zeros(7))]
-    g = torch.Generator().manual_seed(100 + rank)
-    for p in params[:-1]:
-        grad = torch.randn(p.shape, generator=g)
-        p.grad = grad.contiguous(memory_format=torch.channels_last) if p.dim() == 4 else grad
+    def fill():
+        g = torch.Generator().manual_seed(100 + rank)
+        for p in params[:-1]:
+            grad = torch.randn(p.shape, generator=g)
+            p.grad = grad.contiguous(memory_format=torch.channels_last) if p.dim() == 4 else grad
+
+    fill()
+    n0 = dp.GradAllReducer(params, bucket_mb=0.02, inplace_mb=1e-6)()  # every gradient reduced in place (no packing)
+    inplace = [p.grad.clone() for p in params[:-1]]
+    fill()
     red = dp.GradAllReducer(params, bucket_mb=0.02)  # tiny buckets: exercise the bucket boundaries
     n = red()
     expect = []
@@ -42,7 +48,8 @@ def _worker(rank, world, port, q):
         expect.append(acc / world)
     ok = all(torch.allclose(p.grad, e, atol=1e-6) for p, e in zip(params[:-1], expect)) and params[-1].grad is None
     ok = ok and params[2].grad.is_contiguous(memory_format=torch.channels_last)
-    ok = ok and n == sum(p.numel() for p in params[:-1])
+    ok = ok and n == sum(p.numel() for p in params[:-1]) and n0 == n
+    ok = ok and all(torch.allclose(a, p.grad, atol=1e-6) for a, p in zip(inplace, params[:-1]))
     # densification statistics
     vg = torch.full((10, 3), float(rank + 1))
     vis = torch.arange(10) % (rank + 2) == 0
