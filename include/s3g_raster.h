@@ -73,6 +73,14 @@ int s3g_raster_forward(const s3g_raster_inputs* in,
                        float* out_color, float* out_depth, int* radii,
                        int* num_rendered, void* stream /* hipStream_t */);
 
+/* Forward of the SAME geometry (means, scales/rotations or cov3D, opacities, camera, image size) with other per-Gaussian
+ * colours: reuses the arenas of a previous s3g_raster_forward (preprocess, binning and sort are skipped; radii and
+ * num_rendered are those of that call).  Replaces the second Rasterizer::forward of an iteration
+ * (gaussian_renderer/__init__.py:153-166 renders the feature image on the RGB pass's geometry).  Requires
+ * in->colors_precomp.  The image arena's final_T / n_contrib are rewritten with identical values. */
+int s3g_raster_forward_reuse(const s3g_raster_inputs* in, int R, const void* geometry_arena, const void* binning_arena,
+                             void* image_arena, float* out_color, float* out_depth, void* stream);
+
 /* Backward.  `R` is the num_rendered returned by the matching forward; radii / arenas are the ones it filled.
  * `workspace`: device scratch of s3g_raster_backward_workspace_bytes(P, R) bytes (per-instance gradient records;
  * contents need no initialisation and are dead after the call).

@@ -680,6 +680,34 @@ extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geo
   return S3G_OK;
 }
 
+// Second (third, ...) render of the SAME geometry with different per-Gaussian colours (the reference renders RGB and
+// then the feature image with identical means/scales/rotations/opacities, gaussian_renderer/__init__.py:127-166):
+// everything up to the sorted per-tile lists is reused from the arenas of the first call; only the blend runs.
+extern "C" int s3g_raster_forward_reuse(const s3g_raster_inputs* in, int R, const void* geometry_arena,
+                                        const void* binning_arena, void* image_arena, float* out_color, float* out_depth,
+                                        void* stream_) {
+  g_err[0] = 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!in || !in->colors_precomp || !in->background || !geometry_arena || !image_arena || (R > 0 && !binning_arena) ||
+      !out_color || !out_depth || in->P <= 0) {
+    set_error("s3g_raster_forward_reuse: bad argument (needs colors_precomp and the arenas of a previous forward)");
+    return S3G_ERR_INVALID_ARG;
+  }
+  const int P = in->P, W = in->width, H = in->height;
+  const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y, tiles = gx * gy;
+  GeomState g = GeomState::carve(const_cast<void*>(geometry_arena), P, nullptr);
+  ImageState im = ImageState::carve(image_arena, (size_t)W * H, tiles, bin_blocks(P), nullptr);
+  BinningState b = BinningState::carve(const_cast<void*>(binning_arena), (size_t)(R > 0 ? R : 0), nullptr);
+  const uint32_t tile_blocks = round_up8((uint32_t)tiles);
+  profile_begin(0, stream);
+  hipLaunchKernelGGL(blend_forward_kernel, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
+                     b.point_list, g.means2D, g.conic_opacity, in->colors_precomp, g.depths, in->background, im.final_T,
+                     im.n_contrib, im.tile_hi, out_color, out_depth);
+  profile_end(0, stream, (double)R, (double)W * H);
+  S3G_KERNEL_CHECK(stream, in->debug != 0);
+  return S3G_OK;
+}
+
 extern "C" void s3g_profile_enable(int on) { g_prof_on = on != 0; }
 
 // Sums the recorded launches of kernel `id` (0 blend forward, 1 blend backward), synchronising on their events, then

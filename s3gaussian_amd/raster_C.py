@@ -7,6 +7,7 @@ torch is used here for device memory and the current HIP stream only; no torch t
 from __future__ import annotations
 
 import ctypes as C
+import os
 import torch
 
 from . import _lib
@@ -61,16 +62,43 @@ def _inputs(P, D, M, W, H, bg, means3D, sh, colors, opacity, scales, scale_modif
                              int(bool(debug)))
 
 
+# ---- geometry cache: the feature render of an iteration reuses the RGB render's preprocess / binning / sort ------------
+_GEOM_CACHE_ON = os.environ.get("S3G_GEOMETRY_CACHE", "1") != "0"
+_geom_cache = None  # (key, tensors kept alive, outputs)
+
+
+def _geom_key(tensors, scalars):
+    return tuple((id(t), t._version, t.data_ptr(), tuple(t.shape)) for t in tensors) + tuple(scalars)
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug):
     """-> (num_rendered, color[3,H,W], depth[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer)."""
+    global _geom_cache
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _require_gpu(means3D, "means3D")
     L = _lib.lib()
     dev = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
+    geo_tensors = (means3D, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos)
+    key = None
+    if _GEOM_CACHE_ON and P != 0 and sh.numel() == 0 and colors.numel() != 0 and not debug:
+        key = _geom_key(geo_tensors, (float(scale_modifier), float(tan_fovx), float(tan_fovy), H, W, bool(prefiltered)))
+        if _geom_cache is not None and _geom_cache[0] == key:
+            R, radii_c, geom_c, binning_c, img_c = _geom_cache[2]
+            out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+            out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+            keep = [_f32(background, "bg"), _f32(colors, "colors_precomp")]
+            inp = _inputs(P, degree, 0, W, H, keep[0], None, None, keep[1], None, None, scale_modifier, None, None, None,
+                          None, tan_fovx, tan_fovy, None, prefiltered, debug)
+            with torch.cuda.device(dev):
+                code = L.s3g_raster_forward_reuse(C.byref(inp), int(R), _ptr(geom_c), _ptr(binning_c), _ptr(img_c),
+                                                  out_color.data_ptr(), out_depth.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream)
+            _lib.check(code)
+            return R, out_color, out_depth, radii_c, geom_c, binning_c, img_c
     out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
     out_depth = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
     radii = torch.zeros((P,), dtype=torch.int32, device=dev)
@@ -94,6 +122,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             if a.error is not None:
                 raise a.error
         _lib.check(code)
+        if key is not None:  # remember this geometry (inputs are kept alive so the id()/version key stays meaningful)
+            _geom_cache = (key, geo_tensors, (rendered.value, radii, geom.tensor, binning.tensor, img.tensor))
     return rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor
 
 

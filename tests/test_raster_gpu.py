@@ -313,3 +313,39 @@ def test_cfg1_full_size_vs_oracle(gpu_device, oracle):
     assert rel_l2(gpu["leaves"]["means3D"].grad.cpu().numpy(), rb["dL_dmeans3D"]) <= tol
     assert rel_l2(gpu["leaves"]["shs"].grad.cpu().numpy(), rb["dL_dsh"]) <= tol
     assert rel_l2(gpu["leaves"]["scales"].grad.cpu().numpy(), rb["dL_dscales"]) <= tol
+
+
+def test_geometry_cache_second_render_identical(gpu_device):
+    """The feature render of an iteration reuses the RGB render's geometry (preprocess/binning/sort skipped): results and
+    gradients must equal those of an un-cached call bit for bit."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from s3gaussian_amd import raster_C
+    s = tiny_scene(P=600, W=80, H=64, seed=5)
+    dev = gpu_device
+    rast = GaussianRasterizer(raster_settings=settings_from(s, dev))
+    g = torch.Generator().manual_seed(0)
+    feat_cols = torch.rand(600, 3, generator=g)
+    gc, gd = grad_pair(64, 80)
+
+    def run(cache_on):
+        raster_C._GEOM_CACHE_ON = cache_on
+        raster_C._geom_cache = None
+        t = lambda x: x.to(dev).clone().requires_grad_(True)
+        m3, op, sc, rot = t(s["means3D"]), t(s["opacities"]), t(s["scales"]), t(s["rotations"])
+        c1, c2 = t(s["colors_precomp"]), t(feat_cols)
+        m2 = torch.zeros_like(m3, requires_grad=True)
+        img1, r1, d1 = rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=c1, scales=sc, rotations=rot)
+        img2, r2, d2 = rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=c2, scales=sc, rotations=rot)
+        ((img1 * gc.to(dev)).sum() + (d1 * gd.to(dev)).sum() + (img2 * gc.to(dev).flip(0)).sum()).backward()
+        return [img1, img2, d1, d2, r1, r2], [x.grad for x in (m3, op, sc, rot, c1, c2, m2)]
+
+    try:
+        o_on, g_on = run(True)
+        hit = raster_C._geom_cache is not None
+        o_off, g_off = run(False)
+    finally:
+        raster_C._GEOM_CACHE_ON = True
+        raster_C._geom_cache = None
+    assert hit
+    for a, b in zip(o_on + g_on, o_off + g_off):
+        assert torch.equal(a, b)
