@@ -31,17 +31,20 @@ typedef struct s3g_mlp_params {  /* the same struct describes weights (const use
   float *D2, *db2;  /* dino_head.4    [3,64],   [3]  */
 } s3g_mlp_params;
 
-/* bytes of the activation stash written by forward and read by backward: 5 x [P,64] fp32
- * (hidden, pos1, shs1, dino1, dino2); the backward workspace (5 gradient signals) has the same size. */
+/* bytes of the stash written by forward and read by backward: the packed LDS images of the weights
+ * (s3g_deform_mlp_pack_bytes) followed by 5 x [P,64] fp32 activations (hidden, pos1, shs1, dino1, dino2).  The
+ * backward workspace (5 gradient signals) needs 5 * P * 64 * 4 bytes. */
 size_t s3g_deform_mlp_stash_bytes(int P);
+size_t s3g_deform_mlp_pack_bytes(void);
 
-/* features [P,128] -> dx [P,3], dshs [P,48], feat [P,3]; `stash` may be NULL when no backward will follow. */
+/* features [P,128] -> dx [P,3], dshs [P,48], feat [P,3].  `stash`: device scratch of s3g_deform_mlp_stash_bytes(P)
+ * bytes when save_activations != 0 (a backward will follow), else at least s3g_deform_mlp_pack_bytes(). */
 int s3g_deform_mlp_forward(const s3g_mlp_params* w, int P, const float* features, float* dx, float* dshs, float* feat,
-                           float* stash, void* stream);
+                           float* stash, int save_activations, void* stream);
 
 /* g_dx [P,3], g_dshs [P,48], g_feat [P,3] (upstream gradients) -> g_features [P,128] (written) and the parameter
- * gradients in `gw` (ACCUMULATED: the caller zero-fills them).  `stash` from the matching forward; `workspace` of
- * s3g_deform_mlp_stash_bytes(P) bytes, uninitialised. */
+ * gradients in `gw` (ACCUMULATED: the caller zero-fills them).  `stash` from the matching forward (weights must be
+ * unchanged since); `workspace` of 5 * P * 64 * 4 bytes, uninitialised. */
 int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* features, const float* stash, const float* g_dx,
                             const float* g_dshs, const float* g_feat, float* g_features, const s3g_mlp_params* gw,
                             float* workspace, void* stream);

@@ -135,10 +135,6 @@ struct BinningState {
 
 // ---- small device helpers -------------------------------------------------------------------------------
 // Row-vector 4x4 matrices are indexed column-major like the reference (auxiliary.h:58-77).
-struct Mat16 {
-  float m[16];
-};
-
 __device__ __forceinline__ float3 xform_4x3(const float3 p, const float* __restrict__ M) {
   return make_float3(M[0] * p.x + M[4] * p.y + M[8] * p.z + M[12], M[1] * p.x + M[5] * p.y + M[9] * p.z + M[13],
                      M[2] * p.x + M[6] * p.y + M[10] * p.z + M[14]);

@@ -3,10 +3,13 @@
 // Reference: 10 nn.Linear + 7 ReLU modules (scene/deformation.py:53-76) = ~20 library GEMM/elementwise launches forward
 // and ~40 backward on [P,128]/[P,64] activations; with P = 1.2 M the skinny GEMMs (N = 3..128) cost ~23 ms per
 // iteration through hipBLASLt.  Here:
+//   mlp_pack_kernel      builds the LDS image [in][out+1] of every layer once per call (odd stride -> conflict-free as
+//                        MFMA A operand both straight and transposed).
 //   mlp_forward_kernel   one pass: a wave owns a 32-point tile, activations live in LDS as [feature][point] (row
-//                        stride 33 -> conflict-free as MFMA B operand AND for the transposing global loads/stores),
-//                        the layer's weights are staged in LDS as [in][out+1] (odd stride -> conflict-free as A operand
-//                        both straight and transposed); the 5 hidden activations are stashed for the backward.
+//                        stride 33 -> conflict-free as MFMA B operand AND for the transposing global loads/stores);
+//                        while a layer's MFMAs run, the NEXT layer's weight slab streams global -> LDS through the DMA
+//                        path (global_load_lds_dwordx4, no VGPR round trip) into the other half of a double buffer;
+//                        the 5 hidden activations are stashed for the backward.
 //   mlp_backward_kernel  the per-point chain (transposed-weight GEMMs + ReLU masks) -> g_features and 5 gradient signals.
 //   mlp_wgrad_kernel     dW = sum_p g[p] (x) act[p] as an MFMA GEMM whose K dimension is the points (split over
 //                        workgroups, accumulators stay in registers, one atomic flush per workgroup); biases alongside.
@@ -23,7 +26,6 @@ constexpr int MT = 32;    // points per wave tile (MFMA N)
 constexpr int LDA = 33;   // activation row stride in LDS
 constexpr int HID = 64;   // net_width
 constexpr int FEAT = 128; // HexPlane feature width
-constexpr int WREGION = 64 * 65;  // floats: largest weight slab staged at once ([64 in][64 out + 1])
 
 // Workgroup barrier that only orders LDS traffic.  __syncthreads() also drains every outstanding GLOBAL store
 // (s_waitcnt vmcnt(0)): the stash/output stores of a phase nobody in this kernel reads would stall all 4 waves at
@@ -36,25 +38,6 @@ __device__ __forceinline__ void lds_barrier() {
 
 // rows of the 32x32 accumulator held by (lane, reg): row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); col = lane & 31
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
-
-// Stage a [OUT,IN] row-major weight slab (input columns [in0, in0+NIN)) into LDS as wl[(i-in0)*(OUTPAD+1) + o],
-// zero for o >= OUT.  Coalesced global reads along `in`, conflict-free LDS writes (odd row stride).  All loads of a
-// thread are issued before the first LDS write so their latencies overlap.
-template <int OUT, int IN, int OUTPAD, int NIN>
-__device__ __forceinline__ void stage_weight(float* wl, const float* __restrict__ Wg, int in0, int tid) {
-  constexpr int LD = OUTPAD + 1, TOTAL = OUTPAD * NIN, PER = (TOTAL + 255) / 256;
-  float v[PER];
-#pragma unroll
-  for (int u = 0; u < PER; u++) {
-    const int e = u * 256 + tid, o = e / NIN, i = e % NIN;
-    v[u] = (e < TOTAL && o < OUT) ? Wg[(size_t)o * IN + in0 + i] : 0.f;
-  }
-#pragma unroll
-  for (int u = 0; u < PER; u++) {
-    const int e = u * 256 + tid, o = e / NIN, i = e % NIN;
-    if (e < TOTAL) wl[i * LD + o] = v[u];
-  }
-}
 
 // acc[mb] (+)= W[mb*32.., :] * in   -- straight:  A(i,k) = W[out=m0+i][in=k] = wl[k*ld + m0 + i]
 template <int MB, bool RELU_IN>
@@ -148,125 +131,182 @@ __device__ __forceinline__ void tile_store(const float* buf, float* __restrict__
   }
 }
 
+// ---- weight slabs: LDS images built once per call in global memory, streamed into LDS by the DMA engine -----------
+// Slab k is the [in][out+1] image of one layer (feature_out is cut in two K halves), padded to SLAB floats = 17 KiB so a
+// slab is 17 global_load_lds_dwordx4 wave-instructions (1 KiB each).  Forward order 0..8; the backward walks 8..0 with
+// the two W0 halves last.
+constexpr int SLAB = 17 * 256;  // floats
+constexpr int NSLAB = 9;        // W0[:, :64] | W0[:, 64:] | P1 | S1 | P2 | S2 | D0 | D1 | D2
+constexpr int PACK_FLOATS = NSLAB * SLAB + 8 * 64;  // + the 8 bias vectors zero padded to 64
+
+__global__ void __launch_bounds__(256) mlp_pack_kernel(const s3g_mlp_params w, float* __restrict__ packed) {
+  const int k = blockIdx.x, tid = threadIdx.x;
+  float* dst = packed + (size_t)k * SLAB;
+  if (k == NSLAB) {  // biases
+    float* bl = packed + (size_t)NSLAB * SLAB;
+    const float* src[8] = {w.b0, w.pb1, w.sb1, w.pb2, w.sb2, w.db0, w.db1, w.db2};
+    const int n[8] = {64, 64, 64, 3, 48, 64, 64, 3};
+    for (int e = tid; e < 8 * 64; e += 256) bl[e] = (e & 63) < n[e >> 6] ? src[e >> 6][e & 63] : 0.f;
+    return;
+  }
+  const float* W = k <= 1 ? w.W0 : k == 2 ? w.P1 : k == 3 ? w.S1 : k == 4 ? w.P2 : k == 5 ? w.S2 : k == 6 ? w.D0 : k == 7 ? w.D1 : w.D2;
+  const int out = (k == 4 || k == 8) ? 3 : (k == 5 ? 48 : 64), outpad = (k == 4 || k == 8) ? 32 : 64;
+  const int in = k <= 1 ? FEAT : HID, in0 = k == 1 ? 64 : 0, ld = outpad + 1;
+  for (int e = tid; e < SLAB; e += 256) dst[e] = 0.f;
+  __syncthreads();
+  for (int e = tid; e < outpad * 64; e += 256) {
+    const int o = e / 64, i = e % 64;
+    dst[i * ld + o] = o < out ? W[(size_t)o * in + in0 + i] : 0.f;
+  }
+}
+
+// Asynchronous global -> LDS copy of one slab by the 4 waves of the workgroup (no VGPR round trip).
+__device__ __forceinline__ void dma_slab(float* lds_dst, const float* __restrict__ gsrc, int wave, int lane) {
+  for (int c = wave; c < SLAB / 256; c += 4)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + c * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(lds_dst + c * 256), 16, 0, 0);
+}
+// End of a phase: the slab streamed during the phase has landed (vmcnt(0)), everyone is done with the current one.
+#define PHASE_END()                                      \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       \
+  lds_barrier();                                         \
+  cur ^= 1
+
+// accumulator -> global [P][WIDTH] directly (rows = output index, cols = points of the tile)
+template <int WIDTH, int MB>
+__device__ __forceinline__ void acc_store_global(const f32x16 (&acc)[MB], float* __restrict__ g, int p0, int npts, int lane) {
+  const int col = lane & 31;
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = mb * 32 + acc_row(r, lane);
+      if (row < WIDTH && col < npts) g[(size_t)(p0 + col) * WIDTH + row] = acc[mb][r];
+    }
+}
+
 struct MlpFwdArgs {
-  s3g_mlp_params w;
   int P;
   const float* x;
+  const float* packed;
   float *dx, *dshs, *feat, *stash;
 };
 
-// LDS: [WREGION] weights | per wave: X[128][33] | H[64][33] | T[64][33]
-constexpr int WAVE_LDS = (FEAT + HID + HID) * LDA;
-constexpr int MLP_LDS_FLOATS = WREGION + 4 * WAVE_LDS;
+// LDS: two weight slabs (double buffered by DMA) | biases | per wave: X[128][33] | H[64][33]
+constexpr int WAVE_LDS = (FEAT + HID) * LDA;
+constexpr int MLP_LDS_FLOATS = 2 * SLAB + 8 * 64 + 4 * WAVE_LDS;
 
 __global__ void __launch_bounds__(256) mlp_forward_kernel(const MlpFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* wl = lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* X = lds + WREGION + wave * WAVE_LDS;
+  float* bl = lds + 2 * SLAB;  // biases: b0 | pb1 | sb1 | pb2 | sb2 | db0 | db1 | db2
+  float* X = bl + 8 * 64 + wave * WAVE_LDS;
   float* H = X + FEAT * LDA;
-  float* T = H + HID * LDA;
   const int ntiles = (a.P + MT - 1) / MT;
   const size_t PS = (size_t)a.P * HID;  // one stash plane
+  int cur = 0;
+  for (int e = tid; e < 8 * 64; e += 256) bl[e] = a.packed[(size_t)NSLAB * SLAB + e];
+  {
+    const int tile = blockIdx.x * 4 + wave, p0 = tile * MT;
+    tile_load<FEAT, FEAT>(X, a.x, p0, tile < ntiles ? min(MT, a.P - p0) : 0, lane);
+  }
+  dma_slab(lds, a.packed, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();
+#define WCUR (lds + cur * SLAB)
+#define WNEXT(k) dma_slab(lds + (cur ^ 1) * SLAB, a.packed + (size_t)(k) * SLAB, wave, lane)
   for (int t0 = blockIdx.x * 4; t0 < ntiles; t0 += gridDim.x * 4) {  // uniform trip count per workgroup
     const int tile = t0 + wave;
     const int p0 = tile * MT;
     const int npts = tile < ntiles ? min(MT, a.P - p0) : 0;
-    tile_load<FEAT, FEAT>(X, a.x, p0, npts, lane);
     f32x16 acc[2];
-    // ---- hidden = W0 x + b0 (two K halves of W0 staged in turn) ----
-    acc_init_bias<2>(acc, a.w.b0, HID, lane);
-    for (int half = 0; half < 2; half++) {
-      lds_barrier();
-      stage_weight<HID, FEAT, HID, 64>(wl, a.w.W0, half * 64, tid);
-      lds_barrier();
-      gemm_straight<2, false>(wl, 65, X + half * 64 * LDA, 64, acc, lane);
-    }
+    // ---- hidden = W0 x + b0 (two K halves) ----
+    WNEXT(1);
+    acc_init_bias<2>(acc, bl + 0 * 64, HID, lane);
+    gemm_straight<2, false>(WCUR, 65, X, 64, acc, lane);
+    PHASE_END();
+    WNEXT(2);
+    gemm_straight<2, false>(WCUR, 65, X + 64 * LDA, 64, acc, lane);
     acc_store<2, false>(acc, H, lane);
     if (a.stash) tile_store<HID>(H, a.stash + 0 * PS, p0, npts, lane);
+    PHASE_END();
     // ---- pos1 = relu(P1 relu(hidden) + pb1) -> X[0:64] ----
-    lds_barrier();
-    stage_weight<HID, HID, HID, HID>(wl, a.w.P1, 0, tid);
-    lds_barrier();
-    acc_init_bias<2>(acc, a.w.pb1, HID, lane);
-    gemm_straight<2, true>(wl, 65, H, HID, acc, lane);
+    WNEXT(3);
+    acc_init_bias<2>(acc, bl + 1 * 64, HID, lane);
+    gemm_straight<2, true>(WCUR, 65, H, HID, acc, lane);
     acc_store<2, true>(acc, X, lane);
     if (a.stash) tile_store<HID>(X, a.stash + 1 * PS, p0, npts, lane);
+    PHASE_END();
     // ---- shs1 = relu(S1 relu(hidden) + sb1) -> X[64:128] ----
-    lds_barrier();
-    stage_weight<HID, HID, HID, HID>(wl, a.w.S1, 0, tid);
-    lds_barrier();
-    acc_init_bias<2>(acc, a.w.sb1, HID, lane);
-    gemm_straight<2, true>(wl, 65, H, HID, acc, lane);
+    WNEXT(4);
+    acc_init_bias<2>(acc, bl + 2 * 64, HID, lane);
+    gemm_straight<2, true>(WCUR, 65, H, HID, acc, lane);
     acc_store<2, true>(acc, X + 64 * LDA, lane);
     if (a.stash) tile_store<HID>(X + 64 * LDA, a.stash + 2 * PS, p0, npts, lane);
+    PHASE_END();
     // ---- dx = P2 pos1 + pb2 ----
-    lds_barrier();
-    stage_weight<3, HID, 32, HID>(wl, a.w.P2, 0, tid);
-    lds_barrier();
+    WNEXT(5);
     {
       f32x16 o[1];
-      acc_init_bias<1>(o, a.w.pb2, 3, lane);
-      gemm_straight<1, false>(wl, 33, X, HID, o, lane);
-      acc_store<1, false>(o, T, lane);
-      tile_store<3>(T, a.dx, p0, npts, lane);
+      acc_init_bias<1>(o, bl + 3 * 64, 3, lane);
+      gemm_straight<1, false>(WCUR, 33, X, HID, o, lane);
+      acc_store_global<3, 1>(o, a.dx, p0, npts, lane);
     }
+    PHASE_END();
     // ---- dshs = S2 shs1 + sb2 ----
-    lds_barrier();
-    stage_weight<48, HID, 64, HID>(wl, a.w.S2, 0, tid);
-    lds_barrier();
-    acc_init_bias<2>(acc, a.w.sb2, 48, lane);
-    gemm_straight<2, false>(wl, 65, X + 64 * LDA, HID, acc, lane);
-    acc_store<2, false>(acc, T, lane);
-    tile_store<48>(T, a.dshs, p0, npts, lane);
+    WNEXT(6);
+    acc_init_bias<2>(acc, bl + 4 * 64, 48, lane);
+    gemm_straight<2, false>(WCUR, 65, X + 64 * LDA, HID, acc, lane);
+    acc_store_global<48, 2>(acc, a.dshs, p0, npts, lane);
+    PHASE_END();
     // ---- dino1 = relu(D0 hidden + db0) -> X[0:64] ----
-    lds_barrier();
-    stage_weight<HID, HID, HID, HID>(wl, a.w.D0, 0, tid);
-    lds_barrier();
-    acc_init_bias<2>(acc, a.w.db0, HID, lane);
-    gemm_straight<2, false>(wl, 65, H, HID, acc, lane);
+    WNEXT(7);
+    acc_init_bias<2>(acc, bl + 5 * 64, HID, lane);
+    gemm_straight<2, false>(WCUR, 65, H, HID, acc, lane);
     acc_store<2, true>(acc, X, lane);
     if (a.stash) tile_store<HID>(X, a.stash + 3 * PS, p0, npts, lane);
+    PHASE_END();
     // ---- dino2 = relu(D1 dino1 + db1) -> X[64:128] ----
-    lds_barrier();
-    stage_weight<HID, HID, HID, HID>(wl, a.w.D1, 0, tid);
-    lds_barrier();
-    acc_init_bias<2>(acc, a.w.db1, HID, lane);
-    gemm_straight<2, false>(wl, 65, X, HID, acc, lane);
+    WNEXT(8);
+    acc_init_bias<2>(acc, bl + 6 * 64, HID, lane);
+    gemm_straight<2, false>(WCUR, 65, X, HID, acc, lane);
     acc_store<2, true>(acc, X + 64 * LDA, lane);
     if (a.stash) tile_store<HID>(X + 64 * LDA, a.stash + 4 * PS, p0, npts, lane);
-    // ---- feat = D2 dino2 + db2 ----
-    lds_barrier();
-    stage_weight<3, HID, 32, HID>(wl, a.w.D2, 0, tid);
-    lds_barrier();
+    PHASE_END();
+    // ---- feat = D2 dino2 + db2 ; W0's first half and the NEXT tile's features stream in meanwhile ----
+    WNEXT(0);
     {
       f32x16 o[1];
-      acc_init_bias<1>(o, a.w.db2, 3, lane);
-      gemm_straight<1, false>(wl, 33, X + 64 * LDA, HID, o, lane);
-      acc_store<1, false>(o, T, lane);
-      tile_store<3>(T, a.feat, p0, npts, lane);
+      acc_init_bias<1>(o, bl + 7 * 64, 3, lane);
+      gemm_straight<1, false>(WCUR, 33, X + 64 * LDA, HID, o, lane);
+      acc_store_global<3, 1>(o, a.feat, p0, npts, lane);
+      const int ntile = tile + gridDim.x * 4, np0 = ntile * MT;
+      tile_load<FEAT, FEAT>(X, a.x, np0, ntile < ntiles ? min(MT, a.P - np0) : 0, lane);  // X is dead from here on
     }
+    PHASE_END();
   }
 }
 
 struct MlpBwdArgs {
-  s3g_mlp_params w;
   int P;
+  const float* packed;
   const float *stash, *g_dx, *g_dshs, *g_feat;
   float *g_x, *ws;
 };
 
-// Per-point backward chain.  LDS per wave: U0[64][33] | U1[64][33] | H[64][33] | T[64][33]  (same footprint as forward)
+// Per-point backward chain.  LDS per wave: U0[64][33] | U1[64][33] | H[64][33]  (same footprint as forward)
 __global__ void __launch_bounds__(256) mlp_backward_kernel(const MlpBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* wl = lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* U0 = lds + WREGION + wave * WAVE_LDS;
+  float* U0 = lds + 2 * SLAB + 8 * 64 + wave * WAVE_LDS;
   float* U1 = U0 + HID * LDA;
   float* H = U1 + HID * LDA;
-  float* T = H + HID * LDA;
   const int ntiles = (a.P + MT - 1) / MT;
   const size_t PS = (size_t)a.P * HID;
+  int cur = 0;
+  dma_slab(lds, a.packed + (size_t)8 * SLAB, wave, lane);  // D2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();
   for (int t0 = blockIdx.x * 4; t0 < ntiles; t0 += gridDim.x * 4) {
     const int tile = t0 + wave;
     const int p0 = tile * MT;
@@ -274,84 +314,85 @@ __global__ void __launch_bounds__(256) mlp_backward_kernel(const MlpBwdArgs a) {
     f32x16 ghid[2], acc[2];
     acc_init_bias<2>(ghid, nullptr, 0, lane);
     tile_load<HID, HID>(H, a.stash + 0 * PS, p0, npts, lane);            // hidden (raw)
-    // ================= dino head =================
     tile_load<HID, HID>(U1, a.stash + 4 * PS, p0, npts, lane);           // dino2
-    tile_load<3, 32>(T, a.g_feat, p0, npts, lane);                        // g_feat, rows 3..31 zero
-    lds_barrier();
-    stage_weight<3, HID, 32, HID>(wl, a.w.D2, 0, tid);
-    lds_barrier();
+    tile_load<3, 32>(U0, a.g_feat, p0, npts, lane);                       // g_feat in rows 0..2, rows 3..31 zero
+    // ================= dino head =================
+    WNEXT(7);                                                             // D1
     acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(wl, 33, T, 32, acc, lane);                         // D2^T g_feat
-    acc_store_masked<2>(acc, U1, U1, lane);                               // (.) * [dino2 > 0]  -> g wrt dino2 pre-activation
+    gemm_transposed<2>(WCUR, 33, U0, 32, acc, lane);                      // D2^T g_feat
+    acc_store_masked<2>(acc, U1, U1, lane);                               // * [dino2 > 0] -> g wrt dino2 pre-activation
     tile_store<HID>(U1, a.ws + 0 * PS, p0, npts, lane);
     tile_load<HID, HID>(U0, a.stash + 3 * PS, p0, npts, lane);           // dino1
-    lds_barrier();
-    stage_weight<HID, HID, HID, HID>(wl, a.w.D1, 0, tid);
-    lds_barrier();
+    PHASE_END();
+    WNEXT(6);                                                             // D0
     acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(wl, 65, U1, HID, acc, lane);                       // D1^T g_d2
+    gemm_transposed<2>(WCUR, 65, U1, HID, acc, lane);                     // D1^T g_d2
     acc_store_masked<2>(acc, U0, U0, lane);                               // * [dino1 > 0]
     tile_store<HID>(U0, a.ws + 1 * PS, p0, npts, lane);
-    lds_barrier();
-    stage_weight<HID, HID, HID, HID>(wl, a.w.D0, 0, tid);
-    lds_barrier();
-    gemm_transposed<2>(wl, 65, U0, HID, ghid, lane);                      // ghid += D0^T g_d1   (no mask: dino input is raw hidden)
-    // ================= pos head =================
+    PHASE_END();
+    WNEXT(4);                                                             // P2
+    gemm_transposed<2>(WCUR, 65, U0, HID, ghid, lane);                    // ghid += D0^T g_d1 (dino input is raw hidden: no mask)
     tile_load<HID, HID>(U1, a.stash + 1 * PS, p0, npts, lane);           // pos1
-    tile_load<3, 32>(T, a.g_dx, p0, npts, lane);
-    lds_barrier();
-    stage_weight<3, HID, 32, HID>(wl, a.w.P2, 0, tid);
-    lds_barrier();
+    tile_load<3, 32>(U0, a.g_dx, p0, npts, lane);
+    PHASE_END();
+    // ================= pos head =================
+    WNEXT(2);                                                             // P1
     acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(wl, 33, T, 32, acc, lane);
+    gemm_transposed<2>(WCUR, 33, U0, 32, acc, lane);                      // P2^T g_dx
     acc_store_masked<2>(acc, U1, U1, lane);                               // g wrt pos1 pre-activation
     tile_store<HID>(U1, a.ws + 2 * PS, p0, npts, lane);
-    lds_barrier();
-    stage_weight<HID, HID, HID, HID>(wl, a.w.P1, 0, tid);
-    lds_barrier();
+    PHASE_END();
+    WNEXT(5);                                                             // S2
     acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(wl, 65, U1, HID, acc, lane);                       // P1^T g_pos1  (gradient wrt relu(hidden))
+    gemm_transposed<2>(WCUR, 65, U1, HID, acc, lane);                     // P1^T g_pos1 (gradient wrt relu(hidden))
 #pragma unroll
     for (int mb = 0; mb < 2; mb++)
 #pragma unroll
       for (int r = 0; r < 16; r++)
         if (H[(mb * 32 + acc_row(r, lane)) * LDA + (lane & 31)] > 0.f) ghid[mb][r] += acc[mb][r];
-    // ================= shs head =================
     tile_load<HID, HID>(U1, a.stash + 2 * PS, p0, npts, lane);           // shs1
     tile_load<48, 64>(U0, a.g_dshs, p0, npts, lane);                      // g_dshs, rows 48..63 zero
-    lds_barrier();
-    stage_weight<48, HID, 64, HID>(wl, a.w.S2, 0, tid);
-    lds_barrier();
+    PHASE_END();
+    // ================= shs head =================
+    WNEXT(3);                                                             // S1
     acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(wl, 65, U0, 64, acc, lane);
+    gemm_transposed<2>(WCUR, 65, U0, 64, acc, lane);                      // S2^T g_dshs
     acc_store_masked<2>(acc, U1, U1, lane);
     tile_store<HID>(U1, a.ws + 3 * PS, p0, npts, lane);
-    lds_barrier();
-    stage_weight<HID, HID, HID, HID>(wl, a.w.S1, 0, tid);
-    lds_barrier();
+    PHASE_END();
+    WNEXT(0);                                                             // W0[:, :64]
     acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(wl, 65, U1, HID, acc, lane);
+    gemm_transposed<2>(WCUR, 65, U1, HID, acc, lane);                     // S1^T g_shs1
 #pragma unroll
     for (int mb = 0; mb < 2; mb++)
 #pragma unroll
       for (int r = 0; r < 16; r++)
         if (H[(mb * 32 + acc_row(r, lane)) * LDA + (lane & 31)] > 0.f) ghid[mb][r] += acc[mb][r];
-    // ================= feature_out =================
-    acc_store<2, false>(ghid, T, lane);
-    tile_store<HID>(T, a.ws + 4 * PS, p0, npts, lane);
-    for (int half = 0; half < 2; half++) {                                // g_x[:, half*64 : half*64+64] = W0[:, half]^T ghid
-      lds_barrier();
-      stage_weight<HID, FEAT, HID, 64>(wl, a.w.W0, half * 64, tid);
-      lds_barrier();
-      acc_init_bias<2>(acc, nullptr, 0, lane);
-      gemm_transposed<2>(wl, 65, T, HID, acc, lane);
-      acc_store<2, false>(acc, U0, lane);
+    acc_store<2, false>(ghid, U1, lane);                                  // total gradient wrt hidden
+    tile_store<HID>(U1, a.ws + 4 * PS, p0, npts, lane);
+    PHASE_END();
+    // ================= feature_out: g_x[:, half] = W0[:, half]^T ghid =================
+    WNEXT(1);                                                             // W0[:, 64:]
+    acc_init_bias<2>(acc, nullptr, 0, lane);
+    gemm_transposed<2>(WCUR, 65, U1, HID, acc, lane);
+    acc_store<2, false>(acc, U0, lane);
 #pragma unroll 8
-      for (int pt = 0; pt < MT; pt++)
-        if (pt < npts) a.g_x[(size_t)(p0 + pt) * FEAT + half * 64 + lane] = U0[lane * LDA + pt];
-    }
+    for (int pt = 0; pt < MT; pt++)
+      if (pt < npts) a.g_x[(size_t)(p0 + pt) * FEAT + lane] = U0[lane * LDA + pt];
+    PHASE_END();
+    WNEXT(8);                                                             // D2 for the next tile
+    acc_init_bias<2>(acc, nullptr, 0, lane);
+    gemm_transposed<2>(WCUR, 65, U1, HID, acc, lane);
+    acc_store<2, false>(acc, U0, lane);
+#pragma unroll 8
+    for (int pt = 0; pt < MT; pt++)
+      if (pt < npts) a.g_x[(size_t)(p0 + pt) * FEAT + 64 + lane] = U0[lane * LDA + pt];
+    PHASE_END();
   }
 }
+#undef PHASE_END
+#undef WCUR
+#undef WNEXT
 
 // dW[o][i] += sum_p G[p][o] * A[p][i];  db[o] += sum_p G[p][o].   K dimension = points, streamed from HBM:
 // the next tile's G and A rows are prefetched into registers while the current tile's MFMAs run.
@@ -476,7 +517,11 @@ static int launch_wgrad(const float* G, const float* A, float* dW, float* db, in
 
 using namespace s3g;
 
-extern "C" size_t s3g_deform_mlp_stash_bytes(int P) { return (size_t)5 * (size_t)(P > 0 ? P : 0) * HID * sizeof(float); }
+// stash = [packed weight slabs + biases (PACK_FLOATS)] [5 x P x 64 activations]
+extern "C" size_t s3g_deform_mlp_stash_bytes(int P) {
+  return ((size_t)PACK_FLOATS + (size_t)5 * (size_t)(P > 0 ? P : 0) * HID) * sizeof(float);
+}
+extern "C" size_t s3g_deform_mlp_pack_bytes(void) { return (size_t)PACK_FLOATS * sizeof(float); }
 
 static int mlp_set_attrs() {
   static bool done = false;
@@ -489,34 +534,38 @@ static int mlp_set_attrs() {
 }
 
 extern "C" int s3g_deform_mlp_forward(const s3g_mlp_params* w, int P, const float* features, float* dx, float* dshs,
-                                      float* feat, float* stash, void* stream_) {
-  if (!w || P < 0 || (P > 0 && (!features || !dx || !dshs || !feat))) {
+                                      float* feat, float* stash, int save_activations, void* stream_) {
+  if (!w || P < 0 || (P > 0 && (!features || !dx || !dshs || !feat || !stash))) {
     set_error("s3g_deform_mlp_forward: bad argument");
     return S3G_ERR_INVALID_ARG;
   }
   if (P == 0) return S3G_OK;
   if (int e = mlp_set_attrs()) return e;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(NSLAB + 1), dim3(256), 0, stream, *w, stash);
   MlpFwdArgs a;
-  a.w = *w; a.P = P; a.x = features; a.dx = dx; a.dshs = dshs; a.feat = feat; a.stash = stash;
+  a.P = P; a.x = features; a.packed = stash; a.dx = dx; a.dshs = dshs; a.feat = feat;
+  a.stash = save_activations ? stash + PACK_FLOATS : nullptr;
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + 3) / 4, 256);
-  hipLaunchKernelGGL(mlp_forward_kernel, dim3(blocks), dim3(256), MLP_LDS_FLOATS * 4, (hipStream_t)stream_, a);
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3(blocks), dim3(256), MLP_LDS_FLOATS * 4, stream, a);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }
 
-extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* features, const float* stash,
+extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* features, const float* stash_,
                                        const float* g_dx, const float* g_dshs, const float* g_feat, float* g_features,
                                        const s3g_mlp_params* gw, float* workspace, void* stream_) {
-  if (!w || !gw || P < 0 || (P > 0 && (!features || !stash || !g_dx || !g_dshs || !g_feat || !g_features || !workspace))) {
+  if (!w || !gw || P < 0 || (P > 0 && (!features || !stash_ || !g_dx || !g_dshs || !g_feat || !g_features || !workspace))) {
     set_error("s3g_deform_mlp_backward: bad argument");
     return S3G_ERR_INVALID_ARG;
   }
   if (P == 0) return S3G_OK;
   if (int e = mlp_set_attrs()) return e;
   hipStream_t stream = (hipStream_t)stream_;
+  const float* stash = stash_ + PACK_FLOATS;  // activations; the packed weight slabs of the forward sit in front
   MlpBwdArgs b;
-  b.w = *w; b.P = P; b.stash = stash; b.g_dx = g_dx; b.g_dshs = g_dshs; b.g_feat = g_feat; b.g_x = g_features; b.ws = workspace;
+  b.P = P; b.packed = stash_; b.stash = stash; b.g_dx = g_dx; b.g_dshs = g_dshs; b.g_feat = g_feat; b.g_x = g_features; b.ws = workspace;
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + 3) / 4, 256);
   hipLaunchKernelGGL(mlp_backward_kernel, dim3(blocks), dim3(256), MLP_LDS_FLOATS * 4, stream, b);

@@ -28,7 +28,8 @@ def _bind():
         L.s3g_deform_mlp_stash_bytes.restype = C.c_size_t
         L.s3g_deform_mlp_stash_bytes.argtypes = [C.c_int]
         L.s3g_deform_mlp_forward.restype = C.c_int
-        L.s3g_deform_mlp_forward.argtypes = [C.POINTER(_Params), C.c_int, vp, vp, vp, vp, vp, vp]
+        L.s3g_deform_mlp_forward.argtypes = [C.POINTER(_Params), C.c_int, vp, vp, vp, vp, vp, C.c_int, vp]
+        L.s3g_deform_mlp_pack_bytes.restype = C.c_size_t
         L.s3g_deform_mlp_backward.restype = C.c_int
         L.s3g_deform_mlp_backward.argtypes = [C.POINTER(_Params), C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(_Params), vp, vp]
         _bound = True
@@ -56,12 +57,12 @@ class _DeformMLP(torch.autograd.Function):
         dshs = torch.empty((P, 48), dtype=torch.float32, device=dev)
         feat = torch.empty((P, 3), dtype=torch.float32, device=dev)
         need_bwd = any(ctx.needs_input_grad)
-        stash = torch.empty((5, P, 64), dtype=torch.float32, device=dev) if need_bwd else None
+        nbytes = L.s3g_deform_mlp_stash_bytes(P) if need_bwd else L.s3g_deform_mlp_pack_bytes()
+        stash = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         w = _pack([p.detach() for p in params])
         with torch.cuda.device(dev):
             _lib.check(L.s3g_deform_mlp_forward(C.byref(w), P, x.data_ptr(), dx.data_ptr(), dshs.data_ptr(), feat.data_ptr(),
-                                                stash.data_ptr() if stash is not None else None,
-                                                torch.cuda.current_stream().cuda_stream))
+                                                stash.data_ptr(), int(need_bwd), torch.cuda.current_stream().cuda_stream))
         if need_bwd:
             ctx.save_for_backward(x, stash, *params)
         return dx, dshs, feat
