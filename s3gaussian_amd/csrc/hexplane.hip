@@ -297,17 +297,40 @@ __global__ void __launch_bounds__(256) hexsort_rank_kernel(int P, const uint32_t
 // ---- pass B: scatter in sorted order with register run-length combining ----
 constexpr int SEG = 128;  // sorted points walked by one half-wave
 
-struct Slot {
-  int id;
-  float acc;
+// One bilinear footprint being accumulated in registers: key = texel offset of its nw corner (-1 = empty), flags bit0 =
+// ne/se column in range, bit1 = sw/se row in range (the other three corners follow from key, flags and the plane width).
+struct Foot {
+  int key, flags;
+  float a00, a01, a10, a11;
 };
-__device__ __forceinline__ void slot_add(Slot& sl, int id, float v, float* __restrict__ gp, int c) {
-  if (id != sl.id) {
-    if (sl.id >= 0) atomicAdd(&gp[(size_t)sl.id * HEXC + c], sl.acc);
-    sl.id = id;
-    sl.acc = 0.f;
+__device__ __forceinline__ void foot_flush(const Foot& f, float* __restrict__ gp, int W, int c) {
+  if (f.key < 0) return;
+  atomicAdd(&gp[(size_t)f.key * HEXC + c], f.a00);
+  if (f.flags & 1) atomicAdd(&gp[(size_t)(f.key + 1) * HEXC + c], f.a01);
+  if (f.flags & 2) atomicAdd(&gp[(size_t)(f.key + W) * HEXC + c], f.a10);
+  if ((f.flags & 3) == 3) atomicAdd(&gp[(size_t)(f.key + W + 1) * HEXC + c], f.a11);
+}
+// Two-entry footprint cache (A = most recent).  align_corners grids of different levels do not nest, so inside one
+// finest-level cell the points alternate between two (sometimes four) coarse footprints; remembering the previous one
+// as well removes most of those flushes.
+__device__ __forceinline__ void foot_add(Foot& A, Foot& B, const Tap& t, float g, float* __restrict__ gp, int W, int c) {
+  if (t.o00 != A.key) {
+    if (t.o00 == B.key) {
+      const Foot tmp = A;
+      A = B;
+      B = tmp;
+    } else {
+      foot_flush(B, gp, W, c);
+      B = A;
+      A.key = t.o00;
+      A.flags = (t.o01 >= 0 ? 1 : 0) | (t.o10 >= 0 ? 2 : 0);
+      A.a00 = A.a01 = A.a10 = A.a11 = 0.f;
+    }
   }
-  sl.acc += v;
+  A.a00 += g * t.w00;
+  A.a01 += g * t.w01;
+  A.a10 += g * t.w10;
+  A.a11 += g * t.w11;
 }
 
 __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
@@ -321,15 +344,16 @@ __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, 
   const size_t PL = (size_t)a.P * HEXC;
   const int i0 = PLA[o], i1 = PLT[o];
   const int ax00 = PAIR0[i0], ax01 = PAIR1[i0], ax10 = PAIR0[i1], ax11 = PAIR1[i1];
-  constexpr int LG = 4;  // levels handled together: (2 planes x 4 corners) x 4 levels = 32 run-length slots in registers
+  constexpr int LG = 4;  // levels handled together: 4 levels x 2 planes x 2 footprints live in registers
   for (int l0 = 0; l0 < a.d.levels; l0 += LG) {
-    Slot sl[LG][2][4];
+    Foot fa[LG][2], fb[LG][2];
 #pragma unroll
     for (int l = 0; l < LG; l++)
 #pragma unroll
-      for (int q = 0; q < 2; q++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) sl[l][q][r] = Slot{-1, 0.f};
+      for (int q = 0; q < 2; q++) {
+        fa[l][q] = Foot{-1, 0, 0.f, 0.f, 0.f, 0.f};
+        fb[l][q] = Foot{-1, 0, 0.f, 0.f, 0.f, 0.f};
+      }
     for (int k = k0; k < k1; k++) {
       const int p = (int)order[k];
       float u[4];
@@ -347,30 +371,30 @@ __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, 
         float* gp0 = a.gplanes[l0 + l][i0];
         float* gp1 = a.gplanes[l0 + l][i1];
         if (gp0 != nullptr) {
-          const Tap t = make_tap(u[ax00], u[ax01], a.d.res[l0 + l][ax00], a.d.res[l0 + l][ax01]);
-          if (t.o00 >= 0) slot_add(sl[l][0][0], t.o00, g[l][0] * t.w00, gp0, c);
-          if (t.o01 >= 0) slot_add(sl[l][0][1], t.o01, g[l][0] * t.w01, gp0, c);
-          if (t.o10 >= 0) slot_add(sl[l][0][2], t.o10, g[l][0] * t.w10, gp0, c);
-          if (t.o11 >= 0) slot_add(sl[l][0][3], t.o11, g[l][0] * t.w11, gp0, c);
+          const int W = a.d.res[l0 + l][ax00];
+          const Tap t = make_tap(u[ax00], u[ax01], W, a.d.res[l0 + l][ax01]);
+          foot_add(fa[l][0], fb[l][0], t, g[l][0], gp0, W, c);
         }
         if (gp1 != nullptr) {
-          const Tap t = make_tap(u[ax10], u[ax11], a.d.res[l0 + l][ax10], a.d.res[l0 + l][ax11]);
-          if (t.o00 >= 0) slot_add(sl[l][1][0], t.o00, g[l][1] * t.w00, gp1, c);
-          if (t.o01 >= 0) slot_add(sl[l][1][1], t.o01, g[l][1] * t.w01, gp1, c);
-          if (t.o10 >= 0) slot_add(sl[l][1][2], t.o10, g[l][1] * t.w10, gp1, c);
-          if (t.o11 >= 0) slot_add(sl[l][1][3], t.o11, g[l][1] * t.w11, gp1, c);
+          const int W = a.d.res[l0 + l][ax10];
+          const Tap t = make_tap(u[ax10], u[ax11], W, a.d.res[l0 + l][ax11]);
+          foot_add(fa[l][1], fb[l][1], t, g[l][1], gp1, W, c);
         }
       }
     }
 #pragma unroll
     for (int l = 0; l < LG; l++) {
       if (l0 + l >= a.d.levels) break;
-      float* gpq[2] = {a.gplanes[l0 + l][i0], a.gplanes[l0 + l][i1]};
-#pragma unroll
-      for (int q = 0; q < 2; q++)
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          if (sl[l][q][r].id >= 0 && gpq[q] != nullptr) atomicAdd(&gpq[q][(size_t)sl[l][q][r].id * HEXC + c], sl[l][q][r].acc);
+      float* gp0 = a.gplanes[l0 + l][i0];
+      float* gp1 = a.gplanes[l0 + l][i1];
+      if (gp0 != nullptr) {
+        foot_flush(fa[l][0], gp0, a.d.res[l0 + l][ax00], c);
+        foot_flush(fb[l][0], gp0, a.d.res[l0 + l][ax00], c);
+      }
+      if (gp1 != nullptr) {
+        foot_flush(fa[l][1], gp1, a.d.res[l0 + l][ax10], c);
+        foot_flush(fb[l][1], gp1, a.d.res[l0 + l][ax10], c);
+      }
     }
   }
 }
