@@ -23,112 +23,127 @@ namespace s3g {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MT = 32;    // points per wave tile (MFMA N)
-constexpr int LDA = 33;   // activation row stride in LDS
 constexpr int HID = 64;   // net_width
 constexpr int FEAT = 128; // HexPlane feature width
 
-// Workgroup barrier that only orders LDS traffic.  __syncthreads() also drains every outstanding GLOBAL store
-// (s_waitcnt vmcnt(0)): the stash/output stores of a phase nobody in this kernel reads would stall all 4 waves at
-// every one of the 9 phase boundaries.
-__device__ __forceinline__ void lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
+// Accumulator layout of v_mfma_f32_32x32x2_f32: register r of lane l holds (row, col) = (rrow(r) + 4 * (l >> 5), l & 31)
+// with rrow(r) = (r & 3) + 8 * (r >> 2).  Rows are output features, columns the 32 points of the tile.
+__device__ __forceinline__ constexpr int rrow(int r) { return (r & 3) + 8 * (r >> 2); }
+__device__ __forceinline__ int acc_row(int reg, int lane) { return rrow(reg) + 4 * (lane >> 5); }
 
-// rows of the 32x32 accumulator held by (lane, reg): row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); col = lane & 31
-__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
-
-// acc[mb] (+)= W[mb*32.., :] * in   -- straight:  A(i,k) = W[out=m0+i][in=k] = wl[k*ld + m0 + i]
-template <int MB, bool RELU_IN>
-__device__ __forceinline__ void gemm_straight(const float* wl, int ld, const float* in, int K, f32x16 (&acc)[MB], int lane) {
-  const int i = lane & 31, kk = lane >> 5;
-#pragma unroll 4
-  for (int k0 = 0; k0 < K; k0 += 2) {
-    float b = in[(k0 + kk) * LDA + i];
-    if (RELU_IN) b = fmaxf(b, 0.f);
+// The trick that keeps activations out of LDS: the MFMA's K index is a summation index, so its order is free.  At K step
+// (mbi, r) lane l supplies as B operand its OWN accumulator register in[mbi][r] -- that is feature
+// f = 32*mbi + rrow(r) + 4*(l>>5) of point l&31 -- and the A operand is read from the weight image at that same f.
+// A layer's output registers are therefore directly the next layer's input operand: no transposition, no LDS round
+// trip, no barrier; waves run independently.
+//   straight:   acc[mbo] += W[32*mbo + i][f] * in[f]      A = wl[f * ld + 32*mbo + i]     (wl = [in][out+1] image)
+template <int MBO, int MBI, bool RELU_IN, int RSTEPS = 16>
+__device__ __forceinline__ void gemm_reg(const float* wl, int ld, const f32x16 (&in)[MBI], f32x16 (&acc)[MBO], int lane) {
+  const float* base = wl + 4 * (lane >> 5) * ld + (lane & 31);
 #pragma unroll
-    for (int mb = 0; mb < MB; mb++) {
-      const float a = wl[(k0 + kk) * ld + mb * 32 + i];
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mb], 0, 0, 0);
+  for (int mbi = 0; mbi < MBI; mbi++)
+#pragma unroll
+    for (int r = 0; r < RSTEPS; r++) {
+      float b = in[mbi][r];
+      if (RELU_IN) b = fmaxf(b, 0.f);
+#pragma unroll
+      for (int mbo = 0; mbo < MBO; mbo++)
+        acc[mbo] = __builtin_amdgcn_mfma_f32_32x32x2f32(base[(32 * mbi + rrow(r)) * ld + 32 * mbo], b, acc[mbo], 0, 0, 0);
     }
-  }
 }
-// acc[mb] += W^T[mb*32.., :] * in  -- transposed: A(i,k) = W[out=k][in=m0+i] = wl[(m0+i)*ld + k]; K = (padded) out dim
-template <int MB>
-__device__ __forceinline__ void gemm_transposed(const float* wl, int ld, const float* in, int K, f32x16 (&acc)[MB], int lane) {
-  const int i = lane & 31, kk = lane >> 5;
-#pragma unroll 4
-  for (int k0 = 0; k0 < K; k0 += 2) {
-    const float b = in[(k0 + kk) * LDA + i];
+//   transposed: acc[mbo] += W[f][32*mbo + i] * g[f]       A = wl[(32*mbo + i) * ld + f]   (f runs over OUTPUT features)
+template <int MBO, int MBI, int RSTEPS = 16>
+__device__ __forceinline__ void gemm_reg_t(const float* wl, int ld, const f32x16 (&g)[MBI], f32x16 (&acc)[MBO], int lane) {
+  const float* base = wl + (lane & 31) * ld + 4 * (lane >> 5);
 #pragma unroll
-    for (int mb = 0; mb < MB; mb++) {
-      const float a = wl[(mb * 32 + i) * ld + k0 + kk];
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mb], 0, 0, 0);
+  for (int mbi = 0; mbi < MBI; mbi++)
+#pragma unroll
+    for (int r = 0; r < RSTEPS; r++) {
+#pragma unroll
+      for (int mbo = 0; mbo < MBO; mbo++)
+        acc[mbo] = __builtin_amdgcn_mfma_f32_32x32x2f32(base[32 * mbo * ld + 32 * mbi + rrow(r)], g[mbi][r], acc[mbo], 0, 0, 0);
     }
-  }
 }
 
 template <int MB>
-__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[MB], const float* __restrict__ bias, int out, int lane) {
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[MB]) {
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[mb][r] = 0.f;
+}
+// acc = bias (LDS, zero padded to 64): 4 consecutive features per 16-byte read
+template <int MB>
+__device__ __forceinline__ void acc_bias(f32x16 (&acc)[MB], const float* bias, int lane) {
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 v = *reinterpret_cast<const float4*>(bias + 32 * mb + 8 * q + 4 * (lane >> 5));
+      acc[mb][4 * q + 0] = v.x; acc[mb][4 * q + 1] = v.y; acc[mb][4 * q + 2] = v.z; acc[mb][4 * q + 3] = v.w;
+    }
+}
+// Registers <-> a [P][WIDTH] global array, columns col0 .. col0 + 32*MB of it: lane (point j, half h) moves the four
+// consecutive features 32*mb + 8*q + 4*h .. +3 as one 16-byte access (features >= VALID are zero / not stored).
+template <int WIDTH, int MB, int VALID = 32 * MB>
+__device__ __forceinline__ void act_load(f32x16 (&a)[MB], const float* __restrict__ g, int col0, int p0, int npts, int lane) {
+  const int j = lane & 31, h = lane >> 5;
+  const float* row = g + (size_t)(p0 + j) * WIDTH + col0 + 4 * h;
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (32 * mb + 8 * q < VALID && 32 * mb + 8 * q + 4 * h < VALID && j < npts)
+        v = *reinterpret_cast<const float4*>(row + 32 * mb + 8 * q);
+      a[mb][4 * q + 0] = v.x; a[mb][4 * q + 1] = v.y; a[mb][4 * q + 2] = v.z; a[mb][4 * q + 3] = v.w;
+    }
+}
+template <int WIDTH, int MB, bool RELU, int VALID = 32 * MB>
+__device__ __forceinline__ void act_store(const f32x16 (&a)[MB], float* __restrict__ g, int col0, int p0, int npts, int lane) {
+  const int j = lane & 31, h = lane >> 5;
+  float* row = g + (size_t)(p0 + j) * WIDTH + col0 + 4 * h;
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (32 * mb + 8 * q >= VALID) continue;
+      float4 v = make_float4(a[mb][4 * q + 0], a[mb][4 * q + 1], a[mb][4 * q + 2], a[mb][4 * q + 3]);
+      if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      if (32 * mb + 8 * q + 4 * h < VALID && j < npts) *reinterpret_cast<float4*>(row + 32 * mb + 8 * q) = v;
+    }
+}
+// 3-wide heads ([P][3], not 16-byte aligned): features 0..2 sit in registers 0..2 of the h = 0 lanes
+__device__ __forceinline__ void act_load3(f32x16 (&a)[1], const float* __restrict__ g, int p0, int npts, int lane) {
+  acc_zero<1>(a);
+  if (lane < npts) {
+    const float* row = g + (size_t)(p0 + lane) * 3;
+    a[0][0] = row[0]; a[0][1] = row[1]; a[0][2] = row[2];
+  }
+}
+__device__ __forceinline__ void act_store3(const f32x16 (&a)[1], float* __restrict__ g, int p0, int npts, int lane) {
+  if (lane < npts) {
+    float* row = g + (size_t)(p0 + lane) * 3;
+    row[0] = a[0][0]; row[1] = a[0][1]; row[2] = a[0][2];
+  }
+}
+template <int MB>
+__device__ __forceinline__ void relu_inplace(f32x16 (&a)[MB]) {
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) a[mb][r] = fmaxf(a[mb][r], 0.f);
+}
+// dst (op)= acc where mask > 0
+template <int MB, bool ACCUM>
+__device__ __forceinline__ void masked(f32x16 (&dst)[MB], const f32x16 (&acc)[MB], const f32x16 (&mask)[MB]) {
 #pragma unroll
   for (int mb = 0; mb < MB; mb++)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const int row = mb * 32 + acc_row(r, lane);
-      acc[mb][r] = (bias != nullptr && row < out) ? bias[row] : 0.f;
+      const float v = mask[mb][r] > 0.f ? acc[mb][r] : 0.f;
+      dst[mb][r] = ACCUM ? dst[mb][r] + v : v;
     }
-}
-template <int MB, bool RELU>
-__device__ __forceinline__ void acc_store(const f32x16 (&acc)[MB], float* out, int lane) {
-#pragma unroll
-  for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float v = acc[mb][r];
-      out[(mb * 32 + acc_row(r, lane)) * LDA + (lane & 31)] = RELU ? fmaxf(v, 0.f) : v;
-    }
-}
-// out = acc masked by (mask_buf > 0)
-template <int MB>
-__device__ __forceinline__ void acc_store_masked(const f32x16 (&acc)[MB], const float* mask, float* out, int lane) {
-#pragma unroll
-  for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int o = (mb * 32 + acc_row(r, lane)) * LDA + (lane & 31);
-      out[o] = mask[o] > 0.f ? acc[mb][r] : 0.f;
-    }
-}
-
-// Tile <-> global transposing copies.  Global is point-major [P][WIDTH]; LDS is [ROWS >= WIDTH][LDA] (zero padded).
-// Loads are issued in batches of 16 per lane before the LDS writes so their latencies overlap.
-template <int WIDTH, int ROWS, bool RELU = false>
-__device__ __forceinline__ void tile_load(float* buf, const float* __restrict__ g, int p0, int npts, int lane) {
-  constexpr int PER = MT * ROWS / 64, BATCH = PER < 16 ? PER : 16;
-  for (int c = 0; c < PER; c += BATCH) {
-    float v[BATCH];
-#pragma unroll
-    for (int u = 0; u < BATCH; u++) {
-      const int e = (c + u) * 64 + lane, pt = e / ROWS, f = e % ROWS;  // e = point * ROWS + feature
-      float x = (pt < npts && f < WIDTH) ? g[(size_t)(p0 + pt) * WIDTH + f] : 0.f;
-      v[u] = RELU ? fmaxf(x, 0.f) : x;
-    }
-#pragma unroll
-    for (int u = 0; u < BATCH; u++) {
-      const int e = (c + u) * 64 + lane, pt = e / ROWS, f = e % ROWS;
-      buf[f * LDA + pt] = v[u];
-    }
-  }
-}
-template <int WIDTH>
-__device__ __forceinline__ void tile_store(const float* buf, float* __restrict__ g, int p0, int npts, int lane) {
-  constexpr int PER = (MT * WIDTH + 63) / 64;
-#pragma unroll 8
-  for (int u = 0; u < PER; u++) {
-    const int e = u * 64 + lane, pt = e / WIDTH, f = e % WIDTH;
-    if (pt < npts) g[(size_t)(p0 + pt) * WIDTH + f] = buf[f * LDA + pt];
-  }
 }
 
 // ---- weight slabs: LDS images built once per call in global memory, streamed into LDS by the DMA engine -----------
@@ -160,30 +175,20 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(const s3g_mlp_params w, f
   }
 }
 
-// Asynchronous global -> LDS copy of one slab by the 4 waves of the workgroup (no VGPR round trip).
-__device__ __forceinline__ void dma_slab(float* lds_dst, const float* __restrict__ gsrc, int wave, int lane) {
-  for (int c = wave; c < SLAB / 256; c += 4)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + c * 256 + lane * 4),
-                                     (__attribute__((address_space(3))) void*)(lds_dst + c * 256), 16, 0, 0);
-}
-// End of a phase: the slab streamed during the phase has landed (vmcnt(0)), everyone is done with the current one.
-#define PHASE_END()                                      \
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       \
-  lds_barrier();                                         \
-  cur ^= 1
+constexpr int NWAVE = 8;  // waves per workgroup; one persistent workgroup per CU (the weights fill its LDS)
+constexpr int MLP_LDS_FLOATS = PACK_FLOATS;
 
-// accumulator -> global [P][WIDTH] directly (rows = output index, cols = points of the tile)
-template <int WIDTH, int MB>
-__device__ __forceinline__ void acc_store_global(const f32x16 (&acc)[MB], float* __restrict__ g, int p0, int npts, int lane) {
-  const int col = lane & 31;
-#pragma unroll
-  for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int row = mb * 32 + acc_row(r, lane);
-      if (row < WIDTH && col < npts) g[(size_t)(p0 + col) * WIDTH + row] = acc[mb][r];
-    }
+// Whole packed image (9 slabs + biases, 155 KB) global -> LDS through the DMA path, once per workgroup.
+__device__ __forceinline__ void load_weights(float* lds, const float* __restrict__ packed, int wave, int lane) {
+  static_assert(PACK_FLOATS % 256 == 0, "image is a whole number of 1 KiB DMA rows");
+  for (int c = wave; c < PACK_FLOATS / 256; c += NWAVE)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(packed + c * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(lds + c * 256), 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 }
+#define WSLAB(k) (lds + (k) * SLAB)
+#define BIAS(k) (lds + NSLAB * SLAB + (k) * 64)  // b0 | pb1 | sb1 | pb2 | sb2 | db0 | db1 | db2
 
 struct MlpFwdArgs {
   int P;
@@ -192,98 +197,52 @@ struct MlpFwdArgs {
   float *dx, *dshs, *feat, *stash;
 };
 
-// LDS: two weight slabs (double buffered by DMA) | biases | per wave: X[128][33] | H[64][33]
-constexpr int WAVE_LDS = (FEAT + HID) * LDA;
-constexpr int MLP_LDS_FLOATS = 2 * SLAB + 8 * 64 + 4 * WAVE_LDS;
-
-__global__ void __launch_bounds__(256) mlp_forward_kernel(const MlpFwdArgs a) {
+__global__ void __launch_bounds__(NWAVE * 64) mlp_forward_kernel(const MlpFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* bl = lds + 2 * SLAB;  // biases: b0 | pb1 | sb1 | pb2 | sb2 | db0 | db1 | db2
-  float* X = bl + 8 * 64 + wave * WAVE_LDS;
-  float* H = X + FEAT * LDA;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_weights(lds, a.packed, wave, lane);
   const int ntiles = (a.P + MT - 1) / MT;
   const size_t PS = (size_t)a.P * HID;  // one stash plane
-  int cur = 0;
-  for (int e = tid; e < 8 * 64; e += 256) bl[e] = a.packed[(size_t)NSLAB * SLAB + e];
-  {
-    const int tile = blockIdx.x * 4 + wave, p0 = tile * MT;
-    tile_load<FEAT, FEAT>(X, a.x, p0, tile < ntiles ? min(MT, a.P - p0) : 0, lane);
-  }
-  dma_slab(lds, a.packed, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  lds_barrier();
-#define WCUR (lds + cur * SLAB)
-#define WNEXT(k) dma_slab(lds + (cur ^ 1) * SLAB, a.packed + (size_t)(k) * SLAB, wave, lane)
-  for (int t0 = blockIdx.x * 4; t0 < ntiles; t0 += gridDim.x * 4) {  // uniform trip count per workgroup
-    const int tile = t0 + wave;
-    const int p0 = tile * MT;
-    const int npts = tile < ntiles ? min(MT, a.P - p0) : 0;
-    f32x16 acc[2];
-    // ---- hidden = W0 x + b0 (two K halves) ----
-    WNEXT(1);
-    acc_init_bias<2>(acc, bl + 0 * 64, HID, lane);
-    gemm_straight<2, false>(WCUR, 65, X, 64, acc, lane);
-    PHASE_END();
-    WNEXT(2);
-    gemm_straight<2, false>(WCUR, 65, X + 64 * LDA, 64, acc, lane);
-    acc_store<2, false>(acc, H, lane);
-    if (a.stash) tile_store<HID>(H, a.stash + 0 * PS, p0, npts, lane);
-    PHASE_END();
-    // ---- pos1 = relu(P1 relu(hidden) + pb1) -> X[0:64] ----
-    WNEXT(3);
-    acc_init_bias<2>(acc, bl + 1 * 64, HID, lane);
-    gemm_straight<2, true>(WCUR, 65, H, HID, acc, lane);
-    acc_store<2, true>(acc, X, lane);
-    if (a.stash) tile_store<HID>(X, a.stash + 1 * PS, p0, npts, lane);
-    PHASE_END();
-    // ---- shs1 = relu(S1 relu(hidden) + sb1) -> X[64:128] ----
-    WNEXT(4);
-    acc_init_bias<2>(acc, bl + 2 * 64, HID, lane);
-    gemm_straight<2, true>(WCUR, 65, H, HID, acc, lane);
-    acc_store<2, true>(acc, X + 64 * LDA, lane);
-    if (a.stash) tile_store<HID>(X + 64 * LDA, a.stash + 2 * PS, p0, npts, lane);
-    PHASE_END();
-    // ---- dx = P2 pos1 + pb2 ----
-    WNEXT(5);
-    {
-      f32x16 o[1];
-      acc_init_bias<1>(o, bl + 3 * 64, 3, lane);
-      gemm_straight<1, false>(WCUR, 33, X, HID, o, lane);
-      acc_store_global<3, 1>(o, a.dx, p0, npts, lane);
+  for (int tile = blockIdx.x * NWAVE + wave; tile < ntiles; tile += gridDim.x * NWAVE) {
+    const int p0 = tile * MT, npts = min(MT, a.P - p0);
+    f32x16 hid[2], act[2], acc[2], o[1];
+    {  // hidden = W0 x + b0, K = 128 in two halves
+      f32x16 x[2];
+      acc_bias<2>(hid, BIAS(0), lane);
+      act_load<FEAT, 2>(x, a.x, 0, p0, npts, lane);
+      gemm_reg<2, 2, false>(WSLAB(0), 65, x, hid, lane);
+      act_load<FEAT, 2>(x, a.x, 64, p0, npts, lane);
+      gemm_reg<2, 2, false>(WSLAB(1), 65, x, hid, lane);
     }
-    PHASE_END();
-    // ---- dshs = S2 shs1 + sb2 ----
-    WNEXT(6);
-    acc_init_bias<2>(acc, bl + 4 * 64, 48, lane);
-    gemm_straight<2, false>(WCUR, 65, X + 64 * LDA, HID, acc, lane);
-    acc_store_global<48, 2>(acc, a.dshs, p0, npts, lane);
-    PHASE_END();
-    // ---- dino1 = relu(D0 hidden + db0) -> X[0:64] ----
-    WNEXT(7);
-    acc_init_bias<2>(acc, bl + 5 * 64, HID, lane);
-    gemm_straight<2, false>(WCUR, 65, H, HID, acc, lane);
-    acc_store<2, true>(acc, X, lane);
-    if (a.stash) tile_store<HID>(X, a.stash + 3 * PS, p0, npts, lane);
-    PHASE_END();
-    // ---- dino2 = relu(D1 dino1 + db1) -> X[64:128] ----
-    WNEXT(8);
-    acc_init_bias<2>(acc, bl + 6 * 64, HID, lane);
-    gemm_straight<2, false>(WCUR, 65, X, HID, acc, lane);
-    acc_store<2, true>(acc, X + 64 * LDA, lane);
-    if (a.stash) tile_store<HID>(X + 64 * LDA, a.stash + 4 * PS, p0, npts, lane);
-    PHASE_END();
-    // ---- feat = D2 dino2 + db2 ; W0's first half and the NEXT tile's features stream in meanwhile ----
-    WNEXT(0);
-    {
-      f32x16 o[1];
-      acc_init_bias<1>(o, bl + 7 * 64, 3, lane);
-      gemm_straight<1, false>(WCUR, 33, X + 64 * LDA, HID, o, lane);
-      acc_store_global<3, 1>(o, a.feat, p0, npts, lane);
-      const int ntile = tile + gridDim.x * 4, np0 = ntile * MT;
-      tile_load<FEAT, FEAT>(X, a.x, np0, ntile < ntiles ? min(MT, a.P - np0) : 0, lane);  // X is dead from here on
-    }
-    PHASE_END();
+    if (a.stash) act_store<HID, 2, false>(hid, a.stash + 0 * PS, 0, p0, npts, lane);
+    // pos head: dx = P2 relu(P1 relu(hidden) + pb1) + pb2
+    acc_bias<2>(act, BIAS(1), lane);
+    gemm_reg<2, 2, true>(WSLAB(2), 65, hid, act, lane);
+    relu_inplace<2>(act);
+    if (a.stash) act_store<HID, 2, false>(act, a.stash + 1 * PS, 0, p0, npts, lane);
+    acc_bias<1>(o, BIAS(3), lane);
+    gemm_reg<1, 2, false>(WSLAB(4), 33, act, o, lane);
+    act_store3(o, a.dx, p0, npts, lane);
+    // shs head: dshs = S2 relu(S1 relu(hidden) + sb1) + sb2
+    acc_bias<2>(act, BIAS(2), lane);
+    gemm_reg<2, 2, true>(WSLAB(3), 65, hid, act, lane);
+    relu_inplace<2>(act);
+    if (a.stash) act_store<HID, 2, false>(act, a.stash + 2 * PS, 0, p0, npts, lane);
+    acc_bias<2>(acc, BIAS(4), lane);
+    gemm_reg<2, 2, false>(WSLAB(5), 65, act, acc, lane);
+    act_store<48, 2, false, 48>(acc, a.dshs, 0, p0, npts, lane);
+    // dino head: feat = D2 relu(D1 relu(D0 hidden + db0) + db1) + db2   (input is the raw hidden, deformation.py:126)
+    acc_bias<2>(act, BIAS(5), lane);
+    gemm_reg<2, 2, false>(WSLAB(6), 65, hid, act, lane);
+    relu_inplace<2>(act);
+    if (a.stash) act_store<HID, 2, false>(act, a.stash + 3 * PS, 0, p0, npts, lane);
+    acc_bias<2>(acc, BIAS(6), lane);
+    gemm_reg<2, 2, false>(WSLAB(7), 65, act, acc, lane);
+    relu_inplace<2>(acc);
+    if (a.stash) act_store<HID, 2, false>(acc, a.stash + 4 * PS, 0, p0, npts, lane);
+    acc_bias<1>(o, BIAS(7), lane);
+    gemm_reg<1, 2, false>(WSLAB(8), 33, acc, o, lane);
+    act_store3(o, a.feat, p0, npts, lane);
   }
 }
 
@@ -294,108 +253,71 @@ struct MlpBwdArgs {
   float *g_x, *ws;
 };
 
-// Per-point backward chain.  LDS per wave: U0[64][33] | U1[64][33] | H[64][33]  (same footprint as forward)
-__global__ void __launch_bounds__(256) mlp_backward_kernel(const MlpBwdArgs a) {
+// Per-point backward chain, same register-resident scheme with the transposed weight reads.
+__global__ void __launch_bounds__(NWAVE * 64) mlp_backward_kernel(const MlpBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* U0 = lds + 2 * SLAB + 8 * 64 + wave * WAVE_LDS;
-  float* U1 = U0 + HID * LDA;
-  float* H = U1 + HID * LDA;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_weights(lds, a.packed, wave, lane);
   const int ntiles = (a.P + MT - 1) / MT;
   const size_t PS = (size_t)a.P * HID;
-  int cur = 0;
-  dma_slab(lds, a.packed + (size_t)8 * SLAB, wave, lane);  // D2
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  lds_barrier();
-  for (int t0 = blockIdx.x * 4; t0 < ntiles; t0 += gridDim.x * 4) {
-    const int tile = t0 + wave;
-    const int p0 = tile * MT;
-    const int npts = tile < ntiles ? min(MT, a.P - p0) : 0;
-    f32x16 ghid[2], acc[2];
-    acc_init_bias<2>(ghid, nullptr, 0, lane);
-    tile_load<HID, HID>(H, a.stash + 0 * PS, p0, npts, lane);            // hidden (raw)
-    tile_load<HID, HID>(U1, a.stash + 4 * PS, p0, npts, lane);           // dino2
-    tile_load<3, 32>(U0, a.g_feat, p0, npts, lane);                       // g_feat in rows 0..2, rows 3..31 zero
-    // ================= dino head =================
-    WNEXT(7);                                                             // D1
-    acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(WCUR, 33, U0, 32, acc, lane);                      // D2^T g_feat
-    acc_store_masked<2>(acc, U1, U1, lane);                               // * [dino2 > 0] -> g wrt dino2 pre-activation
-    tile_store<HID>(U1, a.ws + 0 * PS, p0, npts, lane);
-    tile_load<HID, HID>(U0, a.stash + 3 * PS, p0, npts, lane);           // dino1
-    PHASE_END();
-    WNEXT(6);                                                             // D0
-    acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(WCUR, 65, U1, HID, acc, lane);                     // D1^T g_d2
-    acc_store_masked<2>(acc, U0, U0, lane);                               // * [dino1 > 0]
-    tile_store<HID>(U0, a.ws + 1 * PS, p0, npts, lane);
-    PHASE_END();
-    WNEXT(4);                                                             // P2
-    gemm_transposed<2>(WCUR, 65, U0, HID, ghid, lane);                    // ghid += D0^T g_d1 (dino input is raw hidden: no mask)
-    tile_load<HID, HID>(U1, a.stash + 1 * PS, p0, npts, lane);           // pos1
-    tile_load<3, 32>(U0, a.g_dx, p0, npts, lane);
-    PHASE_END();
-    // ================= pos head =================
-    WNEXT(2);                                                             // P1
-    acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(WCUR, 33, U0, 32, acc, lane);                      // P2^T g_dx
-    acc_store_masked<2>(acc, U1, U1, lane);                               // g wrt pos1 pre-activation
-    tile_store<HID>(U1, a.ws + 2 * PS, p0, npts, lane);
-    PHASE_END();
-    WNEXT(5);                                                             // S2
-    acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(WCUR, 65, U1, HID, acc, lane);                     // P1^T g_pos1 (gradient wrt relu(hidden))
-#pragma unroll
-    for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++)
-        if (H[(mb * 32 + acc_row(r, lane)) * LDA + (lane & 31)] > 0.f) ghid[mb][r] += acc[mb][r];
-    tile_load<HID, HID>(U1, a.stash + 2 * PS, p0, npts, lane);           // shs1
-    tile_load<48, 64>(U0, a.g_dshs, p0, npts, lane);                      // g_dshs, rows 48..63 zero
-    PHASE_END();
-    // ================= shs head =================
-    WNEXT(3);                                                             // S1
-    acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(WCUR, 65, U0, 64, acc, lane);                      // S2^T g_dshs
-    acc_store_masked<2>(acc, U1, U1, lane);
-    tile_store<HID>(U1, a.ws + 3 * PS, p0, npts, lane);
-    PHASE_END();
-    WNEXT(0);                                                             // W0[:, :64]
-    acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(WCUR, 65, U1, HID, acc, lane);                     // S1^T g_shs1
-#pragma unroll
-    for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++)
-        if (H[(mb * 32 + acc_row(r, lane)) * LDA + (lane & 31)] > 0.f) ghid[mb][r] += acc[mb][r];
-    acc_store<2, false>(ghid, U1, lane);                                  // total gradient wrt hidden
-    tile_store<HID>(U1, a.ws + 4 * PS, p0, npts, lane);
-    PHASE_END();
-    // ================= feature_out: g_x[:, half] = W0[:, half]^T ghid =================
-    WNEXT(1);                                                             // W0[:, 64:]
-    acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(WCUR, 65, U1, HID, acc, lane);
-    acc_store<2, false>(acc, U0, lane);
-#pragma unroll 8
-    for (int pt = 0; pt < MT; pt++)
-      if (pt < npts) a.g_x[(size_t)(p0 + pt) * FEAT + lane] = U0[lane * LDA + pt];
-    PHASE_END();
-    WNEXT(8);                                                             // D2 for the next tile
-    acc_init_bias<2>(acc, nullptr, 0, lane);
-    gemm_transposed<2>(WCUR, 65, U1, HID, acc, lane);
-    acc_store<2, false>(acc, U0, lane);
-#pragma unroll 8
-    for (int pt = 0; pt < MT; pt++)
-      if (pt < npts) a.g_x[(size_t)(p0 + pt) * FEAT + 64 + lane] = U0[lane * LDA + pt];
-    PHASE_END();
+  for (int tile = blockIdx.x * NWAVE + wave; tile < ntiles; tile += gridDim.x * NWAVE) {
+    const int p0 = tile * MT, npts = min(MT, a.P - p0);
+    f32x16 ghid[2], g[2], acc[2], m[2], g3[1];
+    acc_zero<2>(ghid);
+    // ---- dino head ----
+    act_load3(g3, a.g_feat, p0, npts, lane);
+    act_load<HID, 2>(m, a.stash + 4 * PS, 0, p0, npts, lane);  // dino2
+    acc_zero<2>(acc);
+    gemm_reg_t<2, 1, 3>(WSLAB(8), 33, g3, acc, lane);           // D2^T g_feat (3 live K steps)
+    masked<2, false>(g, acc, m);                                 // gradient wrt dino2 pre-activation
+    act_store<HID, 2, false>(g, a.ws + 0 * PS, 0, p0, npts, lane);
+    act_load<HID, 2>(m, a.stash + 3 * PS, 0, p0, npts, lane);  // dino1
+    acc_zero<2>(acc);
+    gemm_reg_t<2, 2>(WSLAB(7), 65, g, acc, lane);               // D1^T
+    masked<2, false>(g, acc, m);
+    act_store<HID, 2, false>(g, a.ws + 1 * PS, 0, p0, npts, lane);
+    gemm_reg_t<2, 2>(WSLAB(6), 65, g, ghid, lane);              // ghid = D0^T (dino input is the raw hidden: no mask)
+    // ---- pos head ----
+    act_load3(g3, a.g_dx, p0, npts, lane);
+    act_load<HID, 2>(m, a.stash + 1 * PS, 0, p0, npts, lane);  // pos1
+    acc_zero<2>(acc);
+    gemm_reg_t<2, 1, 3>(WSLAB(4), 33, g3, acc, lane);           // P2^T g_dx
+    masked<2, false>(g, acc, m);
+    act_store<HID, 2, false>(g, a.ws + 2 * PS, 0, p0, npts, lane);
+    acc_zero<2>(acc);
+    gemm_reg_t<2, 2>(WSLAB(2), 65, g, acc, lane);               // P1^T
+    // ---- shs head ----
+    {
+      f32x16 gs[2], m2[2];
+      act_load<48, 2, 48>(gs, a.g_dshs, 0, p0, npts, lane);
+      act_load<HID, 2>(m2, a.stash + 2 * PS, 0, p0, npts, lane);  // shs1
+      f32x16 t[2];
+      acc_zero<2>(t);
+      gemm_reg_t<2, 2>(WSLAB(5), 65, gs, t, lane);              // S2^T g_dshs (rows 48..63 of the image are zero)
+      masked<2, false>(g, t, m2);
+    }
+    act_store<HID, 2, false>(g, a.ws + 3 * PS, 0, p0, npts, lane);
+    act_load<HID, 2>(m, a.stash + 0 * PS, 0, p0, npts, lane);  // hidden (raw): mask of the two relu(hidden) consumers
+    gemm_reg_t<2, 2>(WSLAB(3), 65, g, acc, lane);               // + S1^T  (same relu(hidden) mask as P1^T)
+    masked<2, true>(ghid, acc, m);
+    act_store<HID, 2, false>(ghid, a.ws + 4 * PS, 0, p0, npts, lane);
+    // ---- feature_out: g_x[:, half] = W0[:, half]^T ghid ----
+    acc_zero<2>(acc);
+    gemm_reg_t<2, 2>(WSLAB(0), 65, ghid, acc, lane);
+    act_store<FEAT, 2, false>(acc, a.g_x, 0, p0, npts, lane);
+    acc_zero<2>(acc);
+    gemm_reg_t<2, 2>(WSLAB(1), 65, ghid, acc, lane);
+    act_store<FEAT, 2, false>(acc, a.g_x, 64, p0, npts, lane);
   }
 }
-#undef PHASE_END
-#undef WCUR
-#undef WNEXT
+#undef WSLAB
+#undef BIAS
 
-// dW[o][i] += sum_p G[p][o] * A[p][i];  db[o] += sum_p G[p][o].   K dimension = points, streamed from HBM:
-// the next tile's G and A rows are prefetched into registers while the current tile's MFMAs run.
+// dW[o][i] += sum_p G[p][o] * A[p][i];  db[o] += sum_p G[p][o].   An MFMA GEMM whose K dimension is the points, fed
+// straight from HBM: at K step s lane (i, k) supplies point p0 + 2s + k, and -- because the order of the M / N rows of an
+// MFMA is as free as its K order -- row i of block t is feature VEC*i + t, so a lane's operand values for all blocks
+// are ONE contiguous VEC-float load and a wave instruction reads two whole rows.  No LDS, no transposition; the next
+// tile's rows are requested step by step as the current ones are consumed.
 struct WgradArgs {
   const float* G;  // [P][GW]
   const float* A;  // [P][AW]
@@ -403,112 +325,109 @@ struct WgradArgs {
   float* db;       // [GW]
   int P;
 };
-template <int GW, int AW>
-struct WgradCfg {
-  static constexpr int MB = GW > 32 ? 2 : 1, NB = AW / 32, GROWS = MB * 32;
-  static constexpr int GPER = MT * GROWS / 64, APER = MT * AW / 64;
+template <int W>
+struct RowSplit {  // floats per lane = number of 32-row blocks
+  static constexpr int VEC = W > 64 ? 4 : (W > 32 ? 2 : 1);
 };
-
-template <int GW, int AW, bool RELU_A>
-__global__ void __launch_bounds__(256) mlp_wgrad_kernel(const WgradArgs a) {
-  using Cf = WgradCfg<GW, AW>;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* Gl = lds + wave * (Cf::GROWS + AW) * LDA;  // [GROWS][33], rows >= GW zero
-  float* Al = Gl + Cf::GROWS * LDA;                  // [AW][33]
-  f32x16 acc[Cf::MB][Cf::NB];
-#pragma unroll
-  for (int m = 0; m < Cf::MB; m++)
-#pragma unroll
-    for (int n = 0; n < Cf::NB; n++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
-  float bsum = 0.f;  // lane o accumulates db[o]
-  const int ntiles = (a.P + MT - 1) / MT;
-  const int i = lane & 31, kk = lane >> 5;
-  float gv[Cf::GPER], av[Cf::APER];
-  auto prefetch = [&](int tile) {
-    const int p0 = tile * MT, npts = min(MT, a.P - p0);
-#pragma unroll
-    for (int u = 0; u < Cf::GPER; u++) {
-      const int e = u * 64 + lane, pt = e / Cf::GROWS, f = e % Cf::GROWS;
-      gv[u] = (pt < npts && f < GW) ? a.G[(size_t)(p0 + pt) * GW + f] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < Cf::APER; u++) {
-      const int e = u * 64 + lane, pt = e / AW, f = e % AW;
-      const float x = pt < npts ? a.A[(size_t)(p0 + pt) * AW + f] : 0.f;
-      av[u] = RELU_A ? fmaxf(x, 0.f) : x;
-    }
-  };
-  int tile = blockIdx.x * 4 + wave;
-  if (tile < ntiles) prefetch(tile);
-  for (; tile < ntiles; tile += gridDim.x * 4) {
-#pragma unroll
-    for (int u = 0; u < Cf::GPER; u++) {
-      const int e = u * 64 + lane, pt = e / Cf::GROWS, f = e % Cf::GROWS;
-      Gl[f * LDA + pt] = gv[u];
-    }
-#pragma unroll
-    for (int u = 0; u < Cf::APER; u++) {
-      const int e = u * 64 + lane, pt = e / AW, f = e % AW;
-      Al[f * LDA + pt] = av[u];
-    }
-    const int next = tile + gridDim.x * 4;
-    if (next < ntiles) prefetch(next);  // global loads fly while the MFMAs below run
-    // one wave owns Gl/Al: LDS ops of a wave execute in order; the fences only pin the compiler
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 2
-    for (int k0 = 0; k0 < MT; k0 += 2) {  // K = points
-      float bv[Cf::NB];
-#pragma unroll
-      for (int n = 0; n < Cf::NB; n++) bv[n] = Al[(n * 32 + i) * LDA + k0 + kk];  // B(k = point, j = in)
-#pragma unroll
-      for (int m = 0; m < Cf::MB; m++) {
-        const float avv = Gl[(m * 32 + i) * LDA + k0 + kk];  // A(i = out, k = point)
-#pragma unroll
-        for (int n = 0; n < Cf::NB; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv, bv[n], acc[m][n], 0, 0, 0);
-      }
-    }
-    if (lane < Cf::GROWS) {
-      float s0 = 0.f;
-#pragma unroll 8
-      for (int j = 0; j < MT; j++) s0 += Gl[lane * LDA + j];
-      bsum += s0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// Branch-free (clamped address + select) so the compiler can count the outstanding loads statically: a guarded load
+// forces an s_waitcnt vmcnt(0) at every join and serialises the stream.
+template <int W, bool RELU, int STRIDE = W>
+__device__ __forceinline__ void row_load(float (&v)[RowSplit<W>::VEC], const float* __restrict__ g, int p, int P, int i) {
+  constexpr int VEC = RowSplit<W>::VEC;
+  const bool ok = p < P && VEC * i < W;
+  const float* src = g + (size_t)min(p, P - 1) * STRIDE + (VEC * i < W ? VEC * i : 0);
+  if constexpr (VEC == 4) {
+    const float4 x = *reinterpret_cast<const float4*>(src);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  } else if constexpr (VEC == 2) {
+    const float2 x = *reinterpret_cast<const float2*>(src);
+    v[0] = x.x; v[1] = x.y;
+  } else {
+    v[0] = src[0];
   }
-  // flush: acc[m][n][r] is dW[m*32 + row][n*32 + col]
 #pragma unroll
-  for (int m = 0; m < Cf::MB; m++)
-#pragma unroll
-    for (int n = 0; n < Cf::NB; n++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int o = m * 32 + acc_row(r, lane);
-        if (o < GW) atomicAdd(&a.dW[(size_t)o * AW + n * 32 + (lane & 31)], acc[m][n][r]);
-      }
-  if (lane < GW && a.db != nullptr) atomicAdd(&a.db[lane], bsum);
+  for (int t = 0; t < VEC; t++) {
+    v[t] = ok ? v[t] : 0.f;
+    if (RELU) v[t] = fmaxf(v[t], 0.f);
+  }
 }
 
-template <int GW, int AW, bool RELU_A>
-static int launch_wgrad(const float* G, const float* A, float* dW, float* db, int P, hipStream_t stream) {
-  using Cf = WgradCfg<GW, AW>;
-  constexpr int lds_bytes = 4 * (Cf::GROWS + AW) * LDA * 4;
-  static bool attr = false;
-  if (!attr) {
-    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_kernel<GW, AW, RELU_A>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    attr = true;
+// ASTRIDE > AW: A (and dW) are AW-column windows of wider [.][ASTRIDE] arrays (feature_out is done as two halves so the
+// accumulators of a wave stay at 64 registers).
+constexpr int WG_WAVES = 8;  // waves per wgrad workgroup (one persistent workgroup per CU)
+template <int GW, int AW, bool RELU_A, int ASTRIDE>
+__global__ void __launch_bounds__(WG_WAVES * 64) mlp_wgrad_kernel(const WgradArgs a) {
+  constexpr int GV = RowSplit<GW>::VEC, AV = RowSplit<AW>::VEC, STEPS = MT / 2;
+  __shared__ float red[32 * GV * AW + 32 * GV];  // the workgroup's dW block and db, combined in LDS before the flush
+  for (int e = threadIdx.x; e < 32 * GV * AW + 32 * GV; e += WG_WAVES * 64) red[e] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, k = lane >> 5;
+  f32x16 acc[GV][AV];
+#pragma unroll
+  for (int m = 0; m < GV; m++)
+#pragma unroll
+    for (int n = 0; n < AV; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+  float bsum[GV];
+#pragma unroll
+  for (int m = 0; m < GV; m++) bsum[m] = 0.f;
+  const int ntiles = (a.P + MT - 1) / MT;
+  const int stride = gridDim.x * WG_WAVES;
+  float gv[STEPS][GV], av[STEPS][AV];
+  int tile = blockIdx.x * WG_WAVES + wave;
+  if (tile < ntiles) {
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      row_load<GW, false>(gv[s], a.G, tile * MT + 2 * s + k, a.P, i);
+      row_load<AW, RELU_A, ASTRIDE>(av[s], a.A, tile * MT + 2 * s + k, a.P, i);
+    }
   }
+  for (; tile < ntiles; tile += stride) {
+    const int np0 = (tile + stride) * MT;  // rows past P load as zeros
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      float ga[GV], ba[AV];
+#pragma unroll
+      for (int m = 0; m < GV; m++) ga[m] = gv[s][m];
+#pragma unroll
+      for (int n = 0; n < AV; n++) ba[n] = av[s][n];
+      row_load<GW, false>(gv[s], a.G, np0 + 2 * s + k, a.P, i);
+      row_load<AW, RELU_A, ASTRIDE>(av[s], a.A, np0 + 2 * s + k, a.P, i);
+#pragma unroll
+      for (int m = 0; m < GV; m++) {
+        bsum[m] += ga[m];
+#pragma unroll
+        for (int n = 0; n < AV; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[m], ba[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+  // acc[m][n][r] of lane l is dW[GV * row + m][AV * col + n], row = acc_row(r, l), col = l & 31
+#pragma unroll
+  for (int m = 0; m < GV; m++)
+#pragma unroll
+    for (int n = 0; n < AV; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        atomicAdd(&red[(GV * acc_row(r, lane) + m) * AW + AV * (lane & 31) + n], acc[m][n][r]);
+#pragma unroll
+  for (int m = 0; m < GV; m++) {
+    const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
+    if (k == 0) atomicAdd(&red[32 * GV * AW + GV * i + m], tot);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < GW * AW; e += WG_WAVES * 64)
+    atomicAdd(&a.dW[(size_t)(e / AW) * ASTRIDE + e % AW], red[e]);
+  if (a.db != nullptr && threadIdx.x < GW) atomicAdd(&a.db[threadIdx.x], red[32 * GV * AW + threadIdx.x]);
+}
+
+template <int GW, int AW, bool RELU_A, int ASTRIDE = AW>
+static int launch_wgrad(const float* G, const float* A, float* dW, float* db, int P, hipStream_t stream) {
   WgradArgs a{G, A, dW, db, P};
   const int ntiles = (P + MT - 1) / MT;
-  const int blocks = min((ntiles + 3) / 4, 512);
-  hipLaunchKernelGGL((mlp_wgrad_kernel<GW, AW, RELU_A>), dim3(blocks), dim3(256), lds_bytes, stream, a);
+  const int blocks = min((ntiles + WG_WAVES - 1) / WG_WAVES, 256);
+  hipLaunchKernelGGL((mlp_wgrad_kernel<GW, AW, RELU_A, ASTRIDE>), dim3(blocks), dim3(WG_WAVES * 64), 0, stream, a);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }
@@ -547,8 +466,8 @@ extern "C" int s3g_deform_mlp_forward(const s3g_mlp_params* w, int P, const floa
   a.P = P; a.x = features; a.packed = stash; a.dx = dx; a.dshs = dshs; a.feat = feat;
   a.stash = save_activations ? stash + PACK_FLOATS : nullptr;
   const int ntiles = (P + MT - 1) / MT;
-  const int blocks = min((ntiles + 3) / 4, 256);
-  hipLaunchKernelGGL(mlp_forward_kernel, dim3(blocks), dim3(256), MLP_LDS_FLOATS * 4, stream, a);
+  const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, a);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }
@@ -567,8 +486,8 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   MlpBwdArgs b;
   b.P = P; b.packed = stash_; b.stash = stash; b.g_dx = g_dx; b.g_dshs = g_dshs; b.g_feat = g_feat; b.g_x = g_features; b.ws = workspace;
   const int ntiles = (P + MT - 1) / MT;
-  const int blocks = min((ntiles + 3) / 4, 256);
-  hipLaunchKernelGGL(mlp_backward_kernel, dim3(blocks), dim3(256), MLP_LDS_FLOATS * 4, stream, b);
+  const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
+  hipLaunchKernelGGL(mlp_backward_kernel, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, b);
   S3G_HIP_CHECK(hipGetLastError());
   const size_t PS = (size_t)P * HID;
   if (int e = launch_wgrad<3, 64, false>(g_feat, stash + 4 * PS, gw->D2, gw->db2, P, stream)) return e;
@@ -578,6 +497,7 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   if (int e = launch_wgrad<64, 64, true>(workspace + 2 * PS, stash + 0 * PS, gw->P1, gw->pb1, P, stream)) return e;
   if (int e = launch_wgrad<48, 64, false>(g_dshs, stash + 2 * PS, gw->S2, gw->sb2, P, stream)) return e;
   if (int e = launch_wgrad<64, 64, true>(workspace + 3 * PS, stash + 0 * PS, gw->S1, gw->sb1, P, stream)) return e;
-  if (int e = launch_wgrad<64, 128, false>(workspace + 4 * PS, features, gw->W0, gw->b0, P, stream)) return e;
+  if (int e = launch_wgrad<64, 64, false, 128>(workspace + 4 * PS, features, gw->W0, gw->b0, P, stream)) return e;
+  if (int e = launch_wgrad<64, 64, false, 128>(workspace + 4 * PS, features + 64, gw->W0 + 64, nullptr, P, stream)) return e;
   return S3G_OK;
 }
