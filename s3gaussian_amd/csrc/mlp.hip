@@ -3,16 +3,19 @@
 // Reference: 10 nn.Linear + 7 ReLU modules (scene/deformation.py:53-76) = ~20 library GEMM/elementwise launches forward
 // and ~40 backward on [P,128]/[P,64] activations; with P = 1.2 M the skinny GEMMs (N = 3..128) cost ~23 ms per
 // iteration through hipBLASLt.  Here:
-//   mlp_pack_kernel      builds the LDS image [in][out+1] of every layer once per call (odd stride -> conflict-free as
-//                        MFMA A operand both straight and transposed).
-//   mlp_forward_kernel   one pass: a wave owns a 32-point tile, activations live in LDS as [feature][point] (row
-//                        stride 33 -> conflict-free as MFMA B operand AND for the transposing global loads/stores);
-//                        while a layer's MFMAs run, the NEXT layer's weight slab streams global -> LDS through the DMA
-//                        path (global_load_lds_dwordx4, no VGPR round trip) into the other half of a double buffer;
-//                        the 5 hidden activations are stashed for the backward.
-//   mlp_backward_kernel  the per-point chain (transposed-weight GEMMs + ReLU masks) -> g_features and 5 gradient signals.
-//   mlp_wgrad_kernel     dW = sum_p g[p] (x) act[p] as an MFMA GEMM whose K dimension is the points (split over
-//                        workgroups, accumulators stay in registers, one atomic flush per workgroup); biases alongside.
+//   mlp_pack_kernel      builds, once per call, the LDS image [in][out+1] of every layer (odd stride -> conflict-free as
+//                        MFMA A operand both straight and transposed); 9 slabs + biases = 155 KB.
+//   mlp_forward_kernel   one persistent workgroup per CU keeps the WHOLE weight image in LDS (one DMA burst,
+//                        global_load_lds_dwordx4).  A wave owns a 32-point tile and its activations never leave the
+//                        MFMA accumulator registers: the K order of an MFMA is free, so the accumulator registers of one
+//                        layer are fed back, as they are, as the B operand of the next (see gemm_reg).  No activation
+//                        LDS traffic, no barriers after the weight load; waves run independently.  The 5 hidden
+//                        activations are stashed for the backward with 16-byte stores.
+//   mlp_backward_kernel  the per-point chain (transposed-weight reads of the same image + ReLU masks from the stash) ->
+//                        g_features and 5 gradient signals, same register-resident scheme.
+//   mlp_wgrad_kernel     dW = sum_p g[p] (x) act[p] as an MFMA GEMM whose K dimension is the points, operands loaded
+//                        straight from HBM (permuted M/N rows make every lane's operands one contiguous load),
+//                        accumulators in registers, one LDS-combined atomic flush per workgroup; biases alongside.
 // HBM scratch is spent freely (2 x 1280 B per point): 3 GB of the 288 GB, ~1 ms of traffic for ~20 ms saved.
 #include "common.hpp"
 
@@ -146,10 +149,9 @@ __device__ __forceinline__ void masked(f32x16 (&dst)[MB], const f32x16 (&acc)[MB
     }
 }
 
-// ---- weight slabs: LDS images built once per call in global memory, streamed into LDS by the DMA engine -----------
-// Slab k is the [in][out+1] image of one layer (feature_out is cut in two K halves), padded to SLAB floats = 17 KiB so a
-// slab is 17 global_load_lds_dwordx4 wave-instructions (1 KiB each).  Forward order 0..8; the backward walks 8..0 with
-// the two W0 halves last.
+// ---- weight slabs: the LDS image is built once per call in global memory and DMA-copied by every workgroup ---------
+// Slab k is the [in][out+1] image of one layer (feature_out is cut in two K halves), padded to SLAB floats = 17 KiB =
+// 17 global_load_lds_dwordx4 wave-instructions (1 KiB each).
 constexpr int SLAB = 17 * 256;  // floats
 constexpr int NSLAB = 9;        // W0[:, :64] | W0[:, 64:] | P1 | S1 | P2 | S2 | D0 | D1 | D2
 constexpr int PACK_FLOATS = NSLAB * SLAB + 8 * 64;  // + the 8 bias vectors zero padded to 64
