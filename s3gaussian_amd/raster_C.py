@@ -65,17 +65,21 @@ def _inputs(P, D, M, W, H, bg, means3D, sh, colors, opacity, scales, scale_modif
 # ---- geometry cache: the feature render of an iteration reuses the RGB render's preprocess / binning / sort ------------
 _GEOM_CACHE_ON = os.environ.get("S3G_GEOMETRY_CACHE", "1") != "0"
 _geom_cache = None  # (key, tensors kept alive, outputs)
+_geom_cache_hits = 0  # number of renders served from the cache (tests, diagnostics)
 
 
 def _geom_key(tensors, scalars):
-    return tuple((id(t), t._version, t.data_ptr(), tuple(t.shape)) for t in tensors) + tuple(scalars)
+    # storage identity + version, not id(): autograd hands Function.forward fresh Python wrappers of the same tensors, and
+    # the rasterizer module builds a new empty placeholder per call for every absent input
+    return tuple(None if t.numel() == 0 else (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
+                 for t in tensors) + tuple(scalars)
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug):
     """-> (num_rendered, color[3,H,W], depth[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer)."""
-    global _geom_cache
+    global _geom_cache, _geom_cache_hits
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _require_gpu(means3D, "means3D")
@@ -88,6 +92,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         key = _geom_key(geo_tensors, (float(scale_modifier), float(tan_fovx), float(tan_fovy), H, W, bool(prefiltered)))
         if _geom_cache is not None and _geom_cache[0] == key:
             R, radii_c, geom_c, binning_c, img_c = _geom_cache[2]
+            _geom_cache_hits += 1
             out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
             out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
             keep = [_f32(background, "bg"), _f32(colors, "colors_precomp")]

@@ -340,8 +340,9 @@ def test_geometry_cache_second_render_identical(gpu_device):
         return [img1, img2, d1, d2, r1, r2], [x.grad for x in (m3, op, sc, rot, c1, c2, m2)]
 
     try:
+        hits0 = raster_C._geom_cache_hits
         o_on, g_on = run(True)
-        hit = raster_C._geom_cache is not None
+        hit = raster_C._geom_cache_hits == hits0 + 1   # the second render of the pair, through the autograd path
         o_off, g_off = run(False)
     finally:
         raster_C._GEOM_CACHE_ON = True
