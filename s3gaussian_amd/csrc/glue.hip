@@ -14,6 +14,10 @@ struct GlueArgs {
   // backward only
   const float *g_colors, *g_scales, *g_rot, *g_opacity;
   float *g_f_dc, *g_f_rest, *g_dshs, *g_xyz, *g_log_scales, *g_rot_raw, *g_opacity_logit;
+  // optional L1 regulariser on dshs (train.py:400-403: lambda_dshs * mean|dshs|), folded in because both kernels stream
+  // dshs anyway: forward accumulates sum|dshs|, backward adds (*g_dshs_l1 / (48 P)) * sign(dshs)
+  double* dshs_abs_sum;
+  const float* g_dshs_l1;
 };
 
 __device__ __forceinline__ void load_sh(const GlueArgs& a, int p, float (&sh)[16][3]) {
@@ -33,6 +37,17 @@ __device__ __forceinline__ void load_sh(const GlueArgs& a, int p, float (&sh)[16
 
 __global__ void __launch_bounds__(256) glue_forward_kernel(const GlueArgs a) {
   const int p = blockIdx.x * 256 + threadIdx.x;
+  if (a.dshs_abs_sum != nullptr && a.dshs != nullptr) {  // coalesced sweep over this block's 256 x 48 slice of dshs
+    __shared__ double part[4];
+    const size_t lo = (size_t)blockIdx.x * 256 * 48, hi = min(lo + (size_t)256 * 48, (size_t)a.P * 48);
+    float s = 0.f;
+    for (size_t e = lo + threadIdx.x; e < hi; e += 256) s += fabsf(a.dshs[e]);
+    double d = (double)s;
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(a.dshs_abs_sum, part[0] + part[1] + part[2] + part[3]);
+  }
   if (p >= a.P) return;
   // activations
 #pragma unroll
@@ -69,9 +84,37 @@ __global__ void __launch_bounds__(256) glue_forward_kernel(const GlueArgs a) {
   }
 }
 
+// Phase 1 (thread = Gaussian): everything but the SH coefficient gradients; the 16 basis values and the 3 colour gradients
+// of the Gaussian go to LDS.  Phase 2 (workgroup, coalesced): g_f_dc / g_f_rest / g_dshs rows are the outer product
+// basis[k] * dRGB[c] -- written as contiguous sweeps instead of 45- / 48-float rows per lane.
+__device__ __forceinline__ void glue_backward_point(const GlueArgs& a, int p, float* stage);
+
 __global__ void __launch_bounds__(256) glue_backward_kernel(const GlueArgs a) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= a.P) return;
+  __shared__ float stage[256 * 19];
+  const int p0 = blockIdx.x * 256, p = p0 + threadIdx.x;
+  if (p < a.P) glue_backward_point(a, p, stage + threadIdx.x * 19);
+  __syncthreads();
+  const int n = min(256, a.P - p0);
+  for (int e = threadIdx.x; e < n * 3; e += 256) a.g_f_dc[(size_t)p0 * 3 + e] = stage[(e / 3) * 19] * stage[(e / 3) * 19 + 16 + e % 3];
+  for (int e = threadIdx.x; e < n * 45; e += 256) {
+    const int q = e / 45, kc = e % 45 + 3;
+    a.g_f_rest[(size_t)p0 * 45 + e] = stage[q * 19 + kc / 3] * stage[q * 19 + 16 + kc % 3];
+  }
+  if (a.g_dshs != nullptr) {
+    const float l1 = a.g_dshs_l1 != nullptr ? *a.g_dshs_l1 / (48.0f * (float)a.P) : 0.f;
+    for (int e = threadIdx.x; e < n * 48; e += 256) {
+      const int q = e / 48, kc = e % 48;
+      float v = stage[q * 19 + kc / 3] * stage[q * 19 + 16 + kc % 3];
+      if (a.g_dshs_l1 != nullptr) {
+        const float d = a.dshs[(size_t)p0 * 48 + e];
+        v += d > 0.f ? l1 : (d < 0.f ? -l1 : 0.f);
+      }
+      a.g_dshs[(size_t)p0 * 48 + e] = v;
+    }
+  }
+}
+
+__device__ __forceinline__ void glue_backward_point(const GlueArgs& a, int p, float* stage) {
   // activations
 #pragma unroll
   for (int k = 0; k < 3; k++)
@@ -146,19 +189,9 @@ __global__ void __launch_bounds__(256) glue_backward_kernel(const GlueArgs a) {
     }
   }
 #pragma unroll
-  for (int c = 0; c < 3; c++) {
-    const float v = dsh[0] * dRGB[c];
-    a.g_f_dc[3 * (size_t)p + c] = v;
-    if (a.g_dshs) a.g_dshs[(size_t)p * 48 + c] = v;
-  }
+  for (int k = 0; k < 16; k++) stage[k] = dsh[k];
 #pragma unroll
-  for (int k = 1; k < 16; k++)
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float v = dsh[k] * dRGB[c];
-      a.g_f_rest[(size_t)p * 45 + (k - 1) * 3 + c] = v;
-      if (a.g_dshs) a.g_dshs[(size_t)p * 48 + k * 3 + c] = v;
-    }
+  for (int c = 0; c < 3; c++) stage[16 + c] = dRGB[c];
   const float ddx = dRdx[0] * dRGB[0] + dRdx[1] * dRGB[1] + dRdx[2] * dRGB[2];
   const float ddy = dRdy[0] * dRGB[0] + dRdy[1] * dRGB[1] + dRdy[2] * dRGB[2];
   const float ddz = dRdz[0] * dRGB[0] + dRdz[1] * dRGB[1] + dRdz[2] * dRGB[2];
@@ -176,7 +209,7 @@ using namespace s3g;
 extern "C" int s3g_glue_forward(int P, int deg, const float* f_dc, const float* f_rest, const float* dshs, const float* xyz,
                                 const float* campos, const float* log_scales, const float* rot_raw,
                                 const float* opacity_logit, float* colors, float* scales, float* rot, float* opacity,
-                                void* stream_) {
+                                double* dshs_abs_sum, void* stream_) {
   if (P < 0 || deg < 0 || deg > 3 ||
       (P > 0 && (!f_dc || !f_rest || !xyz || !campos || !log_scales || !rot_raw || !opacity_logit || !colors || !scales || !rot || !opacity))) {
     set_error("s3g_glue_forward: bad argument");
@@ -188,6 +221,7 @@ extern "C" int s3g_glue_forward(int P, int deg, const float* f_dc, const float* 
   a.P = P; a.deg = deg; a.f_dc = f_dc; a.f_rest = f_rest; a.dshs = dshs; a.xyz = xyz; a.campos = campos;
   a.log_scales = log_scales; a.rot_raw = rot_raw; a.opacity_logit = opacity_logit;
   a.colors = colors; a.scales = scales; a.rot = rot; a.opacity = opacity;
+  a.dshs_abs_sum = dshs_abs_sum;
   hipLaunchKernelGGL(glue_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
@@ -197,7 +231,8 @@ extern "C" int s3g_glue_backward(int P, int deg, const float* f_dc, const float*
                                  const float* campos, const float* rot_raw, const float* colors, const float* scales,
                                  const float* rot, const float* opacity, const float* g_colors, const float* g_scales,
                                  const float* g_rot, const float* g_opacity, float* g_f_dc, float* g_f_rest, float* g_dshs,
-                                 float* g_xyz, float* g_log_scales, float* g_rot_raw, float* g_opacity_logit, void* stream_) {
+                                 float* g_xyz, float* g_log_scales, float* g_rot_raw, float* g_opacity_logit,
+                                 const float* g_dshs_l1, void* stream_) {
   if (P < 0 || deg < 0 || deg > 3 ||
       (P > 0 && (!f_dc || !f_rest || !xyz || !campos || !rot_raw || !colors || !scales || !rot || !opacity || !g_f_dc ||
                  !g_f_rest || !g_xyz || !g_log_scales || !g_rot_raw || !g_opacity_logit))) {
@@ -213,6 +248,7 @@ extern "C" int s3g_glue_backward(int P, int deg, const float* f_dc, const float*
   a.g_colors = g_colors; a.g_scales = g_scales; a.g_rot = g_rot; a.g_opacity = g_opacity;
   a.g_f_dc = g_f_dc; a.g_f_rest = g_f_rest; a.g_dshs = g_dshs; a.g_xyz = g_xyz; a.g_log_scales = g_log_scales;
   a.g_rot_raw = g_rot_raw; a.g_opacity_logit = g_opacity_logit;
+  a.g_dshs_l1 = (dshs != nullptr && g_dshs != nullptr) ? g_dshs_l1 : nullptr;
   hipLaunchKernelGGL(glue_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;

@@ -528,7 +528,7 @@ static inline uint32_t round_up8(uint32_t v) { return (v + 7u) & ~7u; }
 using namespace s3g;
 
 extern "C" const char* s3g_last_error(void) { return g_err; }
-extern "C" int s3g_abi_version(void) { return 2; }
+extern "C" int s3g_abi_version(void) { return 3; }
 
 extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geometry_buffer, void* geometry_user,
                                   s3g_resize_fn binning_buffer, void* binning_user, s3g_resize_fn image_buffer,

@@ -16,9 +16,9 @@ def _bind():
     if not _bound:
         vp = C.c_void_p
         L.s3g_glue_forward.restype = C.c_int
-        L.s3g_glue_forward.argtypes = [C.c_int, C.c_int] + [vp] * 13
+        L.s3g_glue_forward.argtypes = [C.c_int, C.c_int] + [vp] * 14
         L.s3g_glue_backward.restype = C.c_int
-        L.s3g_glue_backward.argtypes = [C.c_int, C.c_int] + [vp] * 22
+        L.s3g_glue_backward.argtypes = [C.c_int, C.c_int] + [vp] * 23
         _bound = True
     return L
 
@@ -29,7 +29,7 @@ def _p(t):
 
 class _Glue(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, deg, f_dc, f_rest, dshs, xyz, campos, log_scales, rot_raw, opacity_logit):
+    def forward(ctx, deg, f_dc, f_rest, dshs, xyz, campos, log_scales, rot_raw, opacity_logit, want_dshs_l1):
         if not xyz.is_cuda:
             raise RuntimeError(f"render glue: tensors must live on the GPU (got {xyz.device}); no CPU fallback")
         L = _bind()
@@ -43,18 +43,22 @@ class _Glue(torch.autograd.Function):
         scales = torch.empty((P, 3), dtype=torch.float32, device=dev)
         rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
         opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
+        want_dshs_l1 = bool(want_dshs_l1) and dshs is not None and P > 0
+        abs_sum = torch.zeros((), dtype=torch.float64, device=dev) if want_dshs_l1 else None
         with torch.cuda.device(dev):
             _lib.check(L.s3g_glue_forward(P, int(deg), _p(f_dc), _p(f_rest), _p(dshs), _p(xyz_c), _p(campos_c), _p(ls), _p(rr),
-                                          _p(ol), _p(colors), _p(scales), _p(rot), _p(opac),
+                                          _p(ol), _p(colors), _p(scales), _p(rot), _p(opac), _p(abs_sum),
                                           torch.cuda.current_stream().cuda_stream))
         ctx.deg = int(deg)
         ctx.has_dshs = dshs is not None
         ctx.save_for_backward(f_dc, f_rest, dshs if dshs is not None else torch.empty(0, device=dev), xyz_c, campos_c, rr,
                               colors, scales, rot, opac)
-        return colors, scales, rot, opac
+        ctx.want_dshs_l1 = want_dshs_l1
+        dshs_l1 = (abs_sum / (48.0 * P)).float() if want_dshs_l1 else torch.zeros((), dtype=torch.float32, device=dev)
+        return colors, scales, rot, opac, dshs_l1
 
     @staticmethod
-    def backward(ctx, g_colors, g_scales, g_rot, g_opac):
+    def backward(ctx, g_colors, g_scales, g_rot, g_opac, g_l1):
         f_dc, f_rest, dshs, xyz, campos, rr, colors, scales, rot, opac = ctx.saved_tensors
         L = _bind()
         P, dev = xyz.shape[0], xyz.device
@@ -64,14 +68,17 @@ class _Glue(torch.autograd.Function):
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         g_f_dc, g_f_rest, g_xyz, g_ls, g_rr, g_ol = e(P, 1, 3), e(P, 15, 3), e(P, 3), e(P, 3), e(P, 4), e(P, 1)
         g_dshs = e(P, 16, 3) if ctx.has_dshs else None
+        g_l1 = g_l1.contiguous().float() if (ctx.want_dshs_l1 and g_l1 is not None) else None
         with torch.cuda.device(dev):
             _lib.check(L.s3g_glue_backward(P, ctx.deg, _p(f_dc), _p(f_rest), _p(dshs), _p(xyz), _p(campos), _p(rr), _p(colors),
                                            _p(scales), _p(rot), _p(opac), _p(g_colors), _p(g_scales), _p(g_rot), _p(g_opac),
-                                           _p(g_f_dc), _p(g_f_rest), _p(g_dshs), _p(g_xyz), _p(g_ls), _p(g_rr), _p(g_ol),
+                                           _p(g_f_dc), _p(g_f_rest), _p(g_dshs), _p(g_xyz), _p(g_ls), _p(g_rr), _p(g_ol), _p(g_l1),
                                            torch.cuda.current_stream().cuda_stream))
-        return None, g_f_dc, g_f_rest, g_dshs, g_xyz, None, g_ls, g_rr, g_ol
+        return None, g_f_dc, g_f_rest, g_dshs, g_xyz, None, g_ls, g_rr, g_ol, None
 
 
-def activations_and_colors(deg, f_dc, f_rest, dshs, xyz, campos, log_scales, rot_raw, opacity_logit):
-    """-> (colors_precomp [P,3], scales [P,3], rotations [P,4], opacity [P,1]); dshs may be None (coarse stage)."""
-    return _Glue.apply(deg, f_dc, f_rest, dshs, xyz, campos, log_scales, rot_raw, opacity_logit)
+def activations_and_colors(deg, f_dc, f_rest, dshs, xyz, campos, log_scales, rot_raw, opacity_logit, with_dshs_l1=False):
+    """-> (colors_precomp [P,3], scales [P,3], rotations [P,4], opacity [P,1]); dshs may be None (coarse stage).
+    with_dshs_l1=True appends mean|dshs| (the train.py:400-403 regulariser, differentiable) computed in the same pass."""
+    out = _Glue.apply(deg, f_dc, f_rest, dshs, xyz, campos, log_scales, rot_raw, opacity_logit, with_dshs_l1)
+    return out if with_dshs_l1 else out[:4]

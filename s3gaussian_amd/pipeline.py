@@ -179,7 +179,7 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
     means2D = screenspace_points
     opacity = pc._opacity
     scales, rotations, cov3D_precomp = pc._scaling, pc._rotation, None
-    dx = feat = dshs = shs_final = None
+    dx = feat = dshs = shs_final = dshs_l1 = None
     net = pc._deformation.deformation_net
     hy = net.args
     glue_ok = (means3D.is_cuda and override_color is None and getattr(pipe, "convert_SHs_python", True)
@@ -203,8 +203,11 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
     colors_precomp = None
     if fused_glue:
         # one kernel per direction for exp / normalize / sigmoid / (shs + dshs) / eval_sh / clamp (include/s3g_glue.h)
-        colors_precomp, scales_final, rotations_final, opacity = activations_and_colors(
-            pc.active_sh_degree, pc._features_dc, pc._features_rest, dshs, pc.get_xyz, cam["campos"], scales, rotations, opacity)
+        want_l1 = dshs is not None and torch.is_grad_enabled()  # mean|dshs| for the lambda_dshs regulariser, same pass
+        glue_out = activations_and_colors(pc.active_sh_degree, pc._features_dc, pc._features_rest, dshs, pc.get_xyz,
+                                          cam["campos"], scales, rotations, opacity, with_dshs_l1=want_l1)
+        colors_precomp, scales_final, rotations_final, opacity = glue_out[:4]
+        dshs_l1 = glue_out[4] if want_l1 else None
     else:
         scales_final = pc.scaling_activation(scales_final)
         rotations_final = pc.rotation_activation(rotations_final)
@@ -241,6 +244,8 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
             out.update({f"render_{tag}": img, f"depth_{tag}": dep, f"visibility_filter_{tag}": rad > 0})
     if return_dx and "fine" in stage:
         out.update({"dx": dx, "dshs": dshs})
+        if dshs_l1 is not None:
+            out["dshs_l1"] = dshs_l1
     return out
 
 
@@ -298,7 +303,8 @@ def training_loss(pc: GaussianParams, pkg: Dict, gt_image, gt_depth, gt_feat, hy
     if "fine" in stage and not hyper.no_dx and opt.lambda_dx != 0:
         loss = loss + torch.mean(torch.abs(pkg["dx"])) * opt.lambda_dx
     if "fine" in stage and not hyper.no_dshs and opt.lambda_dshs != 0:
-        loss = loss + torch.mean(torch.abs(pkg["dshs"])) * opt.lambda_dshs
+        dshs_l1 = pkg["dshs_l1"] if "dshs_l1" in pkg else torch.mean(torch.abs(pkg["dshs"]))
+        loss = loss + dshs_l1 * opt.lambda_dshs
     if opt.lambda_depth != 0:
         loss = loss + compute_depth_l2(pkg["depth"].unsqueeze(0), gt_depth.unsqueeze(0)) * opt.lambda_depth
     if stage == "fine" and hyper.time_smoothness_weight != 0:

@@ -41,13 +41,18 @@ def test_glue_forward_backward_vs_restatement(gpu_device, deg, with_dshs):
     def run(dev, fused):
         L = [leaf(t, dev) for t in (f_dc, f_rest, dshs, xyz, ls, rr, ol)]
         a, b, d, x, s_, r_, o_ = L
+        # with dshs present the lambda_dshs * mean|dshs| regulariser (train.py:400-403) rides along in the fused pass
         if fused:
-            outs = activations_and_colors(deg, a, b, d if with_dshs else None, x, campos.to(dev), s_, r_, o_)
+            outs = activations_and_colors(deg, a, b, d if with_dshs else None, x, campos.to(dev), s_, r_, o_,
+                                          with_dshs_l1=with_dshs)
+            l1 = outs[4] if with_dshs else 0.0
+            outs = outs[:4]
         else:
             shs = torch.cat((a, b), dim=1) + (d if with_dshs else 0)
             outs = (hr.shs_to_colors(deg, shs, x, campos), torch.exp(s_), torch.nn.functional.normalize(r_), torch.sigmoid(o_))
-        sum((o * w.to(dev)).sum() for o, w in zip(outs, ws)).backward()
-        return outs, L
+            l1 = torch.mean(torch.abs(d)) if with_dshs else 0.0
+        (sum((o * w.to(dev)).sum() for o, w in zip(outs, ws)) + 700.0 * l1).backward()
+        return outs + ((l1,) if with_dshs else ()), L
 
     outs_r, Lr = run("cpu", False)
     outs_g, Lg = run(gpu_device, True)
