@@ -49,6 +49,34 @@ typedef struct s3g_plane_reg_desc {
 /* value: device DOUBLE, ACCUMULATED (caller zeroes). */
 int s3g_plane_regulation(int nplanes, const s3g_plane_reg_desc* planes, double* value, void* stream);
 
+/*
+ *   s3g_pixel_losses_*  <- the per-pixel terms of the training loss, /root/reference/train.py:395-425:
+ *       l1_loss(image, gt[:3])                 utils/loss_utils.py:50-51
+ *       compute_depth("l2", depth, gt_depth)   utils/loss_utils.py:21-45 (normalize_depth :21-22, mask :32)
+ *       l2_loss(feat, gt_feat)                 utils/loss_utils.py:53-54
+ *   one read of the images forward, one read + one write backward (the reference: ~45 launches including a nonzero /
+ *   gather for the mask and the radix sort inside index_put's backward).
+ *
+ * Images are [3,H,W], depths [H,W], fp32 device; each (x, gt_x) pair may be NULL to skip that term.
+ * sums: device DOUBLE[5], ACCUMULATED (caller zeroes): [0] is the slot s3g_ssim_forward's ssim_sum is pointed at,
+ * [1] sum|image-gt|, [2] masked squared depth error, [3] mask count, [4] sum (feat-gt)^2. */
+int s3g_pixel_losses_forward(int H, int W, const float* image, const float* gt_image, const float* depth,
+                             const float* gt_depth, const float* feat, const float* gt_feat, float max_depth,
+                             double* sums, void* stream);
+
+/* loss[0] = w_l1 * sums[1]/N + w_depth * sums[2]/sums[3] + w_ssim * (1 - sums[0]/N) + w_feat * sums[4]/N, N = 3*H*W;
+ * a zero weight skips its term (an empty depth mask gives NaN like the reference's mean over no elements). */
+int s3g_pixel_losses_combine(int H, int W, const double* sums, float w_l1, float w_depth, float w_ssim, float w_feat,
+                             float* loss, void* stream);
+
+/* Gradients of  w_l1*L1 + w_depth*depth_l2 + w_feat*feat_l2  times the upstream device scalar *g.  g_image is written,
+ * or added to when accumulate_image != 0 (it then already holds the SSIM term from s3g_ssim_backward); g_depth and
+ * g_feat are written; any output may be NULL. */
+int s3g_pixel_losses_backward(int H, int W, const float* image, const float* gt_image, const float* depth,
+                              const float* gt_depth, const float* feat, const float* gt_feat, float max_depth,
+                              const double* sums, const float* g, float w_l1, float w_depth, float w_feat,
+                              float* g_image, int accumulate_image, float* g_depth, float* g_feat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

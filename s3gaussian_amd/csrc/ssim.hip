@@ -159,11 +159,115 @@ extern "C" int s3g_ssim_backward(int C, int H, int W, const float* img1, const f
   return S3G_OK;
 }
 
+namespace s3g {
+// =========================================================================================================
+// Per-pixel photometric terms of train.py:395-425 in one pass each way:
+//   l1_loss(image, gt)            utils/loss_utils.py:50-51    mean |image - gt|
+//   compute_depth("l2", pred, gt) utils/loss_utils.py:21-45    gt in (0.01, max_depth) selects pixels, both sides are
+//                                                              clamp(x / max_depth, 0, 1), mean squared error
+//   l2_loss(feat, gt_feat)        utils/loss_utils.py:53-54    mean (feat - gt)^2
+// The reference spends ~45 launches here, among them a nonzero + gather for the boolean mask and a radix sort inside
+// index_put's backward.
+// =========================================================================================================
+struct PixelLossArgs {
+  int HW;
+  const float *image, *gt_image, *depth, *gt_depth, *feat, *gt_feat;  // [3,HW] [3,HW] [HW] [HW] [3,HW] [3,HW]; pairs may be NULL
+  float max_depth;
+  double* sums;           // [1] l1  [2] depth squared error  [3] depth count  [4] feat squared error
+  // backward
+  const float* g;         // upstream gradient of the combined loss (device scalar)
+  float w_l1, w_depth, w_feat;
+  float *g_image, *g_depth, *g_feat;
+  int accumulate_image;   // g_image already holds the SSIM gradient
+};
+
+__device__ __forceinline__ double block_sum(double v, double* part) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ void __launch_bounds__(256) pixel_loss_forward_kernel(const PixelLossArgs a) {
+  __shared__ double part[4];
+  float l1 = 0.f, dsq = 0.f, cnt = 0.f, fsq = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.HW; i += gridDim.x * 256) {
+    if (a.image != nullptr) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) l1 += fabsf(a.image[(size_t)c * a.HW + i] - a.gt_image[(size_t)c * a.HW + i]);
+    }
+    if (a.depth != nullptr) {
+      const float gd = a.gt_depth[i];
+      if (gd > 0.01f && gd < a.max_depth) {
+        const float cp = fminf(fmaxf(a.depth[i] / a.max_depth, 0.f), 1.f), cg = fminf(fmaxf(gd / a.max_depth, 0.f), 1.f);
+        dsq += (cp - cg) * (cp - cg);
+        cnt += 1.f;
+      }
+    }
+    if (a.feat != nullptr) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float d = a.feat[(size_t)c * a.HW + i] - a.gt_feat[(size_t)c * a.HW + i];
+        fsq += d * d;
+      }
+    }
+  }
+  const double s1 = block_sum((double)l1, part), s2 = block_sum((double)dsq, part), s3 = block_sum((double)cnt, part),
+               s4 = block_sum((double)fsq, part);
+  if (threadIdx.x == 0) {
+    if (a.image != nullptr) atomicAdd(&a.sums[1], s1);
+    if (a.depth != nullptr) { atomicAdd(&a.sums[2], s2); atomicAdd(&a.sums[3], s3); }
+    if (a.feat != nullptr) atomicAdd(&a.sums[4], s4);
+  }
+}
+
+__global__ void __launch_bounds__(256) pixel_loss_backward_kernel(const PixelLossArgs a) {
+  const float g = *a.g;
+  const float k_l1 = g * a.w_l1 / (3.0f * (float)a.HW), k_feat = g * a.w_feat * 2.0f / (3.0f * (float)a.HW);
+  // empty mask: the reference's mean over zero elements is NaN and so is its gradient; 0/0 reproduces that
+  const float k_depth = a.g_depth != nullptr ? g * a.w_depth * 2.0f / ((float)a.sums[3] * a.max_depth) : 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.HW; i += gridDim.x * 256) {
+    if (a.g_image != nullptr) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float d = a.image[(size_t)c * a.HW + i] - a.gt_image[(size_t)c * a.HW + i];
+        const float v = d > 0.f ? k_l1 : (d < 0.f ? -k_l1 : 0.f);
+        float* dst = &a.g_image[(size_t)c * a.HW + i];
+        *dst = a.accumulate_image ? *dst + v : v;
+      }
+    }
+    if (a.g_depth != nullptr) {
+      const float gd = a.gt_depth[i], x = a.depth[i] / a.max_depth;
+      float v = 0.f;
+      if (gd > 0.01f && gd < a.max_depth && x >= 0.f && x <= 1.f)  // clamp passes the gradient on its closed interval
+        v = k_depth * (x - fminf(fmaxf(gd / a.max_depth, 0.f), 1.f));
+      a.g_depth[i] = v;
+    }
+    if (a.g_feat != nullptr) {
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        a.g_feat[(size_t)c * a.HW + i] = k_feat * (a.feat[(size_t)c * a.HW + i] - a.gt_feat[(size_t)c * a.HW + i]);
+    }
+  }
+}
+
+// loss = w_l1 * l1_sum / N + w_depth * dsq / cnt + w_ssim * (1 - ssim_sum / N) + w_feat * fsq / N      (N = 3 HW)
+__global__ void pixel_loss_combine_kernel(const double* __restrict__ sums, int HW, float w_l1, float w_depth, float w_ssim,
+                                          float w_feat, float* __restrict__ loss) {
+  const double N = 3.0 * (double)HW;
+  double v = 0.0;
+  if (w_l1 != 0.f) v += (double)w_l1 * sums[1] / N;
+  if (w_depth != 0.f) v += (double)w_depth * sums[2] / sums[3];
+  if (w_ssim != 0.f) v += (double)w_ssim * (1.0 - sums[0] / N);
+  if (w_feat != 0.f) v += (double)w_feat * sums[4] / N;
+  *loss = (float)v;
+}
+
+
 // =========================================================================================================
 // Fused HexPlane regulariser: value + gradient of scene/gaussian_model.py:710-749 in one pass over the planes.
 // =========================================================================================================
-namespace s3g {
-
 struct PlaneRegArgs {
   s3g_plane_reg_desc pl[S3G_MAX_REG_PLANES];
   int first_block[S3G_MAX_REG_PLANES + 1];
@@ -236,6 +340,56 @@ extern "C" int s3g_plane_regulation(int nplanes, const s3g_plane_reg_desc* plane
   }
   a.first_block[nplanes] = blocks;
   hipLaunchKernelGGL(plane_reg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
+  S3G_HIP_CHECK(hipGetLastError());
+  return S3G_OK;
+}
+
+extern "C" int s3g_pixel_losses_forward(int H, int W, const float* image, const float* gt_image, const float* depth,
+                                        const float* gt_depth, const float* feat, const float* gt_feat, float max_depth,
+                                        double* sums, void* stream_) {
+  if (H <= 0 || W <= 0 || !sums || (image && !gt_image) || (depth && !gt_depth) || (feat && !gt_feat)) {
+    set_error("s3g_pixel_losses_forward: bad argument");
+    return S3G_ERR_INVALID_ARG;
+  }
+  PixelLossArgs a;
+  memset(&a, 0, sizeof a);
+  a.HW = H * W; a.image = image; a.gt_image = gt_image; a.depth = depth; a.gt_depth = gt_depth; a.feat = feat;
+  a.gt_feat = gt_feat; a.max_depth = max_depth; a.sums = sums;
+  const int blocks = min((a.HW + 255) / 256, 2048);
+  hipLaunchKernelGGL(pixel_loss_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
+  S3G_HIP_CHECK(hipGetLastError());
+  return S3G_OK;
+}
+
+extern "C" int s3g_pixel_losses_combine(int H, int W, const double* sums, float w_l1, float w_depth, float w_ssim,
+                                        float w_feat, float* loss, void* stream_) {
+  if (H <= 0 || W <= 0 || !sums || !loss) {
+    set_error("s3g_pixel_losses_combine: bad argument");
+    return S3G_ERR_INVALID_ARG;
+  }
+  hipLaunchKernelGGL(pixel_loss_combine_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, sums, H * W, w_l1, w_depth, w_ssim,
+                     w_feat, loss);
+  S3G_HIP_CHECK(hipGetLastError());
+  return S3G_OK;
+}
+
+extern "C" int s3g_pixel_losses_backward(int H, int W, const float* image, const float* gt_image, const float* depth,
+                                         const float* gt_depth, const float* feat, const float* gt_feat, float max_depth,
+                                         const double* sums, const float* g, float w_l1, float w_depth, float w_feat,
+                                         float* g_image, int accumulate_image, float* g_depth, float* g_feat, void* stream_) {
+  if (H <= 0 || W <= 0 || !sums || !g || (g_image && (!image || !gt_image)) || (g_depth && (!depth || !gt_depth)) ||
+      (g_feat && (!feat || !gt_feat))) {
+    set_error("s3g_pixel_losses_backward: bad argument");
+    return S3G_ERR_INVALID_ARG;
+  }
+  PixelLossArgs a;
+  memset(&a, 0, sizeof a);
+  a.HW = H * W; a.image = image; a.gt_image = gt_image; a.depth = depth; a.gt_depth = gt_depth; a.feat = feat;
+  a.gt_feat = gt_feat; a.max_depth = max_depth; a.sums = const_cast<double*>(sums); a.g = g;
+  a.w_l1 = w_l1; a.w_depth = w_depth; a.w_feat = w_feat;
+  a.g_image = g_image; a.accumulate_image = accumulate_image; a.g_depth = g_depth; a.g_feat = g_feat;
+  const int blocks = min((a.HW + 255) / 256, 4096);
+  hipLaunchKernelGGL(pixel_loss_backward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }

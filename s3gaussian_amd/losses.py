@@ -21,6 +21,13 @@ def _bind():
         L.s3g_ssim_forward.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.s3g_ssim_backward.restype = C.c_int
         L.s3g_ssim_backward.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.s3g_pixel_losses_forward.restype = C.c_int
+        L.s3g_pixel_losses_forward.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]
+        L.s3g_pixel_losses_combine.restype = C.c_int
+        L.s3g_pixel_losses_combine.argtypes = [C.c_int, C.c_int, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
+        L.s3g_pixel_losses_backward.restype = C.c_int
+        L.s3g_pixel_losses_backward.argtypes = ([C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, C.c_float,
+                                                 C.c_float, C.c_float, vp, C.c_int, vp, vp, vp])
         _bound = True
     return L
 
@@ -63,6 +70,89 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_ave
     if window_size != 11 or not size_average:
         raise NotImplementedError("only the reference's call signature ssim(img1, img2) is accelerated")
     return _SSIM.apply(img1, img2)
+
+
+class _PhotometricLoss(torch.autograd.Function):
+    """l1(image, gt) + w_depth * depth_l2 + w_ssim * (1 - ssim(image, gt)) + w_feat * l2(feat, gt_feat) as three kernels
+    forward and two backward (include/s3g_loss.h)."""
+
+    @staticmethod
+    def forward(ctx, image, gt_image, depth, gt_depth, feat, gt_feat, w_ssim, w_depth, w_feat, max_depth):
+        if not image.is_cuda:
+            raise RuntimeError(f"photometric_loss: images must live on the GPU (got {image.device}); no CPU fallback")
+        L = _bind()
+        c = lambda t: None if t is None else t.detach().contiguous().float()
+        img, gt = c(image), c(gt_image)
+        if img.dim() != 3 or img.shape[0] != 3 or gt.shape != img.shape:
+            raise RuntimeError("photometric_loss expects image and gt_image of shape [3,H,W]")
+        _, H, W = img.shape
+        dev = img.device
+        w_ssim, w_depth, w_feat = float(w_ssim), float(w_depth), float(w_feat)
+        dep, gdep = (c(depth), c(gt_depth)) if (depth is not None and w_depth != 0.0) else (None, None)
+        ft, gft = (c(feat), c(gt_feat)) if (feat is not None and w_feat != 0.0) else (None, None)
+        for a, b, n in ((dep, gdep, H * W), (ft, gft, 3 * H * W)):
+            if a is not None and (a.numel() != n or b.numel() != n):
+                raise RuntimeError("photometric_loss: depth must have H*W and feat 3*H*W elements, like their targets")
+        sums = torch.zeros(5, dtype=torch.float64, device=dev)
+        maps = torch.empty((3, 3, H, W), dtype=torch.float32, device=dev) if w_ssim != 0.0 else None
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            if maps is not None:
+                _lib.check(L.s3g_ssim_forward(3, H, W, p(img), p(gt), p(sums), p(maps[0]), p(maps[1]), p(maps[2]), st))
+            _lib.check(L.s3g_pixel_losses_forward(H, W, p(img), p(gt), p(dep), p(gdep), p(ft), p(gft), float(max_depth),
+                                                  p(sums), st))
+            _lib.check(L.s3g_pixel_losses_combine(H, W, p(sums), 1.0, w_depth if dep is not None else 0.0, w_ssim,
+                                                  w_feat if ft is not None else 0.0, p(loss), st))
+        ctx.save_for_backward(img, gt, *(t for t in (dep, gdep, ft, gft, maps) if t is not None), sums)
+        ctx.cfg = (H, W, dep is not None, ft is not None, maps is not None, w_ssim, w_depth, w_feat, float(max_depth),
+                   None if depth is None else depth.shape, None if feat is None else feat.shape, image.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W, has_d, has_f, has_s, w_ssim, w_depth, w_feat, max_depth, dshape, fshape, ishape = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        img, gt = saved[0], saved[1]
+        k = 2
+        dep = gdep = ft = gft = maps = None
+        if has_d:
+            dep, gdep = saved[k], saved[k + 1]
+            k += 2
+        if has_f:
+            ft, gft = saved[k], saved[k + 1]
+            k += 2
+        if has_s:
+            maps = saved[k]
+            k += 1
+        sums = saved[k]
+        L = _bind()
+        dev = img.device
+        g = g.detach().reshape(1).contiguous().float()
+        g_img = torch.empty_like(img)
+        g_dep = torch.empty_like(dep) if has_d else None
+        g_ft = torch.empty_like(ft) if has_f else None
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            if has_s:
+                gs = g * (-w_ssim)
+                _lib.check(L.s3g_ssim_backward(3, H, W, p(img), p(gt), p(maps[0]), p(maps[1]), p(maps[2]), p(gs), p(g_img), st))
+            _lib.check(L.s3g_pixel_losses_backward(H, W, p(img), p(gt), p(dep), p(gdep), p(ft), p(gft), max_depth, p(sums), p(g),
+                                                   1.0, w_depth, w_feat, p(g_img), int(has_s), p(g_dep), p(g_ft), st))
+        return (g_img.view(ishape), None, g_dep.view(dshape) if has_d else None, None,
+                g_ft.view(fshape) if has_f else None, None, None, None, None, None)
+
+
+def photometric_loss(image, gt_image, depth=None, gt_depth=None, feat=None, gt_feat=None, lambda_dssim=0.0,
+                     lambda_depth=0.0, lambda_feat=0.0, max_depth=80.0):
+    """The per-pixel part of train.py:395-425 for one view:
+        l1_loss(image, gt_image) + lambda_depth * compute_depth("l2", depth, gt_depth)
+        + lambda_dssim * (1 - ssim(image, gt_image)) + lambda_feat * l2_loss(feat, gt_feat)
+    image/gt_image/feat/gt_feat [3,H,W], depth/gt_depth [1,H,W] or [H,W]; a zero weight (or a missing pair) skips a term."""
+    return _PhotometricLoss.apply(image, gt_image, depth, gt_depth, feat, gt_feat, lambda_dssim, lambda_depth, lambda_feat,
+                                  max_depth)
 
 
 class _PlaneRegDesc(C.Structure):

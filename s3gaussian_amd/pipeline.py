@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from .deformation import deform_network
 from .glue import activations_and_colors
 from .knn import distCUDA2
+from .losses import photometric_loss as fused_photometric_loss
 from .losses import plane_regulation as fused_plane_regulation
 from .losses import ssim as fused_ssim
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
@@ -295,24 +296,32 @@ def psnr(img1, img2):
     return 20 * torch.log10(1.0 / torch.sqrt(mse))
 
 
-def training_loss(pc: GaussianParams, pkg: Dict, gt_image, gt_depth, gt_feat, hyper, opt, stage="fine"):
-    """train.py:395-425 for a batch of one view."""
-    image = pkg["render"].unsqueeze(0)
-    gt = gt_image.unsqueeze(0)
-    loss = l1_loss(image, gt[:, :3])
-    if "fine" in stage and not hyper.no_dx and opt.lambda_dx != 0:
+def training_loss(pc: GaussianParams, pkg: Dict, gt_image, gt_depth, gt_feat, hyper, opt, stage="fine", fused_pixel_terms=True):
+    """train.py:395-425 for a batch of one view.  The per-pixel terms (L1, depth L2, DSSIM, feature L2) run as one fused
+    pass (losses.photometric_loss); fused_pixel_terms=False evaluates them step by step like the reference."""
+    fine = "fine" in stage
+    use_feat = stage == "fine" and hyper.feat_head
+    if fused_pixel_terms:
+        loss = fused_photometric_loss(pkg["render"], gt_image[:3], pkg["depth"] if opt.lambda_depth != 0 else None, gt_depth,
+                                      pkg["feat"] if use_feat else None, gt_feat, lambda_dssim=opt.lambda_dssim,
+                                      lambda_depth=opt.lambda_depth, lambda_feat=opt.lambda_feat if use_feat else 0.0)
+    else:
+        image = pkg["render"].unsqueeze(0)
+        gt = gt_image.unsqueeze(0)
+        loss = l1_loss(image, gt[:, :3])
+        if opt.lambda_depth != 0:
+            loss = loss + compute_depth_l2(pkg["depth"].unsqueeze(0), gt_depth.unsqueeze(0)) * opt.lambda_depth
+        if opt.lambda_dssim != 0:
+            loss = loss + opt.lambda_dssim * (1.0 - fused_ssim(image, gt))
+        if use_feat:
+            loss = loss + l2_loss(pkg["feat"], gt_feat) * opt.lambda_feat
+    if fine and not hyper.no_dx and opt.lambda_dx != 0:
         loss = loss + torch.mean(torch.abs(pkg["dx"])) * opt.lambda_dx
-    if "fine" in stage and not hyper.no_dshs and opt.lambda_dshs != 0:
+    if fine and not hyper.no_dshs and opt.lambda_dshs != 0:
         dshs_l1 = pkg["dshs_l1"] if "dshs_l1" in pkg else torch.mean(torch.abs(pkg["dshs"]))
         loss = loss + dshs_l1 * opt.lambda_dshs
-    if opt.lambda_depth != 0:
-        loss = loss + compute_depth_l2(pkg["depth"].unsqueeze(0), gt_depth.unsqueeze(0)) * opt.lambda_depth
     if stage == "fine" and hyper.time_smoothness_weight != 0:
         loss = loss + pc.compute_regulation(hyper.time_smoothness_weight, hyper.l1_time_planes, hyper.plane_tv_weight)
-    if opt.lambda_dssim != 0:
-        loss = loss + opt.lambda_dssim * (1.0 - fused_ssim(image, gt))
-    if stage == "fine" and hyper.feat_head:
-        loss = loss + l2_loss(pkg["feat"], gt_feat) * opt.lambda_feat
     return loss
 
 
