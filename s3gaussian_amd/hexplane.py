@@ -102,7 +102,17 @@ class _HexPlaneSample(torch.autograd.Function):
         P = xyz_c.shape[0]
         gfeat = gfeat.contiguous()
         gxyz = torch.empty_like(xyz_c)
-        gplanes = [torch.zeros_like(p) if ctx.needs_input_grad[3 + i] else None for i, p in enumerate(planes)]
+        # one zero fill for all plane gradients; each is a channels_last [1,C,H,W] view of the flat buffer
+        need = [ctx.needs_input_grad[3 + i] for i in range(len(planes))]
+        flat = torch.zeros(sum(p.numel() for p, n in zip(planes, need) if n), dtype=torch.float32, device=xyz_c.device)
+        gplanes, off = [], 0
+        for p, n in zip(planes, need):
+            if not n:
+                gplanes.append(None)
+                continue
+            _, Cn, Hn, Wn = p.shape
+            gplanes.append(flat[off:off + p.numel()].view(1, Hn, Wn, Cn).permute(0, 3, 1, 2))
+            off += p.numel()
         ptrs = _PlanePtrs()
         for l in range(len(resolutions)):
             for i in range(6):

@@ -75,7 +75,11 @@ class _DeformMLP(torch.autograd.Function):
         z = lambda g, n: (torch.zeros((P, n), dtype=torch.float32, device=dev) if g is None else g.contiguous().float())
         g_dx, g_dshs, g_feat = z(g_dx, 3), z(g_dshs, 48), z(g_feat, 3)
         gx = torch.empty_like(x)
-        grads = [torch.zeros_like(p) for p in params]
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)  # one fill, 16 views
+        grads, off = [], 0
+        for p in params:
+            grads.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
         ws = torch.empty((5, P, 64), dtype=torch.float32, device=dev)
         w, gw = _pack([p.detach() for p in params]), _pack(grads)
         with torch.cuda.device(dev):

@@ -104,9 +104,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                                   torch.cuda.current_stream().cuda_stream)
             _lib.check(code)
             return R, out_color, out_depth, radii_c, geom_c, binning_c, img_c
-    out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
-    out_depth = torch.zeros((1, H, W), dtype=torch.float32, device=dev)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    # the library writes every pixel (background included) and every radius; only the P == 0 early-out needs zeros
+    alloc = torch.zeros if P == 0 else torch.empty
+    out_color = alloc((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_depth = alloc((1, H, W), dtype=torch.float32, device=dev)
+    radii = alloc((P,), dtype=torch.int32, device=dev)
     geom, binning, img = _Arena(dev), _Arena(dev), _Arena(dev)
     rendered = C.c_int(0)
     if P != 0:
