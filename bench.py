@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
+PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32), the dtype the MLP computes in
 
 
 def build_scene(P, width, height, n_frames, device, seed=0):
@@ -183,8 +184,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    L.s3g_profile_read(0, None, None, None)
-    L.s3g_profile_read(1, None, None, None)
+    for i in range(8):
+        L.s3g_profile_read(i, None, None, None)
     L.s3g_profile_enable(1)
     vis_acc = torch.zeros((), device=device, dtype=torch.float64)
     t0 = time.perf_counter()
@@ -217,30 +218,78 @@ def main():
         render_ms = 1000.0 * (time.perf_counter() - t1) / n_frames
 
     if rank == 0:
-        ms, inst, pix = C.c_double(), C.c_double(), C.c_double()
-        n_bwd = L.s3g_profile_read(1, C.byref(ms), C.byref(inst), C.byref(pix))
-        # two raster calls per step share the geometry: V per launch = mean visible Gaussians per step
-        V = float(vis_acc.item()) / max(a.steps, 1)
+        # ---- roofline leg: every hot kernel timed in-library with hipEvents on the launch stream (include/s3g_raster.h),
+        # priced against its ALGORITHMIC bytes / flops (DESIGN.md section 7 states each model) -----------------------------
+        V = float(vis_acc.item()) / max(a.steps, 1)    # mean visible Gaussians per step (both raster calls share them)
+        P = float(a.P)
+        net = pc._deformation.deformation_net
+        planes = [p for p in net.grid.grids.parameters()] if hasattr(net.grid, "grids") else []
+        plane_bytes = float(sum(p.numel() for p in planes) * 4)
+        levels = float(len(getattr(net.grid, "grids", [])) or 4)
+        FEAT = 32.0 * levels
+        MLP_FLOP = 2.0 * (128 * 64 + 4 * 64 * 64 + 2 * 64 * 3 + 64 * 48)   # per point and direction: 56064
+
+        def read(i):
+            ms, x, y = C.c_double(), C.c_double(), C.c_double()
+            n = L.s3g_profile_read(i, C.byref(ms), C.byref(x), C.byref(y))
+            return (n, ms.value / n, x.value / n, y.value / n) if n else (0, 0.0, 0.0, 0.0)
+
+        # id -> (kernel, bytes(R or P, pixels), flops)
+        models = {
+            0: ("s3g::blend_forward_kernel", lambda R, N: 44.0 * R + 24.0 * N, None),
+            1: ("s3g::blend_backward_kernel", lambda R, N: 44.0 * R + 24.0 * N + 40.0 * V, None),
+            2: ("s3g::hexplane_forward_kernel", lambda n, l: n * (16.0 + 4.0 * FEAT) + plane_bytes, None),
+            3: ("s3g::hexplane_backward_point_kernel", lambda n, l: n * (28.0 + 4.0 * FEAT + 6.0 * l * 128.0) + plane_bytes, None),
+            4: ("s3g::hexplane_scatter_kernel", lambda n, l: n * (60.0 + 6.0 * l * 128.0) + plane_bytes, None),
+            5: ("s3g::mlp_forward_kernel", lambda n, _: n * (512.0 + 5 * 256.0 + 216.0), lambda n: n * MLP_FLOP),
+            6: ("s3g::mlp_backward_kernel", lambda n, _: n * (5 * 256.0 + 216.0 + 5 * 256.0 + 512.0), lambda n: n * MLP_FLOP),
+            7: ("s3g::mlp_wgrad_kernel (9 launches)", lambda n, _: n * 4.0 * (2 * 67 + 6 * 128 + 112), lambda n: n * MLP_FLOP),
+        }
+        traffic_db = {}
+        default_workload = (a.P, a.width, a.height, a.frames) == (1_200_000, 1600, 1066, 50)
+        pmc = os.path.join(ROOT, "profiles", "kernel_traffic.json")
+        if os.path.exists(pmc) and default_workload:   # the PMC passes were collected on the default workload only
+            try:
+                traffic_db = json.load(open(pmc)).get("hbm_bytes_per_launch", {})
+            except Exception:
+                traffic_db = {}
+        kernels = []
+        for i, (name, fbytes, fflops) in models.items():
+            n, avg_ms, x, y = read(i)
+            if not n:
+                continue
+            nbytes = fbytes(x, y)
+            t = avg_ms * 1e-3
+            gbs = nbytes / t / 1e9
+            ent = {"kernel": name, "launches_per_step": round(n / a.steps, 2), "avg_launch_ms": round(avg_ms, 4),
+                   "algorithmic_bytes_per_launch": round(nbytes), "hbm_GBps": round(gbs, 1),
+                   "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)}
+            bound, frac = "hbm", gbs / PEAK_HBM_GBS
+            if fflops is not None:
+                tf = fflops(x) / t / 1e12
+                ent.update({"flops_per_launch": round(fflops(x)), "mfma_TFLOPs": round(tf, 2),
+                            "mfma_frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4)})
+                if tf / PEAK_MFMA_F32_TFLOPS > frac:   # the roof this kernel sits closer to
+                    bound, frac = "mfma", tf / PEAK_MFMA_F32_TFLOPS
+            ent["bound"] = bound
+            ent["frac"] = round(frac, 4)
+            ent["ms_per_step"] = round(avg_ms * n / a.steps, 4)
+            base = name.split(" ")[0]
+            if base in traffic_db:   # PMC bytes per launch; the wgrad entry brackets nine launches
+                ent["traffic"] = traffic_db[base] * (9 if i == 7 else 1)
+            kernels.append(ent)
         roof = None
-        if n_bwd > 0:
-            avg_ms = ms.value / n_bwd
-            R, N = inst.value / n_bwd, pix.value / n_bwd
-            alg_bytes = 44.0 * R + 24.0 * N + 40.0 * V          # blend bwd = 44*R + 24*N + 40*V bytes
-            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "blend_backward_pmc.json")
-            default_workload = (a.P, a.width, a.height, a.frames) == (1_200_000, 1600, 1066, 50)
-            if os.path.exists(pmc) and default_workload:  # the PMC pass was collected on the default workload only
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roof = {"kernel": "s3g::blend_backward_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": traffic,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": n_bwd, "instances_per_launch": round(R),
-                    "visible_per_launch": round(V), "algorithmic_bytes_per_launch": round(alg_bytes)}
-        ms_f, inst_f, pix_f = C.c_double(), C.c_double(), C.c_double()
-        n_fwd = L.s3g_profile_read(0, C.byref(ms_f), C.byref(inst_f), C.byref(pix_f))
+        if kernels:
+            dom = max(kernels, key=lambda e: e["ms_per_step"])   # the kernel the step spends most time in
+            if dom["bound"] == "mfma":
+                roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["mfma_TFLOPs"], "peak": PEAK_MFMA_F32_TFLOPS,
+                        "unit": "TFLOP/s", "frac": dom["mfma_frac"], "traffic": dom.get("traffic")}
+            else:
+                roof = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["hbm_GBps"], "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": dom["hbm_frac"], "traffic": dom.get("traffic")}
+            roof.update({"avg_launch_ms": dom["avg_launch_ms"], "launches_per_step": dom["launches_per_step"],
+                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "kernels": kernels})
+        fwd = next((k for k in kernels if k["kernel"] == "s3g::blend_forward_kernel"), None)
         out = {
             "metric": "train_iters_per_sec", "value": round(world * a.steps / dt, 3), "unit": "iters/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 3), "higher_is_better": True,
@@ -249,7 +298,7 @@ def main():
                                    "(hexplane+deformation ON), RGB+depth render + feature render, L1+DSSIM+depthL2+featL2+regs, Adam",
                        "gaussians": a.P, "image": [a.height, a.width], "views_per_step_per_rank": 1,
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
-                       "blend_forward_avg_ms": round(ms_f.value / n_fwd, 4) if n_fwd else None,
+                       "blend_forward_avg_ms": fwd["avg_launch_ms"] if fwd else None,
                        "render_ms_per_frame": round(render_ms, 3)},
             "roofline": roof,
         }

@@ -435,7 +435,9 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
   memset(&a, 0, sizeof a);
   a.d = *d; a.P = P; a.xyz = xyz; a.time = time; a.feat = features; a.proc_order = proc_order;
   const int blocks = min((P + 7) / 8, 256 * 16);
+  profile_begin(S3G_PROFILE_HEXPLANE_FORWARD, (hipStream_t)stream_);
   hipLaunchKernelGGL(hexplane_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
+  profile_end(S3G_PROFILE_HEXPLANE_FORWARD, (hipStream_t)stream_, (double)P, (double)d->levels);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }
@@ -488,11 +490,15 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
   // 2. per-point pass, walking the points in (x,y) order so neighbouring half-waves share texels
   a.proc_order = w.order;
   const int blocks = min((P + 7) / 8, 256 * 16);
+  profile_begin(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream);
   hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3(blocks), dim3(256), 0, stream, a, G, w.rank);
+  profile_end(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream, (double)P, (double)d->levels);
   S3G_HIP_CHECK(hipGetLastError());
   if (order_out) S3G_HIP_CHECK(hipMemcpyAsync(order_out, w.order, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
   const int nseg = (P + SEG - 1) / SEG;
+  profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
   hipLaunchKernelGGL(hexplane_scatter_kernel, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, G, w.order);
+  profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }

@@ -469,7 +469,9 @@ extern "C" int s3g_deform_mlp_forward(const s3g_mlp_params* w, int P, const floa
   a.stash = save_activations ? stash + PACK_FLOATS : nullptr;
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
+  profile_begin(S3G_PROFILE_MLP_FORWARD, stream);
   hipLaunchKernelGGL(mlp_forward_kernel, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, a);
+  profile_end(S3G_PROFILE_MLP_FORWARD, stream, (double)P, 0.0);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }
@@ -489,8 +491,11 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   b.P = P; b.packed = stash_; b.stash = stash; b.g_dx = g_dx; b.g_dshs = g_dshs; b.g_feat = g_feat; b.g_x = g_features; b.ws = workspace;
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
+  profile_begin(S3G_PROFILE_MLP_BACKWARD, stream);
   hipLaunchKernelGGL(mlp_backward_kernel, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, b);
+  profile_end(S3G_PROFILE_MLP_BACKWARD, stream, (double)P, 0.0);
   S3G_HIP_CHECK(hipGetLastError());
+  profile_begin(S3G_PROFILE_MLP_WGRAD, stream);
   const size_t PS = (size_t)P * HID;
   if (int e = launch_wgrad<3, 64, false>(g_feat, stash + 4 * PS, gw->D2, gw->db2, P, stream)) return e;
   if (int e = launch_wgrad<64, 64, false>(workspace + 0 * PS, stash + 3 * PS, gw->D1, gw->db1, P, stream)) return e;
@@ -501,5 +506,6 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   if (int e = launch_wgrad<64, 64, true>(workspace + 3 * PS, stash + 0 * PS, gw->S1, gw->sb1, P, stream)) return e;
   if (int e = launch_wgrad<64, 64, false, 128>(workspace + 4 * PS, features, gw->W0, gw->b0, P, stream)) return e;
   if (int e = launch_wgrad<64, 64, false, 128>(workspace + 4 * PS, features + 64, gw->W0 + 64, nullptr, P, stream)) return e;
+  profile_end(S3G_PROFILE_MLP_WGRAD, stream, (double)P, 0.0);
   return S3G_OK;
 }

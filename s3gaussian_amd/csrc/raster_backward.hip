@@ -484,11 +484,11 @@ extern "C" int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int
   const float* color_ptr = in->colors_precomp ? in->colors_precomp : g.rgb;
   if (R > 0) {
     const uint32_t tile_blocks = ((uint32_t)tiles + 7u) & ~7u;
-    profile_begin(1, stream);
+    profile_begin(S3G_PROFILE_BLEND_BACKWARD, stream);
     hipLaunchKernelGGL(blend_backward_kernel, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
                        im.tile_hi, b.point_list, in->background, g.means2D, g.conic_opacity, color_ptr, g.depths,
                        im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, records);
-    profile_end(1, stream, (double)R, (double)W * H);
+    profile_end(S3G_PROFILE_BLEND_BACKWARD, stream, (double)R, (double)W * H);
     S3G_KERNEL_CHECK(stream, debug);
   }
   GeomBwdArgs ga;

@@ -37,17 +37,17 @@ void set_error(const char* fmt, ...) {
 // ---- in-library kernel timing -----------------------------------------------------------------------------
 struct ProfRec { hipEvent_t a, b; double instances, pixels; };
 static bool g_prof_on = false;
-static std::vector<ProfRec> g_prof[2];
-static hipEvent_t g_prof_pending[2];
+static std::vector<ProfRec> g_prof[S3G_PROFILE_IDS];
+static hipEvent_t g_prof_pending[S3G_PROFILE_IDS];
 void profile_begin(int id, hipStream_t stream) {
-  if (!g_prof_on) return;
+  if (!g_prof_on || id < 0 || id >= S3G_PROFILE_IDS) return;
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return;
   (void)hipEventRecord(e, stream);
   g_prof_pending[id] = e;
 }
 void profile_end(int id, hipStream_t stream, double instances, double pixels) {
-  if (!g_prof_on) return;
+  if (!g_prof_on || id < 0 || id >= S3G_PROFILE_IDS) return;
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return;
   (void)hipEventRecord(e, stream);
@@ -671,11 +671,11 @@ extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geo
     }
   }
   const float* feat = in->colors_precomp ? in->colors_precomp : g.rgb;
-  profile_begin(0, stream);
+  profile_begin(S3G_PROFILE_BLEND_FORWARD, stream);
   hipLaunchKernelGGL(blend_forward_kernel, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
                      b.point_list, g.means2D, g.conic_opacity, feat, g.depths, in->background, im.final_T, im.n_contrib,
                      im.tile_hi, out_color, out_depth);
-  profile_end(0, stream, (double)R, (double)W * H);
+  profile_end(S3G_PROFILE_BLEND_FORWARD, stream, (double)R, (double)W * H);
   S3G_KERNEL_CHECK(stream, debug);
   return S3G_OK;
 }
@@ -699,21 +699,21 @@ extern "C" int s3g_raster_forward_reuse(const s3g_raster_inputs* in, int R, cons
   ImageState im = ImageState::carve(image_arena, (size_t)W * H, tiles, bin_blocks(P), nullptr);
   BinningState b = BinningState::carve(const_cast<void*>(binning_arena), (size_t)(R > 0 ? R : 0), nullptr);
   const uint32_t tile_blocks = round_up8((uint32_t)tiles);
-  profile_begin(0, stream);
+  profile_begin(S3G_PROFILE_BLEND_FORWARD, stream);
   hipLaunchKernelGGL(blend_forward_kernel, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
                      b.point_list, g.means2D, g.conic_opacity, in->colors_precomp, g.depths, in->background, im.final_T,
                      im.n_contrib, im.tile_hi, out_color, out_depth);
-  profile_end(0, stream, (double)R, (double)W * H);
+  profile_end(S3G_PROFILE_BLEND_FORWARD, stream, (double)R, (double)W * H);
   S3G_KERNEL_CHECK(stream, in->debug != 0);
   return S3G_OK;
 }
 
 extern "C" void s3g_profile_enable(int on) { g_prof_on = on != 0; }
 
-// Sums the recorded launches of kernel `id` (0 blend forward, 1 blend backward), synchronising on their events, then
-// forgets them.  Returns the number of launches.
+// Sums the recorded launches of kernel `id` (S3G_PROFILE_* in s3g_raster.h), synchronising on their events, then forgets
+// them.  Returns the number of launches.
 extern "C" int s3g_profile_read(int id, double* total_ms, double* total_instances, double* total_pixels) {
-  if (id < 0 || id > 1) return 0;
+  if (id < 0 || id >= S3G_PROFILE_IDS) return 0;
   double ms = 0, inst = 0, pix = 0;
   int n = 0;
   for (ProfRec& r : g_prof[id]) {

@@ -1,0 +1,59 @@
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, MI355X_MICROARCH.md "HBM") of bench.py into
+profiles/r01_bench_pmc_fetch_write.csv and profiles/kernel_traffic.json (HBM bytes per launch of every s3g kernel).
+
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  python tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w <outdir>
+
+gfx950 correction (same guide): FETCH_SIZE counts 64 B per 128-B request -> doubled.  Both counters are in KB."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def collect(d, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
+            name = re.sub(r"<.*", "", name)
+            if not name.startswith("s3g::"):
+                continue
+            a = acc[name]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return {k: (n, v / n) for k, (n, v) in acc.items()}
+
+
+def main():
+    fdir, wdir, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    fetch, write = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
+    os.makedirs(out, exist_ok=True)
+    rows, traffic = [], {}
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 0))[1] + write.get(k, (0, 0))[1])):
+        n = fetch.get(k, write.get(k))[0]
+        f, w = fetch.get(k, (0, 0.0))[1], write.get(k, (0, 0.0))[1]
+        rows.append((k, n, f, w))
+        traffic[k] = int(round((2.0 * f + w) * 1024.0))
+    with open(os.path.join(out, "r01_bench_pmc_fetch_write.csv"), "w") as fh:
+        fh.write("kernel,launches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg\n")
+        for k, n, f, w in rows:
+            fh.write(f"{k},{n},{f:.1f},{w:.1f}\n")
+    json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 3 --warmup 1 "
+                          "--no-cpu-baseline (two passes)",
+               "formula": "hbm_bytes = (2 * FETCH_SIZE_KB + WRITE_SIZE_KB) * 1024  (gfx950 FETCH_SIZE correction, "
+                          "MI355X_MICROARCH.md 'HBM'); wgrad: average over its template instances",
+               "hbm_bytes_per_launch": traffic}, open(os.path.join(out, "kernel_traffic.json"), "w"), indent=1)
+    for k, n, f, w in rows[:12]:
+        print(f"{k:45s} {n:4d} launches  fetch {f / 1024:9.1f} MB  write {w / 1024:9.1f} MB  -> hbm {traffic[k] / 1e6:9.1f} MB")
+
+
+if __name__ == "__main__":
+    main()
