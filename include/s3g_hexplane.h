@@ -32,19 +32,26 @@ typedef struct s3g_hexplane_desc {
   int res[S3G_HEX_MAX_LEVELS][4];            /* per level: resolution along x, y, z, t */
   const float* planes[S3G_HEX_MAX_LEVELS][6];/* device, channel-last [res[c1]][res[c0]][32] */
   float aabb_max[3], aabb_min[3];            /* aabb[0], aabb[1] */
+  int uniform_time;                          /* != 0: the caller guarantees time[i] == time[0] for every point -- how
+                                              * render() always calls the field (gaussian_renderer/__init__.py:66:
+                                              * one camera timestamp repeated P times).  The three time planes of a level
+                                              * are then pre-interpolated along t into 1-D row tables once per call and
+                                              * sampled with 2 taps instead of 4. */
 } s3g_hexplane_desc;
 
 /* features [P, levels*32].  xyz [P,3], time [P] (device fp32).  proc_order: optional (may be NULL) permutation of
  * [0,P) giving the order in which points are PROCESSED (results do not depend on it); passing the spatial order a
  * previous s3g_hexplane_backward returned makes neighbouring lanes fetch the same texels (L1/L2 hits). */
+size_t s3g_hexplane_forward_workspace_bytes(const s3g_hexplane_desc* d);   /* 0 unless uniform_time (row tables) */
 int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time, float* features,
-                         const unsigned int* proc_order, void* stream);
+                         const unsigned int* proc_order, void* workspace /* may be NULL when the size above is 0 */,
+                         void* stream);
 
 /* dL_dfeatures [P, levels*32] -> dL_dxyz [P,3] (written) and dL_dplanes[l][i] (same layout as planes; ACCUMULATED,
  * the caller zero-fills them; a NULL entry skips that plane).  `workspace`: device scratch of
- * s3g_hexplane_backward_workspace_bytes(levels, P) bytes (3 KB per point: per-plane sample gradients + sort buffers),
- * uninitialised. */
-size_t s3g_hexplane_backward_workspace_bytes(int levels, int P);
+ * s3g_hexplane_backward_workspace_bytes(d, P) bytes (3 KB per point: per-plane sample gradients + sort buffers, plus the
+ * row tables and their gradients when uniform_time), uninitialised. */
+size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P);
 int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
                           const float* dL_dfeatures, float* dL_dxyz, float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6],
                           void* workspace, unsigned int* order_out /* [P] or NULL: the (x,y) spatial order, reusable as

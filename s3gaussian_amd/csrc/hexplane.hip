@@ -399,6 +399,79 @@ __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, 
   }
 }
 
+// ---- uniform time: the (axis, t) planes collapse to 1-D row tables ---------------------------------------------------
+// When every point carries the same t, the t half of the bilinear footprint is the same for all of them:
+//   R[x][c] = P[y0][x][c] * (y1 - iy) + P[y1][x][c] * (iy - y0)       (iy from time[0], exactly as make_tap computes it)
+// The tables are handed to the SAME kernels as planes of height 1 (make_tap then yields iy = 0, weights (x1-ix, ix-x0, 0, 0)
+// and two out-of-range taps), so a time-plane sample costs 2 L1-resident fetches instead of 4 gathers, its scatter is
+// one-dimensional, and the table gradients are folded back into the two plane rows afterwards.
+struct TimeRows {
+  int W[S3G_HEX_MAX_LEVELS][3], H[S3G_HEX_MAX_LEVELS];
+  const float* plane[S3G_HEX_MAX_LEVELS][3];
+  float* gplane[S3G_HEX_MAX_LEVELS][3];
+  float* table[S3G_HEX_MAX_LEVELS][3];
+  float* gtable[S3G_HEX_MAX_LEVELS][3];
+  const float* time;
+};
+__device__ __forceinline__ void time_rows(const float* time, int H, int& y0, int& y1, float& w0, float& w1) {
+  float iy = ((time[0] + 1.f) / 2.f) * (float)(H - 1);
+  iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+  const float f0 = floorf(iy);
+  y0 = (int)f0;
+  y1 = y0 + 1 < H ? y0 + 1 : -1;
+  w0 = (f0 + 1.f) - iy;
+  w1 = iy - f0;
+}
+// grid = (row blocks, 3 planes, levels); BACKWARD: gplane rows += w * gtable (no other kernel touches these rows meanwhile)
+template <bool BACKWARD>
+__global__ void __launch_bounds__(256) hexplane_time_rows_kernel(const TimeRows r) {
+  const int l = blockIdx.z, k = blockIdx.y, W = r.W[l][k];
+  int y0, y1;
+  float w0, w1;
+  time_rows(r.time, r.H[l], y0, y1, w0, w1);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < W * HEXC; e += gridDim.x * 256) {
+    if (!BACKWARD) {
+      float v = r.plane[l][k][(size_t)y0 * W * HEXC + e] * w0;
+      if (y1 >= 0) v += r.plane[l][k][(size_t)y1 * W * HEXC + e] * w1;
+      r.table[l][k][e] = v;
+    } else if (r.gplane[l][k] != nullptr) {
+      const float g = r.gtable[l][k][e];
+      r.gplane[l][k][(size_t)y0 * W * HEXC + e] += g * w0;
+      if (y1 >= 0) r.gplane[l][k][(size_t)y1 * W * HEXC + e] += g * w1;
+    }
+  }
+}
+static size_t time_table_floats(const s3g_hexplane_desc* d) {
+  size_t n = 0;
+  for (int l = 0; l < d->levels; l++)
+    for (int k = 0; k < 3; k++) n += (size_t)d->res[l][k] * HEXC;
+  return n;
+}
+// Fills `r`, points the time planes of `a.d` at the tables (height 1) and launches the table build.
+static void use_time_rows(HexArgs& a, TimeRows& r, float* tables, float* gtables, hipStream_t stream) {
+  static const int TP[3] = {2, 4, 5};  // (x,t) (y,t) (z,t); their spatial axis is 0, 1, 2
+  memset(&r, 0, sizeof r);
+  r.time = a.time;
+  size_t off = 0;
+  int maxW = 0;
+  for (int l = 0; l < a.d.levels; l++) {
+    r.H[l] = a.d.res[l][3];
+    for (int k = 0; k < 3; k++) {
+      r.W[l][k] = a.d.res[l][k];
+      maxW = max(maxW, r.W[l][k]);
+      r.plane[l][k] = a.d.planes[l][TP[k]];
+      r.gplane[l][k] = a.gplanes[l][TP[k]];
+      r.table[l][k] = tables + off;
+      r.gtable[l][k] = gtables ? gtables + off : nullptr;
+      off += (size_t)r.W[l][k] * HEXC;
+      a.d.planes[l][TP[k]] = r.table[l][k];
+      if (gtables) a.gplanes[l][TP[k]] = r.gplane[l][k] ? r.gtable[l][k] : nullptr;
+    }
+    a.d.res[l][3] = 1;
+  }
+  hipLaunchKernelGGL(hexplane_time_rows_kernel<false>, dim3((maxW * HEXC + 255) / 256, 3, a.d.levels), dim3(256), 0, stream, r);
+}
+
 static int check_desc(const s3g_hexplane_desc* d) {
   if (!d || d->levels < 1 || d->levels > S3G_HEX_MAX_LEVELS) {
     set_error("hexplane: bad descriptor (levels)");
@@ -423,10 +496,15 @@ static int check_desc(const s3g_hexplane_desc* d) {
 
 using namespace s3g;
 
+extern "C" size_t s3g_hexplane_forward_workspace_bytes(const s3g_hexplane_desc* d) {
+  if (!d || d->levels < 1 || d->levels > S3G_HEX_MAX_LEVELS || !d->uniform_time) return 0;
+  return time_table_floats(d) * sizeof(float);
+}
+
 extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
-                                    float* features, const uint32_t* proc_order, void* stream_) {
+                                    float* features, const uint32_t* proc_order, void* workspace, void* stream_) {
   if (int e = check_desc(d)) return e;
-  if (P < 0 || (P > 0 && (!xyz || !time || !features))) {
+  if (P < 0 || (P > 0 && (!xyz || !time || !features || (d->uniform_time && !workspace)))) {
     set_error("s3g_hexplane_forward: bad argument");
     return S3G_ERR_INVALID_ARG;
   }
@@ -434,6 +512,8 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
   HexArgs a;
   memset(&a, 0, sizeof a);
   a.d = *d; a.P = P; a.xyz = xyz; a.time = time; a.feat = features; a.proc_order = proc_order;
+  TimeRows rows;
+  if (d->uniform_time) use_time_rows(a, rows, (float*)workspace, nullptr, (hipStream_t)stream_);
   const int blocks = min((P + 7) / 8, 256 * 16);
   profile_begin(S3G_PROFILE_HEXPLANE_FORWARD, (hipStream_t)stream_);
   hipLaunchKernelGGL(hexplane_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
@@ -442,10 +522,12 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
   return S3G_OK;
 }
 
-extern "C" size_t s3g_hexplane_backward_workspace_bytes(int levels, int P) {
-  if (levels < 1 || P < 0) return 0;
+extern "C" size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P) {
+  if (!d || d->levels < 1 || d->levels > S3G_HEX_MAX_LEVELS || P < 0) return 0;
+  const int levels = d->levels;
   Carver c(nullptr);
   c.take<float>((size_t)levels * 6 * P * HEXC);
+  if (d->uniform_time) c.take<float>(2 * time_table_floats(d));
   c.take<uint32_t>((size_t)3 * SORT_NB * SORT_BINS);
   c.take<uint32_t>((size_t)3 * (SORT_BINS + 1));
   c.take<uint32_t>((size_t)3 * P);
@@ -472,6 +554,7 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     for (int i = 0; i < 6; i++) a.gplanes[l][i] = dL_dplanes[l][i];
   Carver c(workspace);
   float* G = c.take<float>((size_t)d->levels * 6 * P * HEXC);
+  float* tables = d->uniform_time ? c.take<float>(2 * time_table_floats(d)) : nullptr;
   SortWork w;
   w.table = c.take<uint32_t>((size_t)3 * SORT_NB * SORT_BINS);
   w.seg_start = c.take<uint32_t>((size_t)3 * (SORT_BINS + 1));
@@ -488,6 +571,13 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
   hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.rank);
   S3G_HIP_CHECK(hipGetLastError());
   // 2. per-point pass, walking the points in (x,y) order so neighbouring half-waves share texels
+  //    (the sorts above used the real resolutions; from here on the time planes are height-1 row tables if uniform_time)
+  TimeRows rows;
+  if (d->uniform_time) {
+    const size_t nt = time_table_floats(d);
+    S3G_HIP_CHECK(hipMemsetAsync(tables + nt, 0, nt * sizeof(float), stream));
+    use_time_rows(a, rows, tables, tables + nt, stream);
+  }
   a.proc_order = w.order;
   const int blocks = min((P + 7) / 8, 256 * 16);
   profile_begin(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream);
@@ -499,6 +589,12 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
   profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
   hipLaunchKernelGGL(hexplane_scatter_kernel, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, G, w.order);
   profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
+  if (d->uniform_time) {
+    int maxW = 0;
+    for (int l = 0; l < d->levels; l++)
+      for (int k = 0; k < 3; k++) maxW = max(maxW, d->res[l][k]);
+    hipLaunchKernelGGL(hexplane_time_rows_kernel<true>, dim3((maxW * HEXC + 255) / 256, 3, d->levels), dim3(256), 0, stream, rows);
+  }
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }

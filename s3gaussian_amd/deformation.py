@@ -69,11 +69,11 @@ class Deformation(nn.Module):
         return (self.D == 1 and self.W == 64 and self.grid.feat_dim == 128 and not a.no_dx and not a.no_dshs and a.no_ds
                 and a.no_dr and a.no_do and a.feat_head)
 
-    def deform_heads(self, xyz, time):
+    def deform_heads(self, xyz, time, uniform_time=None):
         """(dx [P,3], dshs [P,16,3], feat [P,3]) only -- the part of forward_dynamic that is not a pass-through in the
         reference's default configuration.  Lets a caller that fuses `shs + dshs` downstream (pipeline.render) skip
         materialising the [P,16,3] sum."""
-        feats = self.grid(xyz[:, :3], time[:, :1])
+        feats = self.grid(xyz[:, :3], time[:, :1], uniform_time)
         dx, dshs, feat = deform_mlp(feats, self.feature_out, self.pos_deform, self.shs_deform, self.dino_head)
         return dx, dshs.reshape([xyz.shape[0], 16, 3]), feat
 

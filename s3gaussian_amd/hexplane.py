@@ -25,7 +25,7 @@ MAX_LEVELS, CHANNELS = 8, 32
 class _HexDesc(C.Structure):
     """struct s3g_hexplane_desc (include/s3g_hexplane.h)."""
     _fields_ = [("levels", C.c_int), ("res", (C.c_int * 4) * MAX_LEVELS), ("planes", (C.c_void_p * 6) * MAX_LEVELS),
-                ("aabb_max", C.c_float * 3), ("aabb_min", C.c_float * 3)]
+                ("aabb_max", C.c_float * 3), ("aabb_min", C.c_float * 3), ("uniform_time", C.c_int)]
 
 
 _PlanePtrs = (C.c_void_p * 6) * MAX_LEVELS
@@ -38,11 +38,13 @@ def _bind():
     if not _bound:
         vp = C.c_void_p
         L.s3g_hexplane_forward.restype = C.c_int
-        L.s3g_hexplane_forward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, vp]
+        L.s3g_hexplane_forward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, vp, vp]
+        L.s3g_hexplane_forward_workspace_bytes.restype = C.c_size_t
+        L.s3g_hexplane_forward_workspace_bytes.argtypes = [C.POINTER(_HexDesc)]
         L.s3g_hexplane_backward.restype = C.c_int
         L.s3g_hexplane_backward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, C.POINTER(_PlanePtrs), vp, vp, vp]
         L.s3g_hexplane_backward_workspace_bytes.restype = C.c_size_t
-        L.s3g_hexplane_backward_workspace_bytes.argtypes = [C.c_int, C.c_int]
+        L.s3g_hexplane_backward_workspace_bytes.argtypes = [C.POINTER(_HexDesc), C.c_int]
         _bound = True
     return L
 
@@ -53,9 +55,10 @@ def _channels_last_ptr(p: torch.Tensor) -> int:
     return p.data_ptr()
 
 
-def _make_desc(planes, resolutions, aabb_host) -> _HexDesc:
+def _make_desc(planes, resolutions, aabb_host, uniform_time=False) -> _HexDesc:
     d = _HexDesc()
     d.levels = len(resolutions)
+    d.uniform_time = int(bool(uniform_time))
     for l, res in enumerate(resolutions):
         for k in range(4):
             d.res[l][k] = int(res[k])
@@ -72,7 +75,7 @@ class _HexPlaneSample(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, time, meta, *planes):
-        resolutions, aabb_host, cache = meta
+        resolutions, aabb_host, cache, uniform_time = meta
         if not xyz.is_cuda:
             raise RuntimeError(f"xyz must live on the GPU (got {xyz.device}); the HexPlane sampler has no CPU fallback")
         L = _bind()
@@ -82,22 +85,28 @@ class _HexPlaneSample(torch.autograd.Function):
         if t_c.numel() != P:
             raise RuntimeError("time must have one value per point")
         feat = torch.empty((P, len(resolutions) * CHANNELS), dtype=torch.float32, device=xyz.device)
-        d = _make_desc(planes, resolutions, aabb_host)
+        if uniform_time is None:   # one device reduction + host sync; callers that know (render()) pass the flag instead
+            uniform_time = bool(P > 0 and (t_c == t_c[0]).all().item())
+        uniform_time = bool(uniform_time) and P > 0
+        d = _make_desc(planes, resolutions, aabb_host, uniform_time)
+        nws = L.s3g_hexplane_forward_workspace_bytes(C.byref(d))
+        ws = torch.empty(nws, dtype=torch.uint8, device=xyz.device) if nws else None
         order = cache.get("order") if cache is not None else None
         if order is not None and (order.numel() != P or order.device != xyz.device):
             order = None  # stale (densification changed P): fall back to identity order
         with torch.cuda.device(xyz.device):
             _lib.check(L.s3g_hexplane_forward(C.byref(d), P, xyz_c.data_ptr(), t_c.data_ptr(), feat.data_ptr(),
                                               order.data_ptr() if order is not None else None,
+                                              ws.data_ptr() if ws is not None else None,
                                               torch.cuda.current_stream().cuda_stream))
-        ctx.meta = meta
+        ctx.meta = (resolutions, aabb_host, cache, uniform_time)
         ctx.save_for_backward(xyz_c, t_c, *planes)
         return feat
 
     @staticmethod
     def backward(ctx, gfeat):
         xyz_c, t_c, *planes = ctx.saved_tensors
-        resolutions, aabb_host, cache = ctx.meta
+        resolutions, aabb_host, cache, uniform_time = ctx.meta
         L = _bind()
         P = xyz_c.shape[0]
         gfeat = gfeat.contiguous()
@@ -118,8 +127,8 @@ class _HexPlaneSample(torch.autograd.Function):
             for i in range(6):
                 g = gplanes[l * 6 + i]
                 ptrs[l][i] = _channels_last_ptr(g) if g is not None else None
-        d = _make_desc(planes, resolutions, aabb_host)
-        work = torch.empty(L.s3g_hexplane_backward_workspace_bytes(len(resolutions), P), dtype=torch.uint8,
+        d = _make_desc(planes, resolutions, aabb_host, uniform_time)
+        work = torch.empty(L.s3g_hexplane_backward_workspace_bytes(C.byref(d), P), dtype=torch.uint8,
                            device=xyz_c.device)
         order_out = torch.empty(P, dtype=torch.int32, device=xyz_c.device) if cache is not None else None
         with torch.cuda.device(xyz_c.device):
@@ -132,8 +141,10 @@ class _HexPlaneSample(torch.autograd.Function):
         return (gxyz if ctx.needs_input_grad[0] else None, None, None, *gplanes)
 
 
-def hexplane_sample(xyz, time, planes, resolutions, aabb_host, cache=None):
-    return _HexPlaneSample.apply(xyz, time, (tuple(tuple(r) for r in resolutions), aabb_host, cache), *planes)
+def hexplane_sample(xyz, time, planes, resolutions, aabb_host, cache=None, uniform_time=None):
+    """uniform_time: True = the caller guarantees every point carries the same timestamp (fast path: the time planes are
+    pre-interpolated into row tables), False = general per-point time, None = decide by looking at `time` (one host sync)."""
+    return _HexPlaneSample.apply(xyz, time, (tuple(tuple(r) for r in resolutions), aabb_host, cache, uniform_time), *planes)
 
 
 class HexPlaneField(nn.Module):
@@ -196,9 +207,11 @@ class HexPlaneField(nn.Module):
     def _planes(self):
         return [p for planes in self.grids for p in planes]
 
-    def get_density(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None):
+    def get_density(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None, uniform_time=None):
         pts = pts.reshape(-1, pts.shape[-1])
-        return hexplane_sample(pts, timestamps, self._planes(), self.resolutions, self._host_aabb(), self._order_cache)
+        return hexplane_sample(pts, timestamps, self._planes(), self.resolutions, self._host_aabb(), self._order_cache,
+                               uniform_time)
 
-    def forward(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None):
-        return self.get_density(pts, timestamps)
+    def forward(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None, uniform_time=None):
+        """Reference signature (scene/hexplane.py:178-183) plus the optional `uniform_time` hint of hexplane_sample."""
+        return self.get_density(pts, timestamps, uniform_time)

@@ -194,7 +194,7 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
         if fused_glue:
             # default configuration: only dx / dshs / feat are produced by the network (scales, rotations, opacity pass
             # through, deformation.py:126-152); `shs + dshs` is folded into the glue kernel below
-            dx, dshs, feat = net.deform_heads(means3D, time)
+            dx, dshs, feat = net.deform_heads(means3D, time, uniform_time=True)   # `time` is one timestamp repeated
             means3D_final, scales_final, rotations_final, opacity_final = means3D + dx, scales, rotations, opacity
         else:
             (means3D_final, scales_final, rotations_final, opacity_final, shs_final, dx, feat, dshs) = pc._deformation(

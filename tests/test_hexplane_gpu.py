@@ -52,9 +52,13 @@ def test_deform_network_matches_reference_golden(gpu_device):
             assert p.grad is None, k
 
 
+@pytest.mark.parametrize("tmode", ["per_point", 0.37, 1.0, -1.0, -1.4, 0.9999, "hint_false"])
 @pytest.mark.parametrize("P", [1, 7, 8, 1000])
-def test_sampler_vs_restatement_random(gpu_device, P):
-    """Default-resolution field ([64,64,64,25] x [1,2,4,8]); points partly OUTSIDE the aabb (border clamp + zero grad)."""
+def test_sampler_vs_restatement_random(gpu_device, P, tmode):
+    """Default-resolution field ([64,64,64,25] x [1,2,4,8]); points partly OUTSIDE the aabb (border clamp + zero grad).
+    tmode: per-point random times (general 4-tap path), or ONE timestamp for all points -- interior, on both borders,
+    outside, just inside the last row -- which takes the uniform-time path (time planes pre-interpolated to row tables,
+    auto-detected); "hint_false" = uniform data forced through the general path."""
     from oracle import hexplane_ref as hr
     from s3gaussian_amd.hexplane import HexPlaneField
     torch.manual_seed(P)
@@ -69,13 +73,14 @@ def test_sampler_vs_restatement_random(gpu_device, P):
     mine.load_state_dict(ref.state_dict())
     mine = mine.to(gpu_device)
     xyz = (torch.rand(P, 3) * torch.tensor([6.0, 5.5, 3.5]) + torch.tensor([-2.5, -3.0, -1.5]))
-    time = torch.rand(P, 1)
+    time = torch.rand(P, 1) if tmode == "per_point" else torch.full((P, 1), 0.25 if tmode == "hint_false" else float(tmode))
+    hint = False if tmode == "hint_false" else None
     w = torch.randn(P, 128)
     xr = xyz.clone().requires_grad_(True)
     fr = ref(xr, time)
     (fr * w).sum().backward()
     xg = xyz.to(gpu_device).requires_grad_(True)
-    fg = mine(xg, time.to(gpu_device))
+    fg = mine(xg, time.to(gpu_device), uniform_time=hint)
     (fg * w.to(gpu_device)).sum().backward()
     np.testing.assert_allclose(fg.detach().cpu().numpy(), fr.detach().numpy(), rtol=2e-5, atol=1e-6)
     assert rel_l2(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1e-4
