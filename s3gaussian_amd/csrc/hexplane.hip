@@ -84,27 +84,37 @@ __device__ __forceinline__ void point_coords(const HexArgs& a, int p, float* u) 
 __device__ constexpr int PAIR0[6] = {0, 0, 0, 1, 1, 2};
 __device__ constexpr int PAIR1[6] = {1, 2, 3, 2, 3, 3};
 
+__device__ __forceinline__ float4 fetch4(const float* __restrict__ plane, int off, int c4) {
+  return off >= 0 ? *reinterpret_cast<const float4*>(plane + (size_t)off * HEXC + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ float4 operator*(float4 a, float b) { return make_float4(a.x * b, a.y * b, a.z * b, a.w * b); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// EIGHT lanes own one point, four channels each (one 16-byte load per texel and lane; the 8 lanes read its 128-byte
+// line): the kernel is VALU-bound on the tap arithmetic, which every lane of a point repeats -- 8 copies instead of 32.
 __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) {
-  const int c = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  const int c4 = (threadIdx.x & 7) * 4, slot = threadIdx.x >> 3;
   const int F = a.d.levels * HEXC;
-  for (int pi = blockIdx.x * 8 + slot; pi < a.P; pi += gridDim.x * 8) {
+  for (int pi = blockIdx.x * 32 + slot; pi < a.P; pi += gridDim.x * 32) {
     const int p = a.proc_order ? (int)a.proc_order[pi] : pi;
     float u[4];
     point_coords(a, p, u);
     for (int l = 0; l < a.d.levels; l++) {
-      float prod = 1.f;
+      float4 prod = make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
         const Tap t = make_tap(u[PAIR0[i]], u[PAIR1[i]], W, H);
         const float* pl = a.d.planes[l][i];
-        float s = fetch(pl, t.o00, c) * t.w00;
-        s += fetch(pl, t.o01, c) * t.w01;
-        s += fetch(pl, t.o10, c) * t.w10;
-        s += fetch(pl, t.o11, c) * t.w11;
+        float4 s = fetch4(pl, t.o00, c4) * t.w00;
+        s = s + fetch4(pl, t.o01, c4) * t.w01;
+        s = s + fetch4(pl, t.o10, c4) * t.w10;
+        s = s + fetch4(pl, t.o11, c4) * t.w11;
         prod = prod * s;
       }
-      a.feat[(size_t)p * F + l * HEXC + c] = prod;
+      *reinterpret_cast<float4*>(a.feat + (size_t)p * F + l * HEXC + c4) = prod;
     }
   }
 }
@@ -115,12 +125,17 @@ __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) 
 __device__ constexpr int ORI_OF[6] = {0, 2, 0, 1, 1, 2};   // plane i -> orientation pass that scatters it
 __device__ constexpr int KIND_OF[6] = {0, 0, 1, 0, 1, 1};  // 0 = spatial plane of the pass, 1 = its time plane
 
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// Same lane mapping as the forward (8 lanes per point, 4 channels each).  Per plane only the sample s and its two
+// coordinate derivatives are kept:  ds/dix = (ne - nw)(y1 - iy) + (se - sw)(iy - y0),  ds/diy = (sw - nw)(x1 - ix) +
+// (se - ne)(ix - x0)  (the four terms of torch's grid_sampler_2d_backward, grouped).
 __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexArgs a, float* __restrict__ G,
                                                                       const uint32_t* __restrict__ rank_all) {
-  const int c = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  const int c4 = (threadIdx.x & 7) * 4, slot = threadIdx.x >> 3;
   const int F = a.d.levels * HEXC;
   const size_t PL = (size_t)a.P * HEXC;  // one slab of G
-  for (int p0 = blockIdx.x * 8; p0 < a.P; p0 += gridDim.x * 8) {  // uniform trip count: shuffles below need all lanes
+  for (int p0 = blockIdx.x * 32; p0 < a.P; p0 += gridDim.x * 32) {  // uniform trip count: shuffles below need all lanes
     const int pi = p0 + slot;
     const bool live = pi < a.P;
     const int p = live ? (a.proc_order ? (int)a.proc_order[pi] : pi) : 0;
@@ -132,54 +147,54 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
     if (live) point_coords(a, p, u);
     float du[3] = {0.f, 0.f, 0.f};
     for (int l = 0; l < a.d.levels; l++) {
-      Tap t[6];
-      float v00[6], v01[6], v10[6], v11[6], s[6];
+      float4 s[6], dX[6], dY[6];
+      float mx[6], my[6];
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
-        t[i] = make_tap(u[PAIR0[i]], u[PAIR1[i]], W, H);
+        const Tap t = make_tap(u[PAIR0[i]], u[PAIR1[i]], W, H);
         const float* pl = a.d.planes[l][i];
-        v00[i] = live ? fetch(pl, t[i].o00, c) : 0.f;
-        v01[i] = live ? fetch(pl, t[i].o01, c) : 0.f;
-        v10[i] = live ? fetch(pl, t[i].o10, c) : 0.f;
-        v11[i] = live ? fetch(pl, t[i].o11, c) : 0.f;
-        float acc = v00[i] * t[i].w00;
-        acc += v01[i] * t[i].w01;
-        acc += v10[i] * t[i].w10;
-        acc += v11[i] * t[i].w11;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v00 = live ? fetch4(pl, t.o00, c4) : z, v01 = live ? fetch4(pl, t.o01, c4) : z;
+        const float4 v10 = live ? fetch4(pl, t.o10, c4) : z, v11 = live ? fetch4(pl, t.o11, c4) : z;
+        float4 acc = v00 * t.w00;
+        acc = acc + v01 * t.w01;
+        acc = acc + v10 * t.w10;
+        acc = acc + v11 * t.w11;
         s[i] = acc;
+        dX[i] = (v01 - v00) * (t.y1f - t.iy) + (v11 - v10) * (t.iy - t.y0f);
+        dY[i] = (v10 - v00) * (t.x1f - t.ix) + (v11 - v01) * (t.ix - t.x0f);
+        mx[i] = t.mx;
+        my[i] = t.my;
       }
-      const float g = live ? a.gfeat[(size_t)p * F + l * HEXC + c] : 0.f;
+      const float4 g = live ? *reinterpret_cast<const float4*>(a.gfeat + (size_t)p * F + l * HEXC + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
       // product rule in the order autograd applies it to ((((1*s0)*s1)*s2)*s3)*s4)*s5: pre[i] = prod_{j<i} s_j, suffix by recursion
-      float pre[6];
-      pre[0] = 1.f;
+      float4 pre[6];
+      pre[0] = make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
       for (int i = 1; i < 6; i++) pre[i] = pre[i - 1] * s[i - 1];
-      float gs = g;  // dL/d(prefix product through plane i)
+      float4 gs = g;  // dL/d(prefix product through plane i)
 #pragma unroll
       for (int i = 5; i >= 0; i--) {
-        const float gi = gs * pre[i];  // dL/ds_i
+        const float4 gi = gs * pre[i];  // dL/ds_i
         gs = gs * s[i];
         if (live) {
-          G[(size_t)((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * PL + (size_t)rk[ORI_OF[i]] * HEXC + c] = gi;
-          // torch grid_sampler_2d_backward: gix = -nw*(iy_se-iy) + ne*(iy_sw-iy) - sw*(iy-iy_ne) + se*(iy-iy_nw), ...
-          const float gix = (-v00[i] * (t[i].y1f - t[i].iy) + v01[i] * (t[i].y1f - t[i].iy) - v10[i] * (t[i].iy - t[i].y0f) +
-                             v11[i] * (t[i].iy - t[i].y0f)) * gi;
-          const float giy = (-v00[i] * (t[i].x1f - t[i].ix) - v01[i] * (t[i].ix - t[i].x0f) + v10[i] * (t[i].x1f - t[i].ix) +
-                             v11[i] * (t[i].ix - t[i].x0f)) * gi;
-          if (PAIR0[i] < 3) du[PAIR0[i]] += t[i].mx * gix;
-          if (PAIR1[i] < 3) du[PAIR1[i]] += t[i].my * giy;
+          *reinterpret_cast<float4*>(G + (size_t)((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * PL +
+                                     (size_t)rk[ORI_OF[i]] * HEXC + c4) = gi;
+          if (PAIR0[i] < 3) du[PAIR0[i]] += mx[i] * dot4(dX[i], gi);
+          if (PAIR1[i] < 3) du[PAIR1[i]] += my[i] * dot4(dY[i], gi);
         }
       }
     }
-    // sum over the 32 channels (lanes of this half-wave), then undo the aabb normalisation
+    // sum over the 32 channels (the 8 lanes of this point), then undo the aabb normalisation
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       float v = du[k];
-      for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      for (int off = 4; off >= 1; off >>= 1) v += __shfl_xor(v, off);
       du[k] = v;
     }
-    if (live && c < 3) a.gxyz[3 * (size_t)p + c] = du[c] * (2.0f / (a.d.aabb_min[c] - a.d.aabb_max[c]));
+    const int c = threadIdx.x & 7;
+    if (live && c < 3) a.gxyz[3 * (size_t)p + c] = (c == 0 ? du[0] : (c == 1 ? du[1] : du[2])) * (2.0f / (a.d.aabb_min[c] - a.d.aabb_max[c]));
   }
 }
 
@@ -514,7 +529,7 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
   a.d = *d; a.P = P; a.xyz = xyz; a.time = time; a.feat = features; a.proc_order = proc_order;
   TimeRows rows;
   if (d->uniform_time) use_time_rows(a, rows, (float*)workspace, nullptr, (hipStream_t)stream_);
-  const int blocks = min((P + 7) / 8, 256 * 16);
+  const int blocks = min((P + 31) / 32, 256 * 16);
   profile_begin(S3G_PROFILE_HEXPLANE_FORWARD, (hipStream_t)stream_);
   hipLaunchKernelGGL(hexplane_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
   profile_end(S3G_PROFILE_HEXPLANE_FORWARD, (hipStream_t)stream_, (double)P, (double)d->levels);
@@ -579,7 +594,7 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     use_time_rows(a, rows, tables, tables + nt, stream);
   }
   a.proc_order = w.order;
-  const int blocks = min((P + 7) / 8, 256 * 16);
+  const int blocks = min((P + 31) / 32, 256 * 16);
   profile_begin(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream);
   hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3(blocks), dim3(256), 0, stream, a, G, w.rank);
   profile_end(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream, (double)P, (double)d->levels);
