@@ -328,17 +328,21 @@ __device__ __forceinline__ void foot_flush(const Foot& f, float* __restrict__ gp
 // Two-entry footprint cache (A = most recent).  align_corners grids of different levels do not nest, so inside one
 // finest-level cell the points alternate between two (sometimes four) coarse footprints; remembering the previous one
 // as well removes most of those flushes.
-__device__ __forceinline__ void foot_add(Foot& A, Foot& B, const Tap& t, float g, float* __restrict__ gp, int W, int c) {
-  if (t.o00 != A.key) {
-    if (t.o00 == B.key) {
+struct PackedTap {  // what the scatter needs of a Tap: 8 floats in LDS
+  int key, flags;
+  float w00, w01, w10, w11;
+};
+__device__ __forceinline__ void foot_add(Foot& A, Foot& B, const PackedTap& t, float g, float* __restrict__ gp, int W, int c) {
+  if (t.key != A.key) {
+    if (t.key == B.key) {
       const Foot tmp = A;
       A = B;
       B = tmp;
     } else {
       foot_flush(B, gp, W, c);
       B = A;
-      A.key = t.o00;
-      A.flags = (t.o01 >= 0 ? 1 : 0) | (t.o10 >= 0 ? 2 : 0);
+      A.key = t.key;
+      A.flags = t.flags;
       A.a00 = A.a01 = A.a10 = A.a11 = 0.f;
     }
   }
@@ -348,67 +352,107 @@ __device__ __forceinline__ void foot_add(Foot& A, Foot& B, const Tap& t, float g
   A.a11 += g * t.w11;
 }
 
+// A half-wave (32 lanes = the 32 channels) walks SEG consecutive points of the sorted order.  The kernel used to be
+// VALU-bound on make_tap, which all 32 lanes repeated for each of the 8 (level, plane) taps of a point; now the 32 lanes
+// compute the 8 taps of FOUR points at once (lane = point q x tap j), park them in LDS, and every lane reads them back
+// with broadcast loads while it accumulates its channel.
+constexpr int TAPF = 8;  // floats per packed tap in LDS (6 used; 32-byte slots keep the 16-byte reads aligned)
 __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
                                                                const uint32_t* __restrict__ order_all) {
+  __shared__ __attribute__((aligned(16))) float tapbuf[8][2][4][8][TAPF];  // [half-wave][double buffer][point][tap]
   const int o = blockIdx.y;
-  const int c = threadIdx.x & 31;
-  const int seg = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int c = threadIdx.x & 31, hw = threadIdx.x >> 5;
+  const int q = c >> 3, j = c & 7;  // tap-phase role: point q of the group of four, tap j = (level j >> 1, kind j & 1)
+  const int seg = blockIdx.x * 8 + hw;
   const int k0 = seg * SEG, k1 = min(a.P, k0 + SEG);
-  if (k0 >= a.P) return;
+  if (k0 >= a.P) return;  // whole half-waves drop out; the LDS traffic below is private to a half-wave (wave-ordered)
   const uint32_t* order = order_all + (size_t)o * a.P;
   const size_t PL = (size_t)a.P * HEXC;
   const int i0 = PLA[o], i1 = PLT[o];
-  const int ax00 = PAIR0[i0], ax01 = PAIR1[i0], ax10 = PAIR0[i1], ax11 = PAIR1[i1];
+  const int ip = (j & 1) ? i1 : i0;                   // the plane of this lane's tap
+  const int axw = PAIR0[ip], axh = PAIR1[ip];
   constexpr int LG = 4;  // levels handled together: 4 levels x 2 planes x 2 footprints live in registers
   for (int l0 = 0; l0 < a.d.levels; l0 += LG) {
     Foot fa[LG][2], fb[LG][2];
 #pragma unroll
     for (int l = 0; l < LG; l++)
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
-        fa[l][q] = Foot{-1, 0, 0.f, 0.f, 0.f, 0.f};
-        fb[l][q] = Foot{-1, 0, 0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < 2; m++) {
+        fa[l][m] = Foot{-1, 0, 0.f, 0.f, 0.f, 0.f};
+        fb[l][m] = Foot{-1, 0, 0.f, 0.f, 0.f, 0.f};
       }
-    for (int k = k0; k < k1; k++) {
-      const int p = (int)order[k];
+    const int lt = l0 + (j >> 1);                     // level of this lane's tap
+    const bool tap_on = lt < a.d.levels;
+    const int Wt = tap_on ? a.d.res[lt][axw] : 2, Ht = tap_on ? a.d.res[lt][axh] : 2;
+    // taps of the four points kb .. kb+3 -> LDS buffer `buf`
+    auto tap_phase = [&](int kb, int buf) {
+      const int kk = min(kb + q, k1 - 1);
+      const int p = (int)order[kk];
       float u[4];
       point_coords(a, p, u);
-      float g[LG][2];
+      const Tap t = make_tap(u[axw], u[axh], Wt, Ht);
+      float4 lo;
+      lo.x = __int_as_float(t.o00);
+      lo.y = __int_as_float((t.o01 >= 0 ? 1 : 0) | (t.o10 >= 0 ? 2 : 0));
+      lo.z = t.w00;
+      lo.w = t.w01;
+      float* dst = &tapbuf[hw][buf][q][j][0];
+      *reinterpret_cast<float4*>(dst) = lo;
+      *reinterpret_cast<float2*>(dst + 4) = make_float2(t.w10, t.w11);
+    };
+    tap_phase(k0, 0);
+    int buf = 0;
+    for (int kb = k0; kb < k1; kb += 4, buf ^= 1) {
+      // 1. this group's G rows: 4 points x 8 rows requested at once (the walk is latency-bound, not bandwidth-bound)
+      float g[4][LG][2];
 #pragma unroll
-      for (int l = 0; l < LG; l++) {  // all G rows of this point are requested before the first is consumed
-        const bool on = l0 + l < a.d.levels;
-        g[l][0] = (on && a.gplanes[l0 + l][i0]) ? G[(size_t)((o * a.d.levels + l0 + l) * 2 + 0) * PL + (size_t)k * HEXC + c] : 0.f;
-        g[l][1] = (on && a.gplanes[l0 + l][i1]) ? G[(size_t)((o * a.d.levels + l0 + l) * 2 + 1) * PL + (size_t)k * HEXC + c] : 0.f;
-      }
+      for (int qq = 0; qq < 4; qq++) {
+        const size_t k = (size_t)min(kb + qq, k1 - 1);
 #pragma unroll
-      for (int l = 0; l < LG; l++) {
-        if (l0 + l >= a.d.levels) break;
-        float* gp0 = a.gplanes[l0 + l][i0];
-        float* gp1 = a.gplanes[l0 + l][i1];
-        if (gp0 != nullptr) {
-          const int W = a.d.res[l0 + l][ax00];
-          const Tap t = make_tap(u[ax00], u[ax01], W, a.d.res[l0 + l][ax01]);
-          foot_add(fa[l][0], fb[l][0], t, g[l][0], gp0, W, c);
+        for (int l = 0; l < LG; l++) {
+          const bool on = l0 + l < a.d.levels;
+          g[qq][l][0] = (on && a.gplanes[l0 + l][i0]) ? G[(size_t)((o * a.d.levels + l0 + l) * 2 + 0) * PL + k * HEXC + c] : 0.f;
+          g[qq][l][1] = (on && a.gplanes[l0 + l][i1]) ? G[(size_t)((o * a.d.levels + l0 + l) * 2 + 1) * PL + k * HEXC + c] : 0.f;
         }
-        if (gp1 != nullptr) {
-          const int W = a.d.res[l0 + l][ax10];
-          const Tap t = make_tap(u[ax10], u[ax11], W, a.d.res[l0 + l][ax11]);
-          foot_add(fa[l][1], fb[l][1], t, g[l][1], gp1, W, c);
+      }
+      // 2. the NEXT group's taps (its order -> xyz load chain overlaps the G loads above)
+      if (kb + 4 < k1) tap_phase(kb + 4, buf ^ 1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // 3. accumulate
+      const int nq = min(4, k1 - kb);
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) {
+        if (qq >= nq) break;
+#pragma unroll
+        for (int l = 0; l < LG; l++) {
+          if (l0 + l >= a.d.levels) break;
+#pragma unroll
+          for (int m = 0; m < 2; m++) {
+            float* gp = a.gplanes[l0 + l][m ? i1 : i0];
+            if (gp == nullptr) continue;
+            const float* src = &tapbuf[hw][buf][qq][l * 2 + m][0];
+            const float4 lo = *reinterpret_cast<const float4*>(src);
+            const float2 hi = *reinterpret_cast<const float2*>(src + 4);
+            PackedTap t;
+            t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
+            t.w00 = lo.z; t.w01 = lo.w; t.w10 = hi.x; t.w11 = hi.y;
+            foot_add(fa[l][m], fb[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
+          }
         }
       }
     }
 #pragma unroll
     for (int l = 0; l < LG; l++) {
       if (l0 + l >= a.d.levels) break;
-      float* gp0 = a.gplanes[l0 + l][i0];
-      float* gp1 = a.gplanes[l0 + l][i1];
-      if (gp0 != nullptr) {
-        foot_flush(fa[l][0], gp0, a.d.res[l0 + l][ax00], c);
-        foot_flush(fb[l][0], gp0, a.d.res[l0 + l][ax00], c);
-      }
-      if (gp1 != nullptr) {
-        foot_flush(fa[l][1], gp1, a.d.res[l0 + l][ax10], c);
-        foot_flush(fb[l][1], gp1, a.d.res[l0 + l][ax10], c);
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        float* gp = a.gplanes[l0 + l][m ? i1 : i0];
+        if (gp == nullptr) continue;
+        const int W = a.d.res[l0 + l][PAIR0[m ? i1 : i0]];
+        foot_flush(fa[l][m], gp, W, c);
+        foot_flush(fb[l][m], gp, W, c);
       }
     }
   }
