@@ -99,6 +99,22 @@ int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int* radii,
                         float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                         float* dL_dscale, float* dL_drot, void* stream);
 
+/* Backward of TWO images blended from the same geometry -- the RGB+depth render (in->colors_precomp) and a second render
+ * with colours `colors2` [P,3] through s3g_raster_forward_reuse (the feature image of
+ * gaussian_renderer/__init__.py:153-166) -- in one pass instead of two Rasterizer::backward calls whose results autograd
+ * then adds: the alpha test, exp2, transmittance recurrence and the six geometry sums are shared.  dL_dpix2 [3,H,W] is the
+ * upstream gradient of the second image (its depth output is unused by the reference and gets none); dL_dcolor2 [P,3]
+ * is written; every other output is the SUM over both images.  Requires in->colors_precomp (no SH path).
+ * `workspace`: s3g_raster_backward2_workspace_bytes(P, R) bytes. */
+size_t s3g_raster_backward2_workspace_bytes(int P, int R);
+int s3g_raster_backward2(const s3g_raster_inputs* in, const float* colors2, int R, const int* radii,
+                         const void* geometry_arena, const void* binning_arena, const void* image_arena,
+                         void* workspace,
+                         const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix2,
+                         float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dcolor2,
+                         float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dscale, float* dL_drot,
+                         void* stream);
+
 /* present[P] (uint8 0/1) = in_frustum (auxiliary.h:139-164: view-space z > 0.2). */
 int s3g_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);

@@ -37,8 +37,13 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
-// record layout (NREC floats): dcolor r,g,b | ddepth | S0 | Sx | Sy | Sxx | Sxy | Syy
-
+// record layout (NREC floats): dcolor r,g,b | ddepth | S0 | Sx | Sy | Sxx | Sxy | Syy   [| dcolor2 r,g,b | pad]
+//
+// NX = 3: TWO images blended from the same geometry (the RGB+depth render and the feature render of one iteration,
+// gaussian_renderer/__init__.py:127-166) are back-propagated in ONE pass.  Everything that depends only on the geometry
+// -- the alpha test, exp2, the transmittance recurrence, the six S sums and their wave reductions -- is shared; the second
+// image adds its three colour-gradient sums and its term of dL/dalpha.  Records grow from 10 to 14 floats.
+template <int NX>
 __global__ void __launch_bounds__(256)
 blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ ranges,
                       const uint32_t* __restrict__ tile_hi, const uint32_t* __restrict__ point_list,
@@ -46,10 +51,13 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
                       const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
                       const float* __restrict__ depths, const float* __restrict__ final_Ts,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-                      const float* __restrict__ dL_dpixel_depths, float* __restrict__ records /*[R][NREC]*/) {
+                      const float* __restrict__ dL_dpixel_depths, float* __restrict__ records /*[R][NR]*/,
+                      const float* __restrict__ colors2, const float* __restrict__ dL_dpixels2) {
   constexpr uint32_t BATCH = 128;  // Gaussians staged per round
+  constexpr int NR = NX ? NREC + 4 : NREC;
   __shared__ StagedGaussian sg[BATCH];
-  __shared__ float acc[4][NREC][BATCH];  // one slot per wave: combined in fixed order -> bit-reproducible sums
+  __shared__ float4 sg2[NX ? BATCH : 1];  // second image's colour
+  __shared__ float acc[4][NR][BATCH];  // one slot per wave: combined in fixed order -> bit-reproducible sums
 
   const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= (uint32_t)tiles) return;
@@ -72,16 +80,24 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
     gb = dL_dpixels[2 * N + pix];
     gd = dL_dpixel_depths[pix];
   }
-  const float bg_dot = bg[0] * gr + bg[1] * gg + bg[2] * gb;
+  float g2r = 0.f, g2g = 0.f, g2b = 0.f;
+  if (NX && inside) {
+    g2r = dL_dpixels2[pix];
+    g2g = dL_dpixels2[N + pix];
+    g2b = dL_dpixels2[2 * N + pix];
+  }
+  float bg_dot = bg[0] * gr + bg[1] * gg + bg[2] * gb;
+  if (NX) bg_dot += bg[0] * g2r + bg[1] * g2g + bg[2] * g2b;
 
   float T = T_final;
   float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;  // accum_rec (colour, depth)
   float last_alpha = 0.f, lr = 0.f, lg = 0.f, lb = 0.f, ld = 0.f;
+  float a2r = 0.f, a2g = 0.f, a2b = 0.f, l2r = 0.f, l2g = 0.f, l2b = 0.f;  // second image
 
   for (uint32_t done_cnt = 0; done_cnt < hi; done_cnt += BATCH) {
     const uint32_t cnt = min(BATCH, hi - done_cnt);
     __syncthreads();  // previous batch fully consumed (sg, acc)
-    for (uint32_t e = tid; e < 4 * NREC * BATCH; e += 256) (&acc[0][0][0])[e] = 0.f;
+    for (uint32_t e = tid; e < 4 * NR * BATCH; e += 256) (&acc[0][0][0])[e] = 0.f;
     if ((uint32_t)tid < cnt) {
       const uint32_t pos = hi - 1 - (done_cnt + tid);  // back to front
       const uint32_t id = point_list[rg.x + pos];
@@ -92,6 +108,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
       s.b = make_float4(-0.5f * LOG2E * co.z, co.w, depths[id], colors[3 * (size_t)id]);
       s.c = make_float4(colors[3 * (size_t)id + 1], colors[3 * (size_t)id + 2], 0.f, 0.f);
       sg[tid] = s;
+      if (NX) sg2[tid] = make_float4(colors2[3 * (size_t)id], colors2[3 * (size_t)id + 1], colors2[3 * (size_t)id + 2], 0.f);
     }
     __syncthreads();
 
@@ -109,6 +126,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
       if (__ballot(valid) == 0ull) continue;  // wave-uniform: this Gaussian misses all 64 pixels of the wave
 
       float p_r = 0.f, p_g = 0.f, p_b = 0.f, p_d = 0.f, s0 = 0.f, sx = 0.f, sy = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f;
+      float p2_r = 0.f, p2_g = 0.f, p2_b = 0.f;
       if (valid) {
         const float4 Cc = sg[j].c;
         const float cr = B.w, cg = Cc.x, cb = Cc.y, cd = B.z;
@@ -122,6 +140,15 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
         ad = last_alpha * ld + one_m_la * ad;
         lr = cr; lg = cg; lb = cb; ld = cd;
         float dL_dalpha = (cr - ar) * gr + (cg - ag) * gg + (cb - ab) * gb + (cd - ad) * gd;
+        if (NX) {
+          const float4 C2 = sg2[j];
+          a2r = last_alpha * l2r + one_m_la * a2r;
+          a2g = last_alpha * l2g + one_m_la * a2g;
+          a2b = last_alpha * l2b + one_m_la * a2b;
+          l2r = C2.x; l2g = C2.y; l2b = C2.z;
+          dL_dalpha += (C2.x - a2r) * g2r + (C2.y - a2g) * g2g + (C2.z - a2b) * g2b;
+          p2_r = w * g2r; p2_g = w * g2g; p2_b = w * g2b;
+        }
         dL_dalpha *= T;
         last_alpha = alpha;
         dL_dalpha += (-T_final * rcp) * bg_dot;
@@ -134,19 +161,21 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
       p_r = wave_sum_lane63(p_r); p_g = wave_sum_lane63(p_g); p_b = wave_sum_lane63(p_b); p_d = wave_sum_lane63(p_d);
       s0 = wave_sum_lane63(s0); sx = wave_sum_lane63(sx); sy = wave_sum_lane63(sy);
       sxx = wave_sum_lane63(sxx); sxy = wave_sum_lane63(sxy); syy = wave_sum_lane63(syy);
+      if (NX) { p2_r = wave_sum_lane63(p2_r); p2_g = wave_sum_lane63(p2_g); p2_b = wave_sum_lane63(p2_b); }
       if (lane == 63) {
         float* aw = &acc[wave][0][j];
         aw[0 * BATCH] = p_r; aw[1 * BATCH] = p_g; aw[2 * BATCH] = p_b; aw[3 * BATCH] = p_d; aw[4 * BATCH] = s0;
         aw[5 * BATCH] = sx; aw[6 * BATCH] = sy; aw[7 * BATCH] = sxx; aw[8 * BATCH] = sxy; aw[9 * BATCH] = syy;
+        if (NX) { aw[10 * BATCH] = p2_r; aw[11 * BATCH] = p2_g; aw[12 * BATCH] = p2_b; }
       }
     }
     __syncthreads();
     // Epilogue of the batch: lane t owns Gaussian t of the batch and stores its record (zeros if untouched).
     if ((uint32_t)tid < cnt) {
       const uint32_t pos = hi - 1 - (done_cnt + tid);
-      float2* rec = reinterpret_cast<float2*>(records + (size_t)(rg.x + pos) * NREC);
+      float2* rec = reinterpret_cast<float2*>(records + (size_t)(rg.x + pos) * NR);
 #pragma unroll
-      for (int k = 0; k < NREC / 2; k++) {
+      for (int k = 0; k < NR / 2; k++) {
         const float lo = ((acc[0][2 * k][tid] + acc[1][2 * k][tid]) + acc[2][2 * k][tid]) + acc[3][2 * k][tid];
         const float hi2 = ((acc[0][2 * k + 1][tid] + acc[1][2 * k + 1][tid]) + acc[2][2 * k + 1][tid]) + acc[3][2 * k + 1][tid];
         rec[k] = make_float2(lo, hi2);
@@ -186,6 +215,7 @@ struct GeomBwdArgs {
   float* dL_dconic;         // [P,4]  optional (may be NULL)
   float* dL_dopacity;       // [P]
   float* dL_dcolor;         // [P,3]
+  float* dL_dcolor2;        // [P,3]  second image's colours (two-image backward only)
   float* dL_ddepth;         // [P]    optional (may be NULL)
   float* dL_dmean3D;        // [P,3]
   float* dL_dcov3D;         // [P,6]
@@ -195,6 +225,7 @@ struct GeomBwdArgs {
 };
 
 // Sum the records of the tiles k = k0, k0+stride, ... of one Gaussian's rect (row-major inside the rect).
+template <int NR>
 __device__ __forceinline__ void gather_records(const GeomBwdArgs& a, const ushort4 r, uint32_t o, int k0, int stride,
                                                float* acc) {
   const int w = (int)r.z - (int)r.x, n = w * ((int)r.w - (int)r.y);
@@ -203,9 +234,9 @@ __device__ __forceinline__ void gather_records(const GeomBwdArgs& a, const ushor
     const int t = ty * a.gx + tx;
     const uint32_t pos = a.slot_pos[o + k];
     if (pos < a.tile_hi[t]) {  // tile_hi = absolute end of the positions the blend backward wrote
-      const float2* rec = reinterpret_cast<const float2*>(a.records + (size_t)pos * NREC);
+      const float2* rec = reinterpret_cast<const float2*>(a.records + (size_t)pos * NR);
 #pragma unroll
-      for (int q = 0; q < NREC / 2; q++) {
+      for (int q = 0; q < NR / 2; q++) {
         const float2 v = rec[q];
         acc[2 * q] += v.x;
         acc[2 * q + 1] += v.y;
@@ -214,7 +245,9 @@ __device__ __forceinline__ void gather_records(const GeomBwdArgs& a, const ushor
   }
 }
 
+template <int NX>
 __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArgs a) {
+  constexpr int NR = NX ? NREC + 4 : NREC;
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const bool live = gid < a.P;
   const int idx = live ? gid : a.P - 1;  // keep every lane alive for the wave-cooperative gather below
@@ -222,14 +255,14 @@ __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArg
   const bool vis = live && a.radii[idx] > 0;
 
   // ---- gather the per-instance records of this Gaussian (one per tile of its rect) ----
-  float acc[NREC];
+  float acc[NR];
 #pragma unroll
-  for (int k = 0; k < NREC; k++) acc[k] = 0.f;
+  for (int k = 0; k < NR; k++) acc[k] = 0.f;
   const ushort4 r = vis ? a.rect[idx] : make_ushort4(0, 0, 0, 0);
   const uint32_t o = vis ? a.gauss_off[idx] : 0u;
   const int n = ((int)r.z - (int)r.x) * ((int)r.w - (int)r.y);
   constexpr int BIG = 24;
-  if (n > 0 && n <= BIG) gather_records(a, r, o, 0, 1, acc);
+  if (n > 0 && n <= BIG) gather_records<NR>(a, r, o, 0, 1, acc);
   uint64_t big = __ballot(n > BIG);
   const int lane = threadIdx.x & 63;
   while (big) {  // wave-uniform: all 64 lanes gather one large rect together, then reduce with DPP
@@ -239,12 +272,12 @@ __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArg
     br.x = (unsigned short)__shfl((int)r.x, src); br.y = (unsigned short)__shfl((int)r.y, src);
     br.z = (unsigned short)__shfl((int)r.z, src); br.w = (unsigned short)__shfl((int)r.w, src);
     const uint32_t bo = (uint32_t)__shfl((int)o, src);
-    float part[NREC];
+    float part[NR];
 #pragma unroll
-    for (int k = 0; k < NREC; k++) part[k] = 0.f;
-    gather_records(a, br, bo, lane, 64, part);
+    for (int k = 0; k < NR; k++) part[k] = 0.f;
+    gather_records<NR>(a, br, bo, lane, 64, part);
 #pragma unroll
-    for (int k = 0; k < NREC; k++) {
+    for (int k = 0; k < NR; k++) {
       const float tot = __shfl(wave_sum_lane63(part[k]), 63);
       if (lane == src) acc[k] = tot;
     }
@@ -253,6 +286,7 @@ __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArg
   if (!vis) {  // culled: the reference leaves its zero-initialised outputs untouched
     a.dL_dmean2D[i3] = a.dL_dmean2D[i3 + 1] = a.dL_dmean2D[i3 + 2] = 0.f;
     a.dL_dcolor[i3] = a.dL_dcolor[i3 + 1] = a.dL_dcolor[i3 + 2] = 0.f;
+    if (NX) a.dL_dcolor2[i3] = a.dL_dcolor2[i3 + 1] = a.dL_dcolor2[i3 + 2] = 0.f;
     a.dL_dmean3D[i3] = a.dL_dmean3D[i3 + 1] = a.dL_dmean3D[i3 + 2] = 0.f;
     a.dL_dscale[i3] = a.dL_dscale[i3 + 1] = a.dL_dscale[i3 + 2] = 0.f;
     a.dL_dopacity[idx] = 0.f;
@@ -274,6 +308,7 @@ __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArg
   const float gdep = acc[3];
   a.dL_dmean2D[i3] = g2x; a.dL_dmean2D[i3 + 1] = g2y; a.dL_dmean2D[i3 + 2] = 0.f;
   a.dL_dcolor[i3] = acc[0]; a.dL_dcolor[i3 + 1] = acc[1]; a.dL_dcolor[i3 + 2] = acc[2];
+  if (NX) { a.dL_dcolor2[i3] = acc[NREC]; a.dL_dcolor2[i3 + 1] = acc[NREC + 1]; a.dL_dcolor2[i3 + 2] = acc[NREC + 2]; }
   a.dL_dopacity[idx] = S0;
   if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(dcx, dcy, 0.f, dcz);
   if (a.dL_ddepth) a.dL_ddepth[idx] = gdep;
@@ -455,23 +490,29 @@ extern "C" size_t s3g_raster_backward_workspace_bytes(int P, int R) {
   (void)P;
   return ((size_t)(R > 0 ? R : 0) * NREC * sizeof(float) + 127) & ~size_t(127);
 }
+extern "C" size_t s3g_raster_backward2_workspace_bytes(int P, int R) {
+  (void)P;
+  return ((size_t)(R > 0 ? R : 0) * (NREC + 4) * sizeof(float) + 127) & ~size_t(127);
+}
 
-extern "C" int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int* radii, const void* geometry_arena,
-                                   const void* binning_arena, const void* image_arena, void* workspace,
-                                   const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
-                                   float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
-                                   float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream_) {
+template <int NX>
+static int raster_backward_impl(const char* who, const s3g_raster_inputs* in, const float* colors2, int R, const int* radii,
+                                const void* geometry_arena, const void* binning_arena, const void* image_arena,
+                                void* workspace, const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix2,
+                                float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                                float* dL_dcolor2, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                                float* dL_dscale, float* dL_drot, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!in) {
-    set_error("s3g_raster_backward: NULL inputs");
+    set_error("%s: NULL inputs", who);
     return S3G_ERR_INVALID_ARG;
   }
   const int P = in->P, W = in->width, H = in->height;
   if (P == 0) return S3G_OK;
   if (!radii || !geometry_arena || !image_arena || (R > 0 && (!binning_arena || !workspace)) || !dL_dpix ||
       !dL_dpix_depth || !dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale ||
-      !dL_drot || (in->shs && !dL_dsh)) {
-    set_error("s3g_raster_backward: NULL array argument");
+      !dL_drot || (in->shs && !dL_dsh) || (NX && (!colors2 || !dL_dpix2 || !dL_dcolor2 || !in->colors_precomp))) {
+    set_error("%s: NULL array argument", who);
     return S3G_ERR_INVALID_ARG;
   }
   const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y, tiles = gx * gy;
@@ -485,9 +526,9 @@ extern "C" int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int
   if (R > 0) {
     const uint32_t tile_blocks = ((uint32_t)tiles + 7u) & ~7u;
     profile_begin(S3G_PROFILE_BLEND_BACKWARD, stream);
-    hipLaunchKernelGGL(blend_backward_kernel, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
+    hipLaunchKernelGGL(blend_backward_kernel<NX>, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
                        im.tile_hi, b.point_list, in->background, g.means2D, g.conic_opacity, color_ptr, g.depths,
-                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, records);
+                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, records, colors2, dL_dpix2);
     profile_end(S3G_PROFILE_BLEND_BACKWARD, stream, (double)R, (double)W * H);
     S3G_KERNEL_CHECK(stream, debug);
   }
@@ -502,9 +543,30 @@ extern "C" int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int
   ga.rect = g.rect; ga.gauss_off = g.gauss_off; ga.slot_pos = b.slot_pos; ga.tile_hi = im.tile_hi;
   ga.records = records; ga.conic_opacity = g.conic_opacity;
   ga.dL_dmean2D = dL_dmean2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolor = dL_dcolor;
-  ga.dL_ddepth = dL_ddepth;
+  ga.dL_dcolor2 = dL_dcolor2; ga.dL_ddepth = dL_ddepth;
   ga.dL_dmean3D = dL_dmean3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dsh = dL_dsh; ga.dL_dscale = dL_dscale; ga.dL_drot = dL_drot;
-  hipLaunchKernelGGL(geometry_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, ga);
+  hipLaunchKernelGGL(geometry_backward_kernel<NX>, dim3((P + 255) / 256), dim3(256), 0, stream, ga);
   S3G_KERNEL_CHECK(stream, debug);
   return S3G_OK;
+}
+
+extern "C" int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int* radii, const void* geometry_arena,
+                                   const void* binning_arena, const void* image_arena, void* workspace,
+                                   const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
+                                   float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+                                   float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream_) {
+  return raster_backward_impl<0>("s3g_raster_backward", in, nullptr, R, radii, geometry_arena, binning_arena, image_arena,
+                                 workspace, dL_dpix, dL_dpix_depth, nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                                 nullptr, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, stream_);
+}
+
+extern "C" int s3g_raster_backward2(const s3g_raster_inputs* in, const float* colors2, int R, const int* radii,
+                                    const void* geometry_arena, const void* binning_arena, const void* image_arena,
+                                    void* workspace, const float* dL_dpix, const float* dL_dpix_depth,
+                                    const float* dL_dpix2, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                    float* dL_dcolor, float* dL_dcolor2, float* dL_ddepth, float* dL_dmean3D,
+                                    float* dL_dcov3D, float* dL_dscale, float* dL_drot, void* stream_) {
+  return raster_backward_impl<3>("s3g_raster_backward2", in, colors2, R, radii, geometry_arena, binning_arena, image_arena,
+                                 workspace, dL_dpix, dL_dpix_depth, dL_dpix2, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                                 dL_dcolor2, dL_ddepth, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot, stream_);
 }

@@ -223,15 +223,24 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
             colors_precomp = override_color
     if colors_precomp is not None:
         shs_final = None
-    rendered_image, radii, depth = rasterizer(means3D=means3D_final, means2D=means2D, shs=shs_final,
-                                              colors_precomp=colors_precomp, opacities=opacity, scales=scales_final,
-                                              rotations=rotations_final, cov3D_precomp=cov3D_precomp)
+    want_feat = render_feat and "fine" in stage
+    pair = want_feat and colors_precomp is not None and means3D_final.is_cuda and getattr(pipe, "fused_pair", True)
+    if pair:
+        # RGB + feature image from one node: shared geometry forward, ONE fused backward (rasterizer.forward_pair)
+        rendered_image, radii, depth, rendered_image2 = rasterizer.forward_pair(
+            means3D=means3D_final, means2D=means2D, opacities=opacity, colors_a=colors_precomp, colors_b=feat,
+            scales=scales_final, rotations=rotations_final, cov3D_precomp=cov3D_precomp)
+    else:
+        rendered_image, radii, depth = rasterizer(means3D=means3D_final, means2D=means2D, shs=shs_final,
+                                                  colors_precomp=colors_precomp, opacities=opacity, scales=scales_final,
+                                                  rotations=rotations_final, cov3D_precomp=cov3D_precomp)
     out = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
            "radii": radii, "depth": depth}
-    if render_feat and "fine" in stage:
-        rendered_image2, _, _ = rasterizer(means3D=means3D_final, means2D=means2D, shs=None, colors_precomp=feat,
-                                           opacities=opacity, scales=scales_final, rotations=rotations_final,
-                                           cov3D_precomp=cov3D_precomp)
+    if want_feat:
+        if not pair:
+            rendered_image2, _, _ = rasterizer(means3D=means3D_final, means2D=means2D, shs=None, colors_precomp=feat,
+                                               opacities=opacity, scales=scales_final, rotations=rotations_final,
+                                               cov3D_precomp=cov3D_precomp)
         out["feat"] = rendered_image2
     if return_decomposition and dx is not None:
         max_values = torch.max(torch.abs(dx), dim=1)[0]

@@ -184,6 +184,44 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     return out
 
 
+def rasterize_gaussians_backward2(background, means3D, radii, colors, colors2, scales, rotations, scale_modifier,
+                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
+                                  dL_dout_color2, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """Backward of two renders of the same geometry (colours `colors` -> image + depth, `colors2` -> second image) in one
+    pass (include/s3g_raster.h::s3g_raster_backward2).
+    -> (dL_dmeans2D, dL_dcolors, dL_dcolors2, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales, dL_drotations); everything
+    but the two colour gradients is the sum over both images."""
+    L = _lib.lib()
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    v = _grad_slab(P, 0, dev, False)
+    g_col2 = torch.empty((P, NUM_CHANNELS), dtype=torch.float32, device=dev)
+    if P != 0:
+        keep = [_f32(background, "bg"), _f32(means3D, "means3D"), _f32(colors, "colors_precomp"), _f32(colors2, "colors2"),
+                _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp"),
+                _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos"),
+                _f32(dL_dout_color, "dL_dout_color"), _f32(dL_dout_depth, "dL_dout_depth"),
+                _f32(dL_dout_color2, "dL_dout_color2"), radii.contiguous()]
+        bg_, m3_, col_, col2_, sc_, rot_, cov_, view_, proj_, cam_, gcol_, gdep_, gcol2_, radii_ = keep
+        inp = _inputs(P, 0, 0, W, H, bg_, m3_, None, col_, None, sc_, scale_modifier, rot_, cov_, view_, proj_,
+                      tan_fovx, tan_fovy, cam_, False, debug)
+        work = torch.empty(L.s3g_raster_backward2_workspace_bytes(P, int(R)), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            code = L.s3g_raster_backward2(C.byref(inp), col2_.data_ptr(), int(R), radii_.data_ptr(), _ptr(geomBuffer),
+                                          _ptr(binningBuffer), _ptr(imageBuffer), _ptr(work), gcol_.data_ptr(),
+                                          gdep_.data_ptr(), gcol2_.data_ptr(), v["means2D"].data_ptr(), None,
+                                          v["opacity"].data_ptr(), v["colors"].data_ptr(), g_col2.data_ptr(), None,
+                                          v["means3D"].data_ptr(), v["cov3D"].data_ptr(), v["scales"].data_ptr(),
+                                          v["rot"].data_ptr(), stream)
+        _lib.check(code)
+    else:
+        g_col2.zero_()
+    return (v["means2D"].view(P, 3), v["colors"].view(P, NUM_CHANNELS), g_col2, v["opacity"].view(P, 1),
+            v["means3D"].view(P, 3), v["cov3D"].view(P, 6), v["scales"].view(P, 3), v["rot"].view(P, 4))
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """-> bool[P]  (RAST/rasterize_points.cu:204-223)."""
     L = _lib.lib()

@@ -85,6 +85,42 @@ class _RasterizeGaussians(torch.autograd.Function):
         return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rot, g_cov3D, None
 
 
+class _RasterizeGaussiansPair(torch.autograd.Function):
+    """Two renders of one geometry (colours_a -> image + depth, colours_b -> second image) as ONE autograd node: the
+    second forward reuses the first one's preprocess / binning / sort, and the backward is a single fused pass
+    (s3g_raster_backward2) instead of two whose results autograd would add."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, colors_a, colors_b, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        empty = torch.Tensor([])
+        common = (opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                  rs.tanfovy, rs.image_height, rs.image_width, empty, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        num_rendered, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(rs.bg, means3D, colors_a, *common)
+        n2, color2, _depth2, _radii2, _g2, _b2, _i2 = _C.rasterize_gaussians(rs.bg, means3D, colors_b, *common)
+        if n2 != num_rendered:
+            raise RuntimeError("internal: the two renders of a pair disagree on the instance count")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_a, colors_b, means3D, scales, rotations, cov3Ds_precomp, radii, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, color2
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, grad_depth, grad_color2):
+        rs = ctx.raster_settings
+        colors_a, colors_b, means3D, scales, rotations, cov3Ds_precomp, radii, geom, binning, img = ctx.saved_tensors
+        z = lambda c: torch.zeros((c, rs.image_height, rs.image_width), device=means3D.device)
+        grad_color = z(3) if grad_color is None else grad_color
+        grad_depth = z(1) if grad_depth is None else grad_depth
+        grad_color2 = z(3) if grad_color2 is None else grad_color2
+        (g_means2D, g_col_a, g_col_b, g_opac, g_means3D, g_cov3D, g_scales, g_rot) = _C.rasterize_gaussians_backward2(
+            rs.bg, means3D, radii, colors_a, colors_b, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_color2, rs.campos, geom, ctx.num_rendered,
+            binning, img, rs.debug)
+        return g_means3D, g_means2D, g_col_a, g_col_b, g_opac, g_scales, g_rot, g_cov3D, None
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      raster_settings)
@@ -116,3 +152,26 @@ class GaussianRasterizer(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
+
+    def forward_pair(self, means3D, means2D, opacities, colors_a, colors_b, scales=None, rotations=None, cov3D_precomp=None):
+        """Extension (not in the reference): render the SAME Gaussians with two sets of precomputed colours, e.g. RGB and the
+        feature head's output (gaussian_renderer/__init__.py:127-166 does this with two calls).
+        -> (image_a [3,H,W], radii [P], depth [1,H,W], image_b [3,H,W]); gradients equal those of the two separate calls."""
+        has_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        if means3D.shape[0] == 0 or self.raster_settings.debug or not _C._GEOM_CACHE_ON:
+            # nothing to share / debug snapshots wanted / cache disabled: fall back to two ordinary nodes
+            a, radii, depth = self.forward(means3D, means2D, opacities, colors_precomp=colors_a, scales=scales if scales.numel() else None,
+                                           rotations=rotations if rotations.numel() else None,
+                                           cov3D_precomp=cov3D_precomp if cov3D_precomp.numel() else None)
+            b, _, _ = self.forward(means3D, means2D, opacities, colors_precomp=colors_b, scales=scales if scales.numel() else None,
+                                   rotations=rotations if rotations.numel() else None,
+                                   cov3D_precomp=cov3D_precomp if cov3D_precomp.numel() else None)
+            return a, radii, depth, b
+        return _RasterizeGaussiansPair.apply(means3D, means2D, colors_a, colors_b, opacities, scales, rotations, cov3D_precomp,
+                                             self.raster_settings)

@@ -350,3 +350,65 @@ def test_geometry_cache_second_render_identical(gpu_device):
     assert hit
     for a, b in zip(o_on + g_on, o_off + g_off):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("P,W,H", [(600, 80, 64), (3000, 131, 77), (1, 32, 32)])
+def test_forward_pair_matches_two_separate_renders(gpu_device, P, W, H):
+    """GaussianRasterizer.forward_pair (one node, fused two-image backward) vs the reference's way -- two rasterizer calls
+    whose gradients autograd adds.  Images are bit-identical (same forward kernels); gradients agree to fp32 round-off of
+    the re-associated sums (rel-L2 1e-5; the oracle-level tolerance of the single-image path is 1e-4)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    s = tiny_scene(P=P, W=W, H=H, seed=11)
+    dev = gpu_device
+    rast = GaussianRasterizer(raster_settings=settings_from(s, dev))
+    g = torch.Generator().manual_seed(1)
+    feat_cols = torch.rand(P, 3, generator=g)
+    gc, gd = grad_pair(H, W)
+    gc2 = torch.randn(3, H, W, generator=g)
+
+    def run(pair):
+        t = lambda x: x.to(dev).clone().requires_grad_(True)
+        m3, op, sc, rot = t(s["means3D"]), t(s["opacities"]), t(s["scales"]), t(s["rotations"])
+        c1, c2 = t(s["colors_precomp"]), t(feat_cols)
+        m2 = torch.zeros_like(m3, requires_grad=True)
+        if pair:
+            img1, r1, d1, img2 = rast.forward_pair(means3D=m3, means2D=m2, opacities=op, colors_a=c1, colors_b=c2, scales=sc,
+                                                   rotations=rot)
+        else:
+            img1, r1, d1 = rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=c1, scales=sc, rotations=rot)
+            img2, _, _ = rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=c2, scales=sc, rotations=rot)
+        ((img1 * gc.to(dev)).sum() + (d1 * gd.to(dev)).sum() + (img2 * gc2.to(dev)).sum()).backward()
+        return [img1, img2, d1, r1], [x.grad for x in (m3, op, sc, rot, c1, c2, m2)]
+
+    o_pair, g_pair = run(True)
+    o_sep, g_sep = run(False)
+    for a, b in zip(o_pair, o_sep):
+        assert torch.equal(a, b)
+    names = ["means3D", "opacity", "scales", "rotations", "colors_a", "colors_b", "means2D"]
+    for n, a, b in zip(names, g_pair, g_sep):
+        assert a.shape == b.shape, n
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, n
+
+
+def test_forward_pair_only_second_image_has_gradient(gpu_device):
+    """Upstream gradient on the second image alone (first image and depth unused -> None grads from autograd)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    s = tiny_scene(P=400, W=64, H=48, seed=3)
+    dev = gpu_device
+    rast = GaussianRasterizer(raster_settings=settings_from(s, dev))
+    t = lambda x: x.to(dev).clone().requires_grad_(True)
+    cols_b = torch.rand(400, 3, generator=torch.Generator().manual_seed(5))
+    res = []
+    for pair in (True, False):
+        m3, op, sc, rot, c1, c2 = (t(s["means3D"]), t(s["opacities"]), t(s["scales"]), t(s["rotations"]),
+                                   t(s["colors_precomp"]), t(cols_b))
+        m2 = torch.zeros_like(m3, requires_grad=True)
+        if pair:
+            _, _, _, img2 = rast.forward_pair(means3D=m3, means2D=m2, opacities=op, colors_a=c1, colors_b=c2, scales=sc, rotations=rot)
+        else:
+            img2, _, _ = rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=c2, scales=sc, rotations=rot)
+        img2.square().sum().backward()
+        res.append([m3.grad, op.grad, sc.grad, rot.grad, c2.grad, m2.grad, c1.grad])
+    for a, b in zip(res[0][:6], res[1][:6]):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    assert res[0][6] is None or float(res[0][6].abs().max()) == 0.0
