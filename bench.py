@@ -228,6 +228,7 @@ def main():
         levels = float(len(getattr(net.grid, "grids", [])) or 4)
         FEAT = 32.0 * levels
         MLP_FLOP = 2.0 * (128 * 64 + 4 * 64 * 64 + 2 * 64 * 3 + 64 * 48)   # per point and direction: 56064
+        pair = bool(hyper.feat_head)   # pipeline.render blends both images of an iteration in one pass each way
 
         def read(i):
             ms, x, y = C.c_double(), C.c_double(), C.c_double()
@@ -236,8 +237,9 @@ def main():
 
         # id -> (kernel, bytes(R or P, pixels), flops)
         models = {
-            0: ("s3g::blend_forward_kernel", lambda R, N: 44.0 * R + 24.0 * N, None),
-            1: ("s3g::blend_backward_kernel", lambda R, N: 44.0 * R + 24.0 * N + 40.0 * V, None),
+            # two-image pass (RGB+depth and feature image from one geometry): + colors2 per instance, + one image per pixel
+            0: ("s3g::blend_forward_kernel", lambda R, N: (56.0 if pair else 44.0) * R + (36.0 if pair else 24.0) * N, None),
+            1: ("s3g::blend_backward_kernel", lambda R, N: (56.0 if pair else 44.0) * R + (36.0 if pair else 24.0) * N + 40.0 * V, None),
             2: ("s3g::hexplane_forward_kernel", lambda n, l: n * (16.0 + 4.0 * FEAT) + plane_bytes, None),
             3: ("s3g::hexplane_backward_point_kernel", lambda n, l: n * (28.0 + 4.0 * FEAT + 6.0 * l * 128.0) + plane_bytes, None),
             4: ("s3g::hexplane_scatter_kernel", lambda n, l: n * (60.0 + 6.0 * l * 128.0) + plane_bytes, None),

@@ -81,6 +81,17 @@ int s3g_raster_forward(const s3g_raster_inputs* in,
 int s3g_raster_forward_reuse(const s3g_raster_inputs* in, int R, const void* geometry_arena, const void* binning_arena,
                              void* image_arena, float* out_color, float* out_depth, void* stream);
 
+/* Forward of TWO images from one geometry in one blend pass: colours in->colors_precomp -> out_color (+ out_depth) and
+ * colors2 [P,3] -> out_color2 [3,H,W]; otherwise identical to s3g_raster_forward (same arenas, radii, num_rendered).
+ * Replaces the pair of Rasterizer::forward calls of gaussian_renderer/__init__.py:127-166; pairs with
+ * s3g_raster_backward2. */
+int s3g_raster_forward2(const s3g_raster_inputs* in, const float* colors2,
+                        s3g_resize_fn geometry_buffer, void* geometry_user,
+                        s3g_resize_fn binning_buffer, void* binning_user,
+                        s3g_resize_fn image_buffer, void* image_user,
+                        float* out_color, float* out_depth, float* out_color2, int* radii,
+                        int* num_rendered, void* stream /* hipStream_t */);
+
 /* Backward.  `R` is the num_rendered returned by the matching forward; radii / arenas are the ones it filled.
  * `workspace`: device scratch of s3g_raster_backward_workspace_bytes(P, R) bytes (per-instance gradient records;
  * contents need no initialisation and are dead after the call).

@@ -434,14 +434,18 @@ __global__ void __launch_bounds__(256) sort_tiles_kernel(int tiles, int gx, cons
 //    addresses (broadcast).  The conic is pre-scaled by -0.5*log2(e) / -log2(e) while staging so the
 //    Gaussian weight is a bare v_exp_f32:  alpha = min(0.99, o * exp2(qa*dx*dx + qc*dy*dy + qb*dx*dy)).
 // =========================================================================================================
+//    NX = 3: a second image with other per-Gaussian colours (colors2 -> out_color2) is blended in the same pass; the
+//    alpha test, exp2 and the transmittance recurrence are shared.
+template <int NX>
 __global__ void __launch_bounds__(256)
 blend_forward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ ranges,
                      const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
                      const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
                      const float* __restrict__ depths, const float* __restrict__ bg, float* __restrict__ final_T,
                      uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_hi, float* __restrict__ out_color,
-                     float* __restrict__ out_depth) {
+                     float* __restrict__ out_depth, const float* __restrict__ colors2, float* __restrict__ out_color2) {
   __shared__ StagedGaussian sg[256];
+  __shared__ float4 sg2[NX ? 256 : 1];
   __shared__ uint32_t wave_hi[4];
   const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= (uint32_t)tiles) return;
@@ -455,6 +459,7 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ 
 
   bool done = !inside;
   float T = 1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f;
+  float C2r = 0.f, C2g = 0.f, C2b = 0.f;
   uint32_t contributor = 0, last_contributor = 0;
 
   for (uint32_t base = rg.x; base < rg.y; base += 256, todo -= 256) {
@@ -468,6 +473,7 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ 
       s.b = make_float4(-0.5f * LOG2E * co.z, co.w, depths[id], colors[3 * (size_t)id]);
       s.c = make_float4(colors[3 * (size_t)id + 1], colors[3 * (size_t)id + 2], co.x, co.y);
       sg[tid] = s;
+      if (NX) sg2[tid] = make_float4(colors2[3 * (size_t)id], colors2[3 * (size_t)id + 1], colors2[3 * (size_t)id + 2], 0.f);
     }
     __syncthreads();
     const int cnt = min(256, todo);
@@ -491,6 +497,12 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ 
       Cg = __builtin_fmaf(Cc.x, w, Cg);
       Cb = __builtin_fmaf(Cc.y, w, Cb);
       D = __builtin_fmaf(B.z, w, D);
+      if (NX) {
+        const float4 C2 = sg2[j];
+        C2r = __builtin_fmaf(C2.x, w, C2r);
+        C2g = __builtin_fmaf(C2.y, w, C2g);
+        C2b = __builtin_fmaf(C2.z, w, C2b);
+      }
       T = test_T;
       last_contributor = contributor;
     }
@@ -503,6 +515,11 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ 
     out_color[N + pix] = Cg + T * bg[1];
     out_color[2 * N + pix] = Cb + T * bg[2];
     out_depth[pix] = D;
+    if (NX) {
+      out_color2[pix] = C2r + T * bg[0];
+      out_color2[N + pix] = C2g + T * bg[1];
+      out_color2[2 * N + pix] = C2b + T * bg[2];
+    }
   }
   // end (absolute list position) of the deepest contributor of the tile: the backward never looks behind it
   uint32_t m = inside ? last_contributor : 0u;
@@ -530,10 +547,10 @@ using namespace s3g;
 extern "C" const char* s3g_last_error(void) { return g_err; }
 extern "C" int s3g_abi_version(void) { return 3; }
 
-extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geometry_buffer, void* geometry_user,
-                                  s3g_resize_fn binning_buffer, void* binning_user, s3g_resize_fn image_buffer,
-                                  void* image_user, float* out_color, float* out_depth, int* radii, int* num_rendered,
-                                  void* stream_) {
+static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2, float* out_color2,
+                               s3g_resize_fn geometry_buffer, void* geometry_user, s3g_resize_fn binning_buffer,
+                               void* binning_user, s3g_resize_fn image_buffer, void* image_user, float* out_color,
+                               float* out_depth, int* radii, int* num_rendered, void* stream_) {
   g_err[0] = 0;
   hipStream_t stream = (hipStream_t)stream_;
   if (!in || !geometry_buffer || !binning_buffer || !image_buffer || !num_rendered) {
@@ -672,12 +689,39 @@ extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geo
   }
   const float* feat = in->colors_precomp ? in->colors_precomp : g.rgb;
   profile_begin(S3G_PROFILE_BLEND_FORWARD, stream);
-  hipLaunchKernelGGL(blend_forward_kernel, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
-                     b.point_list, g.means2D, g.conic_opacity, feat, g.depths, in->background, im.final_T, im.n_contrib,
-                     im.tile_hi, out_color, out_depth);
+  if (colors2 != nullptr)
+    hipLaunchKernelGGL(blend_forward_kernel<3>, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
+                       b.point_list, g.means2D, g.conic_opacity, feat, g.depths, in->background, im.final_T, im.n_contrib,
+                       im.tile_hi, out_color, out_depth, colors2, out_color2);
+  else
+    hipLaunchKernelGGL(blend_forward_kernel<0>, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
+                       b.point_list, g.means2D, g.conic_opacity, feat, g.depths, in->background, im.final_T, im.n_contrib,
+                       im.tile_hi, out_color, out_depth, nullptr, nullptr);
   profile_end(S3G_PROFILE_BLEND_FORWARD, stream, (double)R, (double)W * H);
   S3G_KERNEL_CHECK(stream, debug);
   return S3G_OK;
+}
+
+extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geometry_buffer, void* geometry_user,
+                                  s3g_resize_fn binning_buffer, void* binning_user, s3g_resize_fn image_buffer,
+                                  void* image_user, float* out_color, float* out_depth, int* radii, int* num_rendered,
+                                  void* stream_) {
+  return raster_forward_impl(in, nullptr, nullptr, geometry_buffer, geometry_user, binning_buffer, binning_user,
+                             image_buffer, image_user, out_color, out_depth, radii, num_rendered, stream_);
+}
+
+// Forward of two images from one geometry (colours in->colors_precomp -> out_color + out_depth, colors2 -> out_color2)
+// with ONE blend pass; the arenas are those of an ordinary forward and feed s3g_raster_backward2.
+extern "C" int s3g_raster_forward2(const s3g_raster_inputs* in, const float* colors2, s3g_resize_fn geometry_buffer,
+                                   void* geometry_user, s3g_resize_fn binning_buffer, void* binning_user,
+                                   s3g_resize_fn image_buffer, void* image_user, float* out_color, float* out_depth,
+                                   float* out_color2, int* radii, int* num_rendered, void* stream_) {
+  if (!in || !in->colors_precomp || !colors2 || !out_color2) {
+    set_error("s3g_raster_forward2: needs colors_precomp, colors2 and out_color2");
+    return S3G_ERR_INVALID_ARG;
+  }
+  return raster_forward_impl(in, colors2, out_color2, geometry_buffer, geometry_user, binning_buffer, binning_user,
+                             image_buffer, image_user, out_color, out_depth, radii, num_rendered, stream_);
 }
 
 // Second (third, ...) render of the SAME geometry with different per-Gaussian colours (the reference renders RGB and
@@ -700,9 +744,9 @@ extern "C" int s3g_raster_forward_reuse(const s3g_raster_inputs* in, int R, cons
   BinningState b = BinningState::carve(const_cast<void*>(binning_arena), (size_t)(R > 0 ? R : 0), nullptr);
   const uint32_t tile_blocks = round_up8((uint32_t)tiles);
   profile_begin(S3G_PROFILE_BLEND_FORWARD, stream);
-  hipLaunchKernelGGL(blend_forward_kernel, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
+  hipLaunchKernelGGL(blend_forward_kernel<0>, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
                      b.point_list, g.means2D, g.conic_opacity, in->colors_precomp, g.depths, in->background, im.final_T,
-                     im.n_contrib, im.tile_hi, out_color, out_depth);
+                     im.n_contrib, im.tile_hi, out_color, out_depth, nullptr, nullptr);
   profile_end(S3G_PROFILE_BLEND_FORWARD, stream, (double)R, (double)W * H);
   S3G_KERNEL_CHECK(stream, in->debug != 0);
   return S3G_OK;

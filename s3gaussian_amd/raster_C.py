@@ -77,8 +77,10 @@ def _geom_key(tensors, scalars):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
-    """-> (num_rendered, color[3,H,W], depth[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer)."""
+                        prefiltered, debug, colors2=None):
+    """-> (num_rendered, color[3,H,W], depth[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer).
+    colors2 [P,3] (extension): a second image with these colours is blended in the same pass (s3g_raster_forward2) and
+    appended to the result tuple."""
     global _geom_cache, _geom_cache_hits
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -88,7 +90,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     P, H, W = means3D.size(0), int(image_height), int(image_width)
     geo_tensors = (means3D, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos)
     key = None
-    if _GEOM_CACHE_ON and P != 0 and sh.numel() == 0 and colors.numel() != 0 and not debug:
+    if _GEOM_CACHE_ON and P != 0 and sh.numel() == 0 and colors.numel() != 0 and not debug and colors2 is None:
         key = _geom_key(geo_tensors, (float(scale_modifier), float(tan_fovx), float(tan_fovy), H, W, bool(prefiltered)))
         if _geom_cache is not None and _geom_cache[0] == key:
             R, radii_c, geom_c, binning_c, img_c = _geom_cache[2]
@@ -109,6 +111,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     out_color = alloc((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
     out_depth = alloc((1, H, W), dtype=torch.float32, device=dev)
     radii = alloc((P,), dtype=torch.int32, device=dev)
+    out_color2 = alloc((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev) if colors2 is not None else None
     geom, binning, img = _Arena(dev), _Arena(dev), _Arena(dev)
     rendered = C.c_int(0)
     if P != 0:
@@ -120,17 +123,27 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         bg_, m3_, sh_, col_, op_, sc_, rot_, cov_, view_, proj_, cam_ = keep
         inp = _inputs(P, degree, M, W, H, bg_, m3_, sh_, col_, op_, sc_, scale_modifier, rot_, cov_, view_, proj_,
                       tan_fovx, tan_fovy, cam_, prefiltered, debug)
+        col2_ = _f32(colors2, "colors2") if colors2 is not None else None
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
-            code = L.s3g_raster_forward(C.byref(inp), geom.cb, None, binning.cb, None, img.cb, None,
-                                        out_color.data_ptr(), out_depth.data_ptr(), radii.data_ptr(),
-                                        C.byref(rendered), stream)
+            if col2_ is not None:
+                if col2_.shape != (P, NUM_CHANNELS):
+                    raise RuntimeError("colors2 must have shape (num_points, 3)")
+                code = L.s3g_raster_forward2(C.byref(inp), col2_.data_ptr(), geom.cb, None, binning.cb, None, img.cb, None,
+                                             out_color.data_ptr(), out_depth.data_ptr(), out_color2.data_ptr(),
+                                             radii.data_ptr(), C.byref(rendered), stream)
+            else:
+                code = L.s3g_raster_forward(C.byref(inp), geom.cb, None, binning.cb, None, img.cb, None,
+                                            out_color.data_ptr(), out_depth.data_ptr(), radii.data_ptr(),
+                                            C.byref(rendered), stream)
         for a in (geom, binning, img):
             if a.error is not None:
                 raise a.error
         _lib.check(code)
         if key is not None:  # remember this geometry (inputs are kept alive so the id()/version key stays meaningful)
             _geom_cache = (key, geo_tensors, (rendered.value, radii, geom.tensor, binning.tensor, img.tensor))
+    if colors2 is not None:
+        return rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor, out_color2
     return rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor
 
 

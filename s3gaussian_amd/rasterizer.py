@@ -86,9 +86,9 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 
 class _RasterizeGaussiansPair(torch.autograd.Function):
-    """Two renders of one geometry (colours_a -> image + depth, colours_b -> second image) as ONE autograd node: the
-    second forward reuses the first one's preprocess / binning / sort, and the backward is a single fused pass
-    (s3g_raster_backward2) instead of two whose results autograd would add."""
+    """Two renders of one geometry (colours_a -> image + depth, colours_b -> second image) as ONE autograd node: one
+    blend pass forward (s3g_raster_forward2) and one backward (s3g_raster_backward2) instead of two each, whose gradients
+    autograd would then add."""
 
     @staticmethod
     def forward(ctx, means3D, means2D, colors_a, colors_b, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
@@ -96,10 +96,8 @@ class _RasterizeGaussiansPair(torch.autograd.Function):
         empty = torch.Tensor([])
         common = (opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
                   rs.tanfovy, rs.image_height, rs.image_width, empty, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
-        num_rendered, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(rs.bg, means3D, colors_a, *common)
-        n2, color2, _depth2, _radii2, _g2, _b2, _i2 = _C.rasterize_gaussians(rs.bg, means3D, colors_b, *common)
-        if n2 != num_rendered:
-            raise RuntimeError("internal: the two renders of a pair disagree on the instance count")
+        num_rendered, color, depth, radii, geom, binning, img, color2 = _C.rasterize_gaussians(
+            rs.bg, means3D, colors_a, *common, colors2=colors_b)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_a, colors_b, means3D, scales, rotations, cov3Ds_precomp, radii, geom, binning, img)
@@ -164,8 +162,8 @@ class GaussianRasterizer(nn.Module):
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
-        if means3D.shape[0] == 0 or self.raster_settings.debug or not _C._GEOM_CACHE_ON:
-            # nothing to share / debug snapshots wanted / cache disabled: fall back to two ordinary nodes
+        if means3D.shape[0] == 0 or self.raster_settings.debug:
+            # nothing to share / debug snapshots wanted: fall back to two ordinary nodes
             a, radii, depth = self.forward(means3D, means2D, opacities, colors_precomp=colors_a, scales=scales if scales.numel() else None,
                                            rotations=rotations if rotations.numel() else None,
                                            cov3D_precomp=cov3D_precomp if cov3D_precomp.numel() else None)
