@@ -16,8 +16,19 @@
 extern "C" {
 #endif
 
-/* img1, img2: [C,H,W] fp32 device.  ssim_sum: device DOUBLE, ACCUMULATED (caller zeroes): sum of the SSIM map, the loss
- * value is ssim_sum / (C*H*W).  dm_dmu1, dm_dsigma1_sq, dm_dsigma12: [C,H,W] scratch kept for the backward. */
+/* Slotted sum accumulators.  Measured on MI355X: thousands of workgroups finishing with an atomicAdd on ONE address
+ * serialise at ~10 ns each (20 100 SSIM tiles = 0.2 ms, more than the kernel's own work).  Every scalar these kernels
+ * accumulate is therefore a device array of S3G_SUM_DOUBLES doubles: workgroup b adds into element
+ * (b % S3G_SUM_SLOTS) * S3G_SUM_STRIDE (one 128-byte line per slot), all other elements stay as the caller left them.
+ * The caller zero-fills the array; the value is the sum over the whole array. */
+#ifndef S3G_SUM_SLOTS
+#define S3G_SUM_SLOTS 64
+#define S3G_SUM_STRIDE 16
+#define S3G_SUM_DOUBLES (S3G_SUM_SLOTS * S3G_SUM_STRIDE)
+#endif
+
+/* img1, img2: [C,H,W] fp32 device.  ssim_sum: slotted accumulator (S3G_SUM_DOUBLES doubles, see above): sum of the SSIM
+ * map, the loss value is sum(ssim_sum) / (C*H*W).  dm_dmu1, dm_dsigma1_sq, dm_dsigma12: [C,H,W] scratch kept for the backward. */
 int s3g_ssim_forward(int C, int H, int W, const float* img1, const float* img2, double* ssim_sum, float* dm_dmu1,
                      float* dm_dsigma1_sq, float* dm_dsigma12, void* stream);
 
@@ -46,7 +57,7 @@ typedef struct s3g_plane_reg_desc {
 } s3g_plane_reg_desc;
 
 #define S3G_MAX_REG_PLANES 48
-/* value: device DOUBLE, ACCUMULATED (caller zeroes). */
+/* value: slotted accumulator (S3G_SUM_DOUBLES doubles). */
 int s3g_plane_regulation(int nplanes, const s3g_plane_reg_desc* planes, double* value, void* stream);
 
 /*
@@ -58,23 +69,25 @@ int s3g_plane_regulation(int nplanes, const s3g_plane_reg_desc* planes, double* 
  *   gather for the mask and the radix sort inside index_put's backward).
  *
  * Images are [3,H,W], depths [H,W], fp32 device; each (x, gt_x) pair may be NULL to skip that term.
- * sums: device DOUBLE[5], ACCUMULATED (caller zeroes): [0] is the slot s3g_ssim_forward's ssim_sum is pointed at,
- * [1] sum|image-gt|, [2] masked squared depth error, [3] mask count, [4] sum (feat-gt)^2. */
+ * sums: FIVE slotted accumulators back to back (5 * S3G_SUM_DOUBLES doubles, caller zeroes): [0] is what
+ * s3g_ssim_forward's ssim_sum is pointed at, [1] sum|image-gt|, [2] masked squared depth error, [3] mask count,
+ * [4] sum (feat-gt)^2. */
 int s3g_pixel_losses_forward(int H, int W, const float* image, const float* gt_image, const float* depth,
                              const float* gt_depth, const float* feat, const float* gt_feat, float max_depth,
                              double* sums, void* stream);
 
-/* loss[0] = w_l1 * sums[1]/N + w_depth * sums[2]/sums[3] + w_ssim * (1 - sums[0]/N) + w_feat * sums[4]/N, N = 3*H*W;
+/* Collapses the five accumulators into totals[5] (device doubles, written) and
+ * loss[0] = w_l1 * T1/N + w_depth * T2/T3 + w_ssim * (1 - T0/N) + w_feat * T4/N, N = 3*H*W;
  * a zero weight skips its term (an empty depth mask gives NaN like the reference's mean over no elements). */
-int s3g_pixel_losses_combine(int H, int W, const double* sums, float w_l1, float w_depth, float w_ssim, float w_feat,
-                             float* loss, void* stream);
+int s3g_pixel_losses_combine(int H, int W, const double* sums, double* totals, float w_l1, float w_depth, float w_ssim,
+                             float w_feat, float* loss, void* stream);
 
 /* Gradients of  w_l1*L1 + w_depth*depth_l2 + w_feat*feat_l2  times the upstream device scalar *g.  g_image is written,
  * or added to when accumulate_image != 0 (it then already holds the SSIM term from s3g_ssim_backward); g_depth and
- * g_feat are written; any output may be NULL. */
+ * g_feat are written; any output may be NULL.  totals: the five doubles s3g_pixel_losses_combine wrote. */
 int s3g_pixel_losses_backward(int H, int W, const float* image, const float* gt_image, const float* depth,
                               const float* gt_depth, const float* feat, const float* gt_feat, float max_depth,
-                              const double* sums, const float* g, float w_l1, float w_depth, float w_feat,
+                              const double* totals, const float* g, float w_l1, float w_depth, float w_feat,
                               float* g_image, int accumulate_image, float* g_depth, float* g_feat, void* stream);
 
 #ifdef __cplusplus

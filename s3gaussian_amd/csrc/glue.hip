@@ -4,6 +4,7 @@
 #include "geom_math.hpp"
 
 #include "../../include/s3g_glue.h"
+#include "../../include/s3g_loss.h"  // S3G_SUM_* (slotted accumulators)
 
 namespace s3g {
 
@@ -46,7 +47,8 @@ __global__ void __launch_bounds__(256) glue_forward_kernel(const GlueArgs a) {
     for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = d;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(a.dshs_abs_sum, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0)
+      atomicAdd(&a.dshs_abs_sum[(blockIdx.x % S3G_SUM_SLOTS) * S3G_SUM_STRIDE], part[0] + part[1] + part[2] + part[3]);
   }
   if (p >= a.P) return;
   // activations

@@ -78,7 +78,10 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(int C, int H, int W, 
   for (int off = 32; off >= 1; off >>= 1) val += __shfl_xor(val, off);
   if ((tid & 63) == 0) red[tid >> 6] = val;
   __syncthreads();
-  if (tid == 0) atomicAdd(ssim_sum, (double)(red[0] + red[1] + red[2] + red[3]));
+  if (tid == 0) {
+    const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    atomicAdd(&ssim_sum[(b % S3G_SUM_SLOTS) * S3G_SUM_STRIDE], (double)(red[0] + red[1] + red[2] + red[3]));
+  }
 }
 
 __global__ void __launch_bounds__(256) ssim_backward_kernel(int C, int H, int W, const float* __restrict__ img1,
@@ -173,7 +176,8 @@ struct PixelLossArgs {
   int HW;
   const float *image, *gt_image, *depth, *gt_depth, *feat, *gt_feat;  // [3,HW] [3,HW] [HW] [HW] [3,HW] [3,HW]; pairs may be NULL
   float max_depth;
-  double* sums;           // [1] l1  [2] depth squared error  [3] depth count  [4] feat squared error
+  double* sums;           // forward: 5 slotted accumulators ([1] l1 [2] depth sq. error [3] depth count [4] feat sq. error);
+                          // backward: the 5 collapsed totals
   // backward
   const float* g;         // upstream gradient of the combined loss (device scalar)
   float w_l1, w_depth, w_feat;
@@ -216,9 +220,10 @@ __global__ void __launch_bounds__(256) pixel_loss_forward_kernel(const PixelLoss
   const double s1 = block_sum((double)l1, part), s2 = block_sum((double)dsq, part), s3 = block_sum((double)cnt, part),
                s4 = block_sum((double)fsq, part);
   if (threadIdx.x == 0) {
-    if (a.image != nullptr) atomicAdd(&a.sums[1], s1);
-    if (a.depth != nullptr) { atomicAdd(&a.sums[2], s2); atomicAdd(&a.sums[3], s3); }
-    if (a.feat != nullptr) atomicAdd(&a.sums[4], s4);
+    double* slot = a.sums + (blockIdx.x % S3G_SUM_SLOTS) * S3G_SUM_STRIDE;
+    if (a.image != nullptr) atomicAdd(&slot[1 * S3G_SUM_DOUBLES], s1);
+    if (a.depth != nullptr) { atomicAdd(&slot[2 * S3G_SUM_DOUBLES], s2); atomicAdd(&slot[3 * S3G_SUM_DOUBLES], s3); }
+    if (a.feat != nullptr) atomicAdd(&slot[4 * S3G_SUM_DOUBLES], s4);
   }
 }
 
@@ -252,18 +257,28 @@ __global__ void __launch_bounds__(256) pixel_loss_backward_kernel(const PixelLos
   }
 }
 
-// loss = w_l1 * l1_sum / N + w_depth * dsq / cnt + w_ssim * (1 - ssim_sum / N) + w_feat * fsq / N      (N = 3 HW)
-__global__ void pixel_loss_combine_kernel(const double* __restrict__ sums, int HW, float w_l1, float w_depth, float w_ssim,
-                                          float w_feat, float* __restrict__ loss) {
+// totals[q] = sum of accumulator q; loss = w_l1 * T1 / N + w_depth * T2 / T3 + w_ssim * (1 - T0 / N) + w_feat * T4 / N  (N = 3 HW)
+__global__ void __launch_bounds__(64) pixel_loss_combine_kernel(const double* __restrict__ sums, double* __restrict__ totals,
+                                                                int HW, float w_l1, float w_depth, float w_ssim, float w_feat,
+                                                                float* __restrict__ loss) {
+  double T[5];
+#pragma unroll
+  for (int q = 0; q < 5; q++) {
+    double v = sums[(size_t)q * S3G_SUM_DOUBLES + threadIdx.x * S3G_SUM_STRIDE];   // S3G_SUM_SLOTS == 64 == one wave
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    T[q] = v;
+  }
+  if (threadIdx.x != 0) return;
+#pragma unroll
+  for (int q = 0; q < 5; q++) totals[q] = T[q];
   const double N = 3.0 * (double)HW;
   double v = 0.0;
-  if (w_l1 != 0.f) v += (double)w_l1 * sums[1] / N;
-  if (w_depth != 0.f) v += (double)w_depth * sums[2] / sums[3];
-  if (w_ssim != 0.f) v += (double)w_ssim * (1.0 - sums[0] / N);
-  if (w_feat != 0.f) v += (double)w_feat * sums[4] / N;
+  if (w_l1 != 0.f) v += (double)w_l1 * T[1] / N;
+  if (w_depth != 0.f) v += (double)w_depth * T[2] / T[3];
+  if (w_ssim != 0.f) v += (double)w_ssim * (1.0 - T[0] / N);
+  if (w_feat != 0.f) v += (double)w_feat * T[4] / N;
   *loss = (float)v;
 }
-
 
 // =========================================================================================================
 // Fused HexPlane regulariser: value + gradient of scene/gaussian_model.py:710-749 in one pass over the planes.
@@ -313,7 +328,8 @@ __global__ void __launch_bounds__(256) plane_reg_kernel(const PlaneRegArgs a) {
   for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(a.value, (double)(red[0] + red[1] + red[2] + red[3]));
+  if (threadIdx.x == 0)
+    atomicAdd(&a.value[(blockIdx.x % S3G_SUM_SLOTS) * S3G_SUM_STRIDE], (double)(red[0] + red[1] + red[2] + red[3]));
 }
 
 }  // namespace s3g
@@ -355,20 +371,21 @@ extern "C" int s3g_pixel_losses_forward(int H, int W, const float* image, const 
   memset(&a, 0, sizeof a);
   a.HW = H * W; a.image = image; a.gt_image = gt_image; a.depth = depth; a.gt_depth = gt_depth; a.feat = feat;
   a.gt_feat = gt_feat; a.max_depth = max_depth; a.sums = sums;
-  const int blocks = min((a.HW + 255) / 256, 2048);
+  const int blocks = min((a.HW + 255) / 256, 1024);
   hipLaunchKernelGGL(pixel_loss_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }
 
-extern "C" int s3g_pixel_losses_combine(int H, int W, const double* sums, float w_l1, float w_depth, float w_ssim,
-                                        float w_feat, float* loss, void* stream_) {
-  if (H <= 0 || W <= 0 || !sums || !loss) {
+extern "C" int s3g_pixel_losses_combine(int H, int W, const double* sums, double* totals, float w_l1, float w_depth,
+                                        float w_ssim, float w_feat, float* loss, void* stream_) {
+  static_assert(S3G_SUM_SLOTS == 64, "the combine kernel reduces the slots with one wave");
+  if (H <= 0 || W <= 0 || !sums || !totals || !loss) {
     set_error("s3g_pixel_losses_combine: bad argument");
     return S3G_ERR_INVALID_ARG;
   }
-  hipLaunchKernelGGL(pixel_loss_combine_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, sums, H * W, w_l1, w_depth, w_ssim,
-                     w_feat, loss);
+  hipLaunchKernelGGL(pixel_loss_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, sums, totals, H * W, w_l1, w_depth,
+                     w_ssim, w_feat, loss);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }

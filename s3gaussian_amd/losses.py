@@ -10,6 +10,7 @@ import torch
 from . import _lib
 
 _bound = False
+SUM_DOUBLES = 64 * 16   # S3G_SUM_DOUBLES (include/s3g_loss.h): one slotted accumulator
 
 
 def _bind():
@@ -24,7 +25,7 @@ def _bind():
         L.s3g_pixel_losses_forward.restype = C.c_int
         L.s3g_pixel_losses_forward.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]
         L.s3g_pixel_losses_combine.restype = C.c_int
-        L.s3g_pixel_losses_combine.argtypes = [C.c_int, C.c_int, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
+        L.s3g_pixel_losses_combine.argtypes = [C.c_int, C.c_int, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp]
         L.s3g_pixel_losses_backward.restype = C.c_int
         L.s3g_pixel_losses_backward.argtypes = ([C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, C.c_float,
                                                  C.c_float, C.c_float, vp, C.c_int, vp, vp, vp])
@@ -43,14 +44,14 @@ class _SSIM(torch.autograd.Function):
         if a.shape != b.shape:
             raise RuntimeError("ssim: shape mismatch")
         Cn, H, W = a.shape
-        total = torch.zeros((), dtype=torch.float64, device=a.device)
+        total = torch.zeros(SUM_DOUBLES, dtype=torch.float64, device=a.device)
         maps = torch.empty((3, Cn, H, W), dtype=torch.float32, device=a.device)
         with torch.cuda.device(a.device):
             _lib.check(L.s3g_ssim_forward(Cn, H, W, a.data_ptr(), b.data_ptr(), total.data_ptr(), maps[0].data_ptr(),
                                           maps[1].data_ptr(), maps[2].data_ptr(), torch.cuda.current_stream().cuda_stream))
         ctx.save_for_backward(a, b, maps)
         ctx.shape = img1.shape
-        return (total / float(Cn * H * W)).float()
+        return (total.sum() / float(Cn * H * W)).float()
 
     @staticmethod
     def backward(ctx, g):
@@ -93,7 +94,8 @@ class _PhotometricLoss(torch.autograd.Function):
         for a, b, n in ((dep, gdep, H * W), (ft, gft, 3 * H * W)):
             if a is not None and (a.numel() != n or b.numel() != n):
                 raise RuntimeError("photometric_loss: depth must have H*W and feat 3*H*W elements, like their targets")
-        sums = torch.zeros(5, dtype=torch.float64, device=dev)
+        sums = torch.zeros(5 * SUM_DOUBLES + 5, dtype=torch.float64, device=dev)   # 5 accumulators + their 5 totals
+        totals = sums[5 * SUM_DOUBLES:]
         maps = torch.empty((3, 3, H, W), dtype=torch.float32, device=dev) if w_ssim != 0.0 else None
         loss = torch.empty((), dtype=torch.float32, device=dev)
         p = lambda t: None if t is None else t.data_ptr()
@@ -103,9 +105,9 @@ class _PhotometricLoss(torch.autograd.Function):
                 _lib.check(L.s3g_ssim_forward(3, H, W, p(img), p(gt), p(sums), p(maps[0]), p(maps[1]), p(maps[2]), st))
             _lib.check(L.s3g_pixel_losses_forward(H, W, p(img), p(gt), p(dep), p(gdep), p(ft), p(gft), float(max_depth),
                                                   p(sums), st))
-            _lib.check(L.s3g_pixel_losses_combine(H, W, p(sums), 1.0, w_depth if dep is not None else 0.0, w_ssim,
+            _lib.check(L.s3g_pixel_losses_combine(H, W, p(sums), p(totals), 1.0, w_depth if dep is not None else 0.0, w_ssim,
                                                   w_feat if ft is not None else 0.0, p(loss), st))
-        ctx.save_for_backward(img, gt, *(t for t in (dep, gdep, ft, gft, maps) if t is not None), sums)
+        ctx.save_for_backward(img, gt, *(t for t in (dep, gdep, ft, gft, maps) if t is not None), totals)
         ctx.cfg = (H, W, dep is not None, ft is not None, maps is not None, w_ssim, w_depth, w_feat, float(max_depth),
                    None if depth is None else depth.shape, None if feat is None else feat.shape, image.shape)
         return loss
@@ -176,11 +178,11 @@ class _PlaneRegulation(torch.autograd.Function):
             if p.dim() != 4 or p.shape[1] != 32 or not p.is_contiguous(memory_format=torch.channels_last):
                 raise RuntimeError("plane regulation expects [1,32,H,W] channels_last planes")
             descs[i] = _PlaneRegDesc(p.data_ptr(), g.data_ptr(), p.shape[2], p.shape[3], ws, wl)
-        value = torch.zeros((), dtype=torch.float64, device=dev)
+        value = torch.zeros(SUM_DOUBLES, dtype=torch.float64, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.s3g_plane_regulation(len(planes), descs, value.data_ptr(), torch.cuda.current_stream().cuda_stream))
         ctx.grads = grads
-        return value.float()
+        return value.sum().float()
 
     @staticmethod
     def backward(ctx, g):
