@@ -164,7 +164,8 @@ def main():
     for v in uniq[:min(len(uniq), 12)]:          # bounded target cache (each is 4 images of 1066x1600)
         targets[v] = make_targets(pc, cams[v], bg, hyper, seed=1000 + v)
     tkeys = list(targets)
-    reducer = dp.GradAllReducer(pc.parameters()) if world > 1 else None
+    # large gradients are all-reduced as soon as backward produces them (overlaps the rest of the backward pass)
+    reducer = dp.OverlappedGradAllReducer(pc.parameters()) if world > 1 else None
 
     def hook(pc_, pkg):
         if reducer is not None:

@@ -115,6 +115,60 @@ class GradAllReducer:
         return total
 
 
+class OverlappedGradAllReducer(GradAllReducer):
+    """GradAllReducer whose large all-reduces start DURING backward: a post-accumulate hook on every parameter launches
+    the collective of that gradient (async, on RCCL's own stream) the moment autograd has finished it, so the wire time
+    hides under the rest of the backward pass.  Order of readiness on this path: SH / opacity / scale / rotation
+    gradients right after the render glue backward (269 MB at cfg3), MLP weights after the MLP backward, HexPlane planes
+    and xyz at the very end.  `finish()` (call between backward and optimizer.step) waits for the collectives in flight,
+    averages, and reduces the small gradients in flat buckets like the base class."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, inplace_mb: float = 16.0):
+        super().__init__(params, bucket_mb, inplace_mb)
+        self._inflight = []   # (work handle, flat view)
+        self._started = set()
+        self._handles = []
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            for p in self.params:
+                if p.requires_grad and p.numel() >= self.inplace_elems:
+                    self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+
+    def _on_grad_ready(self, p: torch.nn.Parameter):
+        g = p.grad
+        v = _flat_view(g) if g is not None else None
+        if v is None:
+            return
+        self._inflight.append((dist.all_reduce(v, op=dist.ReduceOp.SUM, async_op=True), v))
+        self._started.add(id(p))
+
+    def remove_hooks(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    @torch.no_grad()
+    def finish(self) -> int:
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return 0
+        world = dist.get_world_size()
+        total = 0
+        for work, v in self._inflight:
+            work.wait()
+            v.mul_(1.0 / world)
+            total += v.numel()
+        started, self._inflight, self._started = self._started, [], set()
+        # everything the hooks did not cover (small tensors, gradients set outside autograd's accumulation)
+        rest = [p for p in self.params if p.grad is not None and id(p) not in started]
+        saved, self.params = self.params, rest
+        try:
+            total += GradAllReducer.__call__(self)
+        finally:
+            self.params = saved
+        return total
+
+    __call__ = finish
+
+
 @torch.no_grad()
 def reduce_densification_stats(viewspace_grad: torch.Tensor, visibility: torch.Tensor, radii: torch.Tensor):
     """Batch semantics of train.py:387-388,435-437 + scene/gaussian_model.py:693-695 across ranks.

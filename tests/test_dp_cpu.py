@@ -82,6 +82,51 @@ def test_view_parallel_helpers_world_size_2():
     assert results == {0: True, 1: True}
 
 
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from s3gaussian_amd import dp
+    dp.init_from_env(backend="gloo")
+    torch.manual_seed(0)   # identical replicas
+    big = torch.nn.Parameter(torch.randn(4000, 3))                                                     # reduced by its hook
+    plane = torch.nn.Parameter(torch.randn(1, 32, 8, 16).contiguous(memory_format=torch.channels_last))  # hook, NHWC view
+    small = torch.nn.Parameter(torch.randn(7))                                                         # bucketed in finish()
+    unused = torch.nn.Parameter(torch.randn(5))
+    params = [big, plane, small, unused]
+    red = dp.OverlappedGradAllReducer(params, bucket_mb=0.001, inplace_mb=0.004)   # threshold 1024 elements
+    ok = True
+    for step in range(2):   # twice: state must reset between iterations
+        for p in params:
+            p.grad = None
+        x = torch.full((4000, 3), float(rank + 1 + step))            # per-rank data -> per-rank gradients
+        loss = (big * x).sum() + (plane * (rank + 2.0)).sum() * 2.0 + (big ** 2).sum() * 0.5 + (small * (rank + 1.0)).sum()
+        loss.backward()                                              # big gets two contributions: one accumulate, one hook call
+        n = red.finish()
+        mean_x = sum(float(r + 1 + step) for r in range(world)) / world
+        ok = ok and torch.allclose(big.grad, torch.full((4000, 3), mean_x) + big.detach(), atol=1e-5)
+        ok = ok and torch.allclose(plane.grad, torch.full_like(plane, 2.0 * sum(r + 2.0 for r in range(world)) / world), atol=1e-5)
+        ok = ok and plane.grad.is_contiguous(memory_format=torch.channels_last)
+        ok = ok and torch.allclose(small.grad, torch.full((7,), sum(r + 1.0 for r in range(world)) / world), atol=1e-6)
+        ok = ok and unused.grad is None and n == big.numel() + plane.numel() + small.numel()
+        ok = ok and not red._inflight and not red._started
+    red.remove_hooks()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_overlapped_reducer_world_size_2():
+    """Hooks fire during backward (async all-reduce per large gradient), finish() averages + handles the small ones."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert results == {0: True, 1: True}
+
+
 def test_single_process_is_a_noop():
     from s3gaussian_amd import dp
     p = torch.nn.Parameter(torch.zeros(4))
