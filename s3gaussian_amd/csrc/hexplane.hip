@@ -384,12 +384,12 @@ __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, 
     const int lt = l0 + (j >> 1);                     // level of this lane's tap
     const bool tap_on = lt < a.d.levels;
     const int Wt = tap_on ? a.d.res[lt][axw] : 2, Ht = tap_on ? a.d.res[lt][axh] : 2;
-    // taps of the four points kb .. kb+3 -> LDS buffer `buf`
-    auto tap_phase = [&](int kb, int buf) {
-      const int kk = min(kb + q, k1 - 1);
-      const int p = (int)order[kk];
-      float u[4];
-      point_coords(a, p, u);
+    // Three-stage software pipeline per lane role (point q of a group, tap j): the sorted index of group g+2, the
+    // coordinates of group g+1 and the taps of group g+1 are produced while group g is accumulated, so neither the
+    // index -> position load chain nor the tap arithmetic sits between a group's G loads and their use.
+    auto load_index = [&](int kb) { return (int)order[min(kb + q, k1 - 1)]; };
+    auto load_coords = [&](int p, float* u) { point_coords(a, p, u); };
+    auto store_taps = [&](const float* u, int buf) {
       const Tap t = make_tap(u[axw], u[axh], Wt, Ht);
       float4 lo;
       lo.x = __int_as_float(t.o00);
@@ -400,7 +400,14 @@ __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, 
       *reinterpret_cast<float4*>(dst) = lo;
       *reinterpret_cast<float2*>(dst + 4) = make_float2(t.w10, t.w11);
     };
-    tap_phase(k0, 0);
+    float un[4];                       // coordinates of the NEXT group's point
+    {
+      float u0[4];
+      load_coords(load_index(k0), u0);
+      store_taps(u0, 0);
+    }
+    load_coords(load_index(k0 + 4), un);
+    int pnn = load_index(k0 + 8);      // index of the group after next
     int buf = 0;
     for (int kb = k0; kb < k1; kb += 4, buf ^= 1) {
       // 1. this group's G rows: 4 points x 8 rows requested at once (the walk is latency-bound, not bandwidth-bound)
@@ -415,8 +422,10 @@ __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, 
           g[qq][l][1] = (on && a.gplanes[l0 + l][i1]) ? G[(size_t)((o * a.d.levels + l0 + l) * 2 + 1) * PL + k * HEXC + c] : 0.f;
         }
       }
-      // 2. the NEXT group's taps (its order -> xyz load chain overlaps the G loads above)
-      if (kb + 4 < k1) tap_phase(kb + 4, buf ^ 1);
+      // 2. the NEXT group's taps from coordinates loaded one iteration ago; then advance the two prefetch stages
+      store_taps(un, buf ^ 1);
+      load_coords(pnn, un);
+      pnn = load_index(kb + 12);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
