@@ -607,9 +607,10 @@ extern "C" size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc*
 extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
                                      const float* dL_dfeatures, float* dL_dxyz,
                                      float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* workspace,
-                                     uint32_t* order_out, void* stream_) {
+                                     uint32_t* sort_state, int sort_reuse, void* stream_) {
   if (int e = check_desc(d)) return e;
-  if (P < 0 || (P > 0 && (!xyz || !time || !dL_dfeatures || !dL_dxyz || !dL_dplanes || !workspace))) {
+  if (P < 0 || (P > 0 && (!xyz || !time || !dL_dfeatures || !dL_dxyz || !dL_dplanes || !workspace)) ||
+      (sort_reuse && !sort_state)) {
     set_error("s3g_hexplane_backward: bad argument");
     return S3G_ERR_INVALID_ARG;
   }
@@ -629,15 +630,21 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
   w.tmp = c.take<uint32_t>((size_t)3 * P);
   w.order = c.take<uint32_t>((size_t)3 * P);
   w.rank = c.take<uint32_t>((size_t)3 * P);
+  if (sort_state) {  // caller-owned, persistent
+    w.order = sort_state;
+    w.rank = sort_state + (size_t)3 * P;
+  }
 
   // 1. three spatial orders (2-level LDS counting sorts) and their inverse permutations
-  const int chunk = (((P + SORT_NB - 1) / SORT_NB + 255) / 256) * 256;
-  hipLaunchKernelGGL(hexsort_major_kernel<false>, dim3(SORT_NB, 3), dim3(256), 0, stream, a, w, chunk);
-  hipLaunchKernelGGL(hexsort_scan_kernel, dim3(3), dim3(512), 0, stream, w, P);
-  hipLaunchKernelGGL(hexsort_major_kernel<true>, dim3(SORT_NB, 3), dim3(256), 0, stream, a, w, chunk);
-  hipLaunchKernelGGL(hexsort_minor_kernel, dim3(SORT_BINS, 3), dim3(256), 0, stream, a, w);
-  hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.rank);
-  S3G_HIP_CHECK(hipGetLastError());
+  if (!sort_reuse) {
+    const int chunk = (((P + SORT_NB - 1) / SORT_NB + 255) / 256) * 256;
+    hipLaunchKernelGGL(hexsort_major_kernel<false>, dim3(SORT_NB, 3), dim3(256), 0, stream, a, w, chunk);
+    hipLaunchKernelGGL(hexsort_scan_kernel, dim3(3), dim3(512), 0, stream, w, P);
+    hipLaunchKernelGGL(hexsort_major_kernel<true>, dim3(SORT_NB, 3), dim3(256), 0, stream, a, w, chunk);
+    hipLaunchKernelGGL(hexsort_minor_kernel, dim3(SORT_BINS, 3), dim3(256), 0, stream, a, w);
+    hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.rank);
+    S3G_HIP_CHECK(hipGetLastError());
+  }
   // 2. per-point pass, walking the points in (x,y) order so neighbouring half-waves share texels
   //    (the sorts above used the real resolutions; from here on the time planes are height-1 row tables if uniform_time)
   TimeRows rows;
@@ -652,7 +659,6 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
   hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3(blocks), dim3(256), 0, stream, a, G, w.rank);
   profile_end(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream, (double)P, (double)d->levels);
   S3G_HIP_CHECK(hipGetLastError());
-  if (order_out) S3G_HIP_CHECK(hipMemcpyAsync(order_out, w.order, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
   const int nseg = (P + SEG - 1) / SEG;
   profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
   hipLaunchKernelGGL(hexplane_scatter_kernel, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, G, w.order);

@@ -20,6 +20,7 @@ import torch.nn as nn
 from . import _lib
 
 MAX_LEVELS, CHANNELS = 8, 32
+SORT_REFRESH = 8   # backward passes between two re-sorts of the points (see _HexPlaneSample.backward)
 
 
 class _HexDesc(C.Structure):
@@ -42,7 +43,7 @@ def _bind():
         L.s3g_hexplane_forward_workspace_bytes.restype = C.c_size_t
         L.s3g_hexplane_forward_workspace_bytes.argtypes = [C.POINTER(_HexDesc)]
         L.s3g_hexplane_backward.restype = C.c_int
-        L.s3g_hexplane_backward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, C.POINTER(_PlanePtrs), vp, vp, vp]
+        L.s3g_hexplane_backward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, C.POINTER(_PlanePtrs), vp, vp, C.c_int, vp]
         L.s3g_hexplane_backward_workspace_bytes.restype = C.c_size_t
         L.s3g_hexplane_backward_workspace_bytes.argtypes = [C.POINTER(_HexDesc), C.c_int]
         _bound = True
@@ -130,14 +131,27 @@ class _HexPlaneSample(torch.autograd.Function):
         d = _make_desc(planes, resolutions, aabb_host, uniform_time)
         work = torch.empty(L.s3g_hexplane_backward_workspace_bytes(C.byref(d), P), dtype=torch.uint8,
                            device=xyz_c.device)
-        order_out = torch.empty(P, dtype=torch.int32, device=xyz_c.device) if cache is not None else None
+        # the three spatial orders live in the field's cache and are refreshed every SORT_REFRESH backward passes (or when
+        # P changes): they steer the walk, not the result, and the points move slowly between iterations
+        state, reuse = None, 0
+        if cache is not None:
+            state = cache.get("sort_state")
+            if state is None or state.numel() != 6 * P or state.device != xyz_c.device:
+                state = torch.empty(6 * P, dtype=torch.int32, device=xyz_c.device)
+                cache["sort_state"], cache["sort_age"] = state, 0
+            else:
+                cache["sort_age"] = cache.get("sort_age", 0) + 1
+                if cache["sort_age"] >= SORT_REFRESH:
+                    cache["sort_age"] = 0
+                else:
+                    reuse = 1
         with torch.cuda.device(xyz_c.device):
             _lib.check(L.s3g_hexplane_backward(C.byref(d), P, xyz_c.data_ptr(), t_c.data_ptr(), gfeat.data_ptr(),
                                                gxyz.data_ptr(), C.byref(ptrs), work.data_ptr(),
-                                               order_out.data_ptr() if order_out is not None else None,
+                                               state.data_ptr() if state is not None else None, reuse,
                                                torch.cuda.current_stream().cuda_stream))
         if cache is not None:
-            cache["order"] = order_out  # spatial processing order for the next forward (positions move slowly)
+            cache["order"] = state[:P]  # (x,y) processing order for the forwards
         return (gxyz if ctx.needs_input_grad[0] else None, None, None, *gplanes)
 
 
@@ -177,7 +191,7 @@ class HexPlaneField(nn.Module):
             self.grids.append(planes)
             self.feat_dim += CHANNELS
         self._aabb_host = None
-        self._order_cache = {}  # {"order": int32 [P]} spatial processing order left behind by the last backward
+        self._order_cache = {}  # spatial orders of the points left behind by the backward passes (see _HexPlaneSample)
 
     @property
     def get_aabb(self):

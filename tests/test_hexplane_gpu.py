@@ -87,3 +87,37 @@ def test_sampler_vs_restatement_random(gpu_device, P, tmode):
     for (k, pr), (_, pg) in zip(ref.named_parameters(), mine.named_parameters()):
         if pr.grad is not None:
             assert rel_l2(pg.grad.cpu().numpy(), pr.grad.numpy()) < 1e-5, k
+
+
+def test_stale_spatial_order_is_only_a_performance_matter(gpu_device):
+    """The backward re-sorts the points only every SORT_REFRESH passes.  A second, completely different point set of the
+    same size pushed through the same field walks in the FIRST set's (now meaningless) order: results must still match."""
+    from oracle import hexplane_ref as hr
+    from s3gaussian_amd.hexplane import HexPlaneField
+    torch.manual_seed(3)
+    cfg = dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32, resolution=[16, 16, 16, 7])
+    ref = hr.HexPlaneField(1.6, cfg, [1, 2, 4])
+    with torch.no_grad():
+        for p in ref.grids.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    mine = HexPlaneField(1.6, cfg, [1, 2, 4])
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(gpu_device)
+    P = 3000
+    for it in range(3):
+        xyz = torch.rand(P, 3) * 3.0 - 1.5
+        time = torch.full((P, 1), 0.1 * it)
+        w = torch.randn(P, 96)
+        for m in (ref, mine):
+            for p in m.parameters():
+                p.grad = None
+        xr = xyz.clone().requires_grad_(True)
+        (ref(xr, time) * w).sum().backward()
+        xg = xyz.to(gpu_device).requires_grad_(True)
+        fg = mine(xg, time.to(gpu_device))
+        (fg * w.to(gpu_device)).sum().backward()
+        assert mine._order_cache["sort_age"] == it          # sorted on pass 0, reused afterwards
+        assert rel_l2(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1e-4
+        for (k, pr), (_, pg) in zip(ref.named_parameters(), mine.named_parameters()):
+            if pr.grad is not None:
+                assert rel_l2(pg.grad.cpu().numpy(), pr.grad.numpy()) < 1e-5, (it, k)
