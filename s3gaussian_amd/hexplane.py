@@ -76,7 +76,7 @@ class _HexPlaneSample(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, time, meta, *planes):
-        resolutions, aabb_host, cache, uniform_time = meta
+        resolutions, aabb_host, cache, uniform_time, reg_weights = meta
         if not xyz.is_cuda:
             raise RuntimeError(f"xyz must live on the GPU (got {xyz.device}); the HexPlane sampler has no CPU fallback")
         L = _bind()
@@ -102,27 +102,38 @@ class _HexPlaneSample(torch.autograd.Function):
                                               torch.cuda.current_stream().cuda_stream))
         ctx.meta = (resolutions, aabb_host, cache, uniform_time)
         ctx.save_for_backward(xyz_c, t_c, *planes)
-        return feat
+        ctx.set_materialize_grads(False)   # an unused output must arrive as None, not as a [P,128] tensor of zeros
+        ctx.reg_flat = None
+        if reg_weights is None:
+            return feat
+        # plane regulariser (scene/gaussian_model.py:710-749) on the same node: its gradient becomes the INITIAL content of
+        # the plane-gradient buffer the sampler's backward accumulates into (no separate fill, scale and 24 adds)
+        from .losses import plane_regulation_into
+        reg_flat = torch.empty(sum(p.numel() for p in planes), dtype=torch.float32, device=xyz.device)
+        reg = plane_regulation_into(planes, reg_weights, _flat_plane_views(reg_flat, planes))
+        ctx.reg_flat = reg_flat
+        return feat, reg
 
     @staticmethod
-    def backward(ctx, gfeat):
+    def backward(ctx, gfeat, g_reg=None):
         xyz_c, t_c, *planes = ctx.saved_tensors
         resolutions, aabb_host, cache, uniform_time = ctx.meta
         L = _bind()
         P = xyz_c.shape[0]
-        gfeat = gfeat.contiguous()
         gxyz = torch.empty_like(xyz_c)
-        # one zero fill for all plane gradients; each is a channels_last [1,C,H,W] view of the flat buffer
         need = [ctx.needs_input_grad[3 + i] for i in range(len(planes))]
-        flat = torch.zeros(sum(p.numel() for p, n in zip(planes, need) if n), dtype=torch.float32, device=xyz_c.device)
-        gplanes, off = [], 0
-        for p, n in zip(planes, need):
-            if not n:
-                gplanes.append(None)
-                continue
-            _, Cn, Hn, Wn = p.shape
-            gplanes.append(flat[off:off + p.numel()].view(1, Hn, Wn, Cn).permute(0, 3, 1, 2))
-            off += p.numel()
+        if ctx.reg_flat is not None:
+            # every plane needs its gradient on this path (checked by the caller): regulariser gradient x upstream scalar
+            flat = ctx.reg_flat.mul_(g_reg) if g_reg is not None else ctx.reg_flat.zero_()
+            ctx.reg_flat = None
+            gplanes = _flat_plane_views(flat, planes)
+        else:
+            # one zero fill for all plane gradients; each is a channels_last [1,C,H,W] view of the flat buffer
+            flat = torch.zeros(sum(p.numel() for p, n in zip(planes, need) if n), dtype=torch.float32, device=xyz_c.device)
+            gplanes = _flat_plane_views(flat, planes, need)
+        if gfeat is None:   # only the regulariser was used downstream
+            return (None, None, None, *gplanes)
+        gfeat = gfeat.contiguous()
         ptrs = _PlanePtrs()
         for l in range(len(resolutions)):
             for i in range(6):
@@ -155,10 +166,30 @@ class _HexPlaneSample(torch.autograd.Function):
         return (gxyz if ctx.needs_input_grad[0] else None, None, None, *gplanes)
 
 
-def hexplane_sample(xyz, time, planes, resolutions, aabb_host, cache=None, uniform_time=None):
+def _flat_plane_views(flat, planes, need=None):
+    """channels_last [1,C,H,W] views of one flat buffer, in plane order (None where need[i] is False)."""
+    views, off = [], 0
+    for i, p in enumerate(planes):
+        if need is not None and not need[i]:
+            views.append(None)
+            continue
+        _, Cn, Hn, Wn = p.shape
+        views.append(flat[off:off + p.numel()].view(1, Hn, Wn, Cn).permute(0, 3, 1, 2))
+        off += p.numel()
+    return views
+
+
+def hexplane_sample(xyz, time, planes, resolutions, aabb_host, cache=None, uniform_time=None, reg_weights=None):
     """uniform_time: True = the caller guarantees every point carries the same timestamp (fast path: the time planes are
-    pre-interpolated into row tables), False = general per-point time, None = decide by looking at `time` (one host sync)."""
-    return _HexPlaneSample.apply(xyz, time, (tuple(tuple(r) for r in resolutions), aabb_host, cache, uniform_time), *planes)
+    pre-interpolated into row tables), False = general per-point time, None = decide by looking at `time` (one host sync).
+    reg_weights = (time_smoothness_weight, l1_time_planes_weight, plane_tv_weight): also return the plane regulariser of
+    GaussianModel.compute_regulation as a second output of the same autograd node -> (features, regulation)."""
+    if reg_weights is not None and not all(p.requires_grad for p in planes):
+        reg_weights = None   # frozen planes: keep the two computations separate
+        feat = _HexPlaneSample.apply(xyz, time, (tuple(tuple(r) for r in resolutions), aabb_host, cache, uniform_time, None), *planes)
+        return feat, None
+    return _HexPlaneSample.apply(xyz, time, (tuple(tuple(r) for r in resolutions), aabb_host, cache, uniform_time,
+                                             tuple(float(w) for w in reg_weights) if reg_weights is not None else None), *planes)
 
 
 class HexPlaneField(nn.Module):
@@ -221,11 +252,12 @@ class HexPlaneField(nn.Module):
     def _planes(self):
         return [p for planes in self.grids for p in planes]
 
-    def get_density(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None, uniform_time=None):
+    def get_density(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None, uniform_time=None, reg_weights=None):
         pts = pts.reshape(-1, pts.shape[-1])
         return hexplane_sample(pts, timestamps, self._planes(), self.resolutions, self._host_aabb(), self._order_cache,
-                               uniform_time)
+                               uniform_time, reg_weights)
 
-    def forward(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None, uniform_time=None):
-        """Reference signature (scene/hexplane.py:178-183) plus the optional `uniform_time` hint of hexplane_sample."""
-        return self.get_density(pts, timestamps, uniform_time)
+    def forward(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None, uniform_time=None, reg_weights=None):
+        """Reference signature (scene/hexplane.py:178-183) plus the optional hints of hexplane_sample; with reg_weights the
+        result is (features, plane regulation)."""
+        return self.get_density(pts, timestamps, uniform_time, reg_weights)

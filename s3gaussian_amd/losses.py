@@ -191,6 +191,33 @@ class _PlaneRegulation(torch.autograd.Function):
         return (None, *grads)
 
 
+def _plane_weights(n_planes, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight):
+    return [(float(time_smoothness_weight), float(l1_time_planes_weight)) if i % 6 in (2, 4, 5) else (float(plane_tv_weight), 0.0)
+            for i in range(n_planes)]
+
+
+def plane_regulation_into(planes, reg_weights, grad_views):
+    """Value of compute_regulation over `planes` (level-major list of the 6 planes per level) with the gradient written
+    into the caller's channels_last views (no autograd here: s3gaussian_amd.hexplane folds it into the sampler's node).
+    reg_weights = (time_smoothness_weight, l1_time_planes_weight, plane_tv_weight)."""
+    L = _lib.lib()
+    L.s3g_plane_regulation.restype = C.c_int
+    L.s3g_plane_regulation.argtypes = [C.c_int, C.POINTER(_PlaneRegDesc), C.c_void_p, C.c_void_p]
+    dev = planes[0].device
+    weights = _plane_weights(len(planes), *reg_weights)
+    descs = (_PlaneRegDesc * len(planes))()
+    for i, (p, g, (ws, wl)) in enumerate(zip(planes, grad_views, weights)):
+        if p.dim() != 4 or p.shape[1] != 32 or not p.is_contiguous(memory_format=torch.channels_last):
+            raise RuntimeError("plane regulation expects [1,32,H,W] channels_last planes")
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            raise RuntimeError("plane regulation: gradient views must be channels_last")
+        descs[i] = _PlaneRegDesc(p.data_ptr(), g.data_ptr(), p.shape[2], p.shape[3], ws, wl)
+    value = torch.zeros(SUM_DOUBLES, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.s3g_plane_regulation(len(planes), descs, value.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return value.sum().float()
+
+
 def plane_regulation(grids, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight):
     """GaussianModel.compute_regulation (scene/gaussian_model.py:748-749) over HexPlaneField.grids, value and
     gradient in one fused pass."""

@@ -180,7 +180,7 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
     means2D = screenspace_points
     opacity = pc._opacity
     scales, rotations, cov3D_precomp = pc._scaling, pc._rotation, None
-    dx = feat = dshs = shs_final = dshs_l1 = None
+    dx = feat = dshs = shs_final = dshs_l1 = plane_reg = None
     net = pc._deformation.deformation_net
     hy = net.args
     glue_ok = (means3D.is_cuda and override_color is None and getattr(pipe, "convert_SHs_python", True)
@@ -194,7 +194,13 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
         if fused_glue:
             # default configuration: only dx / dshs / feat are produced by the network (scales, rotations, opacity pass
             # through, deformation.py:126-152); `shs + dshs` is folded into the glue kernel below
-            dx, dshs, feat = net.deform_heads(means3D, time, uniform_time=True)   # `time` is one timestamp repeated
+            # `time` is one timestamp repeated; under autograd the plane regulariser (compute_regulation) rides on the
+            # sampler's node so its gradient is the seed the sampler's backward accumulates onto
+            regw = ((hy.time_smoothness_weight, hy.l1_time_planes, hy.plane_tv_weight)
+                    if (stage == "fine" and torch.is_grad_enabled() and hy.time_smoothness_weight != 0) else None)
+            heads = net.deform_heads(means3D, time, uniform_time=True, reg_weights=regw)
+            dx, dshs, feat = heads[:3]
+            plane_reg = heads[3] if regw is not None else None
             means3D_final, scales_final, rotations_final, opacity_final = means3D + dx, scales, rotations, opacity
         else:
             (means3D_final, scales_final, rotations_final, opacity_final, shs_final, dx, feat, dshs) = pc._deformation(
@@ -256,6 +262,8 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
         out.update({"dx": dx, "dshs": dshs})
         if dshs_l1 is not None:
             out["dshs_l1"] = dshs_l1
+    if plane_reg is not None:
+        out["plane_reg"] = plane_reg
     return out
 
 
@@ -330,7 +338,8 @@ def training_loss(pc: GaussianParams, pkg: Dict, gt_image, gt_depth, gt_feat, hy
         dshs_l1 = pkg["dshs_l1"] if "dshs_l1" in pkg else torch.mean(torch.abs(pkg["dshs"]))
         loss = loss + dshs_l1 * opt.lambda_dshs
     if stage == "fine" and hyper.time_smoothness_weight != 0:
-        loss = loss + pc.compute_regulation(hyper.time_smoothness_weight, hyper.l1_time_planes, hyper.plane_tv_weight)
+        loss = loss + (pkg["plane_reg"] if pkg.get("plane_reg") is not None else
+                       pc.compute_regulation(hyper.time_smoothness_weight, hyper.l1_time_planes, hyper.plane_tv_weight))
     return loss
 
 

@@ -121,3 +121,51 @@ def test_stale_spatial_order_is_only_a_performance_matter(gpu_device):
         for (k, pr), (_, pg) in zip(ref.named_parameters(), mine.named_parameters()):
             if pr.grad is not None:
                 assert rel_l2(pg.grad.cpu().numpy(), pr.grad.numpy()) < 1e-5, (it, k)
+
+
+@pytest.mark.parametrize("use", ["both", "features_only", "reg_only"])
+def test_regulariser_on_the_sampler_node_matches_separate_nodes(gpu_device, use):
+    """field(xyz, t, reg_weights=...) -> (features, compute_regulation value) as ONE autograd node (the regulariser's
+    gradient seeds the buffer the sampler's backward accumulates into) vs the two separate nodes autograd would add."""
+    from s3gaussian_amd.hexplane import HexPlaneField
+    from s3gaussian_amd.losses import plane_regulation
+    torch.manual_seed(5)
+    cfg = dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32, resolution=[16, 16, 16, 9])
+    field = HexPlaneField(1.6, cfg, [1, 2]).to(gpu_device)
+    with torch.no_grad():
+        for p in field.grids.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    P = 2000
+    xyz = (torch.rand(P, 3) * 3.0 - 1.5).to(gpu_device)
+    time = torch.full((P, 1), 0.3, device=gpu_device)
+    w = torch.randn(P, 64, device=gpu_device)
+    regw = (0.01, 0.0001, 0.0002)
+    res = []
+    for fused in (True, False):
+        for p in field.parameters():
+            p.grad = None
+        x = xyz.clone().requires_grad_(True)
+        if fused:
+            feat, reg = field(x, time, uniform_time=True, reg_weights=regw)
+        else:
+            feat = field(x, time, uniform_time=True)
+            reg = plane_regulation(field.grids, *regw)
+        loss = 0
+        if use != "reg_only":
+            loss = loss + (feat * w).sum()
+        if use != "features_only":
+            loss = loss + 700.0 * reg
+        loss.backward()
+        res.append((feat.detach(), reg.detach(), x.grad, [p.grad for p in field.grids.parameters()]))
+    (f1, r1, gx1, gp1), (f2, r2, gx2, gp2) = res
+    assert torch.equal(f1, f2) and abs(r1.item() - r2.item()) <= 1e-6 * abs(r2.item())
+    if use == "reg_only":
+        assert gx1 is None and gx2 is None
+    else:
+        assert rel_l2(gx1.cpu().numpy(), gx2.cpu().numpy()) < 1e-5
+    for a, b in zip(gp1, gp2):
+        if use == "features_only" and b is None:
+            assert a is None or float(a.abs().max()) == 0.0
+            continue
+        assert a.is_contiguous(memory_format=torch.channels_last)
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
