@@ -3,20 +3,25 @@
 // Reference: scene/hexplane.py:73-106 runs 4 levels x 6 planes = 24 F.grid_sample launches, each materialising a
 // [P,32] tensor, then 20 elementwise products and a concat; autograd replays the same 24 in backward.
 //
-// Here 32 consecutive lanes own the 32 channels of ONE point (a wave64 handles two points), so with the planes stored
-// channel-last every texel fetch is one coalesced 128-byte line and the product over planes never leaves registers.
-// Arithmetic follows torch's grid_sampler_2d (bilinear, border, align_corners=True) op for op; contraction is off.
+// Planes are stored channel-last, so one texel = 32 channels = one 128-byte line.  Forward and the per-point backward give
+// a point to EIGHT lanes (4 channels each, one 16-byte load per texel): these kernels are VALU-bound on the bilinear-tap
+// arithmetic, which every lane of a point repeats -- 8 copies instead of 32.  The product over planes never leaves
+// registers.  Arithmetic follows torch's grid_sampler_2d (bilinear, border, align_corners=True) op for op; contraction
+// is off.  When all points share one timestamp (desc.uniform_time) the three (axis, t) planes of a level are first
+// collapsed to 1-D row tables (see "uniform time" below).
 //
 // Backward without an atomic storm.  A direct scatter is 96 line-coalesced float atomics per point; MI355X retires
 // ~10 G such line-ops/s whatever the contention (tools/ubench/atomic_lines.hip), i.e. 11.5 ms at 1.2 M points.  So:
 //   pass A  (point order)   re-gathers the taps, applies the product rule, writes dL/ds for all 24 plane-levels to a
 //                           scratch slab G[24][P][32] (3 KB per point -- HBM is 288 GB) and finishes dL/dxyz;
-//   sort    three 2-level counting sorts of the point indices by (major, minor) 512x512 cell, one per plane
-//           orientation, with LDS histograms (no global atomics, no library sort);
-//   pass B  (sorted order, one launch per orientation = 2 plane kinds x all levels): a half-wave walks a run of
-//           spatially consecutive points keeping (texel id, partial sum) per bilinear corner in registers and only
-//           issues an atomic when the texel changes -- consecutive points share texels, so the 96 line-ops per point
-//           drop to ~4.
+//   sort    three 2-level counting sorts of the point indices by (major, minor) finest-level texel cell, one per plane
+//           orientation, with LDS histograms (no global atomics, no library sort); the orders only steer the walk, so the
+//           caller may keep them for several iterations (sort_state / sort_reuse);
+//   pass B  (sorted order, one launch for the three orientations = 2 plane kinds x all levels each): a half-wave (32
+//           lanes = the 32 channels) walks a run of spatially consecutive points keeping two bilinear footprints per
+//           (level, plane) in registers and only issues atomics when a footprint is evicted -- consecutive points share
+//           texels, so the 96 line-ops per point drop to ~7.  Taps are computed cooperatively (lane = point x tap) and
+//           shared through LDS; index, coordinate and tap computation run one to two groups ahead of the accumulation.
 #include "common.hpp"
 
 #include "../../include/s3g_hexplane.h"
