@@ -46,6 +46,29 @@ def test_raster_inputs_struct_matches_header_field_order():
     assert fields == [f[0] for f in _lib.RasterInputs._fields_]
 
 
+def _struct_fields(header, name):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), txt, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = re.sub(r"\[[^\]]*\]", "", decl.strip())      # drop array extents
+        if not decl:
+            continue
+        for part in decl.split(","):
+            fields.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", part)[-1])
+    return fields
+
+
+def test_other_structs_match_their_headers():
+    """ctypes mirrors of the descriptor structs keep the headers' field order (and sizes where arrays are involved)."""
+    from s3gaussian_amd import hexplane, losses, mlp
+    assert _struct_fields("s3g_hexplane.h", "s3g_hexplane_desc") == [f[0] for f in hexplane._HexDesc._fields_]
+    assert ctypes.sizeof(hexplane._HexDesc) == 4 + 8 * 4 * 4 + 4 + 8 * 6 * 8 + 6 * 4 + 4 + 4   # int, res, pad, planes, aabb, flag, pad
+    assert _struct_fields("s3g_loss.h", "s3g_plane_reg_desc") == [f[0] for f in losses._PlaneRegDesc._fields_]
+    assert _struct_fields("s3g_mlp.h", "s3g_mlp_params") == [f[0] for f in mlp._Params._fields_]
+
+
 def test_python_surface_matches_reference_names():
     import diff_gaussian_rasterization as d
     assert d.GaussianRasterizationSettings._fields == (
