@@ -119,3 +119,26 @@ def test_product_package_never_imports_oracle():
         for path in glob.glob(os.path.join(ROOT, root, "**", "*.py"), recursive=True):
             src = open(path).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench_line.json is what `python bench.py` printed on the MI355X: one JSON object with the driver's
+    fields, the roofline of the dominant kernel (measured live, PMC traffic attached) and the CPU baseline."""
+    import json
+    line = open(os.path.join(ROOT, "profiles", "r01_bench_line.json")).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == "train_iters_per_sec" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert isinstance(base, dict)
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - d["n_gpus"] * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] is not None
+    dom = max(r["kernels"], key=lambda k: k["ms_per_step"])
+    assert dom["kernel"] == r["kernel"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
