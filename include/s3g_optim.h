@@ -1,0 +1,41 @@
+/*
+ * s3g_optim.h -- C ABI of the fused Adam step (libs3g.so).
+ *
+ *   s3g_adam_step  <- optimizer.step() of the reference's torch.optim.Adam(l, lr=0.0, eps=1e-15)
+ *                     (/root/reference/scene/gaussian_model.py:177-189, stepped at train.py:521-522): the update of
+ *                     torch/optim/adam.py (no weight decay, no amsgrad, not maximising)
+ *                        m  = m + (g - m) (1 - beta1)            v = beta2 v + (1 - beta2) g g
+ *                        p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)         bc_k = 1 - beta_k^step
+ *                     for EVERY parameter of every group in ONE launch (the reference: ~10 foreach passes per group over
+ *                     426 MB of state; PyTorch's fused variant: one launch per group and 4 GB chunk).
+ */
+#ifndef S3G_OPTIM_H
+#define S3G_OPTIM_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3G_ADAM_MAX_TENSORS 64 /* per call; the binding splits longer lists */
+
+typedef struct s3g_adam_tensor {
+  float* param;         /* device, updated in place */
+  const float* grad;    /* device, same element order as param */
+  float* exp_avg;       /* device, updated in place */
+  float* exp_avg_sq;    /* device, updated in place */
+  size_t numel;
+  float step_size;      /* lr / (1 - beta1^step)  */
+  float inv_sqrt_bc2;   /* 1 / sqrt(1 - beta2^step) */
+  float eps;
+  float pad_;
+} s3g_adam_tensor;
+
+/* All tensors fp32.  param/grad/exp_avg/exp_avg_sq of one entry must share one memory layout (the update is
+ * elementwise over raw storage, so channels_last planes need no special case).  The betas are doubles because torch forms
+ * 1 - beta in double before rounding to fp32 (1 - fp32(0.999) differs from fp32(0.001) by 1.3e-5 relative). */
+int s3g_adam_step(int n, const s3g_adam_tensor* tensors /* host array */, double beta1, double beta2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

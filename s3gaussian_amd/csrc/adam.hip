@@ -1,0 +1,70 @@
+// Adam step for all parameters of the model in one launch (include/s3g_optim.h).  HBM-bound: 16 B read + 12 B written
+// per element (p, g, m, v -> p, m, v); 106 M parameters at cfg3 = 2.98 GB per step.
+#include "common.hpp"
+
+#include "../../include/s3g_optim.h"
+
+namespace s3g {
+
+struct AdamArgs {
+  s3g_adam_tensor t[S3G_ADAM_MAX_TENSORS];
+  float beta1, beta2, w1, w2;  // w_k = 1 - beta_k rounded from DOUBLE, like torch's python-side `1 - beta`
+};
+
+// grid = (blocks per tensor, tensors): a tensor is swept by its own row of workgroups with 16-byte accesses
+__global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
+  const s3g_adam_tensor& t = a.t[blockIdx.y];
+  const float b2 = a.beta2, w1 = a.w1, w2 = a.w2;
+  const float step_size = t.step_size, isb = t.inv_sqrt_bc2, eps = t.eps;
+  // 16-byte accesses when all four arrays allow it (gradients that are views into a flat buffer may start anywhere)
+  const bool vec = ((((uintptr_t)t.param | (uintptr_t)t.grad | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq) & 15) == 0);
+  const size_t n4 = vec ? t.numel / 4 : 0;
+  float4* p4 = reinterpret_cast<float4*>(t.param);
+  const float4* g4 = reinterpret_cast<const float4*>(t.grad);
+  float4* m4 = reinterpret_cast<float4*>(t.exp_avg);
+  float4* v4 = reinterpret_cast<float4*>(t.exp_avg_sq);
+  auto upd = [&](float& p, float g, float& m, float& v) {
+    m = m + (g - m) * w1;                      // torch: exp_avg.lerp_(grad, 1 - beta1)
+    v = b2 * v + w2 * g * g;                   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    const float denom = sqrtf(v) * isb + eps;  // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    p = p - step_size * (m / denom);           // param.addcdiv_(exp_avg, denom, value = -step_size)
+  };
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 p = p4[i], m = m4[i], v = v4[i];
+    const float4 g = g4[i];
+    upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
+    p4[i] = p; m4[i] = m; v4[i] = v;
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < t.numel; i += (size_t)gridDim.x * 256)
+    upd(t.param[i], t.grad[i], t.exp_avg[i], t.exp_avg_sq[i]);  // the numel % 4 tail, or everything when unaligned
+}
+
+}  // namespace s3g
+
+using namespace s3g;
+
+extern "C" int s3g_adam_step(int n, const s3g_adam_tensor* tensors, double beta1, double beta2, void* stream_) {
+  if (n < 0 || n > S3G_ADAM_MAX_TENSORS || (n > 0 && !tensors)) {
+    set_error("s3g_adam_step: bad argument (at most %d tensors per call)", S3G_ADAM_MAX_TENSORS);
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (n == 0) return S3G_OK;
+  AdamArgs a;
+  memset(&a, 0, sizeof a);
+  size_t largest = 0;
+  for (int k = 0; k < n; k++) {
+    const s3g_adam_tensor& t = tensors[k];
+    if (t.numel > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)) {
+      set_error("s3g_adam_step: NULL array in tensor %d", k);
+      return S3G_ERR_INVALID_ARG;
+    }
+    a.t[k] = t;
+    largest = t.numel > largest ? t.numel : largest;
+  }
+  a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.w1 = (float)(1.0 - beta1); a.w2 = (float)(1.0 - beta2);
+  const size_t want = (largest / 4 + 255) / 256;
+  const int bx = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(adam_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream_, a);
+  S3G_HIP_CHECK(hipGetLastError());
+  return S3G_OK;
+}

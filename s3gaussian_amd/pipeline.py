@@ -115,9 +115,13 @@ class GaussianParams(nn.Module):
             {"params": [self._scaling], "lr": opt.scaling_lr, "name": "scaling"},
             {"params": [self._rotation], "lr": opt.rotation_lr, "name": "rotation"},
         ]
-        # same update rule as the reference's torch.optim.Adam(l, lr=0.0, eps=1e-15); `fused=True` only selects
-        # PyTorch's single-kernel multi-tensor implementation instead of ~10 foreach passes over 426 MB of state
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=self._xyz.is_cuda)
+        # same update rule and state layout as the reference's torch.optim.Adam(l, lr=0.0, eps=1e-15); on the GPU the whole
+        # step is one kernel launch over all groups (optim.Adam) instead of ~10 foreach passes per group
+        if self._xyz.is_cuda:
+            from .optim import Adam as FusedAdam
+            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         return self.optimizer
 
     def compute_regulation(self, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight):

@@ -67,6 +67,9 @@ def test_other_structs_match_their_headers():
     assert ctypes.sizeof(hexplane._HexDesc) == 4 + 8 * 4 * 4 + 4 + 8 * 6 * 8 + 6 * 4 + 4 + 4   # int, res, pad, planes, aabb, flag, pad
     assert _struct_fields("s3g_loss.h", "s3g_plane_reg_desc") == [f[0] for f in losses._PlaneRegDesc._fields_]
     assert _struct_fields("s3g_mlp.h", "s3g_mlp_params") == [f[0] for f in mlp._Params._fields_]
+    from s3gaussian_amd import optim
+    assert _struct_fields("s3g_optim.h", "s3g_adam_tensor") == [f[0] for f in optim._AdamTensor._fields_]
+    assert ctypes.sizeof(optim._AdamTensor) == 56
 
 
 def test_python_surface_matches_reference_names():
