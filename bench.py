@@ -165,7 +165,9 @@ def main():
         targets[v] = make_targets(pc, cams[v], bg, hyper, seed=1000 + v)
     tkeys = list(targets)
     # large gradients are all-reduced as soon as backward produces them (overlaps the rest of the backward pass)
-    reducer = dp.OverlappedGradAllReducer(pc.parameters()) if world > 1 else None
+    reducer = dp.OverlappedGradAllReducer(pc.parameters(), average=False) if world > 1 else None
+    if world > 1:
+        pc.optimizer.grad_scale = 1.0 / world   # the SUM all-reduce is averaged inside the Adam kernel
 
     def hook(pc_, pkg):
         if reducer is not None:

@@ -27,7 +27,7 @@ typedef struct s3g_adam_tensor {
   float step_size;      /* lr / (1 - beta1^step)  */
   float inv_sqrt_bc2;   /* 1 / sqrt(1 - beta2^step) */
   float eps;
-  float pad_;
+  float grad_scale;     /* g = grad * grad_scale (1 for plain Adam; 1/world_size folds the data-parallel average in) */
 } s3g_adam_tensor;
 
 /* All tensors fp32.  param/grad/exp_avg/exp_avg_sq of one entry must share one memory layout (the update is

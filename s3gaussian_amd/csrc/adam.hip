@@ -15,7 +15,7 @@ struct AdamArgs {
 __global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
   const s3g_adam_tensor& t = a.t[blockIdx.y];
   const float b2 = a.beta2, w1 = a.w1, w2 = a.w2;
-  const float step_size = t.step_size, isb = t.inv_sqrt_bc2, eps = t.eps;
+  const float step_size = t.step_size, isb = t.inv_sqrt_bc2, eps = t.eps, gs = t.grad_scale;
   // 16-byte accesses when all four arrays allow it (gradients that are views into a flat buffer may start anywhere)
   const bool vec = ((((uintptr_t)t.param | (uintptr_t)t.grad | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq) & 15) == 0);
   const size_t n4 = vec ? t.numel / 4 : 0;
@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
   float4* m4 = reinterpret_cast<float4*>(t.exp_avg);
   float4* v4 = reinterpret_cast<float4*>(t.exp_avg_sq);
   auto upd = [&](float& p, float g, float& m, float& v) {
+    g = g * gs;
     m = m + (g - m) * w1;                      // torch: exp_avg.lerp_(grad, 1 - beta1)
     v = b2 * v + w2 * g * g;                   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
     const float denom = sqrtf(v) * isb + eps;  // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)

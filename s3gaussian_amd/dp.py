@@ -58,8 +58,10 @@ class GradAllReducer:
     """Bucketed average of .grad over all ranks.  Parameters whose grad is None on this rank (unused heads) are
     skipped; they are None on every rank because all replicas run the same graph."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, inplace_mb: float = 16.0):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, inplace_mb: float = 16.0,
+                 average: bool = True):
         self.params = [p for p in params]
+        self.average = average   # False: leave the SUM in .grad (the optimizer applies 1/world, optim.Adam.grad_scale)
         self.bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
         self.inplace_elems = int(inplace_mb * 1024 * 1024 / 4)  # gradients at least this big are reduced where they live
         self._buf = None
@@ -89,7 +91,8 @@ class GradAllReducer:
                 small.append(g)
                 continue
             dist.all_reduce(v, op=dist.ReduceOp.SUM)
-            v.mul_(1.0 / world)
+            if self.average:
+                v.mul_(1.0 / world)
             total += g.numel()
         for bucket in self._buckets(small):
             n = sum(g.numel() for g in bucket)
@@ -102,7 +105,8 @@ class GradAllReducer:
                 flat[off:off + g.numel()].copy_(v if v is not None else g.contiguous().view(-1))
                 off += g.numel()
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.mul_(1.0 / world)
+            if self.average:
+                flat.mul_(1.0 / world)
             off = 0
             for g in bucket:  # unpack in place
                 v = _flat_view(g)
@@ -123,10 +127,11 @@ class OverlappedGradAllReducer(GradAllReducer):
     and xyz at the very end.  `finish()` (call between backward and optimizer.step) waits for the collectives in flight,
     averages, and reduces the small gradients in flat buckets like the base class."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, inplace_mb: float = 1.0):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, inplace_mb: float = 1.0,
+                 average: bool = True):
         # hook threshold 1 MB: at cfg3 that covers every per-Gaussian array and all but the coarsest planes (~99 % of the
         # bytes, ~35 collectives); the rest (MLP weights, 64x64 planes) goes in one flat bucket in finish()
-        super().__init__(params, bucket_mb, inplace_mb)
+        super().__init__(params, bucket_mb, inplace_mb, average)
         self._inflight = []   # (work handle, flat view)
         self._started = set()
         self._handles = []
@@ -156,7 +161,8 @@ class OverlappedGradAllReducer(GradAllReducer):
         total = 0
         for work, v in self._inflight:
             work.wait()
-            v.mul_(1.0 / world)
+            if self.average:
+                v.mul_(1.0 / world)
             total += v.numel()
         started, self._inflight, self._started = self._started, [], set()
         # everything the hooks did not cover (small tensors, gradients set outside autograd's accumulation)

@@ -16,7 +16,7 @@ class _AdamTensor(C.Structure):
     """struct s3g_adam_tensor (include/s3g_optim.h)."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("numel", C.c_size_t), ("step_size", C.c_float), ("inv_sqrt_bc2", C.c_float), ("eps", C.c_float),
-                ("pad_", C.c_float)]
+                ("grad_scale", C.c_float)]
 
 
 def _dense(t: torch.Tensor) -> bool:
@@ -29,6 +29,8 @@ class Adam(torch.optim.Adam):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
+        self.grad_scale = 1.0   # every gradient is multiplied by this inside the kernel; the data-parallel wrapper sets
+                                # 1 / world_size after a SUM all-reduce instead of spending a pass on the average
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -67,7 +69,7 @@ class Adam(torch.optim.Adam):
                 bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
                 by_betas.setdefault((p.device, float(beta1), float(beta2)), []).append(
                     _AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
-                                group["lr"] / bc1, 1.0 / (bc2 ** 0.5), group["eps"], 0.0))
+                                group["lr"] / bc1, 1.0 / (bc2 ** 0.5), group["eps"], float(self.grad_scale)))
         for (dev, beta1, beta2), items in by_betas.items():
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream().cuda_stream

@@ -109,6 +109,15 @@ def _overlap_worker(rank, world, port, q):
         ok = ok and unused.grad is None and n == big.numel() + plane.numel() + small.numel()
         ok = ok and not red._inflight and not red._started
     red.remove_hooks()
+    # average=False leaves the SUM in place (the Adam kernel applies 1/world: optim.Adam.grad_scale)
+    for p in params:
+        p.grad = None
+    red2 = dp.OverlappedGradAllReducer(params, bucket_mb=0.001, inplace_mb=0.004, average=False)
+    ((plane * (rank + 2.0)).sum() + (small * (rank + 1.0)).sum()).backward()
+    red2.finish()
+    ok = ok and torch.allclose(plane.grad, torch.full_like(plane, sum(r + 2.0 for r in range(world))), atol=1e-5)
+    ok = ok and torch.allclose(small.grad, torch.full((7,), sum(r + 1.0 for r in range(world))), atol=1e-6)
+    red2.remove_hooks()
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

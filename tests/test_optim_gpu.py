@@ -77,3 +77,19 @@ def test_adam_refuses_cpu_parameters():
     p.grad = torch.ones(4)
     with pytest.raises(RuntimeError, match="GPU"):
         Adam([p], lr=0.1).step()
+
+
+def test_adam_grad_scale_equals_scaled_gradients(gpu_device):
+    """grad_scale = 1/world folds the data-parallel average into the kernel: same as stepping on grad * scale."""
+    from s3gaussian_amd.optim import Adam
+    g = torch.Generator().manual_seed(3)
+    a = torch.nn.Parameter(torch.randn(513, 3, generator=g))
+    b = torch.nn.Parameter(a.detach().clone().to(gpu_device))
+    ref, mine = torch.optim.Adam([a], lr=0.01, eps=1e-15), Adam([b], lr=0.01, eps=1e-15)
+    mine.grad_scale = 0.125
+    for _ in range(4):
+        grad = torch.randn(513, 3, generator=g)
+        a.grad, b.grad = grad * 0.125, grad.to(gpu_device)
+        ref.step()
+        mine.step()
+    np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().numpy(), rtol=2e-6, atol=1e-7)
