@@ -187,7 +187,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    for i in range(8):
+    for i in range(9):
         L.s3g_profile_read(i, None, None, None)
     L.s3g_profile_enable(1)
     vis_acc = torch.zeros((), device=device, dtype=torch.float64)
@@ -249,6 +249,7 @@ def main():
             5: ("s3g::mlp_forward_kernel", lambda n, _: n * (512.0 + 5 * 256.0 + 216.0), lambda n: n * MLP_FLOP),
             6: ("s3g::mlp_backward_kernel", lambda n, _: n * (5 * 256.0 + 216.0 + 5 * 256.0 + 512.0), lambda n: n * MLP_FLOP),
             7: ("s3g::mlp_wgrad_kernel (9 launches)", lambda n, _: n * 4.0 * (2 * 67 + 6 * 128 + 112), lambda n: n * MLP_FLOP),
+            8: ("s3g::adam_kernel", lambda n, _: n * 28.0, None),   # p, g, m, v read; p, m, v written
         }
         traffic_db = {}
         default_workload = (a.P, a.width, a.height, a.frames) == (1_200_000, 1600, 1066, 50)

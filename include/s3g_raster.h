@@ -133,7 +133,8 @@ int s3g_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 /* Optional in-library timing of the hot kernels with hipEvent pairs recorded on the launch stream (bench.py's roofline
  * leg).  s3g_profile_read sums and clears the recorded launches of one id (synchronising on their events) and returns
  * how many there were; the two totals are per-id work counts:
- *   blend kernels: (sorted instances R, pixels)   hexplane kernels: (points P, levels)   MLP kernels: (points P, 0).
+ *   blend kernels: (sorted instances R, pixels)   hexplane kernels: (points P, levels)   MLP kernels: (points P, 0)
+ *   Adam: (parameters updated, 0).
  * MLP_WGRAD brackets the nine weight-gradient launches of one backward call. */
 enum {
   S3G_PROFILE_BLEND_FORWARD = 0,
@@ -144,7 +145,8 @@ enum {
   S3G_PROFILE_MLP_FORWARD = 5,
   S3G_PROFILE_MLP_BACKWARD = 6,
   S3G_PROFILE_MLP_WGRAD = 7,
-  S3G_PROFILE_IDS = 8
+  S3G_PROFILE_ADAM = 8,
+  S3G_PROFILE_IDS = 9
 };
 void s3g_profile_enable(int on);
 int s3g_profile_read(int id, double* total_ms, double* total_instances, double* total_pixels);

@@ -52,7 +52,7 @@ extern "C" int s3g_adam_step(int n, const s3g_adam_tensor* tensors, double beta1
   if (n == 0) return S3G_OK;
   AdamArgs a;
   memset(&a, 0, sizeof a);
-  size_t largest = 0;
+  size_t largest = 0, total = 0;
   for (int k = 0; k < n; k++) {
     const s3g_adam_tensor& t = tensors[k];
     if (t.numel > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)) {
@@ -61,11 +61,14 @@ extern "C" int s3g_adam_step(int n, const s3g_adam_tensor* tensors, double beta1
     }
     a.t[k] = t;
     largest = t.numel > largest ? t.numel : largest;
+    total += t.numel;
   }
   a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.w1 = (float)(1.0 - beta1); a.w2 = (float)(1.0 - beta2);
   const size_t want = (largest / 4 + 255) / 256;
   const int bx = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  profile_begin(S3G_PROFILE_ADAM, (hipStream_t)stream_);
   hipLaunchKernelGGL(adam_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream_, a);
+  profile_end(S3G_PROFILE_ADAM, (hipStream_t)stream_, (double)total, 0.0);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }
