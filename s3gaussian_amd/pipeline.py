@@ -188,7 +188,7 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
     net = pc._deformation.deformation_net
     hy = net.args
     glue_ok = (means3D.is_cuda and override_color is None and getattr(pipe, "convert_SHs_python", True)
-               and pc.max_sh_degree == 3)
+               and pc.max_sh_degree == 3 and getattr(pipe, "fused_glue", True))   # pipe.fused_glue=False: torch glue (tests)
     fused_glue = glue_ok and ("coarse" in stage or net._fused_ok())
     if "coarse" in stage:
         means3D_final, scales_final, rotations_final, opacity_final = means3D, scales, rotations, opacity

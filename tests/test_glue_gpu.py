@@ -106,3 +106,43 @@ def test_render_fused_and_unfused_paths_agree(gpu_device):
     assert set(g1) == set(g2)
     for k in g1:
         assert rel_l2(g1[k].cpu().numpy(), g2[k].cpu().numpy()) < 2e-4, k
+
+
+def test_coarse_stage_render_and_step(gpu_device):
+    """Coarse stage (train.py's first phase: deformation network bypassed, gaussian_renderer/__init__.py:80-83): the fused
+    glue path equals the step-by-step path (activations + eval_sh evaluated by torch), the deformation parameters get no
+    gradient, and a full training_step runs (single-image raster path: there is no feature render in this stage)."""
+    from types import SimpleNamespace
+    from s3gaussian_amd import synth
+    from s3gaussian_amd.pipeline import GaussianParams, default_hyper, default_opt, render, training_step
+    dev = gpu_device
+    scn = synth.street_scene(P=4000, seed=7, width=144, height=96, n_frames=2)
+    torch.manual_seed(0)
+    hyper, opt = default_hyper(), default_opt()
+    pc = GaussianParams(3, hyper)
+    gs = scn["gaussians"]
+    pc.init_from_tensors(gs["xyz"], gs["log_scales"], gs["rotations_raw"], gs["opacity_logit"], gs["shs"], dev)
+    pc._deformation.deformation_net.set_aabb(*scn["aabb"])
+    cam = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scn["cameras"][0].items()}
+    bg = scn["bg"].to(dev)
+    res = []
+    for fused in (True, False):
+        for p in pc.parameters():
+            p.grad = None
+        pipe = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False, fused_glue=fused)
+        pkg = render(cam, pc, pipe, bg, stage="coarse", return_dx=True, render_feat=True)
+        (pkg["render"].sum() + 0.1 * pkg["depth"].sum()).backward()
+        res.append((pkg, {n: p.grad.clone() for n, p in pc.named_parameters() if p.grad is not None}))
+    (p1, g1), (p2, g2) = res
+    assert torch.equal(p1["radii"], p2["radii"]) and "feat" not in p1 and "dx" not in p1
+    for k in ("render", "depth"):
+        np.testing.assert_allclose(p1[k].detach().cpu().numpy(), p2[k].detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    assert set(g1) == set(g2) and g1 and not any(k.startswith("_deformation") for k in g1)
+    for k in g1:
+        assert rel_l2(g1[k].cpu().numpy(), g2[k].cpu().numpy()) < 2e-4, k
+    pc.training_setup(opt)
+    before = pc._features_dc.detach().clone()
+    loss, pkg = training_step(pc, cam, torch.rand(3, 96, 144, device=dev), torch.rand(1, 96, 144, device=dev) * 50, None,
+                              hyper, opt, bg, stage="coarse")
+    assert torch.isfinite(loss) and pkg["render"].shape == (3, 96, 144)
+    assert not torch.equal(before, pc._features_dc.detach())          # the optimizer stepped
