@@ -146,3 +146,27 @@ def test_coarse_stage_render_and_step(gpu_device):
                               hyper, opt, bg, stage="coarse")
     assert torch.isfinite(loss) and pkg["render"].shape == (3, 96, 144)
     assert not torch.equal(before, pc._features_dc.detach())          # the optimizer stepped
+
+
+def test_render_decomposition_outputs(gpu_device):
+    """return_decomposition=True (gaussian_renderer/__init__.py:168-205): dynamic / static subsets rendered separately."""
+    from types import SimpleNamespace
+    from s3gaussian_amd import synth
+    from s3gaussian_amd.pipeline import GaussianParams, default_hyper, render
+    dev = gpu_device
+    scn = synth.street_scene(P=3000, seed=9, width=128, height=96, n_frames=2)
+    torch.manual_seed(0)
+    pc = GaussianParams(3, default_hyper())
+    gs = scn["gaussians"]
+    pc.init_from_tensors(gs["xyz"], gs["log_scales"], gs["rotations_raw"], gs["opacity_logit"], gs["shs"], dev)
+    pc._deformation.deformation_net.set_aabb(*scn["aabb"])
+    cam = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scn["cameras"][1].items()}
+    pipe = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
+    with torch.no_grad():
+        pkg = render(cam, pc, pipe, scn["bg"].to(dev), stage="fine", return_decomposition=True, return_dx=True)
+    for tag in ("d", "s"):
+        assert pkg[f"render_{tag}"].shape == (3, 96, 128) and pkg[f"depth_{tag}"].shape == (1, 96, 128)
+        assert torch.isfinite(pkg[f"render_{tag}"]).all()
+    n_d, n_s = pkg["visibility_filter_d"].numel(), pkg["visibility_filter_s"].numel()
+    assert n_d + n_s == 3000 and 0 < n_d < 3000
+    assert int(pkg["visibility_filter_d"].sum()) + int(pkg["visibility_filter_s"].sum()) == int(pkg["visibility_filter"].sum())
