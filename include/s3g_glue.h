@@ -20,7 +20,7 @@ extern "C" {
 /* All device fp32.  f_dc [P,1,3], f_rest [P,15,3], dshs [P,16,3] or NULL, xyz [P,3], campos [3],
  * log_scales [P,3], rot_raw [P,4], opacity_logit [P]  ->  colors [P,3], scales [P,3], rot [P,4], opacity [P].
  * dshs_abs_sum (slotted accumulator of S3G_SUM_DOUBLES doubles as in s3g_loss.h, caller zeroes, may be NULL): += sum |dshs| -- the numerator of the reference's
- * lambda_dshs * mean|dshs| regulariser (/root/reference/train.py:400-403), taken while dshs streams through anyway. */
+ * lambda_dshs * mean|dshs| regulariser (/root/reference/train.py:407-410), taken while dshs streams through anyway. */
 int s3g_glue_forward(int P, int deg, const float* f_dc, const float* f_rest, const float* dshs, const float* xyz,
                      const float* campos, const float* log_scales, const float* rot_raw, const float* opacity_logit,
                      float* colors, float* scales, float* rot, float* opacity, double* dshs_abs_sum, void* stream);

@@ -15,7 +15,7 @@ struct GlueArgs {
   // backward only
   const float *g_colors, *g_scales, *g_rot, *g_opacity;
   float *g_f_dc, *g_f_rest, *g_dshs, *g_xyz, *g_log_scales, *g_rot_raw, *g_opacity_logit;
-  // optional L1 regulariser on dshs (train.py:400-403: lambda_dshs * mean|dshs|), folded in because both kernels stream
+  // optional L1 regulariser on dshs (train.py:407-410: lambda_dshs * mean|dshs|), folded in because both kernels stream
   // dshs anyway: forward accumulates sum|dshs|, backward adds (*g_dshs_l1 / (48 P)) * sign(dshs)
   double* dshs_abs_sum;
   const float* g_dshs_l1;

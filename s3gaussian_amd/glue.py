@@ -79,6 +79,6 @@ class _Glue(torch.autograd.Function):
 
 def activations_and_colors(deg, f_dc, f_rest, dshs, xyz, campos, log_scales, rot_raw, opacity_logit, with_dshs_l1=False):
     """-> (colors_precomp [P,3], scales [P,3], rotations [P,4], opacity [P,1]); dshs may be None (coarse stage).
-    with_dshs_l1=True appends mean|dshs| (the train.py:400-403 regulariser, differentiable) computed in the same pass."""
+    with_dshs_l1=True appends mean|dshs| (the train.py:407-410 regulariser, differentiable) computed in the same pass."""
     out = _Glue.apply(deg, f_dc, f_rest, dshs, xyz, campos, log_scales, rot_raw, opacity_logit, with_dshs_l1)
     return out if with_dshs_l1 else out[:4]

@@ -41,7 +41,7 @@ def test_glue_forward_backward_vs_restatement(gpu_device, deg, with_dshs):
     def run(dev, fused):
         L = [leaf(t, dev) for t in (f_dc, f_rest, dshs, xyz, ls, rr, ol)]
         a, b, d, x, s_, r_, o_ = L
-        # with dshs present the lambda_dshs * mean|dshs| regulariser (train.py:400-403) rides along in the fused pass
+        # with dshs present the lambda_dshs * mean|dshs| regulariser (train.py:407-410) rides along in the fused pass
         if fused:
             outs = activations_and_colors(deg, a, b, d if with_dshs else None, x, campos.to(dev), s_, r_, o_,
                                           with_dshs_l1=with_dshs)
