@@ -33,7 +33,7 @@ typedef struct s3g_hexplane_desc {
   const float* planes[S3G_HEX_MAX_LEVELS][6];/* device, channel-last [res[c1]][res[c0]][32] */
   float aabb_max[3], aabb_min[3];            /* aabb[0], aabb[1] */
   int uniform_time;                          /* != 0: the caller guarantees time[i] == time[0] for every point -- how
-                                              * render() always calls the field (gaussian_renderer/__init__.py:66:
+                                              * render() always calls the field (gaussian_renderer/__init__.py:58:
                                               * one camera timestamp repeated P times).  The three time planes of a level
                                               * are then pre-interpolated along t into 1-D row tables once per call and
                                               * sampled with 2 taps instead of 4. */

@@ -109,7 +109,7 @@ def test_render_fused_and_unfused_paths_agree(gpu_device):
 
 
 def test_coarse_stage_render_and_step(gpu_device):
-    """Coarse stage (train.py's first phase: deformation network bypassed, gaussian_renderer/__init__.py:80-83): the fused
+    """Coarse stage (train.py's first phase: deformation network bypassed, gaussian_renderer/__init__.py:82-84): the fused
     glue path equals the step-by-step path (activations + eval_sh evaluated by torch), the deformation parameters get no
     gradient, and a full training_step runs (single-image raster path: there is no feature render in this stage)."""
     from types import SimpleNamespace
