@@ -378,24 +378,51 @@ __global__ void __launch_bounds__(WG_WAVES * 64) mlp_wgrad_kernel(const WgradArg
   const int ntiles = (a.P + MT - 1) / MT;
   const int stride = gridDim.x * WG_WAVES;
   float gv[STEPS][GV], av[STEPS][AV];
+  // GW == 3 (the dx / feat heads): a tile's 32 x 3 gradient block is 384 contiguous bytes -- two coalesced 4-byte loads per
+  // lane (lanes 0..47) instead of 16 three-lane loads; the MFMA operand of step s is then picked out with two ds_bpermute.
+  float2 g3 = make_float2(0.f, 0.f);
+  auto load_g3 = [&](int t) {
+    const long long e0 = (long long)t * (MT * 3) + 2 * lane, lim = (long long)a.P * 3;  // element index of .x
+    float2 v = make_float2(0.f, 0.f);
+    if (lane < 48) {  // two 4-byte loads with clamped indices (branch-free inside: the load count stays static)
+      const long long top = lim - 1;
+      v.x = a.G[e0 < top ? e0 : top];
+      v.y = a.G[e0 + 1 < top ? e0 + 1 : top];
+      v.x = e0 < lim ? v.x : 0.f;
+      v.y = e0 + 1 < lim ? v.y : 0.f;
+    }
+    return v;
+  };
+  auto pick_g3 = [&](float2 v, int s) {  // G[p0 + 2s + k][i] for lanes i < 3
+    const int e = 6 * s + 3 * k + (i < 3 ? i : 0);
+    const float x = __shfl(v.x, e >> 1), y = __shfl(v.y, e >> 1);
+    return i < 3 ? ((e & 1) ? y : x) : 0.f;
+  };
   int tile = blockIdx.x * WG_WAVES + wave;
   if (tile < ntiles) {
+    if constexpr (GW == 3) g3 = load_g3(tile);
 #pragma unroll
     for (int s = 0; s < STEPS; s++) {
-      row_load<GW, false>(gv[s], a.G, tile * MT + 2 * s + k, a.P, i);
+      if constexpr (GW != 3) row_load<GW, false>(gv[s], a.G, tile * MT + 2 * s + k, a.P, i);
       row_load<AW, RELU_A, ASTRIDE>(av[s], a.A, tile * MT + 2 * s + k, a.P, i);
     }
   }
   for (; tile < ntiles; tile += stride) {
     const int np0 = (tile + stride) * MT;  // rows past P load as zeros
+    float2 g3cur = g3;
+    if constexpr (GW == 3) g3 = load_g3(tile + stride);
 #pragma unroll
     for (int s = 0; s < STEPS; s++) {
       float ga[GV], ba[AV];
+      if constexpr (GW == 3) {
+        ga[0] = pick_g3(g3cur, s);
+      } else {
 #pragma unroll
-      for (int m = 0; m < GV; m++) ga[m] = gv[s][m];
+        for (int m = 0; m < GV; m++) ga[m] = gv[s][m];
+      }
 #pragma unroll
       for (int n = 0; n < AV; n++) ba[n] = av[s][n];
-      row_load<GW, false>(gv[s], a.G, np0 + 2 * s + k, a.P, i);
+      if constexpr (GW != 3) row_load<GW, false>(gv[s], a.G, np0 + 2 * s + k, a.P, i);
       row_load<AW, RELU_A, ASTRIDE>(av[s], a.A, np0 + 2 * s + k, a.P, i);
 #pragma unroll
       for (int m = 0; m < GV; m++) {
