@@ -587,7 +587,7 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
   a.d = *d; a.P = P; a.xyz = xyz; a.time = time; a.feat = features; a.proc_order = proc_order;
   TimeRows rows;
   if (d->uniform_time) use_time_rows(a, rows, (float*)workspace, nullptr, (hipStream_t)stream_);
-  const int blocks = min((P + 31) / 32, 256 * 16);
+  const int blocks = (P + 31) / 32;  // one group of 32 points per workgroup measured best (0.567 -> 0.535 ms vs a 4096 cap)
   profile_begin(S3G_PROFILE_HEXPLANE_FORWARD, (hipStream_t)stream_);
   hipLaunchKernelGGL(hexplane_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
   profile_end(S3G_PROFILE_HEXPLANE_FORWARD, (hipStream_t)stream_, (double)P, (double)d->levels);
@@ -659,7 +659,7 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     use_time_rows(a, rows, tables, tables + nt, stream);
   }
   a.proc_order = w.order;
-  const int blocks = min((P + 31) / 32, 256 * 16);
+  const int blocks = (P + 31) / 32;
   profile_begin(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream);
   hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3(blocks), dim3(256), 0, stream, a, G, w.rank);
   profile_end(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream, (double)P, (double)d->levels);
