@@ -10,10 +10,11 @@
 //   1. the six geometry sums are re-associated so that everything depending only on the Gaussian (conic, opacity,
 //      0.5*W) is factored out of the pixel sum: with v = dL/dalpha * G the kernel accumulates
 //      S0=sum v, Sx=sum v*dx, Sy=sum v*dy, Sxx=sum v*dx*dx, Sxy=sum v*dx*dy, Syy=sum v*dy*dy (+3 colour, +1 depth);
-//   2. each of the 10 sums is reduced across the 64 lanes of a wave with DPP row-shift/broadcast adds (no LDS, no
-//      shuffles through memory), skipped outright when no lane of the wave is touched by the Gaussian;
-//   3. the 4 waves of the tile park their sums in per-wave LDS slots, added in fixed order (no float atomics anywhere);
-//   4. once per 64-Gaussian batch each lane owns one Gaussian and stores its 10 sums as one 40-byte record at the
+//   2. each of the 10 sums is reduced across the 16 lanes of a row with DPP row-shift adds (no shuffles through memory),
+//      skipped outright when no lane of the wave is touched by the Gaussian;
+//   3. the 16 lane-rows of the tile (4 waves x 4 rows) park their sums in LDS slots, added in fixed order (no float atomics
+//      anywhere);
+//   4. once per 32-Gaussian batch each lane owns one Gaussian and stores its 10 sums as one 40-byte record at the
 //      instance's position in the sorted list (coalesced: consecutive lanes -> consecutive records);
 //   5. geometry_backward_kernel gathers each Gaussian's records through slot_pos[] (the instance -> position map
 //      the forward's sort emitted), applies the factored-out coefficients and runs the per-Gaussian chain.
@@ -37,6 +38,17 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
+// Sum within each row of 16 lanes only (4 DPP adds; lane 15 of every row holds its row's total).  The blend backward stops
+// here and parks the four row totals in LDS: the two row_bcast steps that finish a wave total cost three instructions each
+// (zero, v_mov_dpp, add) per value -- 78 of the ~240 VALU instructions of a (Gaussian, wave) visit in a VALU-bound kernel.
+__device__ __forceinline__ float row_sum_lane15(float v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  return v;
+}
+
 // record layout (NREC floats): dcolor r,g,b | ddepth | S0 | Sx | Sy | Sxx | Sxy | Syy   [| dcolor2 r,g,b | pad]
 //
 // NX = 3: TWO images blended from the same geometry (the RGB+depth render and the feature render of one iteration,
@@ -53,11 +65,12 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                       const float* __restrict__ dL_dpixel_depths, float* __restrict__ records /*[R][NR]*/,
                       const float* __restrict__ colors2, const float* __restrict__ dL_dpixels2) {
-  constexpr uint32_t BATCH = 64;  // Gaussians staged per round (64 measured 2-3 % faster than 128: twice the workgroups per CU)
+  constexpr uint32_t BATCH = 32;  // Gaussians staged per round
   constexpr int NR = NX ? NREC + 4 : NREC;
+  constexpr int SLOTS = 16;       // 4 waves x 4 rows of 16 lanes
   __shared__ StagedGaussian sg[BATCH];
   __shared__ float4 sg2[NX ? BATCH : 1];  // second image's colour
-  __shared__ float acc[4][NR][BATCH];  // one slot per wave: combined in fixed order -> bit-reproducible sums
+  __shared__ float acc[SLOTS][NR][BATCH];  // one slot per (wave, row): combined in fixed order -> bit-reproducible sums
 
   const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= (uint32_t)tiles) return;
@@ -97,7 +110,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
   for (uint32_t done_cnt = 0; done_cnt < hi; done_cnt += BATCH) {
     const uint32_t cnt = min(BATCH, hi - done_cnt);
     __syncthreads();  // previous batch fully consumed (sg, acc)
-    for (uint32_t e = tid; e < 4 * NR * BATCH; e += 256) (&acc[0][0][0])[e] = 0.f;
+    for (uint32_t e = tid; e < SLOTS * NR * BATCH; e += 256) (&acc[0][0][0])[e] = 0.f;
     if ((uint32_t)tid < cnt) {
       const uint32_t pos = hi - 1 - (done_cnt + tid);  // back to front
       const uint32_t id = point_list[rg.x + pos];
@@ -157,13 +170,13 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
         const float vx = v * dx, vy = v * dy;
         s0 = v; sx = vx; sy = vy; sxx = vx * dx; sxy = vx * dy; syy = vy * dy;
       }
-      // wave-uniform from here: all 64 lanes take part in the DPP reductions
-      p_r = wave_sum_lane63(p_r); p_g = wave_sum_lane63(p_g); p_b = wave_sum_lane63(p_b); p_d = wave_sum_lane63(p_d);
-      s0 = wave_sum_lane63(s0); sx = wave_sum_lane63(sx); sy = wave_sum_lane63(sy);
-      sxx = wave_sum_lane63(sxx); sxy = wave_sum_lane63(sxy); syy = wave_sum_lane63(syy);
-      if (NX) { p2_r = wave_sum_lane63(p2_r); p2_g = wave_sum_lane63(p2_g); p2_b = wave_sum_lane63(p2_b); }
-      if (lane == 63) {
-        float* aw = &acc[wave][0][j];
+      // wave-uniform from here: all 64 lanes take part in the DPP reductions (within rows of 16 lanes)
+      p_r = row_sum_lane15(p_r); p_g = row_sum_lane15(p_g); p_b = row_sum_lane15(p_b); p_d = row_sum_lane15(p_d);
+      s0 = row_sum_lane15(s0); sx = row_sum_lane15(sx); sy = row_sum_lane15(sy);
+      sxx = row_sum_lane15(sxx); sxy = row_sum_lane15(sxy); syy = row_sum_lane15(syy);
+      if (NX) { p2_r = row_sum_lane15(p2_r); p2_g = row_sum_lane15(p2_g); p2_b = row_sum_lane15(p2_b); }
+      if ((lane & 15) == 15) {
+        float* aw = &acc[wave * 4 + (lane >> 4)][0][j];
         aw[0 * BATCH] = p_r; aw[1 * BATCH] = p_g; aw[2 * BATCH] = p_b; aw[3 * BATCH] = p_d; aw[4 * BATCH] = s0;
         aw[5 * BATCH] = sx; aw[6 * BATCH] = sy; aw[7 * BATCH] = sxx; aw[8 * BATCH] = sxy; aw[9 * BATCH] = syy;
         if (NX) { aw[10 * BATCH] = p2_r; aw[11 * BATCH] = p2_g; aw[12 * BATCH] = p2_b; }
@@ -176,8 +189,12 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
       float2* rec = reinterpret_cast<float2*>(records + (size_t)(rg.x + pos) * NR);
 #pragma unroll
       for (int k = 0; k < NR / 2; k++) {
-        const float lo = ((acc[0][2 * k][tid] + acc[1][2 * k][tid]) + acc[2][2 * k][tid]) + acc[3][2 * k][tid];
-        const float hi2 = ((acc[0][2 * k + 1][tid] + acc[1][2 * k + 1][tid]) + acc[2][2 * k + 1][tid]) + acc[3][2 * k + 1][tid];
+        float lo = acc[0][2 * k][tid], hi2 = acc[0][2 * k + 1][tid];
+#pragma unroll
+        for (int q = 1; q < SLOTS; q++) {  // fixed order: rows of wave 0, then wave 1, ...
+          lo += acc[q][2 * k][tid];
+          hi2 += acc[q][2 * k + 1][tid];
+        }
         rec[k] = make_float2(lo, hi2);
       }
     }
