@@ -126,6 +126,16 @@ int s3g_raster_backward2(const s3g_raster_inputs* in, const float* colors2, int 
                          float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dscale, float* dL_drot,
                          void* stream);
 
+/* Exact (tile, Gaussian) culling at binning time, ON by default.  The reference bins a Gaussian into every tile of the
+ * bounding square of its 3-sigma radius (auxiliary.h:46-56, rasterizer_impl.cu:88-115); tiles in which it cannot reach
+ * alpha >= 1/255 on any pixel are evaluated and discarded pixel by pixel (forward.cu:330-341).  With culling on, such
+ * (tile, Gaussian) instances are never created: images, depths, radii and every gradient are unchanged bit for bit, only
+ * num_rendered and the private per-tile lists shrink (half the instances at BASELINE cfg3).  s3g_raster_set_exact_cull(0)
+ * restores the reference's bounding-square binning (used by the tests that compare the lists with the oracle).
+ * Process-wide; applies to forwards issued after the call. */
+void s3g_raster_set_exact_cull(int on);
+int s3g_raster_get_exact_cull(void);
+
 /* present[P] (uint8 0/1) = in_frustum (auxiliary.h:139-164: view-space z > 0.2). */
 int s3g_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);

@@ -37,5 +37,9 @@ def decode_image(buf: torch.Tensor, W: int, H: int) -> dict:
 
 
 def decode_binning(buf: torch.Tensor, R: int) -> dict:
+    """slot_pos is the last array: one entry per tile of every Gaussian's rect (S >= R entries, -1 = culled tile)."""
     c = _Carver(buf)
-    return dict(keys=c.take(R, torch.int64), point_list=c.take(R, torch.int32), slot_pos=c.take(R, torch.int32))
+    keys, point_list = c.take(R, torch.int64), c.take(R, torch.int32)
+    c.off = (c.off + 127) & ~127
+    slot_pos = buf[c.off:c.off + ((buf.numel() - c.off) // 4) * 4].view(torch.int32)
+    return dict(keys=keys, point_list=point_list, slot_pos=slot_pos)

@@ -66,6 +66,9 @@ def lib() -> C.CDLL:
     L.s3g_raster_forward2.restype = C.c_int
     L.s3g_raster_forward2.argtypes = [C.POINTER(RasterInputs), vp, RESIZE_FN, vp, RESIZE_FN, vp, RESIZE_FN, vp, vp, vp, vp, vp,
                                       C.POINTER(C.c_int), vp]
+    L.s3g_raster_set_exact_cull.restype = None
+    L.s3g_raster_set_exact_cull.argtypes = [C.c_int]
+    L.s3g_raster_get_exact_cull.restype = C.c_int
     L.s3g_raster_backward2.restype = C.c_int
     L.s3g_raster_backward2.argtypes = [C.POINTER(RasterInputs), vp, C.c_int] + [vp] * 19
     L.s3g_raster_backward2_workspace_bytes.restype = C.c_size_t
@@ -84,4 +87,4 @@ def check(code: int) -> None:
         raise RuntimeError(f"libs3g error {code}: {msg}")
 
 
-EXPORTED_SYMBOLS = ["s3g_raster_forward", "s3g_raster_forward_reuse", "s3g_raster_forward2", "s3g_raster_backward", "s3g_raster_backward_workspace_bytes", "s3g_raster_backward2", "s3g_raster_backward2_workspace_bytes", "s3g_hexplane_forward_workspace_bytes", "s3g_knn_workspace_bytes", "s3g_knn_mean_dist2", "s3g_hexplane_forward", "s3g_hexplane_backward", "s3g_hexplane_backward_workspace_bytes", "s3g_profile_enable", "s3g_profile_read", "s3g_ssim_forward", "s3g_ssim_backward", "s3g_plane_regulation", "s3g_pixel_losses_forward", "s3g_pixel_losses_combine", "s3g_pixel_losses_backward", "s3g_glue_forward", "s3g_glue_backward", "s3g_deform_mlp_forward", "s3g_deform_mlp_backward", "s3g_deform_mlp_stash_bytes", "s3g_deform_mlp_pack_bytes", "s3g_adam_step", "s3g_mark_visible", "s3g_last_error", "s3g_abi_version"]
+EXPORTED_SYMBOLS = ["s3g_raster_forward", "s3g_raster_forward_reuse", "s3g_raster_forward2", "s3g_raster_backward", "s3g_raster_backward_workspace_bytes", "s3g_raster_backward2", "s3g_raster_backward2_workspace_bytes", "s3g_hexplane_forward_workspace_bytes", "s3g_knn_workspace_bytes", "s3g_knn_mean_dist2", "s3g_hexplane_forward", "s3g_hexplane_backward", "s3g_hexplane_backward_workspace_bytes", "s3g_profile_enable", "s3g_profile_read", "s3g_ssim_forward", "s3g_ssim_backward", "s3g_plane_regulation", "s3g_pixel_losses_forward", "s3g_pixel_losses_combine", "s3g_pixel_losses_backward", "s3g_glue_forward", "s3g_glue_backward", "s3g_deform_mlp_forward", "s3g_deform_mlp_backward", "s3g_deform_mlp_stash_bytes", "s3g_deform_mlp_pack_bytes", "s3g_adam_step", "s3g_mark_visible", "s3g_raster_set_exact_cull", "s3g_raster_get_exact_cull", "s3g_last_error", "s3g_abi_version"]

@@ -121,13 +121,15 @@ struct ImageState {
 struct BinningState {
   uint64_t* keys;        // [R]  (depth bits << 32 | gaussian index), sorted ascending inside each tile range
   uint32_t* point_list;  // [R]  gaussian index, tile-major, front-to-back
-  uint32_t* slot_pos;    // [R]  slot_pos[gauss_off[g] + k] = position in point_list of g's k-th tile (row-major in its rect)
-  static BinningState carve(void* p, size_t R, size_t* bytes) {
+  uint32_t* slot_pos;    // [S]  slot_pos[gauss_off[g] + k] = position in point_list of g's k-th tile (row-major in its rect),
+                         //      0xffffffff if that tile was culled.  S = sum of rect areas >= R; LAST in the arena so that
+                         //      code which only knows R (backward, reuse) still finds it.
+  static BinningState carve(void* p, size_t R, size_t S, size_t* bytes) {
     Carver c(p);
     BinningState b;
     b.keys = c.take<uint64_t>(R);
     b.point_list = c.take<uint32_t>(R);
-    b.slot_pos = c.take<uint32_t>(R);
+    b.slot_pos = c.take<uint32_t>(S);
     if (bytes) *bytes = c.bytes();
     return b;
   }

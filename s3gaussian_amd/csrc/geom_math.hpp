@@ -93,6 +93,39 @@ struct StagedGaussian {  // 48 B, three ds_read_b128
   float4 c;              // g, b, conic.x, conic.y       (un-scaled conic only used by the backward epilogue)
 };
 
+// Can this Gaussian put alpha >= 1/255 on ANY pixel of tile (tx, ty)?  The reference bins a Gaussian into every tile of
+// the bounding square of its 3-sigma radius (auxiliary.h:46-56 getRect); an elongated Gaussian never touches most of them
+// (half of all instances at cfg3), yet every pixel of those tiles evaluates it and throws the result away
+// (forward.cu:330-341: `if (alpha < 1/255) continue`).  The test minimises the quadratic form q = a dx^2 + 2 b dx dy + c dy^2
+// over the tile's rectangle of pixel centres (closed box, so at least as small as the minimum over the lattice): zero if
+// the mean is inside, otherwise attained on one of the four edges; the tile is dropped only if
+// 0.5 * q_min > ln(255 o) padded by 0.1 % + 1e-5 (alpha <= (1/255)(1 - 1e-5) everywhere), so rounding can never drop a
+// pixel the exact test would keep.  o < 1/255 never passes (power <= 0); a degenerate conic keeps every tile.
+__device__ __forceinline__ float edge_min_q(float X, float a, float b, float c, float lo, float hi) {
+  // min over y in [lo, hi] of a X^2 + 2 b X y + c y^2
+  float y = -(b * X) / c;
+  y = fminf(hi, fmaxf(lo, y));
+  return a * X * X + 2.f * b * X * y + c * y * y;
+}
+__device__ __forceinline__ bool tile_can_contribute(float2 m, float4 co, int tx, int ty, int W, int H) {
+  const float a = co.x, b = co.y, c = co.z, o = co.w;
+  const float det = a * c - b * b;
+  if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f) || !(o == o)) return true;
+  const float L = __logf(255.0f * o);
+  if (L < 0.f) return false;
+  const float budget = 2.0f * (L * 1.001f + 1.0e-5f);  // keep the tile iff q_min <= budget
+  // d = mean - pixel; pixel centres span [x0, x1] x [y0, y1], widened by 0.01 px
+  const float x0 = (float)(tx * TILE_X) - 0.01f, x1 = (float)min(tx * TILE_X + TILE_X - 1, W - 1) + 0.01f;
+  const float y0 = (float)(ty * TILE_Y) - 0.01f, y1 = (float)min(ty * TILE_Y + TILE_Y - 1, H - 1) + 0.01f;
+  const float dx_lo = m.x - x1, dx_hi = m.x - x0, dy_lo = m.y - y1, dy_hi = m.y - y0;
+  if (dx_lo <= 0.f && dx_hi >= 0.f && dy_lo <= 0.f && dy_hi >= 0.f) return true;  // mean inside the tile
+  float q = edge_min_q(dx_lo, a, b, c, dy_lo, dy_hi);
+  q = fminf(q, edge_min_q(dx_hi, a, b, c, dy_lo, dy_hi));
+  q = fminf(q, edge_min_q(dy_lo, c, b, a, dx_lo, dx_hi));
+  q = fminf(q, edge_min_q(dy_hi, c, b, a, dx_lo, dx_hi));
+  return q <= budget;
+}
+
 __device__ __forceinline__ float gaussian_exponent2(float dx, float dy, float qa, float qb, float qc) {
   float q = (qb * dx) * dy;
   q = __builtin_fmaf(qc * dy, dy, q);

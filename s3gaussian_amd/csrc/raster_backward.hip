@@ -536,7 +536,7 @@ static int raster_backward_impl(const char* who, const s3g_raster_inputs* in, co
   const bool debug = in->debug != 0;
   GeomState g = GeomState::carve(const_cast<void*>(geometry_arena), P, nullptr);
   ImageState im = ImageState::carve(const_cast<void*>(image_arena), (size_t)W * H, tiles, bin_blocks(P), nullptr);
-  BinningState b = BinningState::carve(const_cast<void*>(binning_arena), (size_t)(R > 0 ? R : 0), nullptr);
+  BinningState b = BinningState::carve(const_cast<void*>(binning_arena), (size_t)(R > 0 ? R : 0), 0, nullptr);
   float* records = reinterpret_cast<float*>(workspace);
 
   const float* color_ptr = in->colors_precomp ? in->colors_precomp : g.rgb;

@@ -34,6 +34,10 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Exact (tile, Gaussian) culling at binning time (geom_math.hpp::tile_can_contribute); on by default, switchable so the
+// instance lists can be compared bit for bit with the reference's bounding-square binning.
+static bool g_exact_cull = true;
+
 // ---- in-library kernel timing -----------------------------------------------------------------------------
 struct ProfRec { hipEvent_t a, b; double instances, pixels; };
 static bool g_prof_on = false;
@@ -199,6 +203,10 @@ struct BinArgs {
   const uint2* ranges;             // bin_write only
   uint64_t* keys;                  // bin_write only
   uint32_t* gauss_off;             // bin_write only
+  // exact (tile, Gaussian) culling (geom_math.hpp::tile_can_contribute); cull == 0: the reference's bounding square
+  int cull, W, H;
+  const float2* means2D;
+  const float4* conic_opacity;
 };
 
 template <bool WRITE>
@@ -220,8 +228,11 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
     const int w = (int)r.z - (int)r.x, h = (int)r.w - (int)r.y;
     const uint32_t area = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
     uint64_t key = 0;
+    float2 gm = make_float2(0.f, 0.f);
+    float4 gco = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.cull && area) { gm = a.means2D[g]; gco = a.conic_opacity[g]; }
     if (WRITE) {
-      // block-wide exclusive scan of area -> gauss_off
+      // block-wide exclusive scan of area -> gauss_off (slots are counted per rect tile whether or not it survives)
       uint32_t incl = area;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
@@ -247,6 +258,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
     if (area != 0 && area <= BIG_RECT) {
       for (int y = r.y; y < r.w; y++)
         for (int x = r.x; x < r.z; x++) {
+          if (a.cull && !tile_can_contribute(gm, gco, x, y, a.W, a.H)) continue;
           const uint32_t pos = atomicAdd(&cell[y * a.gx + x], 1u);
           if (WRITE) a.keys[pos] = key;
         }
@@ -258,8 +270,11 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
       const int bx = __shfl((int)r.x, src), by = __shfl((int)r.y, src), bw = __shfl(w, src);
       const uint32_t barea = (uint32_t)__shfl((int)area, src);
       const uint32_t klo = (uint32_t)__shfl((int)(uint32_t)key, src), khi = (uint32_t)__shfl((int)(uint32_t)(key >> 32), src);
+      const float2 bm = make_float2(__shfl(gm.x, src), __shfl(gm.y, src));
+      const float4 bco = make_float4(__shfl(gco.x, src), __shfl(gco.y, src), __shfl(gco.z, src), __shfl(gco.w, src));
       for (uint32_t k = lane; k < barea; k += 64) {
         const int ty = by + (int)(k / (uint32_t)bw), tx = bx + (int)(k % (uint32_t)bw);
+        if (a.cull && !tile_can_contribute(bm, bco, tx, ty, a.W, a.H)) continue;
         const uint32_t pos = atomicAdd(&cell[ty * a.gx + tx], 1u);
         if (WRITE) a.keys[pos] = ((uint64_t)khi << 32) | klo;
       }
@@ -295,7 +310,7 @@ __global__ void __launch_bounds__(256) bin_scan_kernel(int tiles, int nb, uint32
   tile_count[t] = run;
 }
 
-// Exclusive scan over tiles: ranges[t] = [start, end); ctrl[0] = R, ctrl[1] = longest tile list; also turns
+// Exclusive scan over tiles: ranges[t] = [start, end); ctrl[0] = R, ctrl[1] = longest tile list, ctrl[3] = slots; also turns
 // chunk_total[nb] into its exclusive prefix.  One 1024-thread workgroup; tiles is O(10^3..10^4), nb <= 1024.
 __device__ __forceinline__ uint32_t block_inclusive_scan_1024(uint32_t v, uint32_t (*buf)[1024], int tid, uint32_t* total) {
   int cur = 0;
@@ -336,6 +351,7 @@ __global__ void __launch_bounds__(1024) scan_tiles_kernel(int tiles, const uint3
     const uint32_t v = tid < nb ? chunk_total[tid] : 0u;
     const uint32_t incl = block_inclusive_scan_1024(v, buf, tid, &total);
     if (tid < nb) chunk_total[tid] = incl - v;
+    if (tid == 0) ctrl[3] = total;  // S: slots = sum of rect areas (== R without culling)
   }
   for (int off = 32; off >= 1; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off));
   if ((tid & 63) == 0) wmax[tid >> 6] = vmax;
@@ -630,6 +646,7 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   BinArgs ba;
   ba.P = P; ba.gx = gx; ba.tiles = tiles; ba.chunk = chunk; ba.rect = g.rect; ba.depths = g.depths;
   ba.table = im.table; ba.chunk_total = im.chunk_total; ba.ranges = im.ranges; ba.keys = nullptr; ba.gauss_off = g.gauss_off;
+  ba.cull = g_exact_cull ? 1 : 0; ba.W = W; ba.H = H; ba.means2D = g.means2D; ba.conic_opacity = g.conic_opacity;
   hipLaunchKernelGGL(bin_kernel<false>, dim3(nb), dim3(BIN_THREADS), bin_lds, stream, ba);
   S3G_KERNEL_CHECK(stream, debug);
   hipLaunchKernelGGL(bin_scan_kernel, dim3((tiles + 255) / 256), dim3(256), 0, stream, tiles, nb, im.table, im.tile_count);
@@ -641,9 +658,9 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   // the one host sync of the forward (reference: rasterizer_impl.cu:282): R sizes the binning arena
   static thread_local uint32_t* h_ctrl = nullptr;
   if (!h_ctrl) S3G_HIP_CHECK(hipHostMalloc((void**)&h_ctrl, 8 * sizeof(uint32_t), hipHostMallocDefault));
-  S3G_HIP_CHECK(hipMemcpyAsync(h_ctrl, im.ctrl, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  S3G_HIP_CHECK(hipMemcpyAsync(h_ctrl, im.ctrl, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   S3G_HIP_CHECK(hipStreamSynchronize(stream));
-  const uint32_t R = h_ctrl[0], max_tile = h_ctrl[1];
+  const uint32_t R = h_ctrl[0], max_tile = h_ctrl[1], S = h_ctrl[3];
   if (h_ctrl[2] & 1u) {
     set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
     return S3G_ERR_PREFILTERED;
@@ -655,13 +672,14 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   *num_rendered = (int)R;
 
   size_t bin_bytes = 0;
-  BinningState::carve(nullptr, R, &bin_bytes);
+  BinningState::carve(nullptr, R, S, &bin_bytes);
   void* bin_p = binning_buffer(binning_user, bin_bytes);
   if (!bin_p && R > 0) {
     set_error("resize callback returned NULL");
     return S3G_ERR_ALLOC;
   }
-  BinningState b = BinningState::carve(bin_p, R, nullptr);
+  BinningState b = BinningState::carve(bin_p, R, S, nullptr);
+  if (S > 0) S3G_HIP_CHECK(hipMemsetAsync(b.slot_pos, 0xff, (size_t)S * sizeof(uint32_t), stream));  // culled slots
 
   const uint32_t tile_blocks = round_up8((uint32_t)tiles);
   if (R > 0) {
@@ -741,7 +759,7 @@ extern "C" int s3g_raster_forward_reuse(const s3g_raster_inputs* in, int R, cons
   const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y, tiles = gx * gy;
   GeomState g = GeomState::carve(const_cast<void*>(geometry_arena), P, nullptr);
   ImageState im = ImageState::carve(image_arena, (size_t)W * H, tiles, bin_blocks(P), nullptr);
-  BinningState b = BinningState::carve(const_cast<void*>(binning_arena), (size_t)(R > 0 ? R : 0), nullptr);
+  BinningState b = BinningState::carve(const_cast<void*>(binning_arena), (size_t)(R > 0 ? R : 0), 0, nullptr);
   const uint32_t tile_blocks = round_up8((uint32_t)tiles);
   profile_begin(S3G_PROFILE_BLEND_FORWARD, stream);
   hipLaunchKernelGGL(blend_forward_kernel<0>, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
@@ -751,6 +769,9 @@ extern "C" int s3g_raster_forward_reuse(const s3g_raster_inputs* in, int R, cons
   S3G_KERNEL_CHECK(stream, in->debug != 0);
   return S3G_OK;
 }
+
+extern "C" void s3g_raster_set_exact_cull(int on) { g_exact_cull = on != 0; }
+extern "C" int s3g_raster_get_exact_cull(void) { return g_exact_cull ? 1 : 0; }
 
 extern "C" void s3g_profile_enable(int on) { g_prof_on = on != 0; }
 

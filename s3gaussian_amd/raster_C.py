@@ -235,6 +235,17 @@ def rasterize_gaussians_backward2(background, means3D, radii, colors, colors2, s
             v["means3D"].view(P, 3), v["cov3D"].view(P, 6), v["scales"].view(P, 3), v["rot"].view(P, 4))
 
 
+def set_exact_cull(on: bool) -> bool:
+    """Exact (tile, Gaussian) culling at binning time (include/s3g_raster.h); returns the previous setting.  Off = the
+    reference's bounding-square binning, instance lists bit-identical to it."""
+    global _geom_cache
+    L = _lib.lib()
+    prev = bool(L.s3g_raster_get_exact_cull())
+    L.s3g_raster_set_exact_cull(int(bool(on)))
+    _geom_cache = None   # cached arenas were binned under the previous setting
+    return prev
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """-> bool[P]  (RAST/rasterize_points.cu:204-223)."""
     L = _lib.lib()

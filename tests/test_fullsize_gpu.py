@@ -33,12 +33,18 @@ def _raw_forward(c, colors):
                                   cam["image_width"], e, 0, cam["campos"].to(dev), False, False)
 
 
-def test_binning_and_sort_invariants_at_full_size(cfg3):
+@pytest.mark.parametrize("cull", [True, False])
+def test_binning_and_sort_invariants_at_full_size(cfg3, cull):
     from s3gaussian_amd import _debug
     P = cfg3["xyz"].shape[0]
     H, W = cfg3["cam"]["image_height"], cfg3["cam"]["image_width"]
+    from s3gaussian_amd import raster_C
     colors = torch.rand(P, 3, device=cfg3["dev"])
-    R, color, depth, radii, geom, binning, img = _raw_forward(cfg3, colors)
+    prev = raster_C.set_exact_cull(cull)
+    try:
+        R, color, depth, radii, geom, binning, img = _raw_forward(cfg3, colors)
+    finally:
+        raster_C.set_exact_cull(prev)
     g, im, b = _debug.decode_geometry(geom, P), _debug.decode_image(img, W, H), _debug.decode_binning(binning, R)
     ranges = im["ranges"].long()
     cnt = ranges[:, 1] - ranges[:, 0]
@@ -46,7 +52,8 @@ def test_binning_and_sort_invariants_at_full_size(cfg3):
     assert torch.equal(ranges[1:, 0], ranges[:-1, 1]) and int(ranges[0, 0]) == 0 and int(ranges[-1, 1]) == R
     rect = g["rect"].long()
     touched = (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])
-    assert int(touched.sum()) == R                                   # every (Gaussian, tile) instance is binned exactly once
+    S = int(touched.sum())                                           # slots: tiles of the 3-sigma bounding squares
+    assert (R < 0.7 * S) if cull else (R == S)                       # reference binning: every slot is an instance
     assert torch.equal(touched > 0, radii > 0)
     pl = b["point_list"].long()
     keys = (g["depths"].view(torch.int32).long()[pl] << 32) | pl      # the sort key of every list entry, rebuilt
@@ -54,8 +61,9 @@ def test_binning_and_sort_invariants_at_full_size(cfg3):
     same_tile = tile_of[1:] == tile_of[:-1]
     assert bool(((keys[1:] > keys[:-1]) | ~same_tile).all())          # (depth bits << 32 | index) strictly ascending inside every tile
     assert torch.equal(torch.sort(b["keys"] & 0xFFFFFFFF).values, torch.sort(pl).values)  # same multiset as was binned
-    pos = b["slot_pos"].long()
-    assert torch.equal(torch.sort(pos).values, torch.arange(R, device=pos.device))   # instance -> position map is a permutation
+    pos = b["slot_pos"][:S].long()                                   # slot -> list position, -1 for culled tiles
+    live = pos[pos >= 0]
+    assert live.numel() == R and torch.equal(torch.sort(live).values, torch.arange(R, device=pos.device))
     T = im["final_T"]
     assert float(T.min()) >= 0.0 and float(T.max()) <= 1.0
     assert bool((im["n_contrib"].view(-1).long() <= cnt.max()).all())

@@ -96,7 +96,7 @@ def test_forward_backward_vs_oracle(gpu_device, oracle, mode, shape):
         assert rel_l2(L["shs"].grad.cpu().numpy(), rb["dL_dsh"]) <= GRAD_TOL
 
 
-def test_internal_state_bit_exact(gpu_device, oracle):
+def test_internal_state_bit_exact(gpu_device, oracle, reference_binning):
     """Geometry state, instance count and per-tile sorted lists are integer/index work: exact equality."""
     from s3gaussian_amd import _debug
     from diff_gaussian_rasterization import _C
@@ -133,7 +133,7 @@ def test_internal_state_bit_exact(gpu_device, oracle):
     np.testing.assert_array_equal(b["point_list"].cpu().numpy().astype(np.uint32), st["point_list"])
 
 
-def test_depth_ties_resolve_by_index(gpu_device, oracle):
+def test_depth_ties_resolve_by_index(gpu_device, oracle, reference_binning):
     """Equal depths: order inside a tile must be ascending Gaussian index (stable radix order of the reference)."""
     from s3gaussian_amd import _debug
     from diff_gaussian_rasterization import _C
@@ -153,7 +153,7 @@ def test_depth_ties_resolve_by_index(gpu_device, oracle):
     np.testing.assert_array_equal(pl, ref["state"]["point_list"])
 
 
-def test_long_tile_lists_use_every_sort_path(gpu_device, oracle):
+def test_long_tile_lists_use_every_sort_path(gpu_device, oracle, reference_binning):
     """> 4096 and > 16384 instances in one tile: second LDS launch and the in-global-memory network."""
     from s3gaussian_amd import _debug
     from diff_gaussian_rasterization import _C
@@ -412,3 +412,44 @@ def test_forward_pair_only_second_image_has_gradient(gpu_device):
     for a, b in zip(res[0][:6], res[1][:6]):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
     assert res[0][6] is None or float(res[0][6].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("scene", ["elongated", "round", "faint"])
+def test_exact_tile_culling_changes_nothing_but_the_lists(gpu_device, scene):
+    """Exact (tile, Gaussian) culling at binning time (include/s3g_raster.h): images, depth, radii and every gradient are
+    bit-identical to the reference's bounding-square binning; the instance list is a subset of it."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from s3gaussian_amd import _debug, raster_C
+    W, H, P = 176, 120, 3000
+    s = tiny_scene(P=P, W=W, H=H, seed=21, scale=0.08)
+    g = torch.Generator().manual_seed(4)
+    if scene == "elongated":      # needles: most tiles of the bounding square are never touched
+        s["scales"] = s["scales"] * torch.tensor([6.0, 0.15, 0.15])
+    elif scene == "faint":        # opacities around and below 1/255: some Gaussians can never pass the alpha test
+        s["opacities"] = 0.012 * torch.rand(P, 1, generator=g)
+    dev = gpu_device
+    rast = GaussianRasterizer(raster_settings=settings_from(s, dev))
+    gc, gd = grad_pair(H, W)
+    res = {}
+    for cull in (True, False):
+        prev = raster_C.set_exact_cull(cull)
+        try:
+            t = lambda k: s[k].to(dev).clone().requires_grad_(True)
+            m3, op, sc, rot, col = t("means3D"), t("opacities"), t("scales"), t("rotations"), t("colors_precomp")
+            m2 = torch.zeros_like(m3, requires_grad=True)
+            color, radii, depth = rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=col, scales=sc, rotations=rot)
+            R, geom, binning, img = raster_C._geom_cache[2][0], *raster_C._geom_cache[2][2:]
+            ((color * gc.to(dev)).sum() + (depth * gd.to(dev)).sum()).backward()
+            im = _debug.decode_image(img, W, H)
+            b = _debug.decode_binning(binning, R)
+            lists = set((int(tile), int(gid)) for tile, (lo, hi) in enumerate(im["ranges"].cpu().tolist())
+                        for gid in b["point_list"][lo:hi].cpu().tolist())
+            res[cull] = (R, [color, depth, radii], [x.grad for x in (m3, m2, op, sc, rot, col)], lists)
+        finally:
+            raster_C.set_exact_cull(prev)
+    (R1, o1, g1, l1), (R0, o0, g0, l0) = res[True], res[False]
+    for a, b in zip(o1 + g1, o0 + g0):
+        assert torch.equal(a, b)
+    assert l1 <= l0 and R1 == len(l1) and R0 == len(l0)
+    if scene != "round":
+        assert R1 < 0.8 * R0, (R1, R0)     # the cull actually removes instances
