@@ -25,7 +25,7 @@ def decode_geometry(buf: torch.Tensor, P: int) -> dict:
     return dict(depths=c.take(P, torch.float32), means2D=c.take(2 * P, torch.float32).view(P, 2),
                 conic_opacity=c.take(4 * P, torch.float32).view(P, 4), cov3D=c.take(6 * P, torch.float32).view(P, 6),
                 rgb=c.take(3 * P, torch.float32).view(P, 3), clamped=c.take(3 * P, torch.uint8).view(P, 3),
-                rect=c.take(4 * P, torch.int16).view(P, 4), gauss_off=c.take(P, torch.int32))
+                rect=c.take(4 * P, torch.int16).view(P, 4), gauss_off=c.take(P, torch.int32), tile_mask=c.take(P, torch.int32))
 
 
 def decode_image(buf: torch.Tensor, W: int, H: int) -> dict:

@@ -75,6 +75,7 @@ struct GeomState {
   uint8_t* clamped;       // [P,3]
   ushort4* rect;          // [P]   tile rect (min.x, min.y, max.x, max.y), zero area when culled
   uint32_t* gauss_off;    // [P]   exclusive scan of tiles_touched: first slot of the Gaussian in slot_pos[]
+  uint32_t* tile_mask;    // [P]   rects of <= 32 tiles: bit k = tile k (row-major in the rect) survives the exact cull
   static GeomState carve(void* p, size_t P, size_t* bytes) {
     Carver c(p);
     GeomState g;
@@ -86,6 +87,7 @@ struct GeomState {
     g.clamped = c.take<uint8_t>(P * 3);
     g.rect = c.take<ushort4>(P);
     g.gauss_off = c.take<uint32_t>(P);
+    g.tile_mask = c.take<uint32_t>(P);
     if (bytes) *bytes = c.bytes();
     return g;
   }

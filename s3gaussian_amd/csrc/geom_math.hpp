@@ -98,32 +98,42 @@ struct StagedGaussian {  // 48 B, three ds_read_b128
 // (half of all instances at cfg3), yet every pixel of those tiles evaluates it and throws the result away
 // (forward.cu:330-341: `if (alpha < 1/255) continue`).  The test minimises the quadratic form q = a dx^2 + 2 b dx dy + c dy^2
 // over the tile's rectangle of pixel centres (closed box, so at least as small as the minimum over the lattice): zero if
-// the mean is inside, otherwise attained on one of the four edges; the tile is dropped only if
+// the mean is inside, otherwise attained on the edge(s) of the box facing the mean; the tile is dropped only if
 // 0.5 * q_min > ln(255 o) padded by 0.1 % + 1e-5 (alpha <= (1/255)(1 - 1e-5) everywhere), so rounding can never drop a
 // pixel the exact test would keep.  o < 1/255 never passes (power <= 0); a degenerate conic keeps every tile.
-__device__ __forceinline__ float edge_min_q(float X, float a, float b, float c, float lo, float hi) {
-  // min over y in [lo, hi] of a X^2 + 2 b X y + c y^2
-  float y = -(b * X) / c;
-  y = fminf(hi, fmaxf(lo, y));
-  return a * X * X + 2.f * b * X * y + c * y * y;
-}
-__device__ __forceinline__ bool tile_can_contribute(float2 m, float4 co, int tx, int ty, int W, int H) {
-  const float a = co.x, b = co.y, c = co.z, o = co.w;
-  const float det = a * c - b * b;
-  if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f) || !(o == o)) return true;
+struct TileCull {      // per-Gaussian part of the test, prepared once
+  float a, b, c, inv_a, inv_c, budget, mx, my;
+  int verdict;         // 0 = test each tile, 1 = keep every tile (degenerate conic), -1 = keep none (o < 1/255)
+};
+__device__ __forceinline__ TileCull tile_cull_prepare(float2 m, float4 co) {
+  TileCull t;
+  t.a = co.x; t.b = co.y; t.c = co.z; t.mx = m.x; t.my = m.y;
+  const float o = co.w, det = t.a * t.c - t.b * t.b;
   const float L = __logf(255.0f * o);
-  if (L < 0.f) return false;
-  const float budget = 2.0f * (L * 1.001f + 1.0e-5f);  // keep the tile iff q_min <= budget
+  t.verdict = (!(det > 0.f) || !(t.a > 0.f) || !(t.c > 0.f) || !(o == o)) ? 1 : (L < 0.f ? -1 : 0);
+  t.inv_a = 1.0f / t.a; t.inv_c = 1.0f / t.c;
+  t.budget = 2.0f * (L * 1.001f + 1.0e-5f);  // keep a tile iff q_min <= budget
+  return t;
+}
+// min over y in [lo, hi] of A X^2 + 2 B X y + C y^2
+__device__ __forceinline__ float edge_min_q(float X, float A, float B, float C, float inv_C, float lo, float hi) {
+  const float y = fminf(hi, fmaxf(lo, -(B * X) * inv_C));
+  return A * X * X + 2.f * B * X * y + C * y * y;
+}
+__device__ __forceinline__ bool tile_can_contribute(const TileCull& t, int tx, int ty, int W, int H) {
+  if (t.verdict != 0) return t.verdict > 0;
   // d = mean - pixel; pixel centres span [x0, x1] x [y0, y1], widened by 0.01 px
   const float x0 = (float)(tx * TILE_X) - 0.01f, x1 = (float)min(tx * TILE_X + TILE_X - 1, W - 1) + 0.01f;
   const float y0 = (float)(ty * TILE_Y) - 0.01f, y1 = (float)min(ty * TILE_Y + TILE_Y - 1, H - 1) + 0.01f;
-  const float dx_lo = m.x - x1, dx_hi = m.x - x0, dy_lo = m.y - y1, dy_hi = m.y - y0;
-  if (dx_lo <= 0.f && dx_hi >= 0.f && dy_lo <= 0.f && dy_hi >= 0.f) return true;  // mean inside the tile
-  float q = edge_min_q(dx_lo, a, b, c, dy_lo, dy_hi);
-  q = fminf(q, edge_min_q(dx_hi, a, b, c, dy_lo, dy_hi));
-  q = fminf(q, edge_min_q(dy_lo, c, b, a, dx_lo, dx_hi));
-  q = fminf(q, edge_min_q(dy_hi, c, b, a, dx_lo, dx_hi));
-  return q <= budget;
+  const float dx_lo = t.mx - x1, dx_hi = t.mx - x0, dy_lo = t.my - y1, dy_hi = t.my - y0;
+  const bool in_x = dx_lo <= 0.f && dx_hi >= 0.f, in_y = dy_lo <= 0.f && dy_hi >= 0.f;
+  if (in_x && in_y) return true;  // mean inside the tile
+  // the nearer vertical and the nearer horizontal edge (the minimum over the box lies on one of them)
+  const float X = in_x ? 0.f : (dx_lo > 0.f ? dx_lo : dx_hi), Y = in_y ? 0.f : (dy_lo > 0.f ? dy_lo : dy_hi);
+  float q = 3.0e38f;
+  if (!in_x) q = edge_min_q(X, t.a, t.b, t.c, t.inv_c, dy_lo, dy_hi);
+  if (!in_y) q = fminf(q, edge_min_q(Y, t.c, t.b, t.a, t.inv_a, dx_lo, dx_hi));
+  return q <= t.budget;
 }
 
 __device__ __forceinline__ float gaussian_exponent2(float dx, float dy, float qa, float qb, float qc) {

@@ -97,8 +97,11 @@ __device__ __forceinline__ float3 sh_to_rgb(int idx, int deg, int M, const float
   return make_float3(res[0], res[1], res[2]);
 }
 
+constexpr int BIG_RECT = 32;  // rects of more tiles are walked by a whole wave in the binning kernels
+
 struct PreprocessArgs {
   int P, D, M, W, H, gx, gy;
+  int cull;  // exact (tile, Gaussian) culling: tile_mask is filled here for rects of <= BIG_RECT tiles
   const float* means3D;
   const float* scales;
   float scale_modifier;
@@ -177,6 +180,16 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreprocessArgs a)
   a.g.means2D[idx] = make_float2(px, py);
   a.g.conic_opacity[idx] = make_float4(conic.x, conic.y, conic.z, a.opacities[idx]);
   a.g.rect[idx] = make_ushort4((unsigned short)rx0, (unsigned short)ry0, (unsigned short)rx1, (unsigned short)ry1);
+  // exact tile culling (geom_math.hpp::tile_can_contribute) evaluated HERE, one well-occupied thread per Gaussian; the two
+  // binning passes (few fat workgroups, latency-bound) only replay the mask
+  if (a.cull && (rx1 - rx0) * (ry1 - ry0) <= BIG_RECT) {
+    const TileCull tc = tile_cull_prepare(make_float2(px, py), make_float4(conic.x, conic.y, conic.z, a.opacities[idx]));
+    uint32_t mask = 0u, bit = 1u;
+    for (int y = ry0; y < ry1; y++)
+      for (int x = rx0; x < rx1; x++, bit <<= 1)
+        if (tile_can_contribute(tc, x, y, a.W, a.H)) mask |= bit;
+    a.g.tile_mask[idx] = mask;
+  }
 }
 
 // =========================================================================================================
@@ -192,7 +205,6 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreprocessArgs a)
 //    (*) order inside a tile is arbitrary here; the per-tile sort fixes it.
 // =========================================================================================================
 constexpr int BIN_THREADS = 256;
-constexpr int BIG_RECT = 32;
 
 struct BinArgs {
   int P, gx, tiles, chunk;         // chunk = Gaussians per workgroup (multiple of BIN_THREADS)
@@ -207,6 +219,7 @@ struct BinArgs {
   int cull, W, H;
   const float2* means2D;
   const float4* conic_opacity;
+  const uint32_t* tile_mask;       // from preprocess_kernel (rects of <= BIG_RECT tiles)
 };
 
 template <bool WRITE>
@@ -228,9 +241,9 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
     const int w = (int)r.z - (int)r.x, h = (int)r.w - (int)r.y;
     const uint32_t area = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
     uint64_t key = 0;
-    float2 gm = make_float2(0.f, 0.f);
-    float4 gco = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.cull && area) { gm = a.means2D[g]; gco = a.conic_opacity[g]; }
+    TileCull tc;
+    tc.verdict = 1;
+    if (a.cull && area > BIG_RECT) tc = tile_cull_prepare(a.means2D[g], a.conic_opacity[g]);  // small rects: mask replay
     if (WRITE) {
       // block-wide exclusive scan of area -> gauss_off (slots are counted per rect tile whether or not it survives)
       uint32_t incl = area;
@@ -256,9 +269,11 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
       my_total += area;
     }
     if (area != 0 && area <= BIG_RECT) {
+      const uint32_t mask = a.cull ? a.tile_mask[g] : 0xffffffffu;  // computed by preprocess_kernel
+      uint32_t bit = 1u;
       for (int y = r.y; y < r.w; y++)
-        for (int x = r.x; x < r.z; x++) {
-          if (a.cull && !tile_can_contribute(gm, gco, x, y, a.W, a.H)) continue;
+        for (int x = r.x; x < r.z; x++, bit <<= 1) {
+          if (!(mask & bit)) continue;
           const uint32_t pos = atomicAdd(&cell[y * a.gx + x], 1u);
           if (WRITE) a.keys[pos] = key;
         }
@@ -270,11 +285,13 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
       const int bx = __shfl((int)r.x, src), by = __shfl((int)r.y, src), bw = __shfl(w, src);
       const uint32_t barea = (uint32_t)__shfl((int)area, src);
       const uint32_t klo = (uint32_t)__shfl((int)(uint32_t)key, src), khi = (uint32_t)__shfl((int)(uint32_t)(key >> 32), src);
-      const float2 bm = make_float2(__shfl(gm.x, src), __shfl(gm.y, src));
-      const float4 bco = make_float4(__shfl(gco.x, src), __shfl(gco.y, src), __shfl(gco.z, src), __shfl(gco.w, src));
+      TileCull bt;
+      bt.a = __shfl(tc.a, src); bt.b = __shfl(tc.b, src); bt.c = __shfl(tc.c, src); bt.inv_a = __shfl(tc.inv_a, src);
+      bt.inv_c = __shfl(tc.inv_c, src); bt.budget = __shfl(tc.budget, src); bt.mx = __shfl(tc.mx, src);
+      bt.my = __shfl(tc.my, src); bt.verdict = __shfl(tc.verdict, src);
       for (uint32_t k = lane; k < barea; k += 64) {
         const int ty = by + (int)(k / (uint32_t)bw), tx = bx + (int)(k % (uint32_t)bw);
-        if (a.cull && !tile_can_contribute(bm, bco, tx, ty, a.W, a.H)) continue;
+        if (a.cull && !tile_can_contribute(bt, tx, ty, a.W, a.H)) continue;
         const uint32_t pos = atomicAdd(&cell[ty * a.gx + tx], 1u);
         if (WRITE) a.keys[pos] = ((uint64_t)khi << 32) | klo;
       }
@@ -623,6 +640,7 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
 
   PreprocessArgs pa;
   pa.P = P; pa.D = in->D; pa.M = in->M; pa.W = W; pa.H = H; pa.gx = gx; pa.gy = gy;
+  pa.cull = g_exact_cull ? 1 : 0;
   pa.means3D = in->means3D; pa.scales = in->scales; pa.scale_modifier = in->scale_modifier;
   pa.rotations = in->rotations; pa.opacities = in->opacities; pa.shs = in->shs;
   pa.cov3D_precomp = in->cov3D_precomp; pa.colors_precomp = in->colors_precomp;
@@ -647,6 +665,7 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   ba.P = P; ba.gx = gx; ba.tiles = tiles; ba.chunk = chunk; ba.rect = g.rect; ba.depths = g.depths;
   ba.table = im.table; ba.chunk_total = im.chunk_total; ba.ranges = im.ranges; ba.keys = nullptr; ba.gauss_off = g.gauss_off;
   ba.cull = g_exact_cull ? 1 : 0; ba.W = W; ba.H = H; ba.means2D = g.means2D; ba.conic_opacity = g.conic_opacity;
+  ba.tile_mask = g.tile_mask;
   hipLaunchKernelGGL(bin_kernel<false>, dim3(nb), dim3(BIN_THREADS), bin_lds, stream, ba);
   S3G_KERNEL_CHECK(stream, debug);
   hipLaunchKernelGGL(bin_scan_kernel, dim3((tiles + 255) / 256), dim3(256), 0, stream, tiles, nb, im.table, im.tile_count);
