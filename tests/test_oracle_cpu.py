@@ -160,3 +160,68 @@ def test_knn_oracle_equals_brute_force(P):
         np.testing.assert_allclose(got, want, rtol=1e-6)
     else:
         assert np.all(np.isinf(got) | (got > 1e30))  # fewer than 3 neighbours: FLT_MAX sums overflow like the reference
+
+
+def _tile_can_contribute_np(mx, my, a, b, c, o, tx, ty, W, H):
+    """float32 numpy mirror of s3gaussian_amd/csrc/geom_math.hpp::tile_can_contribute (exact tile culling)."""
+    f = np.float32
+    det = f(a * c - b * b)
+    if not (det > 0 and a > 0 and c > 0 and o == o):
+        return True
+    L = f(np.log(f(255.0) * o))
+    if L < 0:
+        return False
+    budget = f(2.0) * f(L * f(1.001) + f(1.0e-5))
+    x0, x1 = f(tx * 16) - f(0.01), f(min(tx * 16 + 15, W - 1)) + f(0.01)
+    y0, y1 = f(ty * 16) - f(0.01), f(min(ty * 16 + 15, H - 1)) + f(0.01)
+    dx_lo, dx_hi, dy_lo, dy_hi = f(mx - x1), f(mx - x0), f(my - y1), f(my - y0)
+    in_x, in_y = dx_lo <= 0 <= dx_hi, dy_lo <= 0 <= dy_hi
+    if in_x and in_y:
+        return True
+
+    def edge(X, A, B, C, lo, hi):
+        y = f(min(hi, max(lo, f(-(B * X) * f(1.0 / C)))))
+        return f(A * X * X + f(2.0) * B * X * y + C * y * y)
+
+    q = f(3.0e38)
+    if not in_x:
+        q = edge(dx_lo if dx_lo > 0 else dx_hi, a, b, c, dy_lo, dy_hi)
+    if not in_y:
+        q = min(q, edge(dy_lo if dy_lo > 0 else dy_hi, c, b, a, dx_lo, dx_hi))
+    return bool(q <= budget)
+
+
+def test_exact_tile_cull_never_drops_a_contributing_pixel():
+    """The binning-time cull (include/s3g_raster.h: s3g_raster_set_exact_cull) must be conservative: whenever it drops a
+    (tile, Gaussian) pair, NO pixel centre of that tile passes the blend loops' test alpha = min(0.99, o * exp(power)) >=
+    1/255 with power <= 0 (forward.cu:330-341), evaluated here in float32 like the kernels.  Brute force over random
+    conics (round, elongated, rotated), opacities around the 1/255 threshold and all tiles of a 5 x 5 neighbourhood; also
+    checks that the cull is not vacuous."""
+    rng = np.random.default_rng(0)
+    f = np.float32
+    W, H = 200, 150                      # right / bottom tiles are partial (200 = 12.5 tiles, 150 = 9.4 tiles)
+    lat = np.arange(16, dtype=np.float32)
+    dropped = kept = 0
+    for _ in range(1500):
+        sx, sy = np.exp(rng.uniform(np.log(0.6), np.log(40.0), 2))
+        th = rng.uniform(0, np.pi)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        cov = R @ np.diag([sx * sx, sy * sy]) @ R.T + 0.3 * np.eye(2)
+        inv = np.linalg.inv(cov)
+        a, b, c = f(inv[0, 0]), f(inv[0, 1]), f(inv[1, 1])
+        o = f(rng.choice([rng.uniform(0.003, 0.006), rng.uniform(0.006, 0.05), rng.uniform(0.05, 1.0)]))
+        mx, my = f(rng.uniform(-20, W + 20)), f(rng.uniform(-20, H + 20))
+        ctx, cty = int(np.clip(mx // 16, 0, 12)), int(np.clip(my // 16, 0, 9))
+        for ty in range(max(0, cty - 2), min(10, cty + 3)):
+            for tx in range(max(0, ctx - 2), min(13, ctx + 3)):
+                px = (f(tx * 16) + lat)[(tx * 16 + lat) < W]
+                py = (f(ty * 16) + lat)[(ty * 16 + lat) < H]
+                dx, dy = (mx - px)[None, :], (my - py)[:, None]
+                power = f(-0.5) * (a * dx * dx + c * dy * dy) - b * dx * dy
+                alpha = np.minimum(f(0.99), o * np.exp(power, dtype=np.float32))
+                contributes = bool(((power <= 0) & (alpha >= f(1.0 / 255.0))).any())
+                keep = _tile_can_contribute_np(mx, my, a, b, c, o, tx, ty, W, H)
+                assert keep or not contributes, (mx, my, a, b, c, o, tx, ty)
+                dropped += not keep
+                kept += keep
+    assert dropped > 0.3 * (dropped + kept)      # the test above is not vacuous: a third of the pairs are culled
