@@ -38,7 +38,9 @@ size_t s3g_deform_mlp_stash_bytes(int P);
 size_t s3g_deform_mlp_pack_bytes(void);
 
 /* features [P,128] -> dx [P,3], dshs [P,48], feat [P,3].  `stash`: device scratch of s3g_deform_mlp_stash_bytes(P)
- * bytes when save_activations != 0 (a backward will follow), else at least s3g_deform_mlp_pack_bytes(). */
+ * bytes when save_activations != 0 (a backward will follow), else at least s3g_deform_mlp_pack_bytes().
+ * feat may be NULL when save_activations == 0: the feature (dino) head is then skipped -- a render that does not draw the
+ * feature image (gaussian_renderer/__init__.py:153, render_feat=False) has no use for it. */
 int s3g_deform_mlp_forward(const s3g_mlp_params* w, int P, const float* features, float* dx, float* dshs, float* feat,
                            float* stash, int save_activations, void* stream);
 

@@ -69,7 +69,7 @@ class Deformation(nn.Module):
         return (self.D == 1 and self.W == 64 and self.grid.feat_dim == 128 and not a.no_dx and not a.no_dshs and a.no_ds
                 and a.no_dr and a.no_do and a.feat_head)
 
-    def deform_heads(self, xyz, time, uniform_time=None, reg_weights=None):
+    def deform_heads(self, xyz, time, uniform_time=None, reg_weights=None, need_feat=True):
         """(dx [P,3], dshs [P,16,3], feat [P,3]) only -- the part of forward_dynamic that is not a pass-through in the
         reference's default configuration.  Lets a caller that fuses `shs + dshs` downstream (pipeline.render) skip
         materialising the [P,16,3] sum."""
@@ -78,7 +78,8 @@ class Deformation(nn.Module):
             feats, reg = self.grid(xyz[:, :3], time[:, :1], uniform_time, reg_weights)
         else:
             feats = self.grid(xyz[:, :3], time[:, :1], uniform_time)
-        dx, dshs, feat = deform_mlp(feats, self.feature_out, self.pos_deform, self.shs_deform, self.dino_head)
+        # need_feat=False (honoured only when no backward follows): skip the feature head, `feat` is then None
+        dx, dshs, feat = deform_mlp(feats, self.feature_out, self.pos_deform, self.shs_deform, self.dino_head, need_feat)
         out = (dx, dshs.reshape([xyz.shape[0], 16, 3]), feat)
         return out + (reg,) if reg_weights is not None else out
 

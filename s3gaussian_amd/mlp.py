@@ -47,7 +47,7 @@ def _pack(tensors) -> _Params:
 
 class _DeformMLP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, features, *params):
+    def forward(ctx, features, need_feat, *params):
         if not features.is_cuda:
             raise RuntimeError(f"deform MLP: features must live on the GPU (got {features.device}); no CPU fallback")
         L = _bind()
@@ -55,17 +55,18 @@ class _DeformMLP(torch.autograd.Function):
         P, dev = x.shape[0], x.device
         dx = torch.empty((P, 3), dtype=torch.float32, device=dev)
         dshs = torch.empty((P, 48), dtype=torch.float32, device=dev)
-        feat = torch.empty((P, 3), dtype=torch.float32, device=dev)
         need_bwd = any(ctx.needs_input_grad)
+        need_feat = bool(need_feat) or need_bwd          # the feature head is only skippable when no backward follows
+        feat = torch.empty((P, 3), dtype=torch.float32, device=dev) if need_feat else None
         nbytes = L.s3g_deform_mlp_stash_bytes(P) if need_bwd else L.s3g_deform_mlp_pack_bytes()
         stash = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         w = _pack([p.detach() for p in params])
         with torch.cuda.device(dev):
-            _lib.check(L.s3g_deform_mlp_forward(C.byref(w), P, x.data_ptr(), dx.data_ptr(), dshs.data_ptr(), feat.data_ptr(),
+            _lib.check(L.s3g_deform_mlp_forward(C.byref(w), P, x.data_ptr(), dx.data_ptr(), dshs.data_ptr(), feat.data_ptr() if feat is not None else None,
                                                 stash.data_ptr(), int(need_bwd), torch.cuda.current_stream().cuda_stream))
         if need_bwd:
             ctx.save_for_backward(x, stash, *params)
-        return dx, dshs, feat
+        return dx, dshs, feat     # feat is None when the head was skipped (need_feat=False under no_grad)
 
     @staticmethod
     def backward(ctx, g_dx, g_dshs, g_feat):
@@ -86,10 +87,10 @@ class _DeformMLP(torch.autograd.Function):
             _lib.check(L.s3g_deform_mlp_backward(C.byref(w), P, x.data_ptr(), stash.data_ptr(), g_dx.data_ptr(),
                                                  g_dshs.data_ptr(), g_feat.data_ptr(), gx.data_ptr(), C.byref(gw),
                                                  ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
-        return (gx, *grads)
+        return (gx, None, *grads)
 
 
-def deform_mlp(features, feature_out, pos_deform, shs_deform, dino_head):
+def deform_mlp(features, feature_out, pos_deform, shs_deform, dino_head, need_feat=True):
     """features [P,128] -> (dx [P,3], dshs [P,48], feat [P,3]) with the reference's Sequential modules as parameter
     holders (feature_out = Sequential(Linear); heads = Sequential(ReLU, Linear, ReLU, Linear); dino = Sequential(Linear,
     ReLU, Linear, ReLU, Linear))."""
@@ -97,4 +98,4 @@ def deform_mlp(features, feature_out, pos_deform, shs_deform, dino_head):
           pos_deform[3].bias, shs_deform[1].weight, shs_deform[1].bias, shs_deform[3].weight, shs_deform[3].bias,
           dino_head[0].weight, dino_head[0].bias, dino_head[2].weight, dino_head[2].bias, dino_head[4].weight,
           dino_head[4].bias]
-    return _DeformMLP.apply(features, *ps)
+    return _DeformMLP.apply(features, need_feat, *ps)

@@ -202,7 +202,8 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
             # sampler's node so its gradient is the seed the sampler's backward accumulates onto
             regw = ((hy.time_smoothness_weight, hy.l1_time_planes, hy.plane_tv_weight)
                     if (stage == "fine" and torch.is_grad_enabled() and hy.time_smoothness_weight != 0) else None)
-            heads = net.deform_heads(means3D, time, uniform_time=True, reg_weights=regw)
+            heads = net.deform_heads(means3D, time, uniform_time=True, reg_weights=regw,
+                                     need_feat=render_feat or torch.is_grad_enabled())
             dx, dshs, feat = heads[:3]
             plane_reg = heads[3] if regw is not None else None
             means3D_final, scales_final, rotations_final, opacity_final = means3D + dx, scales, rotations, opacity
