@@ -47,7 +47,7 @@ def _pack(tensors) -> _Params:
 
 class _DeformMLP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, features, need_feat, *params):
+    def forward(ctx, features, need_feat, grad_mode, *params):
         if not features.is_cuda:
             raise RuntimeError(f"deform MLP: features must live on the GPU (got {features.device}); no CPU fallback")
         L = _bind()
@@ -55,7 +55,9 @@ class _DeformMLP(torch.autograd.Function):
         P, dev = x.shape[0], x.device
         dx = torch.empty((P, 3), dtype=torch.float32, device=dev)
         dshs = torch.empty((P, 48), dtype=torch.float32, device=dev)
-        need_bwd = any(ctx.needs_input_grad)
+        # needs_input_grad is True for parameters even under torch.no_grad(); the caller's grad mode decides whether a
+        # backward can follow (inside Function.forward grad mode is always off)
+        need_bwd = bool(grad_mode) and any(ctx.needs_input_grad)
         need_feat = bool(need_feat) or need_bwd          # the feature head is only skippable when no backward follows
         feat = torch.empty((P, 3), dtype=torch.float32, device=dev) if need_feat else None
         nbytes = L.s3g_deform_mlp_stash_bytes(P) if need_bwd else L.s3g_deform_mlp_pack_bytes()
@@ -87,7 +89,7 @@ class _DeformMLP(torch.autograd.Function):
             _lib.check(L.s3g_deform_mlp_backward(C.byref(w), P, x.data_ptr(), stash.data_ptr(), g_dx.data_ptr(),
                                                  g_dshs.data_ptr(), g_feat.data_ptr(), gx.data_ptr(), C.byref(gw),
                                                  ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
-        return (gx, None, *grads)
+        return (gx, None, None, *grads)
 
 
 def deform_mlp(features, feature_out, pos_deform, shs_deform, dino_head, need_feat=True):
@@ -98,4 +100,4 @@ def deform_mlp(features, feature_out, pos_deform, shs_deform, dino_head, need_fe
           pos_deform[3].bias, shs_deform[1].weight, shs_deform[1].bias, shs_deform[3].weight, shs_deform[3].bias,
           dino_head[0].weight, dino_head[0].bias, dino_head[2].weight, dino_head[2].bias, dino_head[4].weight,
           dino_head[4].bias]
-    return _DeformMLP.apply(features, need_feat, *ps)
+    return _DeformMLP.apply(features, need_feat, torch.is_grad_enabled(), *ps)

@@ -109,3 +109,17 @@ def test_deformation_module_uses_fused_path_and_matches_golden(gpu_device):
     for k, p in mine.named_parameters():
         if gr[k].grad is not None:
             assert rel_l2(p.grad.cpu().numpy(), gr[k].grad.numpy()) < 1e-4, k
+
+
+def test_feature_head_can_be_skipped_for_inference(gpu_device):
+    """need_feat=False under no_grad: dx and dshs are unchanged, feat is None; with autograd on the flag is ignored."""
+    from s3gaussian_amd.mlp import deform_mlp
+    d = _modules(7).float().to(gpu_device)
+    x = torch.randn(777, 128, generator=torch.Generator().manual_seed(2)).to(gpu_device)
+    with torch.no_grad():
+        full = deform_mlp(x, d.feature_out, d.pos_deform, d.shs_deform, d.dino_head)
+        lean = deform_mlp(x, d.feature_out, d.pos_deform, d.shs_deform, d.dino_head, need_feat=False)
+    assert lean[2] is None and torch.equal(full[0], lean[0]) and torch.equal(full[1], lean[1])
+    xg = x.clone().requires_grad_(True)
+    outs = deform_mlp(xg, d.feature_out, d.pos_deform, d.shs_deform, d.dino_head, need_feat=False)
+    assert outs[2] is not None and torch.equal(outs[2], full[2])
