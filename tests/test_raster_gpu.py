@@ -72,18 +72,26 @@ def grad_pair(H, W, seed=5):
     return torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g)
 
 
+def backprop_masked(gpu, gc, gd, bad, dev):
+    """Back-propagates the upstream gradient with the flipped / out-of-tolerance pixels `bad` ([H,W] bool) zeroed, and
+    returns the same masked pair for the oracle: both sides then differentiate the same set of blended pairs, so the
+    gradient comparison never depends on the seed producing no borderline flip."""
+    keep = torch.from_numpy(~bad).to(torch.float32)
+    gcm, gdm = gc * keep, gd * keep
+    (gpu["color"] * gcm.to(dev)).sum().add((gpu["depth"] * gdm.to(dev)).sum()).backward()
+    return gcm.numpy(), gdm.numpy()
+
+
 @pytest.mark.parametrize("mode", ["precomp", "sh"])
 @pytest.mark.parametrize("shape", [(48, 40), (64, 64), (33, 17)])
 def test_forward_backward_vs_oracle(gpu_device, oracle, mode, shape):
     W, H = shape
     s = tiny_scene(P=400, W=W, H=H, seed=1)
     gc, gd = grad_pair(H, W)
-    gpu = run_gpu(s, gpu_device, mode=mode, grads=(gc, gd))
+    gpu = run_gpu(s, gpu_device, mode=mode)
     ref = oracle_forward(oracle, s, mode=mode)
     bad = check_forward(gpu, ref, H, W)
-    if bad.any():  # gradients are only comparable when both sides blended the same pairs
-        pytest.skip("borderline skip flip in this seed; covered by other seeds")
-    rb = oracle.backward(ref, gc.numpy(), gd.numpy())
+    rb = oracle.backward(ref, *backprop_masked(gpu, gc, gd, bad, gpu_device))
     L = gpu["leaves"]
     assert rel_l2(L["means3D"].grad.cpu().numpy(), rb["dL_dmeans3D"]) <= GRAD_TOL
     assert rel_l2(L["means2D"].grad.cpu().numpy(), rb["dL_dmeans2D"]) <= GRAD_TOL
@@ -184,13 +192,12 @@ def test_cov3d_precomp_path(gpu_device, oracle):
     f0 = oracle_forward(oracle, s)
     cov3D = torch.from_numpy(f0["state"]["cov3D"].copy())
     gc, gd = grad_pair(H, W)
-    gpu = run_gpu(s, gpu_device, cov3D=cov3D, grads=(gc, gd))
+    gpu = run_gpu(s, gpu_device, cov3D=cov3D)
     ref = oracle_forward(oracle, s, scales=None, rotations=None, cov3D_precomp=cov3D.numpy())
     bad = check_forward(gpu, ref, H, W)
-    if not bad.any():
-        rb = oracle.backward(ref, gc.numpy(), gd.numpy())
-        assert rel_l2(gpu["leaves"]["cov3D"].grad.cpu().numpy(), rb["dL_dcov3D"]) <= GRAD_TOL
-        assert rel_l2(gpu["leaves"]["means3D"].grad.cpu().numpy(), rb["dL_dmeans3D"]) <= GRAD_TOL
+    rb = oracle.backward(ref, *backprop_masked(gpu, gc, gd, bad, gpu_device))
+    assert rel_l2(gpu["leaves"]["cov3D"].grad.cpu().numpy(), rb["dL_dcov3D"]) <= GRAD_TOL
+    assert rel_l2(gpu["leaves"]["means3D"].grad.cpu().numpy(), rb["dL_dmeans3D"]) <= GRAD_TOL
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
@@ -198,13 +205,12 @@ def test_sh_degrees(gpu_device, oracle, deg):
     W, H = 32, 32
     s = tiny_scene(P=200, W=W, H=H, seed=4)
     gc, gd = grad_pair(H, W)
-    gpu = run_gpu(s, gpu_device, mode="sh", sh_degree=deg, grads=(gc, gd))
+    gpu = run_gpu(s, gpu_device, mode="sh", sh_degree=deg)
     ref = oracle_forward(oracle, s, mode="sh", sh_degree=deg)
     bad = check_forward(gpu, ref, H, W)
-    if not bad.any():
-        rb = oracle.backward(ref, gc.numpy(), gd.numpy())
-        assert rel_l2(gpu["leaves"]["shs"].grad.cpu().numpy(), rb["dL_dsh"]) <= GRAD_TOL
-        assert rel_l2(gpu["leaves"]["means3D"].grad.cpu().numpy(), rb["dL_dmeans3D"]) <= GRAD_TOL
+    rb = oracle.backward(ref, *backprop_masked(gpu, gc, gd, bad, gpu_device))
+    assert rel_l2(gpu["leaves"]["shs"].grad.cpu().numpy(), rb["dL_dsh"]) <= GRAD_TOL
+    assert rel_l2(gpu["leaves"]["means3D"].grad.cpu().numpy(), rb["dL_dmeans3D"]) <= GRAD_TOL
 
 
 def test_empty_scene_returns_zero_image(gpu_device):
@@ -237,10 +243,10 @@ def test_single_huge_gaussian(gpu_device, oracle):
     s["scales"][:] = 5.0
     s["opacities"][:] = 0.9
     gc, gd = grad_pair(48, 80)
-    gpu = run_gpu(s, gpu_device, grads=(gc, gd))
+    gpu = run_gpu(s, gpu_device)
     ref = oracle_forward(oracle, s)
-    check_forward(gpu, ref, 48, 80)
-    rb = oracle.backward(ref, gc.numpy(), gd.numpy())
+    bad = check_forward(gpu, ref, 48, 80)
+    rb = oracle.backward(ref, *backprop_masked(gpu, gc, gd, bad, gpu_device))
     assert rel_l2(gpu["leaves"]["opacities"].grad.cpu().numpy(), rb["dL_dopacity"]) <= GRAD_TOL
 
 
@@ -275,7 +281,8 @@ def test_non_contiguous_and_masked_inputs(gpu_device, oracle):
         sub[k] = s[k][mask].contiguous()
     ref = oracle_forward(oracle, sub)
     np.testing.assert_array_equal(radii.cpu().numpy(), ref["radii"])
-    assert np.abs(color.cpu().numpy() - ref["color"]).max() <= 1e-3
+    bad = np.abs(color.cpu().numpy() - ref["color"]).max(0) > COLOR_TOL
+    assert bad.mean() <= OUTLIER_FRAC
 
 
 def test_mark_visible(gpu_device, oracle):
@@ -305,11 +312,11 @@ def test_cfg1_full_size_vs_oracle(gpu_device, oracle):
              opacities=torch.sigmoid(gs["opacity_logit"]), shs=gs["shs"], colors_precomp=torch.rand(10_000, 3),
              cam=sc["cameras"][0], bg=sc["bg"])
     gc, gd = grad_pair(400, 400)
-    gpu = run_gpu(s, gpu_device, mode="sh", grads=(gc, gd))
+    gpu = run_gpu(s, gpu_device, mode="sh")
     ref = oracle_forward(oracle, s, mode="sh")
     bad = check_forward(gpu, ref, 400, 400)
-    rb = oracle.backward(ref, gc.numpy(), gd.numpy())
-    tol = GRAD_TOL if not bad.any() else 5e-3
+    rb = oracle.backward(ref, *backprop_masked(gpu, gc, gd, bad, gpu_device))
+    tol = GRAD_TOL
     assert rel_l2(gpu["leaves"]["means3D"].grad.cpu().numpy(), rb["dL_dmeans3D"]) <= tol
     assert rel_l2(gpu["leaves"]["shs"].grad.cpu().numpy(), rb["dL_dsh"]) <= tol
     assert rel_l2(gpu["leaves"]["scales"].grad.cpu().numpy(), rb["dL_dscales"]) <= tol
