@@ -5,14 +5,18 @@
  * call this file; it is the checker the HIP path is compared against (tests/,
  * __graft_entry__.smoke(), bench.py's cpu_baseline leg).
  *
- * PARITY UNPINNED BY THE REFERENCE: the reference ships no tests, golden
- * vectors or CPU path for its rasterizer and its
- * CUDA sources cannot be built here (no nvcc, no NVIDIA GPU).  This file is a
- * line-by-line restatement of the algorithm in
- *   RAST = /root/reference/submodules/depth-diff-gaussian-rasterization
- *   RAST/cuda_rasterizer/forward.cu, backward.cu, rasterizer_impl.cu,
- *   auxiliary.h, config.h and RAST/rasterize_points.cu
- * cross-validated (tests/test_oracle_*.py) against
+ * PINNED BY THE REFERENCE ITSELF (round 2).  The reference ships no tests, golden vectors or CPU path for its
+ * rasterizer, so the pin is the reference's own kernels: oracle/build_ref.sh hipifies
+ * RAST = /root/reference/submodules/depth-diff-gaussian-rasterization/cuda_rasterizer/{forward,backward,
+ * rasterizer_impl}.cu in a temporary directory and builds oracle/_ref/libref_raster.so for gfx950 (test-only);
+ * tests/test_raster_ref_gpu.py::test_cpu_oracle_is_pinned_by_the_reference_build runs this file against it on twelve
+ * scenes up to BASELINE cfg3 size (1.2 M Gaussians, 1066x1600, R = 11.4 M): radii, tiles_touched, point_offsets,
+ * num_rendered, tile ranges, sorted 64-bit keys, point_list, n_contrib EXACT; depths / means2D / cov3D / conic_opacity
+ * / rgb / clamped BIT-EXACT (against the -ffp-contract=off build); colour <= 2.1e-5, final_T <= 4.8e-6; all ten
+ * gradient arrays rel-L2 <= 3.3e-5 (the reference's own run-to-run atomics noise is 1.3e-5), numbers in
+ * profiles/r02_parity_stats.jsonl.  This file is a line-by-line restatement of the algorithm in
+ *   RAST/cuda_rasterizer/forward.cu, backward.cu, rasterizer_impl.cu, auxiliary.h, config.h, RAST/rasterize_points.cu
+ * additionally cross-validated on CPU (tests/test_oracle_cpu.py) against
  *   - a float64 PyTorch autograd restatement of the forward (oracle/torch_ref.py)
  *     for every returned gradient (the fp64 build of this file agrees to 1e-9),
  *   - the reference's own utils/sh_utils.py::eval_sh for the SH path
