@@ -46,7 +46,9 @@ int s3g_deform_mlp_forward(const s3g_mlp_params* w, int P, const float* features
 
 /* g_dx [P,3], g_dshs [P,48], g_feat [P,3] (upstream gradients) -> g_features [P,128] (written) and the parameter
  * gradients in `gw` (ACCUMULATED: the caller zero-fills them).  `stash` from the matching forward (weights must be
- * unchanged since); `workspace` of 5 * P * 64 * 4 bytes, uninitialised. */
+ * unchanged since); `workspace` of 5 * P * 64 * 4 bytes, uninitialised.
+ * g_feat may be NULL = the feature output received no gradient (the feature image is not in the loss): the dino head's
+ * backward is skipped and gw->D0..db2 are left untouched, like autograd leaving those parameters' .grad at None. */
 int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* features, const float* stash, const float* g_dx,
                             const float* g_dshs, const float* g_feat, float* g_features, const s3g_mlp_params* gw,
                             float* workspace, void* stream);

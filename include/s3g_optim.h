@@ -35,6 +35,17 @@ typedef struct s3g_adam_tensor {
  * 1 - beta in double before rounding to fp32 (1 - fp32(0.999) differs from fp32(0.001) by 1.3e-5 relative). */
 int s3g_adam_step(int n, const s3g_adam_tensor* tensors /* host array */, double beta1, double beta2, void* stream);
 
+/* Densification bookkeeping of one iteration in one pass over [P] (train.py:489-493 +
+ * scene/gaussian_model.py:693-695; the reference: ~8 indexing / norm / max launches):
+ *     where visible[i]:  xyz_gradient_accum[i] += sqrt(gx^2 + gy^2);  denom[i] += 1;
+ *                        max_radii2D[i] = max(max_radii2D[i], radii[i])
+ * grad_xy: [P, grad_stride] fp32 (the viewspace gradient, columns 0 and 1 used); visible: uint8 [P] or NULL (then
+ * radii[i] > 0, the reference's visibility_filter).  This is the stand-alone form for gradients that were summed over
+ * several backward calls or all-reduced over ranks; s3g_raster_backward*_accum (s3g_raster.h) fuses the same update into
+ * the rasterizer's per-Gaussian backward when one call produces the whole viewspace gradient. */
+int s3g_densify_stats(int P, const float* grad_xy, int grad_stride, const int* radii, const unsigned char* visible,
+                      float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,16 @@ int s3g_raster_forward(const s3g_raster_inputs* in,
 int s3g_raster_forward_reuse(const s3g_raster_inputs* in, int R, const void* geometry_arena, const void* binning_arena,
                              void* image_arena, float* out_color, float* out_depth, void* stream);
 
+/* Static / dynamic decomposition renders (gaussian_renderer/__init__.py:168-204: `render_d`/`depth_d` from the Gaussians
+ * with is_dynamic != 0, `render_s`/`depth_s` from the others) out of the arenas of a previous s3g_raster_forward of ALL
+ * Gaussians: one extra blend pass over the full sorted lists with one transmittance chain per class, instead of two more
+ * complete rasterizations of boolean-masked copies.  Images are bit-identical to those (a subset's tile list is the full
+ * list minus the other class, in the same order).  The arenas are only read.  Colours: in->colors_precomp, or the
+ * forward's own SH colours when NULL.  is_dynamic: uint8 [P], device.  Outputs [3,H,W] / [1,H,W], fully written. */
+int s3g_raster_forward_decompose(const s3g_raster_inputs* in, int R, const void* geometry_arena, const void* binning_arena,
+                                 const void* image_arena, const uint8_t* is_dynamic, float* out_color_d, float* out_depth_d,
+                                 float* out_color_s, float* out_depth_s, void* stream);
+
 /* Forward of TWO images from one geometry in one blend pass: colours in->colors_precomp -> out_color (+ out_depth) and
  * colors2 [P,3] -> out_color2 [3,H,W]; otherwise identical to s3g_raster_forward (same arenas, radii, num_rendered).
  * Replaces the pair of Rasterizer::forward calls of gaussian_renderer/__init__.py:127-166; pairs with
@@ -125,6 +135,33 @@ int s3g_raster_backward2(const s3g_raster_inputs* in, const float* colors2, int 
                          float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dcolor2,
                          float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dscale, float* dL_drot,
                          void* stream);
+
+/* Backward + densification bookkeeping in the same per-Gaussian pass.  The reference follows every
+ * backward with three PyTorch passes over [P] (train.py:489-493, scene/gaussian_model.py:693-695):
+ *     max_radii2D[vis] = max(max_radii2D[vis], radii[vis]);  xyz_gradient_accum[vis] += ||viewspace_grad[vis,:2]||;
+ *     denom[vis] += 1                                          with vis = radii > 0.
+ * The per-Gaussian backward kernel has dL_dmean2D and the radius in registers, so `dens` (all three arrays, device fp32
+ * [P], caller-owned accumulators, read-modify-written for visible Gaussians only) makes it do the update itself.
+ * Valid when this backward produces the WHOLE viewspace gradient of the iteration (one render, or the two-image pass);
+ * with several backward calls per iteration or a data-parallel batch the norm must be taken after the sum: use
+ * s3g_densify_stats (s3g_optim.h) on the summed gradient instead.  dens == NULL: identical to the plain entry points. */
+typedef struct s3g_densify_accum {
+  float* xyz_gradient_accum;  /* [P]   (the reference's [P,1]) */
+  float* denom;               /* [P]   (the reference's [P,1]) */
+  float* max_radii2D;         /* [P] */
+} s3g_densify_accum;
+int s3g_raster_backward_accum(const s3g_raster_inputs* in, int R, const int* radii,
+                              const void* geometry_arena, const void* binning_arena, const void* image_arena,
+                              void* workspace, const float* dL_dpix, const float* dL_dpix_depth,
+                              float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                              float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                              float* dL_dscale, float* dL_drot, const s3g_densify_accum* dens, void* stream);
+int s3g_raster_backward2_accum(const s3g_raster_inputs* in, const float* colors2, int R, const int* radii,
+                               const void* geometry_arena, const void* binning_arena, const void* image_arena,
+                               void* workspace, const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix2,
+                               float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                               float* dL_dcolor2, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D,
+                               float* dL_dscale, float* dL_drot, const s3g_densify_accum* dens, void* stream);
 
 /* Exact (tile, Gaussian) culling at binning time, ON by default.  The reference bins a Gaussian into every tile of the
  * bounding square of its 3-sigma radius (auxiliary.h:46-56, rasterizer_impl.cu:88-115); tiles in which it cannot reach

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libs3g.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -28,6 +28,11 @@ class RasterInputs(C.Structure):
         ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p),
         ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int), ("debug", C.c_int),
     ]
+
+
+class DensifyAccum(C.Structure):
+    """struct s3g_densify_accum (include/s3g_raster.h)."""
+    _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p)]
 
 
 def build(force: bool = False) -> str:
@@ -75,6 +80,14 @@ def lib() -> C.CDLL:
     L.s3g_raster_backward2_workspace_bytes.argtypes = [C.c_int, C.c_int]
     L.s3g_mark_visible.restype = C.c_int
     L.s3g_mark_visible.argtypes = [C.c_int, vp, vp, vp, vp, vp]
+    L.s3g_raster_forward_decompose.restype = C.c_int
+    L.s3g_raster_forward_decompose.argtypes = [C.POINTER(RasterInputs), C.c_int] + [vp] * 9
+    L.s3g_raster_backward_accum.restype = C.c_int
+    L.s3g_raster_backward_accum.argtypes = [C.POINTER(RasterInputs), C.c_int] + [vp] * 17 + [C.POINTER(DensifyAccum), vp]
+    L.s3g_raster_backward2_accum.restype = C.c_int
+    L.s3g_raster_backward2_accum.argtypes = [C.POINTER(RasterInputs), vp, C.c_int] + [vp] * 18 + [C.POINTER(DensifyAccum), vp]
+    L.s3g_densify_stats.restype = C.c_int
+    L.s3g_densify_stats.argtypes = [C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -87,4 +100,4 @@ def check(code: int) -> None:
         raise RuntimeError(f"libs3g error {code}: {msg}")
 
 
-EXPORTED_SYMBOLS = ["s3g_raster_forward", "s3g_raster_forward_reuse", "s3g_raster_forward2", "s3g_raster_backward", "s3g_raster_backward_workspace_bytes", "s3g_raster_backward2", "s3g_raster_backward2_workspace_bytes", "s3g_hexplane_forward_workspace_bytes", "s3g_knn_workspace_bytes", "s3g_knn_mean_dist2", "s3g_hexplane_forward", "s3g_hexplane_backward", "s3g_hexplane_backward_workspace_bytes", "s3g_profile_enable", "s3g_profile_read", "s3g_ssim_forward", "s3g_ssim_backward", "s3g_plane_regulation", "s3g_pixel_losses_forward", "s3g_pixel_losses_combine", "s3g_pixel_losses_backward", "s3g_glue_forward", "s3g_glue_backward", "s3g_deform_mlp_forward", "s3g_deform_mlp_backward", "s3g_deform_mlp_stash_bytes", "s3g_deform_mlp_pack_bytes", "s3g_adam_step", "s3g_mark_visible", "s3g_raster_set_exact_cull", "s3g_raster_get_exact_cull", "s3g_last_error", "s3g_abi_version"]
+EXPORTED_SYMBOLS = ["s3g_raster_forward", "s3g_raster_forward_reuse", "s3g_raster_forward_decompose", "s3g_raster_forward2", "s3g_raster_backward", "s3g_raster_backward_workspace_bytes", "s3g_raster_backward2", "s3g_raster_backward2_workspace_bytes", "s3g_hexplane_forward_workspace_bytes", "s3g_knn_workspace_bytes", "s3g_knn_mean_dist2", "s3g_hexplane_forward", "s3g_hexplane_backward", "s3g_hexplane_backward_workspace_bytes", "s3g_profile_enable", "s3g_profile_read", "s3g_ssim_forward", "s3g_ssim_backward", "s3g_plane_regulation", "s3g_pixel_losses_forward", "s3g_pixel_losses_combine", "s3g_pixel_losses_backward", "s3g_glue_forward", "s3g_glue_backward", "s3g_deform_mlp_forward", "s3g_deform_mlp_backward", "s3g_deform_mlp_stash_bytes", "s3g_deform_mlp_pack_bytes", "s3g_adam_step", "s3g_densify_stats", "s3g_raster_backward_accum", "s3g_raster_backward2_accum", "s3g_mark_visible", "s3g_raster_set_exact_cull", "s3g_raster_get_exact_cull", "s3g_last_error", "s3g_abi_version"]

@@ -40,9 +40,36 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
     upd(t.param[i], t.grad[i], t.exp_avg[i], t.exp_avg_sq[i]);  // the numel % 4 tail, or everything when unaligned
 }
 
+__global__ void __launch_bounds__(256) densify_stats_kernel(int P, const float* __restrict__ g, int stride,
+                                                            const int* __restrict__ radii, const unsigned char* __restrict__ visible,
+                                                            float* __restrict__ accum, float* __restrict__ denom,
+                                                            float* __restrict__ max_radii) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const int r = radii[i];
+  if (!(visible ? visible[i] != 0 : r > 0)) return;
+  const float gx = g[(size_t)i * stride], gy = g[(size_t)i * stride + 1];
+  accum[i] += sqrtf(gx * gx + gy * gy);
+  denom[i] += 1.f;
+  max_radii[i] = fmaxf(max_radii[i], (float)r);
+}
+
 }  // namespace s3g
 
 using namespace s3g;
+
+extern "C" int s3g_densify_stats(int P, const float* grad_xy, int grad_stride, const int* radii, const unsigned char* visible,
+                                 float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream_) {
+  if (P < 0 || grad_stride < 2 || (P > 0 && (!grad_xy || !radii || !xyz_gradient_accum || !denom || !max_radii2D))) {
+    set_error("s3g_densify_stats: bad argument");
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (P == 0) return S3G_OK;
+  hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, grad_xy, grad_stride,
+                     radii, visible, xyz_gradient_accum, denom, max_radii2D);
+  S3G_HIP_CHECK(hipGetLastError());
+  return S3G_OK;
+}
 
 extern "C" int s3g_adam_step(int n, const s3g_adam_tensor* tensors, double beta1, double beta2, void* stream_) {
   if (n < 0 || n > S3G_ADAM_MAX_TENSORS || (n > 0 && !tensors)) {

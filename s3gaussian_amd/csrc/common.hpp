@@ -5,9 +5,21 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/s3g_raster.h"
 
 namespace s3g {
+
+// hipFuncSetAttribute is per DEVICE: a process that drives several GPUs (one Python process, two `cuda:k` tensors) must
+// raise the dynamic-LDS limit on each of them.  True the first time it is called with `seen` on the current device.
+inline bool first_call_on_this_device(std::atomic<uint64_t>& seen) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  return (seen.fetch_or(bit) & bit) == 0;
+}
+
 
 constexpr int TILE_X = 16;  // reference BLOCK_X/BLOCK_Y, RAST/cuda_rasterizer/config.h:16-17
 constexpr int TILE_Y = 16;

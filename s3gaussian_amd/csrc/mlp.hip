@@ -267,7 +267,8 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_backward_kernel(const MlpBwdAr
     const int p0 = tile * MT, npts = min(MT, a.P - p0);
     f32x16 ghid[2], g[2], acc[2], m[2], g3[1];
     acc_zero<2>(ghid);
-    // ---- dino head ----
+    // ---- dino head (skipped when the feature image has no gradient: g_feat == NULL) ----
+    if (a.g_feat != nullptr) {
     act_load3(g3, a.g_feat, p0, npts, lane);
     act_load<HID, 2>(m, a.stash + 4 * PS, 0, p0, npts, lane);  // dino2
     acc_zero<2>(acc);
@@ -280,6 +281,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_backward_kernel(const MlpBwdAr
     masked<2, false>(g, acc, m);
     act_store<HID, 2, false>(g, a.ws + 1 * PS, 0, p0, npts, lane);
     gemm_reg_t<2, 2>(WSLAB(6), 65, g, ghid, lane);              // ghid = D0^T (dino input is the raw hidden: no mask)
+    }
     // ---- pos head ----
     act_load3(g3, a.g_dx, p0, npts, lane);
     act_load<HID, 2>(m, a.stash + 1 * PS, 0, p0, npts, lane);  // pos1
@@ -473,11 +475,10 @@ extern "C" size_t s3g_deform_mlp_stash_bytes(int P) {
 extern "C" size_t s3g_deform_mlp_pack_bytes(void) { return (size_t)PACK_FLOATS * sizeof(float); }
 
 static int mlp_set_attrs() {
-  static bool done = false;
-  if (!done) {
+  static std::atomic<uint64_t> done{0};
+  if (first_call_on_this_device(done)) {
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
-    done = true;
   }
   return S3G_OK;
 }
@@ -507,7 +508,7 @@ extern "C" int s3g_deform_mlp_forward(const s3g_mlp_params* w, int P, const floa
 extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* features, const float* stash_,
                                        const float* g_dx, const float* g_dshs, const float* g_feat, float* g_features,
                                        const s3g_mlp_params* gw, float* workspace, void* stream_) {
-  if (!w || !gw || P < 0 || (P > 0 && (!features || !stash_ || !g_dx || !g_dshs || !g_feat || !g_features || !workspace))) {
+  if (!w || !gw || P < 0 || (P > 0 && (!features || !stash_ || !g_dx || !g_dshs || !g_features || !workspace))) {
     set_error("s3g_deform_mlp_backward: bad argument");
     return S3G_ERR_INVALID_ARG;
   }
@@ -525,9 +526,11 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   S3G_HIP_CHECK(hipGetLastError());
   profile_begin(S3G_PROFILE_MLP_WGRAD, stream);
   const size_t PS = (size_t)P * HID;
-  if (int e = launch_wgrad<3, 64, false>(g_feat, stash + 4 * PS, gw->D2, gw->db2, P, stream)) return e;
-  if (int e = launch_wgrad<64, 64, false>(workspace + 0 * PS, stash + 3 * PS, gw->D1, gw->db1, P, stream)) return e;
-  if (int e = launch_wgrad<64, 64, false>(workspace + 1 * PS, stash + 0 * PS, gw->D0, gw->db0, P, stream)) return e;
+  if (g_feat != nullptr) {  // NULL: the dino head received no gradient; its six parameter gradients are left untouched
+    if (int e = launch_wgrad<3, 64, false>(g_feat, stash + 4 * PS, gw->D2, gw->db2, P, stream)) return e;
+    if (int e = launch_wgrad<64, 64, false>(workspace + 0 * PS, stash + 3 * PS, gw->D1, gw->db1, P, stream)) return e;
+    if (int e = launch_wgrad<64, 64, false>(workspace + 1 * PS, stash + 0 * PS, gw->D0, gw->db0, P, stream)) return e;
+  }
   if (int e = launch_wgrad<3, 64, false>(g_dx, stash + 1 * PS, gw->P2, gw->pb2, P, stream)) return e;
   if (int e = launch_wgrad<64, 64, true>(workspace + 2 * PS, stash + 0 * PS, gw->P1, gw->pb1, P, stream)) return e;
   if (int e = launch_wgrad<48, 64, false>(g_dshs, stash + 2 * PS, gw->S2, gw->sb2, P, stream)) return e;

@@ -239,6 +239,10 @@ struct GeomBwdArgs {
   float* dL_dsh;            // [P,M,3]
   float* dL_dscale;         // [P,3]
   float* dL_drot;           // [P,4]
+  // optional densification bookkeeping (train.py:489-493, scene/gaussian_model.py:693-695), all three or none
+  float* dens_accum;        // [P] xyz_gradient_accum += ||dL_dmean2D.xy|| where visible
+  float* dens_denom;        // [P] denom += 1 where visible
+  float* dens_max_radii;    // [P] max_radii2D = max(max_radii2D, radii) where visible
 };
 
 // Sum the records of the tiles k = k0, k0+stride, ... of one Gaussian's rect (row-major inside the rect).
@@ -329,6 +333,11 @@ __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArg
   a.dL_dopacity[idx] = S0;
   if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(dcx, dcy, 0.f, dcz);
   if (a.dL_ddepth) a.dL_ddepth[idx] = gdep;
+  if (a.dens_accum) {  // the viewspace gradient and the radius are in registers: no separate passes over [P]
+    a.dens_accum[idx] += sqrtf(g2x * g2x + g2y * g2y);
+    a.dens_denom[idx] += 1.f;
+    a.dens_max_radii[idx] = fmaxf(a.dens_max_radii[idx], (float)a.radii[idx]);
+  }
 
   const float3 mean = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
   const float* V = a.view;
@@ -518,8 +527,12 @@ static int raster_backward_impl(const char* who, const s3g_raster_inputs* in, co
                                 void* workspace, const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix2,
                                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                                 float* dL_dcolor2, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                                float* dL_dscale, float* dL_drot, void* stream_) {
+                                float* dL_dscale, float* dL_drot, const s3g_densify_accum* dens, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (dens && !(dens->xyz_gradient_accum && dens->denom && dens->max_radii2D)) {
+    set_error("%s: s3g_densify_accum needs all three arrays", who);
+    return S3G_ERR_INVALID_ARG;
+  }
   if (!in) {
     set_error("%s: NULL inputs", who);
     return S3G_ERR_INVALID_ARG;
@@ -562,6 +575,9 @@ static int raster_backward_impl(const char* who, const s3g_raster_inputs* in, co
   ga.dL_dmean2D = dL_dmean2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolor = dL_dcolor;
   ga.dL_dcolor2 = dL_dcolor2; ga.dL_ddepth = dL_ddepth;
   ga.dL_dmean3D = dL_dmean3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dsh = dL_dsh; ga.dL_dscale = dL_dscale; ga.dL_drot = dL_drot;
+  ga.dens_accum = dens ? dens->xyz_gradient_accum : nullptr;
+  ga.dens_denom = dens ? dens->denom : nullptr;
+  ga.dens_max_radii = dens ? dens->max_radii2D : nullptr;
   hipLaunchKernelGGL(geometry_backward_kernel<NX>, dim3((P + 255) / 256), dim3(256), 0, stream, ga);
   S3G_KERNEL_CHECK(stream, debug);
   return S3G_OK;
@@ -574,7 +590,18 @@ extern "C" int s3g_raster_backward(const s3g_raster_inputs* in, int R, const int
                                    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream_) {
   return raster_backward_impl<0>("s3g_raster_backward", in, nullptr, R, radii, geometry_arena, binning_arena, image_arena,
                                  workspace, dL_dpix, dL_dpix_depth, nullptr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
-                                 nullptr, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, stream_);
+                                 nullptr, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, nullptr, stream_);
+}
+extern "C" int s3g_raster_backward_accum(const s3g_raster_inputs* in, int R, const int* radii, const void* geometry_arena,
+                                         const void* binning_arena, const void* image_arena, void* workspace,
+                                         const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D,
+                                         float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
+                                         float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                                         float* dL_drot, const s3g_densify_accum* dens, void* stream_) {
+  return raster_backward_impl<0>("s3g_raster_backward_accum", in, nullptr, R, radii, geometry_arena, binning_arena,
+                                 image_arena, workspace, dL_dpix, dL_dpix_depth, nullptr, dL_dmean2D, dL_dconic, dL_dopacity,
+                                 dL_dcolor, nullptr, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dens,
+                                 stream_);
 }
 
 extern "C" int s3g_raster_backward2(const s3g_raster_inputs* in, const float* colors2, int R, const int* radii,
@@ -585,5 +612,17 @@ extern "C" int s3g_raster_backward2(const s3g_raster_inputs* in, const float* co
                                     float* dL_dcov3D, float* dL_dscale, float* dL_drot, void* stream_) {
   return raster_backward_impl<3>("s3g_raster_backward2", in, colors2, R, radii, geometry_arena, binning_arena, image_arena,
                                  workspace, dL_dpix, dL_dpix_depth, dL_dpix2, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
-                                 dL_dcolor2, dL_ddepth, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot, stream_);
+                                 dL_dcolor2, dL_ddepth, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot, nullptr, stream_);
+}
+extern "C" int s3g_raster_backward2_accum(const s3g_raster_inputs* in, const float* colors2, int R, const int* radii,
+                                          const void* geometry_arena, const void* binning_arena, const void* image_arena,
+                                          void* workspace, const float* dL_dpix, const float* dL_dpix_depth,
+                                          const float* dL_dpix2, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                          float* dL_dcolor, float* dL_dcolor2, float* dL_ddepth, float* dL_dmean3D,
+                                          float* dL_dcov3D, float* dL_dscale, float* dL_drot,
+                                          const s3g_densify_accum* dens, void* stream_) {
+  return raster_backward_impl<3>("s3g_raster_backward2_accum", in, colors2, R, radii, geometry_arena, binning_arena,
+                                 image_arena, workspace, dL_dpix, dL_dpix_depth, dL_dpix2, dL_dmean2D, dL_dconic, dL_dopacity,
+                                 dL_dcolor, dL_dcolor2, dL_ddepth, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot, dens,
+                                 stream_);
 }

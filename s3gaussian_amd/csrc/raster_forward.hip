@@ -562,6 +562,85 @@ blend_forward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ 
   if (tid == 0) tile_hi[tile] = rg.x + max(max(wave_hi[0], wave_hi[1]), max(wave_hi[2], wave_hi[3]));
 }
 
+
+// ---- static / dynamic decomposition renders of one geometry in ONE blend pass -------------------------
+// gaussian_renderer/__init__.py:168-204 renders the Gaussians with max|dx| above / below the mean a second and third time
+// (full preprocess + binning + sort + blend on boolean-masked copies of every input).  A subset's per-tile list is the full
+// list with the other class removed -- same depth order, ties still by index -- so both subset images fall out of one walk
+// over the FULL sorted lists with one transmittance chain per class: alpha is evaluated once per (pixel, Gaussian) and
+// updates only the chain of the Gaussian's class.  Results are bit-identical to the two separate subset renders.
+__global__ void __launch_bounds__(256)
+blend_decompose_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__ ranges,
+                       const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
+                       const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
+                       const float* __restrict__ depths, const float* __restrict__ bg, const uint8_t* __restrict__ cls,
+                       float* __restrict__ out_color_d, float* __restrict__ out_depth_d, float* __restrict__ out_color_s,
+                       float* __restrict__ out_depth_s) {
+  __shared__ StagedGaussian sg[256];
+  __shared__ uint8_t scls[256];
+  const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  if (tile >= (uint32_t)tiles) return;
+  const int tx = tile % gx, ty = tile / gx;
+  const int tid = threadIdx.x;
+  const int px = tx * TILE_X + (tid & 15), py = ty * TILE_Y + (tid >> 4);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const uint2 rg = ranges[tile];
+  int todo = (int)(rg.y - rg.x);
+  bool done[2] = {!inside, !inside};   // [0] static chain, [1] dynamic chain
+  float T[2] = {1.f, 1.f}, Cr[2] = {0.f, 0.f}, Cg[2] = {0.f, 0.f}, Cb[2] = {0.f, 0.f}, D[2] = {0.f, 0.f};
+  for (uint32_t base = rg.x; base < rg.y; base += 256, todo -= 256) {
+    if (__syncthreads_count(done[0] && done[1]) == 256) break;
+    if (base + tid < rg.y) {
+      const uint32_t id = point_list[base + tid];
+      const float2 m = means2D[id];
+      const float4 co = conic_opacity[id];
+      StagedGaussian s;
+      s.a = make_float4(m.x, m.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
+      s.b = make_float4(-0.5f * LOG2E * co.z, co.w, depths[id], colors[3 * (size_t)id]);
+      s.c = make_float4(colors[3 * (size_t)id + 1], colors[3 * (size_t)id + 2], co.x, co.y);
+      sg[tid] = s;
+      scls[tid] = cls[id] ? 1 : 0;
+    }
+    __syncthreads();
+    const int cnt = min(256, todo);
+    for (int j = 0; j < cnt && !(done[0] && done[1]); j++) {
+      const int k = scls[j];
+      if (done[k]) continue;
+      const float4 A = sg[j].a;
+      const float dx = A.x - pxf, dy = A.y - pyf;
+      const float4 B = sg[j].b;
+      const float q = gaussian_exponent2(dx, dy, A.z, A.w, B.x);
+      if (q > 0.f) continue;
+      const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(q));
+      if (alpha < 1.0f / 255.0f) continue;
+      const float test_T = T[k] * (1.f - alpha);
+      if (test_T < 0.0001f) {
+        done[k] = true;
+        continue;
+      }
+      const float w = alpha * T[k];
+      const float4 Cc = sg[j].c;
+      Cr[k] = __builtin_fmaf(B.w, w, Cr[k]);
+      Cg[k] = __builtin_fmaf(Cc.x, w, Cg[k]);
+      Cb[k] = __builtin_fmaf(Cc.y, w, Cb[k]);
+      D[k] = __builtin_fmaf(B.z, w, D[k]);
+      T[k] = test_T;
+    }
+  }
+  if (inside) {
+    const size_t pix = (size_t)py * W + px, N = (size_t)H * W;
+    out_color_s[pix] = Cr[0] + T[0] * bg[0];
+    out_color_s[N + pix] = Cg[0] + T[0] * bg[1];
+    out_color_s[2 * N + pix] = Cb[0] + T[0] * bg[2];
+    out_depth_s[pix] = D[0];
+    out_color_d[pix] = Cr[1] + T[1] * bg[0];
+    out_color_d[N + pix] = Cg[1] + T[1] * bg[1];
+    out_color_d[2 * N + pix] = Cb[1] + T[1] * bg[2];
+    out_depth_d[pix] = D[1];
+  }
+}
+
 __global__ void __launch_bounds__(256) check_frustum_kernel(int P, const float* __restrict__ means3D,
                                                             const float* __restrict__ viewmatrix,
                                                             uint8_t* __restrict__ present) {
@@ -578,7 +657,7 @@ static inline uint32_t round_up8(uint32_t v) { return (v + 7u) & ~7u; }
 using namespace s3g;
 
 extern "C" const char* s3g_last_error(void) { return g_err; }
-extern "C" int s3g_abi_version(void) { return 3; }
+extern "C" int s3g_abi_version(void) { return 4; }
 
 static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2, float* out_color2,
                                s3g_resize_fn geometry_buffer, void* geometry_user, s3g_resize_fn binning_buffer,
@@ -653,13 +732,12 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
 
   // atomic-free binning, counting half
   const size_t bin_lds = ((size_t)tiles + 8) * sizeof(uint32_t);
-  static bool bin_attr_set = false;
-  if (!bin_attr_set) {
+  static std::atomic<uint64_t> bin_attr_set{0};
+  if (first_call_on_this_device(bin_attr_set)) {
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)bin_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (MAX_TILES_LDS + 8) * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)bin_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (MAX_TILES_LDS + 8) * 4));
-    bin_attr_set = true;
   }
   BinArgs ba;
   ba.P = P; ba.gx = gx; ba.tiles = tiles; ba.chunk = chunk; ba.rect = g.rect; ba.depths = g.depths;
@@ -713,11 +791,10 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
     S3G_KERNEL_CHECK(stream, debug);
     if (max_tile > SMALL) {
       const uint32_t large_cap = max_tile < LARGE ? max_tile : LARGE;
-      static bool attr_set = false;
-      if (!attr_set) {
+      static std::atomic<uint64_t> attr_set{0};
+      if (first_call_on_this_device(attr_set)) {
         S3G_HIP_CHECK(hipFuncSetAttribute((const void*)sort_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           LARGE * 8));
-        attr_set = true;
       }
       hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)large_cap * 8, stream, tiles, gx,
                          im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, b.slot_pos, SMALL, 0xffffffffu, large_cap);
@@ -785,6 +862,30 @@ extern "C" int s3g_raster_forward_reuse(const s3g_raster_inputs* in, int R, cons
                      b.point_list, g.means2D, g.conic_opacity, in->colors_precomp, g.depths, in->background, im.final_T,
                      im.n_contrib, im.tile_hi, out_color, out_depth, nullptr, nullptr);
   profile_end(S3G_PROFILE_BLEND_FORWARD, stream, (double)R, (double)W * H);
+  S3G_KERNEL_CHECK(stream, in->debug != 0);
+  return S3G_OK;
+}
+
+extern "C" int s3g_raster_forward_decompose(const s3g_raster_inputs* in, int R, const void* geometry_arena,
+                                            const void* binning_arena, const void* image_arena, const uint8_t* is_dynamic,
+                                            float* out_color_d, float* out_depth_d, float* out_color_s, float* out_depth_s,
+                                            void* stream_) {
+  g_err[0] = 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!in || !in->background || !geometry_arena || !image_arena || (R > 0 && !binning_arena) || !is_dynamic ||
+      !out_color_d || !out_depth_d || !out_color_s || !out_depth_s || in->P <= 0) {
+    set_error("s3g_raster_forward_decompose: bad argument (needs the arenas of a previous forward and the class mask)");
+    return S3G_ERR_INVALID_ARG;
+  }
+  const int P = in->P, W = in->width, H = in->height;
+  const int gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y, tiles = gx * gy;
+  GeomState g = GeomState::carve(const_cast<void*>(geometry_arena), P, nullptr);
+  ImageState im = ImageState::carve(const_cast<void*>(image_arena), (size_t)W * H, tiles, bin_blocks(P), nullptr);
+  BinningState b = BinningState::carve(const_cast<void*>(binning_arena), (size_t)(R > 0 ? R : 0), 0, nullptr);
+  const float* color_ptr = in->colors_precomp ? in->colors_precomp : g.rgb;   // SH path: the forward's own colours
+  hipLaunchKernelGGL(blend_decompose_kernel, dim3(round_up8((uint32_t)tiles)), dim3(256), 0, stream, W, H, gx, tiles,
+                     im.ranges, b.point_list, g.means2D, g.conic_opacity, color_ptr, g.depths, in->background, is_dynamic,
+                     out_color_d, out_depth_d, out_color_s, out_depth_s);
   S3G_KERNEL_CHECK(stream, in->debug != 0);
   return S3G_OK;
 }

@@ -7,8 +7,15 @@ loss over the batch, radii max, visibility any, viewspace gradients summed).  Pe
   * one bucketed all-reduce (average) of every parameter gradient: 59 floats per Gaussian + 35.7 M HexPlane floats
     + the MLP  (~426 MB at 1.2 M Gaussians) in <= `bucket_mb` flat buckets, so RCCL can drive all 7 xGMI links with a
     few large collectives instead of hundreds of small ones;
-  * three small all-reduces for the densification statistics (sum of ||viewspace grad||*visible, sum of visible,
-    max of radii) so that the replicated densify/prune decisions stay identical on every rank.
+  * three small all-reduces for the densification statistics (viewspace gradient vectors summed and scaled by
+    1/world before the norm, visibility ANY, radii MAX -- exactly train.py:387-388,435-437 at batch_size = world)
+    so that the replicated densify/prune decisions stay identical on every rank;
+  * optionally (`SparseRowExchange`) the per-Gaussian gradients that are exactly zero outside the union of the ranks'
+    visible sets (SH, opacity, scale, rotation: 56 of the 59 floats per Gaussian) travel as compact visible rows.
+
+Densify / prune replace the per-Gaussian nn.Parameters (scene/gaussian_model.py:397-494): build the reducers from the
+OPTIMIZER (parameters are then resolved from `optimizer.param_groups` at every reduce) or call `rebind()` afterwards.
+No multi-GPU scaling curve has been measured on hardware yet (gpurun leases one GPU); see DESIGN.md section 8.
 
 Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests (tests/test_dp_cpu.py).
 """
@@ -54,17 +61,40 @@ def _flat_view(t: torch.Tensor) -> Optional[torch.Tensor]:
     return None
 
 
+def _resolve(source) -> List[torch.nn.Parameter]:
+    """Current parameter list of `source`: an optimizer (param_groups, the object the reference's densification code
+    edits), a callable returning parameters, or a plain iterable captured once."""
+    if isinstance(source, torch.optim.Optimizer):
+        return [p for g in source.param_groups for p in g["params"]]
+    if callable(source):
+        return list(source())
+    return source
+
+
 class GradAllReducer:
     """Bucketed average of .grad over all ranks.  Parameters whose grad is None on this rank (unused heads) are
-    skipped; they are None on every rank because all replicas run the same graph."""
+    skipped; they are None on every rank because all replicas run the same graph.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, inplace_mb: float = 16.0,
-                 average: bool = True):
-        self.params = [p for p in params]
+    `params`: a torch optimizer or a zero-argument callable (resolved at EVERY reduce, so parameters replaced by
+    densify / prune are picked up), or a fixed iterable of parameters (then call `rebind(new_params)` after any
+    operation that replaces nn.Parameter objects -- a stale list would silently stop reducing those gradients)."""
+
+    def __init__(self, params, bucket_mb: float = 256.0, inplace_mb: float = 16.0, average: bool = True):
+        self._source = params if (isinstance(params, torch.optim.Optimizer) or callable(params)) else [p for p in params]
         self.average = average   # False: leave the SUM in .grad (the optimizer applies 1/world, optim.Adam.grad_scale)
         self.bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
         self.inplace_elems = int(inplace_mb * 1024 * 1024 / 4)  # gradients at least this big are reduced where they live
         self._buf = None
+        self._only = None   # set by subclasses to restrict one call to a subset
+
+    @property
+    def params(self) -> List[torch.nn.Parameter]:
+        return _resolve(self._source)
+
+    def rebind(self, params=None) -> None:
+        """Adopt a new parameter source (same kinds as the constructor); no argument = re-resolve the current one."""
+        if params is not None:
+            self._source = params if (isinstance(params, torch.optim.Optimizer) or callable(params)) else [p for p in params]
 
     def _buckets(self, grads: Sequence[torch.Tensor]):
         cur, n = [], 0
@@ -82,7 +112,7 @@ class GradAllReducer:
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return 0
         world = dist.get_world_size()
-        grads = [p.grad for p in self.params if p.grad is not None]
+        grads = [p.grad for p in (self._only if self._only is not None else self.params) if p.grad is not None]
         total = 0
         small = []
         for g in grads:  # big tensors (xyz/f_rest/planes: ~95 % of the bytes): no pack/unpack copies at all
@@ -127,18 +157,29 @@ class OverlappedGradAllReducer(GradAllReducer):
     and xyz at the very end.  `finish()` (call between backward and optimizer.step) waits for the collectives in flight,
     averages, and reduces the small gradients in flat buckets like the base class."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 256.0, inplace_mb: float = 1.0,
-                 average: bool = True):
+    def __init__(self, params, bucket_mb: float = 256.0, inplace_mb: float = 1.0, average: bool = True):
         # hook threshold 1 MB: at cfg3 that covers every per-Gaussian array and all but the coarsest planes (~99 % of the
         # bytes, ~35 collectives); the rest (MLP weights, 64x64 planes) goes in one flat bucket in finish()
         super().__init__(params, bucket_mb, inplace_mb, average)
         self._inflight = []   # (work handle, flat view)
         self._started = set()
-        self._handles = []
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            for p in self.params:
-                if p.requires_grad and p.numel() >= self.inplace_elems:
-                    self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+        self._hooks = {}      # id(param) -> (param, hook handle)
+        self.rebinds = 0      # how often the hooked set had to follow replaced parameters (diagnostics / tests)
+        self.rebind()
+
+    def rebind(self, params=None) -> None:
+        """(Re-)registers the post-accumulate hooks on the CURRENT parameters; stale hooks (parameters densify / prune
+        replaced) are removed.  finish() calls this itself when it sees the optimizer's parameters changed, so a missed
+        rebind costs one iteration of non-overlapped reduction, never a silent divergence."""
+        super().rebind(params)
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        want = {id(p): p for p in self.params if p.requires_grad and p.numel() >= self.inplace_elems}
+        for k in [k for k in self._hooks if k not in want]:
+            self._hooks.pop(k)[1].remove()
+        for k, p in want.items():
+            if k not in self._hooks:
+                self._hooks[k] = (p, p.register_post_accumulate_grad_hook(self._on_grad_ready))
 
     def _on_grad_ready(self, p: torch.nn.Parameter):
         g = p.grad
@@ -149,9 +190,9 @@ class OverlappedGradAllReducer(GradAllReducer):
         self._started.add(id(p))
 
     def remove_hooks(self):
-        for h in self._handles:
+        for _, h in self._hooks.values():
             h.remove()
-        self._handles = []
+        self._hooks = {}
 
     @torch.no_grad()
     def finish(self) -> int:
@@ -165,27 +206,94 @@ class OverlappedGradAllReducer(GradAllReducer):
                 v.mul_(1.0 / world)
             total += v.numel()
         started, self._inflight, self._started = self._started, [], set()
-        # everything the hooks did not cover (small tensors, gradients set outside autograd's accumulation)
-        rest = [p for p in self.params if p.grad is not None and id(p) not in started]
-        saved, self.params = self.params, rest
+        current = self.params
+        # everything the hooks did not cover: small tensors, gradients set outside autograd's accumulation, and parameters
+        # that replaced hooked ones since the last rebind (their gradients exist but no hook fired)
+        rest = [p for p in current if p.grad is not None and id(p) not in started]
+        self._only = rest
         try:
             total += GradAllReducer.__call__(self)
         finally:
-            self.params = saved
+            self._only = None
+        hookable = {id(p) for p in current if p.requires_grad and p.numel() >= self.inplace_elems}
+        if hookable != set(self._hooks):
+            self.rebinds += 1
+            self.rebind()
         return total
 
     __call__ = finish
 
 
 @torch.no_grad()
-def reduce_densification_stats(viewspace_grad: torch.Tensor, visibility: torch.Tensor, radii: torch.Tensor):
-    """Batch semantics of train.py:387-388,435-437 + scene/gaussian_model.py:693-695 across ranks.
-    Returns (sum over ranks of ||grad.xy|| on visible Gaussians [P,1], visible count [P,1], max radii [P])."""
-    gnorm = torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True) * visibility[:, None].to(viewspace_grad.dtype)
-    count = visibility[:, None].to(viewspace_grad.dtype).clone()
+def reduce_densification_stats(viewspace_grad: torch.Tensor, visibility: torch.Tensor, radii: torch.Tensor,
+                               grads_are_sums: bool = True):
+    """The reference's batch semantics (train.py:387-388 radii max / visibility any, :435-437 viewspace gradients SUMMED
+    over the views of a batch whose loss is the batch MEAN) with batch = the ranks' views.
+
+    viewspace_grad [P,>=2]: this rank's d(loss_rank)/d(means2D) of its own un-averaged loss (grads_are_sums=True, what
+    training_step produces; the 1/world of the batch mean is applied here) or already scaled by 1/world (False).
+    Returns (viewspace gradient of the batch [P,2], visible in ANY view [P] bool, max radii [P]); feed them to
+    `add_densification_stats` (scene/gaussian_model.py:693-695: accum += ||grad.xy||, denom += 1 where visible)."""
+    g = viewspace_grad[:, :2].contiguous().clone()
+    any_vis = visibility.to(torch.int32).clone()
     rmax = radii.clone()
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(gnorm, op=dist.ReduceOp.SUM)
-        dist.all_reduce(count, op=dist.ReduceOp.SUM)
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        dist.all_reduce(any_vis, op=dist.ReduceOp.MAX)
         dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
-    return gnorm, count, rmax
+        if grads_are_sums:
+            g.mul_(1.0 / dist.get_world_size())
+    return g, any_vis.bool(), rmax
+
+
+@torch.no_grad()
+def add_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor,
+                            viewspace_grad_xy: torch.Tensor, visible: torch.Tensor, radii: torch.Tensor) -> None:
+    """train.py:489-493 + scene/gaussian_model.py:693-695 on the reduced statistics (one fused HIP pass on the GPU:
+    include/s3g_optim.h::s3g_densify_stats; plain torch on CPU tensors for the gloo tests)."""
+    if xyz_gradient_accum.is_cuda:
+        from .optim import densify_stats
+        densify_stats(xyz_gradient_accum, denom, max_radii2D, viewspace_grad_xy, radii, visible)
+        return
+    xyz_gradient_accum[visible] += torch.norm(viewspace_grad_xy[visible, :2], dim=-1, keepdim=True)
+    denom[visible] += 1
+    max_radii2D[visible] = torch.max(max_radii2D[visible], radii[visible].to(max_radii2D.dtype))
+
+
+class SparseRowExchange:
+    """Optional sparse gradient exchange for per-Gaussian arrays whose rows are EXACTLY zero for Gaussians no rank sees:
+    d/d(SH dc, SH rest, opacity, scaling, rotation) -- 56 of the 59 floats per Gaussian (xyz also receives the HexPlane
+    gradient of the dx / dshs regularisers and stays dense).  Per step: union of the ranks' visibility masks (one
+    all-reduce MAX over P bytes), compact the union's rows of every listed gradient into one flat buffer, ONE all-reduce,
+    scatter back.  At cfg3 one view sees ~22 % of the Gaussians, so for small world sizes this moves a fraction of the
+    269 MB the dense path moves; with many ranks the union approaches P and the dense path is as good.  Opt-in; results
+    are identical to the dense reduce (tests/test_dp_cpu.py), rows outside the union are never touched."""
+
+    def __init__(self, average: bool = True):
+        self.average = average
+        self.last_rows = 0
+
+    @torch.no_grad()
+    def __call__(self, params: Sequence[torch.nn.Parameter], visibility: torch.Tensor) -> int:
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return 0
+        world = dist.get_world_size()
+        grads = [p.grad for p in params if p.grad is not None]
+        if not grads:
+            return 0
+        P = visibility.shape[0]
+        assert all(g.shape[0] == P and g.is_contiguous() for g in grads), "per-Gaussian row-major gradients expected"
+        union = visibility.to(torch.uint8).clone()
+        dist.all_reduce(union, op=dist.ReduceOp.MAX)
+        idx = union.nonzero(as_tuple=True)[0]           # identical on every rank
+        self.last_rows = int(idx.numel())
+        widths = [g[0].numel() for g in grads]
+        flat = torch.cat([g.view(P, -1).index_select(0, idx) for g in grads], dim=1)   # [rows, sum(widths)]
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if self.average:
+            flat.mul_(1.0 / world)
+        off = 0
+        for g, w in zip(grads, widths):
+            g.view(P, -1).index_copy_(0, idx, flat[:, off:off + w])
+            off += w
+        return int(flat.numel())

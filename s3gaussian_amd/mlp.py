@@ -68,6 +68,7 @@ class _DeformMLP(torch.autograd.Function):
                                                 stash.data_ptr(), int(need_bwd), torch.cuda.current_stream().cuda_stream))
         if need_bwd:
             ctx.save_for_backward(x, stash, *params)
+            ctx.set_materialize_grads(False)   # an output the loss never touched must arrive as None, not as zeros
         return dx, dshs, feat     # feat is None when the head was skipped (need_feat=False under no_grad)
 
     @staticmethod
@@ -76,7 +77,11 @@ class _DeformMLP(torch.autograd.Function):
         L = _bind()
         P, dev = x.shape[0], x.device
         z = lambda g, n: (torch.zeros((P, n), dtype=torch.float32, device=dev) if g is None else g.contiguous().float())
-        g_dx, g_dshs, g_feat = z(g_dx, 3), z(g_dshs, 48), z(g_feat, 3)
+        g_dx, g_dshs = z(g_dx, 3), z(g_dshs, 48)
+        # no gradient on the feature output (feature image not in the loss): like the reference, the dino head's parameters
+        # then get grad None -- Adam skips them (no moment decay, no step count) -- and its part of the backward is skipped
+        no_feat = g_feat is None
+        g_feat = None if no_feat else g_feat.contiguous().float()
         gx = torch.empty_like(x)
         flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)  # one fill, 16 views
         grads, off = [], 0
@@ -87,8 +92,10 @@ class _DeformMLP(torch.autograd.Function):
         w, gw = _pack([p.detach() for p in params]), _pack(grads)
         with torch.cuda.device(dev):
             _lib.check(L.s3g_deform_mlp_backward(C.byref(w), P, x.data_ptr(), stash.data_ptr(), g_dx.data_ptr(),
-                                                 g_dshs.data_ptr(), g_feat.data_ptr(), gx.data_ptr(), C.byref(gw),
-                                                 ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                                 g_dshs.data_ptr(), None if no_feat else g_feat.data_ptr(), gx.data_ptr(),
+                                                 C.byref(gw), ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        if no_feat:
+            grads = [None if n.startswith(("D", "db")) else g for n, g in zip(_NAMES, grads)]
         return (gx, None, None, *grads)
 
 

@@ -41,10 +41,10 @@ class Adam(torch.optim.Adam):
         L = _lib.lib()
         L.s3g_adam_step.restype = C.c_int
         L.s3g_adam_step.argtypes = [C.c_int, C.POINTER(_AdamTensor), C.c_double, C.c_double, C.c_void_p]
-        by_betas = {}
-        keep = []   # tensors created here must outlive the launch call
+        # 1. validate everything before touching any state: an exception must not leave some parameters with an advanced
+        #    step count and others without
+        todo = []
         for group in self.param_groups:
-            beta1, beta2 = group["betas"]
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -52,24 +52,30 @@ class Adam(torch.optim.Adam):
                     raise RuntimeError("s3gaussian_amd.optim.Adam: parameters must live on the GPU (no CPU fallback)")
                 if p.dtype != torch.float32 or p.grad.is_sparse or not _dense(p):
                     raise RuntimeError("s3gaussian_amd.optim.Adam handles dense float32 parameters only")
-                st = self.state[p]
-                if len(st) == 0:   # same lazy initialisation as torch/optim/adam.py::_init_group
-                    st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                step = float(st["step"])
-                g = p.grad
-                if g.dtype != torch.float32 or g.stride() != p.stride():
-                    g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
-                    keep.append(g)
-                for name in ("exp_avg", "exp_avg_sq"):   # densification code may have replaced them with other layouts
-                    if st[name].stride() != p.stride():
-                        st[name] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[name])
-                bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
-                by_betas.setdefault((p.device, float(beta1), float(beta2)), []).append(
-                    _AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
-                                group["lr"] / bc1, 1.0 / (bc2 ** 0.5), group["eps"], float(self.grad_scale)))
+                todo.append((group, p))
+        # 2. lazy state, step counters, launch records
+        by_betas = {}
+        keep = []   # tensors created here must outlive the launch call
+        for group, p in todo:
+            beta1, beta2 = group["betas"]
+            st = self.state[p]
+            if len(st) == 0:   # same lazy initialisation as torch/optim/adam.py::_init_group
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            step = float(st["step"])
+            g = p.grad
+            if g.dtype != torch.float32 or g.stride() != p.stride():
+                g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
+                keep.append(g)
+            for name in ("exp_avg", "exp_avg_sq"):   # densification code may have replaced them with other layouts
+                if st[name].stride() != p.stride():
+                    st[name] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[name])
+            bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+            by_betas.setdefault((p.device, float(beta1), float(beta2)), []).append(
+                _AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                            group["lr"] / bc1, 1.0 / (bc2 ** 0.5), group["eps"], float(self.grad_scale)))
         for (dev, beta1, beta2), items in by_betas.items():
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream().cuda_stream
@@ -77,4 +83,39 @@ class Adam(torch.optim.Adam):
                     chunk = items[k:k + MAX_TENSORS]
                     arr = (_AdamTensor * len(chunk))(*chunk)
                     _lib.check(L.s3g_adam_step(len(chunk), arr, beta1, beta2, stream))
+        # 3. the kernel wrote the parameters (and moments) through raw pointers: tell PyTorch.  Version counters are what
+        #    autograd's saved-tensor checks and the rasterizer's geometry cache (raster_C._geom_key) look at; without the
+        #    bump a render of the SAME parameter tensors after this step could be served the previous step's binning.
+        for _, p in todo:
+            torch.autograd.graph.increment_version(p)
+            st = self.state[p]
+            torch.autograd.graph.increment_version(st["exp_avg"])
+            torch.autograd.graph.increment_version(st["exp_avg_sq"])
+        if todo:
+            from . import raster_C
+            raster_C.invalidate_geometry_cache()
         return loss
+
+
+@torch.no_grad()
+def densify_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor,
+                  viewspace_grad: torch.Tensor, radii: torch.Tensor, visible: torch.Tensor = None) -> None:
+    """train.py:489-493 + scene/gaussian_model.py:693-695 in one pass (include/s3g_optim.h::s3g_densify_stats):
+    `max_radii2D[vis] = max(., radii[vis]); xyz_gradient_accum[vis] += ||viewspace_grad[vis,:2]||; denom[vis] += 1`
+    with vis = `visible` (bool [P]) or radii > 0.  Accumulators are the reference's tensors ([P,1], [P,1], [P] fp32),
+    updated in place."""
+    L = _lib.lib()
+    P = radii.shape[0]
+    for name, t_, n in (("xyz_gradient_accum", xyz_gradient_accum, P), ("denom", denom, P), ("max_radii2D", max_radii2D, P)):
+        if not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == n):
+            raise RuntimeError(f"densify_stats: {name} must be a contiguous float32 GPU tensor with {n} elements")
+    g = viewspace_grad if (viewspace_grad.dtype == torch.float32 and viewspace_grad.stride(-1) == 1 and viewspace_grad.dim() == 2) \
+        else viewspace_grad.float().contiguous()
+    r = radii if radii.dtype == torch.int32 and radii.is_contiguous() else radii.to(torch.int32).contiguous()
+    v = None if visible is None else visible.to(torch.uint8).contiguous()
+    with torch.cuda.device(radii.device):
+        _lib.check(L.s3g_densify_stats(P, g.data_ptr(), int(g.stride(0)), r.data_ptr(), v.data_ptr() if v is not None else None,
+                                       xyz_gradient_accum.data_ptr(), denom.data_ptr(), max_radii2D.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream))
+    for t_ in (xyz_gradient_accum, denom, max_radii2D):
+        torch.autograd.graph.increment_version(t_)

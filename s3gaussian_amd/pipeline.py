@@ -117,12 +117,82 @@ class GaussianParams(nn.Module):
         ]
         # same update rule and state layout as the reference's torch.optim.Adam(l, lr=0.0, eps=1e-15); on the GPU the whole
         # step is one kernel launch over all groups (optim.Adam) instead of ~10 foreach passes per group
+        P = self._xyz.shape[0]   # densification accumulators, scene/gaussian_model.py:172-174
+        self.xyz_gradient_accum = torch.zeros((P, 1), device=self._xyz.device)
+        self.denom = torch.zeros((P, 1), device=self._xyz.device)
         if self._xyz.is_cuda:
             from .optim import Adam as FusedAdam
             self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
         else:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         return self.optimizer
+
+    # ---- checkpoint / point-cloud I/O with the reference's formats -------------------------------------
+    def capture(self):
+        """The 14-tuple of scene/gaussian_model.py:71-88 (what train.py saves with torch.save)."""
+        return (self.active_sh_degree, self._xyz, self._deformation.state_dict(), self._deformation_table,
+                self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity, self.max_radii2D,
+                self.xyz_gradient_accum, self.denom, self.optimizer.state_dict(), self.spatial_lr_scale)
+
+    def restore(self, model_args, training_args):
+        """scene/gaussian_model.py:90-111: accepts a tuple captured here or by the reference's GaussianModel."""
+        (self.active_sh_degree, xyz, deform_state, self._deformation_table, f_dc, f_rest, scaling, rotation, opacity,
+         self.max_radii2D, xyz_gradient_accum, denom, opt_dict, self.spatial_lr_scale) = model_args
+        dev = xyz.device
+        as_param = lambda t_: nn.Parameter(t_.detach().clone().float().contiguous().to(dev))
+        self._xyz, self._features_dc, self._features_rest = as_param(xyz), as_param(f_dc), as_param(f_rest)
+        self._scaling, self._rotation, self._opacity = as_param(scaling), as_param(rotation), as_param(opacity)
+        self._deformation.load_state_dict(deform_state)
+        self._deformation = self._deformation.to(dev)
+        self.training_setup(training_args)
+        self.xyz_gradient_accum, self.denom = xyz_gradient_accum, denom
+        self.optimizer.load_state_dict(opt_dict)
+
+    def construct_list_of_attributes(self):
+        """scene/gaussian_model.py:220-234."""
+        l = ['x', 'y', 'z', 'nx', 'ny', 'nz']
+        l += [f'f_dc_{i}' for i in range(self._features_dc.shape[1] * self._features_dc.shape[2])]
+        l += [f'f_rest_{i}' for i in range(self._features_rest.shape[1] * self._features_rest.shape[2])]
+        l += ['opacity'] + [f'scale_{i}' for i in range(self._scaling.shape[1])] + [f'rot_{i}' for i in range(self._rotation.shape[1])]
+        return l
+
+    @torch.no_grad()
+    def save_ply(self, path):
+        """scene/gaussian_model.py:258-275: same attribute order and layout (SH coefficients channel-major)."""
+        import numpy as np
+        from .plyio import write_vertices
+        n = lambda t_: t_.detach().cpu().numpy()
+        xyz = n(self._xyz)
+        cols = [xyz, np.zeros_like(xyz), n(self._features_dc.transpose(1, 2).flatten(start_dim=1).contiguous()),
+                n(self._features_rest.transpose(1, 2).flatten(start_dim=1).contiguous()), n(self._opacity), n(self._scaling),
+                n(self._rotation)]
+        write_vertices(path, self.construct_list_of_attributes(), np.concatenate(cols, axis=1))
+
+    @torch.no_grad()
+    def load_ply(self, path, device=None):
+        """scene/gaussian_model.py:355-395."""
+        import numpy as np
+        from .plyio import read_vertices
+        device = device if device is not None else (self._xyz.device if hasattr(self, "_xyz") else "cuda")
+        names, v = read_vertices(path)
+        col = lambda prefix: sorted((k for k in names if k.startswith(prefix)), key=lambda x: int(x.split('_')[-1]))
+        xyz = np.stack((v["x"], v["y"], v["z"]), axis=1)
+        f_dc = np.stack([v[f"f_dc_{k}"] for k in range(3)], axis=1)[:, :, None]
+        extra = col("f_rest_")
+        assert len(extra) == 3 * (self.max_sh_degree + 1) ** 2 - 3
+        f_rest = np.stack([v[k] for k in extra], axis=1).reshape(xyz.shape[0], 3, (self.max_sh_degree + 1) ** 2 - 1)
+        scales = np.stack([v[k] for k in col("scale_")], axis=1)
+        rots = np.stack([v[k] for k in col("rot")], axis=1)
+        tt = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float, device=device)
+        self._xyz = nn.Parameter(tt(xyz))
+        self._features_dc = nn.Parameter(tt(f_dc).transpose(1, 2).contiguous())
+        self._features_rest = nn.Parameter(tt(f_rest).transpose(1, 2).contiguous())
+        self._opacity = nn.Parameter(tt(v["opacity"][:, None]))
+        self._scaling = nn.Parameter(tt(scales))
+        self._rotation = nn.Parameter(tt(rots))
+        self.active_sh_degree = self.max_sh_degree
+        self._deformation_table = torch.ones(xyz.shape[0], dtype=torch.bool, device=device)
+        self.max_radii2D = torch.zeros(xyz.shape[0], device=device)
 
     def compute_regulation(self, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight):
         """scene/gaussian_model.py:710-749."""
@@ -162,10 +232,13 @@ def eval_sh(deg, sh, dirs):
 
 def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg_color: torch.Tensor,
            scaling_modifier=1.0, override_color=None, stage="fine", return_decomposition=False, return_dx=False,
-           render_feat=False):
+           render_feat=False, densify_accum=None):
     """Mirror of gaussian_renderer/__init__.py::render.  `viewpoint_camera` is a dict with the fields the reference
     reads from a Camera (image_height/width, FoVx/FoVy or tanfovx/tanfovy, world_view_transform=viewmatrix,
-    full_proj_transform=projmatrix, camera_center=campos, time)."""
+    full_proj_transform=projmatrix, camera_center=campos, time).
+    densify_accum (extension): (xyz_gradient_accum, denom, max_radii2D) updated by the rasterizer's backward itself when the
+    RGB + feature pair runs as one node (train.py:489-493 otherwise does it in separate passes); the result dict then carries
+    "densify_stats_fused": True."""
     dev = pc.get_xyz.device
     screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
     try:
@@ -235,8 +308,19 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
     if colors_precomp is not None:
         shs_final = None
     want_feat = render_feat and "fine" in stage
+    decomposed = None
+    if (return_decomposition and dx is not None and means3D_final.is_cuda and not torch.is_grad_enabled()
+            and not want_feat and getattr(pipe, "fused_decomposition", True)):
+        # evaluation path: full + dynamic-only + static-only renders from ONE preprocess / binning / sort
+        max_values = torch.max(torch.abs(dx), dim=1)[0]
+        dynamic_mask = max_values > torch.mean(max_values)
+        decomposed = rasterizer.forward_decomposed(means3D=means3D_final, opacities=opacity, dynamic_mask=dynamic_mask,
+                                                   shs=shs_final, colors_precomp=colors_precomp, scales=scales_final,
+                                                   rotations=rotations_final, cov3D_precomp=cov3D_precomp)
     pair = want_feat and colors_precomp is not None and means3D_final.is_cuda and getattr(pipe, "fused_pair", True)
-    if pair:
+    if decomposed is not None:
+        rendered_image, radii, depth = decomposed["render"], decomposed["radii"], decomposed["depth"]
+    elif pair:
         # RGB + feature image from one node: shared geometry forward, ONE fused backward (rasterizer.forward_pair)
         rendered_image, radii, depth, rendered_image2 = rasterizer.forward_pair(
             means3D=means3D_final, means2D=means2D, opacities=opacity, colors_a=colors_precomp, colors_b=feat,
@@ -247,13 +331,19 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
                                                   rotations=rotations_final, cov3D_precomp=cov3D_precomp)
     out = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
            "radii": radii, "depth": depth}
+    if densify_accum is not None:
+        out["densify_stats_fused"] = bool(pair and means3D_final.shape[0] > 0 and not rs.debug)
     if want_feat:
         if not pair:
             rendered_image2, _, _ = rasterizer(means3D=means3D_final, means2D=means2D, shs=None, colors_precomp=feat,
                                                opacities=opacity, scales=scales_final, rotations=rotations_final,
                                                cov3D_precomp=cov3D_precomp)
         out["feat"] = rendered_image2
-    if return_decomposition and dx is not None:
+    if decomposed is not None:
+        vis = radii > 0
+        out.update({"render_d": decomposed["render_d"], "depth_d": decomposed["depth_d"], "visibility_filter_d": vis[dynamic_mask],
+                    "render_s": decomposed["render_s"], "depth_s": decomposed["depth_s"], "visibility_filter_s": vis[~dynamic_mask]})
+    elif return_decomposition and dx is not None:
         max_values = torch.max(torch.abs(dx), dim=1)[0]
         dynamic_mask = max_values > torch.mean(max_values)
         for tag, m in (("d", dynamic_mask), ("s", ~dynamic_mask)):
@@ -349,13 +439,22 @@ def training_loss(pc: GaussianParams, pkg: Dict, gt_image, gt_depth, gt_feat, hy
 
 
 def training_step(pc: GaussianParams, cam: Dict, gt_image, gt_depth, gt_feat, hyper, opt, bg, stage="fine",
-                  pipe: Optional[SimpleNamespace] = None, grad_hook=None):
+                  pipe: Optional[SimpleNamespace] = None, grad_hook=None, densify_stats=False):
     """One iteration of train.py for one view: render -> loss -> backward -> Adam step.  `grad_hook(pc, pkg)` runs
-    between backward and the optimizer step (used by the data-parallel wrapper for the RCCL all-reduce)."""
+    between backward and the optimizer step (used by the data-parallel wrapper for the RCCL all-reduce).
+    densify_stats=True also does the bookkeeping of train.py:489-493 (max_radii2D, xyz_gradient_accum, denom) for this
+    single-view batch: inside the rasterizer's per-Gaussian backward when the iteration has one raster node, else as one
+    fused pass over the viewspace gradient (optim.densify_stats).  Data-parallel runs reduce the statistics first
+    (dp.reduce_densification_stats) and must leave this off."""
     pipe = pipe or SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
-    pkg = render(cam, pc, pipe, bg, stage=stage, return_dx=True, render_feat=(stage == "fine" and hyper.feat_head))
+    acc = (pc.xyz_gradient_accum, pc.denom, pc.max_radii2D) if densify_stats else None
+    pkg = render(cam, pc, pipe, bg, stage=stage, return_dx=True, render_feat=(stage == "fine" and hyper.feat_head),
+                 densify_accum=acc)
     loss = training_loss(pc, pkg, gt_image, gt_depth, gt_feat, hyper, opt, stage)
     loss.backward()
+    if densify_stats and not pkg.get("densify_stats_fused", False):
+        from .optim import densify_stats as _densify_stats
+        _densify_stats(pc.xyz_gradient_accum, pc.denom, pc.max_radii2D, pkg["viewspace_points"].grad, pkg["radii"])
     if grad_hook is not None:
         grad_hook(pc, pkg)
     pc.optimizer.step()

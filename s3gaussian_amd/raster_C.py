@@ -68,6 +68,13 @@ _geom_cache = None  # (key, tensors kept alive, outputs)
 _geom_cache_hits = 0  # number of renders served from the cache (tests, diagnostics)
 
 
+def invalidate_geometry_cache() -> None:
+    """Drops the cached arenas (and the references that keep the last render's inputs alive).  Called by
+    optim.Adam.step(); call it after writing parameters through `.data` or raw pointers, which bump no version counter."""
+    global _geom_cache
+    _geom_cache = None
+
+
 def _geom_key(tensors, scalars):
     # storage identity + version, not id(): autograd hands Function.forward fresh Python wrappers of the same tensors, and
     # the rasterizer module builds a new empty placeholder per call for every absent input
@@ -147,6 +154,29 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor
 
 
+def rasterize_decomposition(background, colors, is_dynamic, tan_fovx, tan_fovy, image_height, image_width, P, R, geomBuffer,
+                            binningBuffer, imageBuffer, debug=False):
+    """Extension: the dynamic-only and static-only images of a geometry that `rasterize_gaussians` has already processed
+    (its arenas), in one extra blend pass (include/s3g_raster.h::s3g_raster_forward_decompose).
+    colors [P,3] precomputed colours, or an empty tensor to use the forward's own SH colours; is_dynamic bool/uint8 [P].
+    -> (color_d [3,H,W], depth_d [1,H,W], color_s [3,H,W], depth_s [1,H,W])"""
+    L = _lib.lib()
+    dev = geomBuffer.device
+    H, W = int(image_height), int(image_width)
+    out = [torch.empty((c, H, W), dtype=torch.float32, device=dev) for c in (NUM_CHANNELS, 1, NUM_CHANNELS, 1)]
+    keep = [_f32(background, "bg"), _f32(colors, "colors_precomp"), is_dynamic.to(torch.uint8).contiguous()]
+    if keep[2].numel() != P or not keep[2].is_cuda:
+        raise RuntimeError("is_dynamic must be a GPU mask with one entry per Gaussian")
+    inp = _inputs(P, 0, 0, W, H, keep[0], None, None, keep[1], None, None, 1.0, None, None, None, None, tan_fovx, tan_fovy,
+                  None, False, debug)
+    with torch.cuda.device(dev):
+        code = L.s3g_raster_forward_decompose(C.byref(inp), int(R), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                                              keep[2].data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                              out[3].data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(code)
+    return tuple(out)
+
+
 def _grad_slab(P: int, M: int, dev, internals: bool) -> dict:
     """One uninitialised slab carved into the gradient arrays (the library writes every element)."""
     widths = [("rot", 4), ("conic", 4 if internals else 0), ("means3D", 3), ("means2D", 3), ("colors", 3), ("scales", 3),
@@ -162,7 +192,8 @@ def _grad_slab(P: int, M: int, dev, internals: bool) -> dict:
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, sh, degree,
-                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, return_internals=False):
+                                 campos, geomBuffer, R, binningBuffer, imageBuffer, debug, return_internals=False,
+                                 densify_accum=None):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
            dL_dscales[P,3], dL_drotations[P,4])   (RAST/rasterize_points.cu:201).
     return_internals=True appends (dL_dconic[P,2,2], dL_ddepths[P,1]), the reference's internal intermediates."""
@@ -183,12 +214,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         work = torch.empty(L.s3g_raster_backward_workspace_bytes(P, int(R)), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
-            code = L.s3g_raster_backward(C.byref(inp), int(R), radii_.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer),
-                                         _ptr(imageBuffer), _ptr(work), gcol_.data_ptr(), gdep_.data_ptr(),
-                                         v["means2D"].data_ptr(), _ptr(v["conic"]), v["opacity"].data_ptr(),
-                                         v["colors"].data_ptr(), _ptr(v["depths"]), v["means3D"].data_ptr(),
-                                         v["cov3D"].data_ptr(), _ptr(v["sh"]), v["scales"].data_ptr(),
-                                         v["rot"].data_ptr(), stream)
+            args = (C.byref(inp), int(R), radii_.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer),
+                    _ptr(imageBuffer), _ptr(work), gcol_.data_ptr(), gdep_.data_ptr(),
+                    v["means2D"].data_ptr(), _ptr(v["conic"]), v["opacity"].data_ptr(),
+                    v["colors"].data_ptr(), _ptr(v["depths"]), v["means3D"].data_ptr(),
+                    v["cov3D"].data_ptr(), _ptr(v["sh"]), v["scales"].data_ptr(), v["rot"].data_ptr())
+            if densify_accum is None:
+                code = L.s3g_raster_backward(*args, stream)
+            else:
+                code = L.s3g_raster_backward_accum(*args, C.byref(_densify_struct(densify_accum, P)), stream)
         _lib.check(code)
     out = (v["means2D"].view(P, 3), v["colors"].view(P, NUM_CHANNELS), v["opacity"].view(P, 1), v["means3D"].view(P, 3),
            v["cov3D"].view(P, 6), v["sh"].view(P, M, 3), v["scales"].view(P, 3), v["rot"].view(P, 4))
@@ -199,11 +233,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
 
 def rasterize_gaussians_backward2(background, means3D, radii, colors, colors2, scales, rotations, scale_modifier,
                                   cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
-                                  dL_dout_color2, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                  dL_dout_color2, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, densify_accum=None):
     """Backward of two renders of the same geometry (colours `colors` -> image + depth, `colors2` -> second image) in one
     pass (include/s3g_raster.h::s3g_raster_backward2).
     -> (dL_dmeans2D, dL_dcolors, dL_dcolors2, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales, dL_drotations); everything
-    but the two colour gradients is the sum over both images."""
+    but the two colour gradients is the sum over both images.
+    densify_accum = (xyz_gradient_accum [P,1], denom [P,1], max_radii2D [P]) float32: the per-Gaussian kernel also does the
+    reference's add_densification_stats / max_radii2D update (s3g_raster_backward2_accum)."""
     L = _lib.lib()
     dev = means3D.device
     P = means3D.size(0)
@@ -222,17 +258,29 @@ def rasterize_gaussians_backward2(background, means3D, radii, colors, colors2, s
         work = torch.empty(L.s3g_raster_backward2_workspace_bytes(P, int(R)), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
-            code = L.s3g_raster_backward2(C.byref(inp), col2_.data_ptr(), int(R), radii_.data_ptr(), _ptr(geomBuffer),
-                                          _ptr(binningBuffer), _ptr(imageBuffer), _ptr(work), gcol_.data_ptr(),
-                                          gdep_.data_ptr(), gcol2_.data_ptr(), v["means2D"].data_ptr(), None,
-                                          v["opacity"].data_ptr(), v["colors"].data_ptr(), g_col2.data_ptr(), None,
-                                          v["means3D"].data_ptr(), v["cov3D"].data_ptr(), v["scales"].data_ptr(),
-                                          v["rot"].data_ptr(), stream)
+            args = (C.byref(inp), col2_.data_ptr(), int(R), radii_.data_ptr(), _ptr(geomBuffer),
+                    _ptr(binningBuffer), _ptr(imageBuffer), _ptr(work), gcol_.data_ptr(),
+                    gdep_.data_ptr(), gcol2_.data_ptr(), v["means2D"].data_ptr(), None,
+                    v["opacity"].data_ptr(), v["colors"].data_ptr(), g_col2.data_ptr(), None,
+                    v["means3D"].data_ptr(), v["cov3D"].data_ptr(), v["scales"].data_ptr(),
+                    v["rot"].data_ptr())
+            if densify_accum is None:
+                code = L.s3g_raster_backward2(*args, stream)
+            else:
+                code = L.s3g_raster_backward2_accum(*args, C.byref(_densify_struct(densify_accum, P)), stream)
         _lib.check(code)
     else:
         g_col2.zero_()
     return (v["means2D"].view(P, 3), v["colors"].view(P, NUM_CHANNELS), g_col2, v["opacity"].view(P, 1),
             v["means3D"].view(P, 3), v["cov3D"].view(P, 6), v["scales"].view(P, 3), v["rot"].view(P, 4))
+
+
+def _densify_struct(acc, P) -> _lib.DensifyAccum:
+    a, d, m = acc
+    for name, t_ in (("xyz_gradient_accum", a), ("denom", d), ("max_radii2D", m)):
+        if not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == P):
+            raise RuntimeError(f"densify_accum: {name} must be a contiguous float32 GPU tensor with {P} elements")
+    return _lib.DensifyAccum(a.data_ptr(), d.data_ptr(), m.data_ptr())
 
 
 def set_exact_cull(on: bool) -> bool:

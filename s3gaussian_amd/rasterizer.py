@@ -91,7 +91,8 @@ class _RasterizeGaussiansPair(torch.autograd.Function):
     autograd would then add."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, colors_a, colors_b, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, colors_a, colors_b, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                densify_accum=None):
         rs = raster_settings
         empty = torch.Tensor([])
         common = (opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
@@ -100,6 +101,7 @@ class _RasterizeGaussiansPair(torch.autograd.Function):
             rs.bg, means3D, colors_a, *common, colors2=colors_b)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.densify_accum = densify_accum
         ctx.save_for_backward(colors_a, colors_b, means3D, scales, rotations, cov3Ds_precomp, radii, geom, binning, img)
         ctx.mark_non_differentiable(radii)
         return color, radii, depth, color2
@@ -115,8 +117,8 @@ class _RasterizeGaussiansPair(torch.autograd.Function):
         (g_means2D, g_col_a, g_col_b, g_opac, g_means3D, g_cov3D, g_scales, g_rot) = _C.rasterize_gaussians_backward2(
             rs.bg, means3D, radii, colors_a, colors_b, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_color2, rs.campos, geom, ctx.num_rendered,
-            binning, img, rs.debug)
-        return g_means3D, g_means2D, g_col_a, g_col_b, g_opac, g_scales, g_rot, g_cov3D, None
+            binning, img, rs.debug, densify_accum=ctx.densify_accum)
+        return g_means3D, g_means2D, g_col_a, g_col_b, g_opac, g_scales, g_rot, g_cov3D, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
@@ -151,10 +153,46 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
 
-    def forward_pair(self, means3D, means2D, opacities, colors_a, colors_b, scales=None, rotations=None, cov3D_precomp=None):
+    @torch.no_grad()
+    def forward_decomposed(self, means3D, opacities, dynamic_mask, shs=None, colors_precomp=None, scales=None, rotations=None,
+                           cov3D_precomp=None):
+        """Extension for the evaluation path (gaussian_renderer/__init__.py:168-204, `return_decomposition=True`): the full
+        render plus the dynamic-only and static-only renders, sharing ONE preprocess / binning / sort; the two subset images
+        come from one extra blend pass and equal `self(...)` on the masked inputs bit for bit.  Inference only (no autograd).
+        -> dict(render, radii, depth, render_d, depth_d, render_s, depth_s)"""
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        e = torch.Tensor([])
+        n = lambda x: e if x is None else x
+        P = means3D.shape[0]
+        R, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
+            rs.bg, means3D, n(colors_precomp), opacities, n(scales), n(rotations), rs.scale_modifier, n(cov3D_precomp),
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, n(shs), rs.sh_degree,
+            rs.campos, rs.prefiltered, rs.debug)
+        if P == 0:
+            z3, z1 = torch.zeros_like(color), torch.zeros_like(depth)
+            return dict(render=color, radii=radii, depth=depth, render_d=z3, depth_d=z1, render_s=z3.clone(), depth_s=z1.clone())
+        cd, dd, cs, ds = _C.rasterize_decomposition(rs.bg, n(colors_precomp), dynamic_mask, rs.tanfovx, rs.tanfovy,
+                                                    rs.image_height, rs.image_width, P, R, geom, binning, img, rs.debug)
+        n_dyn = int(dynamic_mask.sum())     # an EMPTY subset renders as zeros without background (rasterize_points.cu:81-116)
+        if n_dyn == 0:
+            cd.zero_(), dd.zero_()
+        if n_dyn == P:
+            cs.zero_(), ds.zero_()
+        return dict(render=color, radii=radii, depth=depth, render_d=cd, depth_d=dd, render_s=cs, depth_s=ds)
+
+    def forward_pair(self, means3D, means2D, opacities, colors_a, colors_b, scales=None, rotations=None, cov3D_precomp=None,
+                     densify_accum=None):
         """Extension (not in the reference): render the SAME Gaussians with two sets of precomputed colours, e.g. RGB and the
         feature head's output (gaussian_renderer/__init__.py:127-166 does this with two calls).
-        -> (image_a [3,H,W], radii [P], depth [1,H,W], image_b [3,H,W]); gradients equal those of the two separate calls."""
+        -> (image_a [3,H,W], radii [P], depth [1,H,W], image_b [3,H,W]); gradients equal those of the two separate calls.
+        densify_accum = (xyz_gradient_accum, denom, max_radii2D): the backward of this node also performs the reference's
+        densification bookkeeping (train.py:489-493) in its per-Gaussian pass -- valid because this node yields the whole
+        viewspace gradient of the iteration."""
         has_sr = scales is not None or rotations is not None
         if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
@@ -170,6 +208,8 @@ class GaussianRasterizer(nn.Module):
             b, _, _ = self.forward(means3D, means2D, opacities, colors_precomp=colors_b, scales=scales if scales.numel() else None,
                                    rotations=rotations if rotations.numel() else None,
                                    cov3D_precomp=cov3D_precomp if cov3D_precomp.numel() else None)
+            if densify_accum is not None:
+                raise RuntimeError("densify_accum needs the fused two-image node (P > 0, debug off)")
             return a, radii, depth, b
         return _RasterizeGaussiansPair.apply(means3D, means2D, colors_a, colors_b, opacities, scales, rotations, cov3D_precomp,
-                                             self.raster_settings)
+                                             self.raster_settings, densify_accum)

@@ -50,15 +50,37 @@ def _worker(rank, world, port, q):
     ok = ok and params[2].grad.is_contiguous(memory_format=torch.channels_last)
     ok = ok and n == sum(p.numel() for p in params[:-1]) and n0 == n
     ok = ok and all(torch.allclose(a, p.grad, atol=1e-6) for a, p in zip(inplace, params[:-1]))
-    # densification statistics
-    vg = torch.full((10, 3), float(rank + 1))
+    # densification statistics: the reference's batch semantics (train.py:387-388,435-437) with batch = ranks
+    vg = torch.stack([torch.full((10,), float(rank + 1)), torch.full((10,), -2.0 * (rank + 1)), torch.zeros(10)], 1)
     vis = torch.arange(10) % (rank + 2) == 0
+    vg = vg * vis[:, None]                       # invisible Gaussians have zero viewspace gradient
     radii = torch.arange(10, dtype=torch.int32) * (rank + 1)
-    gn, cnt, rmax = dp.reduce_densification_stats(vg, vis, radii)
-    exp_gn = sum((torch.full((10,), (rr + 1) * 2 ** 0.5) * (torch.arange(10) % (rr + 2) == 0)) for rr in range(world))
-    exp_cnt = sum((torch.arange(10) % (rr + 2) == 0).float() for rr in range(world))
-    ok = ok and torch.allclose(gn[:, 0], exp_gn, atol=1e-5) and torch.allclose(cnt[:, 0], exp_cnt)
+    gsum, any_vis, rmax = dp.reduce_densification_stats(vg, vis, radii)
+    exp_g = sum(torch.stack([torch.full((10,), float(rr + 1)), torch.full((10,), -2.0 * (rr + 1))], 1)
+                * (torch.arange(10) % (rr + 2) == 0)[:, None] for rr in range(world)) / world
+    exp_vis = torch.stack([(torch.arange(10) % (rr + 2) == 0) for rr in range(world)]).any(0)
+    ok = ok and torch.allclose(gsum, exp_g, atol=1e-6) and torch.equal(any_vis, exp_vis)
     ok = ok and torch.equal(rmax, torch.arange(10, dtype=torch.int32) * world)
+    accum, denom, maxr = torch.zeros(10, 1), torch.zeros(10, 1), torch.zeros(10)
+    dp.add_densification_stats(accum, denom, maxr, gsum, any_vis, rmax)
+    ok = ok and torch.allclose(accum[:, 0], exp_g.norm(dim=1) * exp_vis, atol=1e-6) and torch.equal(denom[:, 0], exp_vis.float())
+    ok = ok and torch.equal(maxr, (torch.arange(10) * world * exp_vis).float())
+    # sparse row exchange == dense reduce on per-Gaussian gradients that are zero outside the visible sets
+    P = 50
+    rows = [torch.nn.Parameter(torch.zeros(P, 15, 3)), torch.nn.Parameter(torch.zeros(P, 1)), torch.nn.Parameter(torch.zeros(P, 4)),
+            torch.nn.Parameter(torch.zeros(P, 3))]
+    visr = (torch.arange(P) % (3 + rank)) == 0
+    gr = torch.Generator().manual_seed(7 + rank)
+    for prm in rows[:-1]:
+        prm.grad = torch.randn(prm.shape, generator=gr) * visr.view(P, *([1] * (prm.dim() - 1)))
+    dense = [prm.grad.clone() for prm in rows[:-1]]
+    for d_ in dense:
+        dist.all_reduce(d_)
+    sx = dp.SparseRowExchange(average=False)
+    moved = sx(rows, visr)
+    union = sum(((torch.arange(P) % (3 + rr)) == 0).int() for rr in range(world)) > 0
+    ok = ok and all(torch.equal(prm.grad, d_) for prm, d_ in zip(rows[:-1], dense)) and rows[-1].grad is None
+    ok = ok and sx.last_rows == int(union.sum()) and moved == int(union.sum()) * (45 + 1 + 4)
     # view sharding: disjoint, covering, same permutation on every rank
     mine = dp.shard_views(150, rank, world, seed=0)
     gathered = [None] * world
@@ -118,6 +140,23 @@ def _overlap_worker(rank, world, port, q):
     ok = ok and torch.allclose(plane.grad, torch.full_like(plane, sum(r + 2.0 for r in range(world))), atol=1e-5)
     ok = ok and torch.allclose(small.grad, torch.full((7,), sum(r + 1.0 for r in range(world))), atol=1e-6)
     red2.remove_hooks()
+    # densify / prune replace nn.Parameter objects (scene/gaussian_model.py:397-494): a reducer built from the OPTIMIZER
+    # follows them; the first step after the swap is reduced in finish() (no hook yet), then the hooks are re-armed
+    opt_p = torch.nn.Parameter(torch.randn(3000, 3))
+    sgd = torch.optim.SGD([{"params": [opt_p], "name": "xyz"}, {"params": [small], "name": "s"}], lr=0.0)
+    red3 = dp.OverlappedGradAllReducer(sgd, bucket_mb=0.001, inplace_mb=0.004)
+    for step in range(3):
+        if step == 1:   # "densification": a new, larger parameter takes the place of the old one in the optimizer group
+            opt_p = torch.nn.Parameter(torch.randn(5000, 3))
+            sgd.param_groups[0]["params"] = [opt_p]
+        for p_ in (opt_p, small):
+            p_.grad = None
+        ((opt_p * float(rank + 1)).sum() + (small * 2.0).sum()).backward()
+        n = red3.finish()
+        ok = ok and torch.allclose(opt_p.grad, torch.full_like(opt_p, sum(r + 1.0 for r in range(world)) / world), atol=1e-6)
+        ok = ok and n == opt_p.numel() + small.numel()
+    ok = ok and red3.rebinds == 1 and set(red3._hooks) == {id(opt_p)}
+    red3.remove_hooks()
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

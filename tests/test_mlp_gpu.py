@@ -123,3 +123,27 @@ def test_feature_head_can_be_skipped_for_inference(gpu_device):
     xg = x.clone().requires_grad_(True)
     outs = deform_mlp(xg, d.feature_out, d.pos_deform, d.shs_deform, d.dino_head, need_feat=False)
     assert outs[2] is not None and torch.equal(outs[2], full[2])
+
+
+def test_unused_feature_head_gets_no_gradient(gpu_device):
+    """No gradient on `feat` (feature image not in the loss): the dino head's parameters keep grad None -- so Adam does not
+    decay their moments or advance their step (reference behaviour with torch autograd) -- and everything else matches a
+    run whose feature gradient is explicitly zero."""
+    from s3gaussian_amd.mlp import deform_mlp
+    d = _modules(11).float().to(gpu_device)
+    x = torch.randn(1500, 128, generator=torch.Generator().manual_seed(4)).to(gpu_device)
+    res = []
+    for explicit_zero in (False, True):
+        d.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        dx, dshs, feat = deform_mlp(xg, d.feature_out, d.pos_deform, d.shs_deform, d.dino_head)
+        loss = dx.square().sum() + dshs.sum() * 0.3 + (feat.sum() * 0.0 if explicit_zero else 0.0)
+        loss.backward()
+        res.append((xg.grad.clone(), {k: (None if p.grad is None else p.grad.clone()) for k, p in d.named_parameters()}))
+    (gx0, g0), (gx1, g1) = res
+    assert torch.equal(gx0, gx1)
+    for k in g0:
+        if k.startswith("dino_head"):
+            assert g0[k] is None and g1[k] is not None and float(g1[k].abs().max()) == 0.0, k
+        elif g1[k] is not None:
+            assert g0[k] is not None and torch.equal(g0[k], g1[k]), k
