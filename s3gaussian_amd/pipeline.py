@@ -324,7 +324,7 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
         # RGB + feature image from one node: shared geometry forward, ONE fused backward (rasterizer.forward_pair)
         rendered_image, radii, depth, rendered_image2 = rasterizer.forward_pair(
             means3D=means3D_final, means2D=means2D, opacities=opacity, colors_a=colors_precomp, colors_b=feat,
-            scales=scales_final, rotations=rotations_final, cov3D_precomp=cov3D_precomp)
+            scales=scales_final, rotations=rotations_final, cov3D_precomp=cov3D_precomp, densify_accum=densify_accum)
     else:
         rendered_image, radii, depth = rasterizer(means3D=means3D_final, means2D=means2D, shs=shs_final,
                                                   colors_precomp=colors_precomp, opacities=opacity, scales=scales_final,

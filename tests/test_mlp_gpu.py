@@ -145,5 +145,5 @@ def test_unused_feature_head_gets_no_gradient(gpu_device):
     for k in g0:
         if k.startswith("dino_head"):
             assert g0[k] is None and g1[k] is not None and float(g1[k].abs().max()) == 0.0, k
-        elif g1[k] is not None:
-            assert g0[k] is not None and torch.equal(g0[k], g1[k]), k
+        elif g1[k] is not None:   # weight gradients are flushed with float atomics: equal to summation-order round-off
+            assert g0[k] is not None and rel_l2(g0[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-6, k
