@@ -360,28 +360,41 @@ __device__ __forceinline__ void row_load(float (&v)[RowSplit<W>::VEC], const flo
 // ASTRIDE > AW: A (and dW) are AW-column windows of wider [.][ASTRIDE] arrays (feature_out is done as two halves so the
 // accumulators of a wave stay at 64 registers).
 //
-// ONE launch for all nine weight-gradient GEMMs: a persistent workgroup of 8 waves walks its share of the 32-point tiles and
-// wave w owns GEMM w for every one of them (wave 7 owns the two 3-row heads).  The eight GEMMs of a tile run concurrently
-// on one CU, so the `hidden` activations that three of them share and the `ghid` signal that two share are fetched from HBM
-// once (the other readers hit L1/L2): 3288 B per point instead of the 4056 B of nine separate launches, one pipeline
-// fill/drain instead of nine, and no LDS combine -- a wave's accumulators already are the workgroup's whole contribution.
-constexpr int WG_WAVES = 8;
+// Software pipeline: the operand rows of a wave's NEXT tile are requested before the 64 MFMAs of the current tile are issued
+// and are not touched until the following iteration, in two alternating register sets (the loop is unrolled by two), so a
+// whole tile of MFMA work (~3.4 us at two waves per SIMD) covers the HBM latency.  Loads of full tiles carry no bounds
+// select at all: a select on a loaded value is scheduled where the value is consumed and -- when that is the loop's last
+// instruction group -- turns into `s_waitcnt vmcnt(0)` in front of the back-edge (the previous version of this kernel exposed
+// the full memory latency once per tile that way: ~9 us per tile for 1.7 us of MFMA work).  The one ragged tile at the end
+// of the array is handled separately with masked loads.
+constexpr int WG_WAVES = 8;  // waves per wgrad workgroup (one persistent workgroup per CU)
 
-struct WgradJob {
-  const float* G;  // [P][GW]   (NULL = this GEMM is skipped)
-  const float* A;  // [P][ASTRIDE] window starting at the job's first column
-  float* dW;       // [GW][ASTRIDE] window
-  float* db;       // [GW] or NULL
-};
-struct WgradAllArgs {
-  WgradJob job[10];  // W0a W0b P1 S1 D0 D1 S2 | P2 D2 (wave 7) | unused
-  int P;
-};
+// raw (select-free) operand loads of a FULL tile: columns are clamped statically so lanes beyond the row's width re-read
+// valid data (their MFMA rows are discarded at the flush)
+template <int W, int STRIDE>
+__device__ __forceinline__ void row_load_full(float (&v)[RowSplit<W>::VEC], const float* __restrict__ g, int p, int i) {
+  constexpr int VEC = RowSplit<W>::VEC;
+  const int col = VEC * i < W ? VEC * i : W - VEC;
+  const float* src = g + (size_t)p * STRIDE + col;
+  if constexpr (VEC == 4) {
+    const float4 x = *reinterpret_cast<const float4*>(src);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  } else if constexpr (VEC == 2) {
+    const float2 x = *reinterpret_cast<const float2*>(src);
+    v[0] = x.x; v[1] = x.y;
+  } else {
+    v[0] = src[0];
+  }
+}
 
 template <int GW, int AW, bool RELU_A, int ASTRIDE>
-__device__ __forceinline__ void wgrad_wave(const WgradJob j, int P, int lane) {
-  if (j.G == nullptr) return;
+__global__ void __launch_bounds__(WG_WAVES * 64) mlp_wgrad_kernel(const WgradArgs a) {
   constexpr int GV = RowSplit<GW>::VEC, AV = RowSplit<AW>::VEC, STEPS = MT / 2;
+  constexpr int GLOADS = GW == 3 ? 1 : STEPS;
+  __shared__ float red[32 * GV * AW + 32 * GV];  // the workgroup's dW block and db, combined in LDS before the flush
+  for (int e = threadIdx.x; e < 32 * GV * AW + 32 * GV; e += WG_WAVES * 64) red[e] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, k = lane >> 5;
   f32x16 acc[GV][AV];
 #pragma unroll
@@ -393,55 +406,90 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob j, int P, int lane) {
   float bsum[GV];
 #pragma unroll
   for (int m = 0; m < GV; m++) bsum[m] = 0.f;
-  const int ntiles = (P + MT - 1) / MT;
-  const int stride = gridDim.x;
-  float gv[STEPS][GV], av[STEPS][AV];
-  // GW == 3 (the dx / feat heads): a tile's 32 x 3 gradient block is 384 contiguous bytes -- two coalesced 4-byte loads per
-  // lane (lanes 0..47) instead of 16 three-lane loads; the MFMA operand of step s is then picked out with two ds_bpermute.
-  float2 g3 = make_float2(0.f, 0.f);
-  auto load_g3 = [&](int t) {
-    const long long e0 = (long long)t * (MT * 3) + 2 * lane, lim = (long long)P * 3;  // element index of .x
-    float2 v = make_float2(0.f, 0.f);
-    if (lane < 48) {  // two 4-byte loads with clamped indices (branch-free inside: the load count stays static)
-      const long long top = lim - 1;
-      v.x = j.G[e0 < top ? e0 : top];
-      v.y = j.G[e0 + 1 < top ? e0 + 1 : top];
-      v.x = e0 < lim ? v.x : 0.f;
-      v.y = e0 + 1 < lim ? v.y : 0.f;
+  const int nfull = a.P / MT;  // tiles whose 32 rows all exist
+  const int stride = gridDim.x * WG_WAVES;
+  // GW == 3 (the dx / feat heads): a tile's 32 x 3 gradient block is 384 contiguous bytes -- one coalesced 8-byte load per
+  // lane (lanes 48.. re-read the block's start) instead of 16 three-lane loads; the MFMA operand of step s is then picked
+  // out with two ds_bpermute.
+  struct Set {
+    float g[GLOADS][GW == 3 ? 2 : GV];
+    float v[STEPS][AV];
+  };
+  auto issue = [&](Set& S, int tile) {  // requires tile < nfull
+    const int p0 = tile * MT;
+    if constexpr (GW == 3) {
+      const float2 x = *reinterpret_cast<const float2*>(a.G + (size_t)p0 * 3 + 2 * (lane < 48 ? lane : lane - 48));
+      S.g[0][0] = x.x; S.g[0][1] = x.y;
     }
-    return v;
-  };
-  auto pick_g3 = [&](float2 v, int s) {  // G[p0 + 2s + k][i] for lanes i < 3
-    const int e = 6 * s + 3 * k + (i < 3 ? i : 0);
-    const float x = __shfl(v.x, e >> 1), y = __shfl(v.y, e >> 1);
-    return i < 3 ? ((e & 1) ? y : x) : 0.f;
-  };
-  int tile = blockIdx.x;
-  if (tile < ntiles) {
-    if constexpr (GW == 3) g3 = load_g3(tile);
 #pragma unroll
     for (int s = 0; s < STEPS; s++) {
-      if constexpr (GW != 3) row_load<GW, false>(gv[s], j.G, tile * MT + 2 * s + k, P, i);
-      row_load<AW, RELU_A, ASTRIDE>(av[s], j.A, tile * MT + 2 * s + k, P, i);
+      if constexpr (GW != 3) row_load_full<GW, GW>(S.g[s], a.G, p0 + 2 * s + k, i);
+      row_load_full<AW, ASTRIDE>(S.v[s], a.A, p0 + 2 * s + k, i);
     }
-  }
-  for (; tile < ntiles; tile += stride) {
-    const int np0 = (tile + stride) * MT;  // rows past P load as zeros
-    float2 g3cur = g3;
-    if constexpr (GW == 3) g3 = load_g3(tile + stride);
+  };
+  auto pick_g3 = [&](const float (&g)[2], int s) {  // G[p0 + 2s + k][i] for lanes i < 3
+    const int e = 6 * s + 3 * k + (i < 3 ? i : 0);
+    const float x = __shfl(g[0], e >> 1), y = __shfl(g[1], e >> 1);
+    return i < 3 ? ((e & 1) ? y : x) : 0.f;
+  };
+  auto consume = [&](const Set& S) {
 #pragma unroll
     for (int s = 0; s < STEPS; s++) {
       float ga[GV], ba[AV];
       if constexpr (GW == 3) {
-        ga[0] = pick_g3(g3cur, s);
+        ga[0] = pick_g3(S.g[0], s);
       } else {
 #pragma unroll
-        for (int m = 0; m < GV; m++) ga[m] = gv[s][m];
+        for (int m = 0; m < GV; m++) ga[m] = S.g[s][m];
       }
 #pragma unroll
-      for (int n = 0; n < AV; n++) ba[n] = av[s][n];
-      if constexpr (GW != 3) row_load<GW, false>(gv[s], j.G, np0 + 2 * s + k, P, i);
-      row_load<AW, RELU_A, ASTRIDE>(av[s], j.A, np0 + 2 * s + k, P, i);
+      for (int n = 0; n < AV; n++) ba[n] = RELU_A ? fmaxf(S.v[s][n], 0.f) : S.v[s][n];
+#pragma unroll
+      for (int m = 0; m < GV; m++) {
+        bsum[m] += ga[m];
+#pragma unroll
+        for (int n = 0; n < AV; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[m], ba[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  };
+  {
+    // Loads are issued UNCONDITIONALLY (tile index clamped to the last full tile: one wasted prefetch per wave at the end):
+    // a load behind a branch makes the compiler's waitcnt pass merge the "issued" and "not issued" paths at the join and
+    // wait for the stricter of the two counts -- i.e. for the loads it has just issued.
+    Set A, B;
+    const int t0 = blockIdx.x * WG_WAVES + wave;
+    const int cnt = t0 < nfull ? (nfull - t0 + stride - 1) / stride : 0;
+    const int last = nfull - 1;
+    if (cnt > 0) {
+      // sched_barrier(0): nothing moves across it -- without it the machine scheduler sinks the prefetch loads down to
+      // shorten their live ranges and the pipeline collapses into load -> wait -> use
+      issue(A, t0);
+      for (int it = 0; it < cnt; it += 2) {
+        issue(B, min(t0 + (it + 1) * stride, last));
+        __builtin_amdgcn_sched_barrier(0);
+        consume(A);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 >= cnt) break;
+        issue(A, min(t0 + (it + 2) * stride, last));
+        __builtin_amdgcn_sched_barrier(0);
+        consume(B);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // the ragged last tile (P % 32 rows): masked loads, handled by the wave whose sequence it continues
+  if (a.P % MT != 0 && (nfull % stride) == blockIdx.x * WG_WAVES + wave) {
+    const int p0 = nfull * MT;
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      float ga[GV], ba[AV];
+      const int p = p0 + 2 * s + k;
+      if constexpr (GW == 3) {
+        ga[0] = (p < a.P && i < 3) ? a.G[(size_t)p * 3 + i] : 0.f;
+      } else {
+        row_load<GW, false>(ga, a.G, p, a.P, i);
+      }
+      row_load<AW, RELU_A, ASTRIDE>(ba, a.A, p, a.P, i);
 #pragma unroll
       for (int m = 0; m < GV; m++) {
         bsum[m] += ga[m];
@@ -456,34 +504,27 @@ __device__ __forceinline__ void wgrad_wave(const WgradJob j, int P, int lane) {
 #pragma unroll
     for (int n = 0; n < AV; n++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int o = GV * acc_row(r, lane) + m, c = AV * (lane & 31) + n;
-        if (o < GW && c < AW) atomicAdd(&j.dW[(size_t)o * ASTRIDE + c], acc[m][n][r]);
-      }
-  if (j.db != nullptr) {
+      for (int r = 0; r < 16; r++)
+        atomicAdd(&red[(GV * acc_row(r, lane) + m) * AW + AV * (lane & 31) + n], acc[m][n][r]);
 #pragma unroll
-    for (int m = 0; m < GV; m++) {
-      const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
-      if (k == 0 && GV * i + m < GW) atomicAdd(&j.db[GV * i + m], tot);
-    }
+  for (int m = 0; m < GV; m++) {
+    const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
+    if (k == 0) atomicAdd(&red[32 * GV * AW + GV * i + m], tot);
   }
+  __syncthreads();
+  for (int e = threadIdx.x; e < GW * AW; e += WG_WAVES * 64)
+    atomicAdd(&a.dW[(size_t)(e / AW) * ASTRIDE + e % AW], red[e]);
+  if (a.db != nullptr && threadIdx.x < GW) atomicAdd(&a.db[threadIdx.x], red[32 * GV * AW + threadIdx.x]);
 }
 
-__global__ void __launch_bounds__(WG_WAVES * 64) mlp_wgrad_all_kernel(const WgradAllArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  switch (wave) {  // wave-uniform: every wave runs exactly one specialisation
-    case 0: wgrad_wave<64, 64, false, 128>(a.job[0], a.P, lane); break;  // W0[:, :64]   ghid x features[:, :64]
-    case 1: wgrad_wave<64, 64, false, 128>(a.job[1], a.P, lane); break;  // W0[:, 64:]
-    case 2: wgrad_wave<64, 64, true, 64>(a.job[2], a.P, lane); break;    // P1           x relu(hidden)
-    case 3: wgrad_wave<64, 64, true, 64>(a.job[3], a.P, lane); break;    // S1           x relu(hidden)
-    case 4: wgrad_wave<64, 64, false, 64>(a.job[4], a.P, lane); break;   // D0           x hidden (raw)
-    case 5: wgrad_wave<64, 64, false, 64>(a.job[5], a.P, lane); break;   // D1           x dino1
-    case 6: wgrad_wave<48, 64, false, 64>(a.job[6], a.P, lane); break;   // S2           g_dshs x shs1
-    default:
-      wgrad_wave<3, 64, false, 64>(a.job[7], a.P, lane);                 // P2           g_dx x pos1
-      wgrad_wave<3, 64, false, 64>(a.job[8], a.P, lane);                 // D2           g_feat x dino2
-      break;
-  }
+template <int GW, int AW, bool RELU_A, int ASTRIDE = AW>
+static int launch_wgrad(const float* G, const float* A, float* dW, float* db, int P, hipStream_t stream) {
+  WgradArgs a{G, A, dW, db, P};
+  const int ntiles = (P + MT - 1) / MT;
+  const int blocks = min((ntiles + WG_WAVES - 1) / WG_WAVES, 256);
+  hipLaunchKernelGGL((mlp_wgrad_kernel<GW, AW, RELU_A, ASTRIDE>), dim3(blocks), dim3(WG_WAVES * 64), 0, stream, a);
+  S3G_HIP_CHECK(hipGetLastError());
+  return S3G_OK;
 }
 
 }  // namespace s3g
@@ -548,24 +589,17 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   S3G_HIP_CHECK(hipGetLastError());
   profile_begin(S3G_PROFILE_MLP_WGRAD, stream);
   const size_t PS = (size_t)P * HID;
-  WgradAllArgs wa;
-  memset(&wa, 0, sizeof wa);
-  wa.P = P;
-  const bool dino = g_feat != nullptr;  // NULL: the dino head received no gradient; its six parameter gradients stay untouched
-  wa.job[0] = WgradJob{workspace + 4 * PS, features, gw->W0, gw->b0};
-  wa.job[1] = WgradJob{workspace + 4 * PS, features + 64, gw->W0 + 64, nullptr};
-  wa.job[2] = WgradJob{workspace + 2 * PS, stash + 0 * PS, gw->P1, gw->pb1};
-  wa.job[3] = WgradJob{workspace + 3 * PS, stash + 0 * PS, gw->S1, gw->sb1};
-  wa.job[4] = WgradJob{dino ? workspace + 1 * PS : nullptr, stash + 0 * PS, gw->D0, gw->db0};
-  wa.job[5] = WgradJob{dino ? workspace + 0 * PS : nullptr, stash + 3 * PS, gw->D1, gw->db1};
-  wa.job[6] = WgradJob{g_dshs, stash + 2 * PS, gw->S2, gw->sb2};
-  wa.job[7] = WgradJob{g_dx, stash + 1 * PS, gw->P2, gw->pb2};
-  wa.job[8] = WgradJob{dino ? g_feat : nullptr, stash + 4 * PS, gw->D2, gw->db2};
-  {
-    const int blocks = min(ntiles, 256);
-    hipLaunchKernelGGL(mlp_wgrad_all_kernel, dim3(blocks), dim3(WG_WAVES * 64), 0, stream, wa);
-    S3G_HIP_CHECK(hipGetLastError());
+  if (g_feat != nullptr) {  // NULL: the dino head received no gradient; its six parameter gradients are left untouched
+    if (int e = launch_wgrad<3, 64, false>(g_feat, stash + 4 * PS, gw->D2, gw->db2, P, stream)) return e;
+    if (int e = launch_wgrad<64, 64, false>(workspace + 0 * PS, stash + 3 * PS, gw->D1, gw->db1, P, stream)) return e;
+    if (int e = launch_wgrad<64, 64, false>(workspace + 1 * PS, stash + 0 * PS, gw->D0, gw->db0, P, stream)) return e;
   }
+  if (int e = launch_wgrad<3, 64, false>(g_dx, stash + 1 * PS, gw->P2, gw->pb2, P, stream)) return e;
+  if (int e = launch_wgrad<64, 64, true>(workspace + 2 * PS, stash + 0 * PS, gw->P1, gw->pb1, P, stream)) return e;
+  if (int e = launch_wgrad<48, 64, false>(g_dshs, stash + 2 * PS, gw->S2, gw->sb2, P, stream)) return e;
+  if (int e = launch_wgrad<64, 64, true>(workspace + 3 * PS, stash + 0 * PS, gw->S1, gw->sb1, P, stream)) return e;
+  if (int e = launch_wgrad<64, 64, false, 128>(workspace + 4 * PS, features, gw->W0, gw->b0, P, stream)) return e;
+  if (int e = launch_wgrad<64, 64, false, 128>(workspace + 4 * PS, features + 64, gw->W0 + 64, nullptr, P, stream)) return e;
   profile_end(S3G_PROFILE_MLP_WGRAD, stream, (double)P, 0.0);
   return S3G_OK;
 }

@@ -29,3 +29,19 @@ for it in range(4):
     e[2].record()
     torch.cuda.synchronize()
     print(f"iter {it}: forward {e[0].elapsed_time(e[1]):.3f} ms  backward(+loss) {e[1].elapsed_time(e[2]):.3f} ms")
+
+import ctypes as C  # noqa: E402
+from s3gaussian_amd import _lib  # noqa: E402
+L = _lib.lib()
+L.s3g_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+L.s3g_profile_enable(1)
+for it in range(6):
+    for p in f.parameters():
+        p.grad = None
+    (f(xyz, t, uniform_time=True) * w).sum().backward()
+torch.cuda.synchronize()
+for i, name in ((2, "hexplane_forward"), (3, "hexplane_backward_point"), (4, "hexplane_scatter")):
+    ms = C.c_double()
+    n = L.s3g_profile_read(i, C.byref(ms), None, None)
+    print(f"{name}: {ms.value / max(n, 1):.4f} ms avg over {n}")
+L.s3g_profile_enable(0)
