@@ -440,9 +440,11 @@ def main():
             # plane gradients written once; reading the scratch back is implementation
             4: ("s3g::hexplane_scatter_kernel", lambda n, l: plane_bytes, lambda n, l: n * (60.0 + G_ROWS * 128.0) + plane_bytes, None),
             # features in, three heads out; the 5 stashed activations are implementation
-            5: ("s3g::mlp_forward_kernel", lambda n, _: n * (512.0 + 216.0), lambda n, _: n * (512.0 + 5 * 256.0 + 216.0),
+            # implementation: + 5 stashed activation planes (for the weight gradients) + 5 ReLU mask words per lane (40 B/point)
+            5: ("s3g::mlp_forward_kernel", lambda n, _: n * (512.0 + 216.0), lambda n, _: n * (512.0 + 5 * 256.0 + 40.0 + 216.0),
                 lambda n: n * MLP_FLOP),
-            6: ("s3g::mlp_backward_kernel", lambda n, _: n * (216.0 + 512.0), lambda n, _: n * (5 * 256.0 + 216.0 + 5 * 256.0 + 512.0),
+            # implementation: mask words in, 5 gradient-signal planes out (read back by the weight-gradient launches)
+            6: ("s3g::mlp_backward_kernel", lambda n, _: n * (216.0 + 512.0), lambda n, _: n * (40.0 + 216.0 + 5 * 256.0 + 512.0),
                 lambda n: n * MLP_FLOP),
             7: ("s3g::mlp_wgrad_kernel", lambda n, _: n * 512.0, lambda n, _: n * 4.0 * (2 * 67 + 6 * 128 + 112), lambda n: n * MLP_FLOP),
             8: ("s3g::adam_kernel", lambda n, _: n * 28.0, None, None),   # p, g, m, v read; p, m, v written

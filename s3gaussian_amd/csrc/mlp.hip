@@ -149,6 +149,36 @@ __device__ __forceinline__ void masked(f32x16 (&dst)[MB], const f32x16 (&acc)[MB
     }
 }
 
+// ReLU masks as bits: bit (16*mb + r) of a lane's word = (a[mb][r] > 0).  The backward chain needs the forward activations
+// only as ReLU masks; reading them as one 32-bit word per lane and plane (8 B per point and plane) instead of the fp32
+// activation planes (256 B per point and plane) removes 1280 of the 3288 bytes per point the backward used to move AND every
+// dependent load from its critical path (the words of the next tile are prefetched a whole tile ahead).
+template <int MB>
+__device__ __forceinline__ uint32_t pack_positive(const f32x16 (&a)[MB]) {
+  uint32_t b = 0;
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      // x > 0  <=>  its bit pattern as a signed integer is >= 1 (negative floats and -0 are negative integers, +0 is 0):
+      // med3(x, 0, 1) is the bit, one v_med3_i32 + one v_lshl_or_b32 per element
+      const int bit = min(max(__float_as_int(a[mb][r]), 0), 1);
+      b |= (uint32_t)bit << (16 * mb + r);
+    }
+  return b;
+}
+// dst (op)= acc where the mask bit is set
+template <int MB, bool ACCUM>
+__device__ __forceinline__ void masked_bits(f32x16 (&dst)[MB], const f32x16 (&acc)[MB], uint32_t bits) {
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float v = ((bits >> (16 * mb + r)) & 1u) ? acc[mb][r] : 0.f;
+      dst[mb][r] = ACCUM ? dst[mb][r] + v : v;
+    }
+}
+
 // ---- weight slabs: the LDS image is built once per call in global memory and DMA-copied by every workgroup ---------
 // Slab k is the [in][out+1] image of one layer (feature_out is cut in two K halves), padded to SLAB floats = 17 KiB =
 // 17 global_load_lds_dwordx4 wave-instructions (1 KiB each).
@@ -197,6 +227,7 @@ struct MlpFwdArgs {
   const float* x;
   const float* packed;
   float *dx, *dshs, *feat, *stash;
+  uint32_t* maskbits;  // [tiles][5][64] ReLU mask words (NULL when no backward follows)
 };
 
 __global__ void __launch_bounds__(NWAVE * 64) mlp_forward_kernel(const MlpFwdArgs a) {
@@ -205,23 +236,48 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_forward_kernel(const MlpFwdArg
   load_weights(lds, a.packed, wave, lane);
   const int ntiles = (a.P + MT - 1) / MT;
   const size_t PS = (size_t)a.P * HID;  // one stash plane
-  for (int tile = blockIdx.x * NWAVE + wave; tile < ntiles; tile += gridDim.x * NWAVE) {
+  // the 128 input features of the NEXT tile are requested before this tile's MFMAs are issued (raw loads, clamped row: lanes
+  // past the end of the array re-read the last point, whose outputs are never stored)
+  struct XIn { float4 v[16]; };   // chunk c = columns 8c + 4h .. +3 of the lane's point
+  const int jj = lane & 31, hh = lane >> 5;
+  auto issue = [&](XIn& X, int tile) {
+    const float* row = a.x + (size_t)min(tile * MT + jj, a.P - 1) * FEAT + 4 * hh;
+#pragma unroll
+    for (int c = 0; c < 16; c++) X.v[c] = *reinterpret_cast<const float4*>(row + 8 * c);
+  };
+  auto unpack = [&](f32x16 (&x)[2], const XIn& X, int half) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const float4 v = X.v[8 * half + c];
+      x[c >> 2][4 * (c & 3) + 0] = v.x; x[c >> 2][4 * (c & 3) + 1] = v.y;
+      x[c >> 2][4 * (c & 3) + 2] = v.z; x[c >> 2][4 * (c & 3) + 3] = v.w;
+    }
+  };
+  const int stride = gridDim.x * NWAVE, t0 = blockIdx.x * NWAVE + wave;
+  XIn cur, nxt;
+  if (t0 < ntiles) issue(cur, t0);
+  for (int tile = t0; tile < ntiles; tile += stride) {
+    issue(nxt, min(tile + stride, ntiles - 1));
+    __builtin_amdgcn_sched_barrier(0);
     const int p0 = tile * MT, npts = min(MT, a.P - p0);
     f32x16 hid[2], act[2], acc[2], o[1];
     {  // hidden = W0 x + b0, K = 128 in two halves
       f32x16 x[2];
       acc_bias<2>(hid, BIAS(0), lane);
-      act_load<FEAT, 2>(x, a.x, 0, p0, npts, lane);
+      unpack(x, cur, 0);
       gemm_reg<2, 2, false>(WSLAB(0), 65, x, hid, lane);
-      act_load<FEAT, 2>(x, a.x, 64, p0, npts, lane);
+      unpack(x, cur, 1);
       gemm_reg<2, 2, false>(WSLAB(1), 65, x, hid, lane);
     }
+    uint32_t* mw = a.maskbits ? a.maskbits + (size_t)tile * 5 * 64 + lane : nullptr;
     if (a.stash) act_store<HID, 2, false>(hid, a.stash + 0 * PS, 0, p0, npts, lane);
+    if (mw) mw[0 * 64] = pack_positive<2>(hid);
     // pos head: dx = P2 relu(P1 relu(hidden) + pb1) + pb2
     acc_bias<2>(act, BIAS(1), lane);
     gemm_reg<2, 2, true>(WSLAB(2), 65, hid, act, lane);
     relu_inplace<2>(act);
     if (a.stash) act_store<HID, 2, false>(act, a.stash + 1 * PS, 0, p0, npts, lane);
+    if (mw) mw[1 * 64] = pack_positive<2>(act);
     acc_bias<1>(o, BIAS(3), lane);
     gemm_reg<1, 2, false>(WSLAB(4), 33, act, o, lane);
     act_store3(o, a.dx, p0, npts, lane);
@@ -230,30 +286,45 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_forward_kernel(const MlpFwdArg
     gemm_reg<2, 2, true>(WSLAB(3), 65, hid, act, lane);
     relu_inplace<2>(act);
     if (a.stash) act_store<HID, 2, false>(act, a.stash + 2 * PS, 0, p0, npts, lane);
+    if (mw) mw[2 * 64] = pack_positive<2>(act);
     acc_bias<2>(acc, BIAS(4), lane);
     gemm_reg<2, 2, false>(WSLAB(5), 65, act, acc, lane);
     act_store<48, 2, false, 48>(acc, a.dshs, 0, p0, npts, lane);
-    if (a.feat == nullptr) continue;  // inference renders that do not draw the feature image: skip the head (31 % of the MFMAs)
+    if (a.feat != nullptr) {  // inference renders that do not draw the feature image skip the head (31 % of the MFMAs)
     // dino head: feat = D2 relu(D1 relu(D0 hidden + db0) + db1) + db2   (input is the raw hidden, deformation.py:126)
     acc_bias<2>(act, BIAS(5), lane);
     gemm_reg<2, 2, false>(WSLAB(6), 65, hid, act, lane);
     relu_inplace<2>(act);
     if (a.stash) act_store<HID, 2, false>(act, a.stash + 3 * PS, 0, p0, npts, lane);
+    if (mw) mw[3 * 64] = pack_positive<2>(act);
     acc_bias<2>(acc, BIAS(6), lane);
     gemm_reg<2, 2, false>(WSLAB(7), 65, act, acc, lane);
     relu_inplace<2>(acc);
     if (a.stash) act_store<HID, 2, false>(acc, a.stash + 4 * PS, 0, p0, npts, lane);
+    if (mw) mw[4 * 64] = pack_positive<2>(acc);
     acc_bias<1>(o, BIAS(7), lane);
     gemm_reg<1, 2, false>(WSLAB(8), 33, acc, o, lane);
     act_store3(o, a.feat, p0, npts, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;   // copies at the very end: the prefetch has had the whole tile to land
   }
 }
 
 struct MlpBwdArgs {
   int P;
   const float* packed;
-  const float *stash, *g_dx, *g_dshs, *g_feat;
+  const uint32_t* maskbits;  // [tiles][5][64] from the forward: hidden | pos1 | shs1 | dino1 | dino2
+  const float *g_dx, *g_dshs, *g_feat;
   float *g_x, *ws;
+};
+
+// Everything the backward chain of one tile reads from memory: the three upstream gradients of the lane's point and the five
+// ReLU mask words -- 45 registers, requested for the NEXT tile before the current tile's ~600 MFMAs are issued.
+struct BwdIn {
+  float gd[3], gf[3];
+  float4 gs[6];       // g_dshs columns 8q + 4h .. +3 (q = 0..3) and 32 + 8q + 4h .. +3 (q = 0, 1): the 48 live columns
+  uint32_t bits[5];
 };
 
 // Per-point backward chain, same register-resident scheme with the transposed weight reads.
@@ -263,48 +334,75 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_backward_kernel(const MlpBwdAr
   load_weights(lds, a.packed, wave, lane);
   const int ntiles = (a.P + MT - 1) / MT;
   const size_t PS = (size_t)a.P * HID;
-  for (int tile = blockIdx.x * NWAVE + wave; tile < ntiles; tile += gridDim.x * NWAVE) {
+  const int j = lane & 31, h = lane >> 5;
+  const bool dino = a.g_feat != nullptr;
+  // Raw, select-free loads with clamped addresses (lanes past the end of the array re-read the last point: their columns are
+  // never stored): a bounds select on a loaded value would be scheduled where the load was issued and stall there.
+  auto issue = [&](BwdIn& I, int tile) {
+    const size_t p = (size_t)min(tile * MT + j, a.P - 1);
+    const uint32_t* mw = a.maskbits + (size_t)tile * 5 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 5; k++) I.bits[k] = mw[k * 64];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      I.gd[k] = a.g_dx[p * 3 + k];
+      I.gf[k] = dino ? a.g_feat[p * 3 + k] : 0.f;
+    }
+    const float* row = a.g_dshs + p * 48 + 4 * h;
+#pragma unroll
+    for (int c = 0; c < 6; c++) I.gs[c] = *reinterpret_cast<const float4*>(row + 8 * c);
+  };
+  auto head3 = [&](f32x16 (&g3)[1], const float (&v)[3]) {  // features 0..2 live in registers 0..2 of the h = 0 lanes
+    acc_zero<1>(g3);
+#pragma unroll
+    for (int k = 0; k < 3; k++) g3[0][k] = h == 0 ? v[k] : 0.f;
+  };
+  const int stride = gridDim.x * NWAVE, t0 = blockIdx.x * NWAVE + wave;
+  BwdIn cur, nxt;
+  if (t0 < ntiles) issue(cur, t0);
+  for (int tile = t0; tile < ntiles; tile += stride) {
+    issue(nxt, min(tile + stride, ntiles - 1));   // unconditional (clamped): see mlp_wgrad_kernel
+    __builtin_amdgcn_sched_barrier(0);
     const int p0 = tile * MT, npts = min(MT, a.P - p0);
-    f32x16 ghid[2], g[2], acc[2], m[2], g3[1];
+    f32x16 ghid[2], g[2], acc[2], g3[1];
     acc_zero<2>(ghid);
     // ---- dino head (skipped when the feature image has no gradient: g_feat == NULL) ----
-    if (a.g_feat != nullptr) {
-    act_load3(g3, a.g_feat, p0, npts, lane);
-    act_load<HID, 2>(m, a.stash + 4 * PS, 0, p0, npts, lane);  // dino2
-    acc_zero<2>(acc);
-    gemm_reg_t<2, 1, 3>(WSLAB(8), 33, g3, acc, lane);           // D2^T g_feat (3 live K steps)
-    masked<2, false>(g, acc, m);                                 // gradient wrt dino2 pre-activation
-    act_store<HID, 2, false>(g, a.ws + 0 * PS, 0, p0, npts, lane);
-    act_load<HID, 2>(m, a.stash + 3 * PS, 0, p0, npts, lane);  // dino1
-    acc_zero<2>(acc);
-    gemm_reg_t<2, 2>(WSLAB(7), 65, g, acc, lane);               // D1^T
-    masked<2, false>(g, acc, m);
-    act_store<HID, 2, false>(g, a.ws + 1 * PS, 0, p0, npts, lane);
-    gemm_reg_t<2, 2>(WSLAB(6), 65, g, ghid, lane);              // ghid = D0^T (dino input is the raw hidden: no mask)
+    if (dino) {
+      head3(g3, cur.gf);
+      acc_zero<2>(acc);
+      gemm_reg_t<2, 1, 3>(WSLAB(8), 33, g3, acc, lane);           // D2^T g_feat (3 live K steps)
+      masked_bits<2, false>(g, acc, cur.bits[4]);                  // gradient wrt dino2 pre-activation
+      act_store<HID, 2, false>(g, a.ws + 0 * PS, 0, p0, npts, lane);
+      acc_zero<2>(acc);
+      gemm_reg_t<2, 2>(WSLAB(7), 65, g, acc, lane);               // D1^T
+      masked_bits<2, false>(g, acc, cur.bits[3]);
+      act_store<HID, 2, false>(g, a.ws + 1 * PS, 0, p0, npts, lane);
+      gemm_reg_t<2, 2>(WSLAB(6), 65, g, ghid, lane);              // ghid = D0^T (dino input is the raw hidden: no mask)
     }
     // ---- pos head ----
-    act_load3(g3, a.g_dx, p0, npts, lane);
-    act_load<HID, 2>(m, a.stash + 1 * PS, 0, p0, npts, lane);  // pos1
+    head3(g3, cur.gd);
     acc_zero<2>(acc);
-    gemm_reg_t<2, 1, 3>(WSLAB(4), 33, g3, acc, lane);           // P2^T g_dx
-    masked<2, false>(g, acc, m);
+    gemm_reg_t<2, 1, 3>(WSLAB(4), 33, g3, acc, lane);             // P2^T g_dx
+    masked_bits<2, false>(g, acc, cur.bits[1]);
     act_store<HID, 2, false>(g, a.ws + 2 * PS, 0, p0, npts, lane);
     acc_zero<2>(acc);
-    gemm_reg_t<2, 2>(WSLAB(2), 65, g, acc, lane);               // P1^T
+    gemm_reg_t<2, 2>(WSLAB(2), 65, g, acc, lane);                 // P1^T
     // ---- shs head ----
     {
-      f32x16 gs[2], m2[2];
-      act_load<48, 2, 48>(gs, a.g_dshs, 0, p0, npts, lane);
-      act_load<HID, 2>(m2, a.stash + 2 * PS, 0, p0, npts, lane);  // shs1
-      f32x16 t[2];
+      f32x16 gs[2], t[2];
+#pragma unroll
+      for (int c = 0; c < 8; c++) {  // chunk c = columns 8c + 4h .. +3; chunks 6, 7 (columns >= 48) do not exist
+        const float4 v = c < 6 ? cur.gs[c < 6 ? c : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        gs[c >> 2][4 * (c & 3) + 0] = v.x; gs[c >> 2][4 * (c & 3) + 1] = v.y;
+        gs[c >> 2][4 * (c & 3) + 2] = v.z; gs[c >> 2][4 * (c & 3) + 3] = v.w;
+      }
       acc_zero<2>(t);
-      gemm_reg_t<2, 2>(WSLAB(5), 65, gs, t, lane);              // S2^T g_dshs (rows 48..63 of the image are zero)
-      masked<2, false>(g, t, m2);
+      gemm_reg_t<2, 2>(WSLAB(5), 65, gs, t, lane);                // S2^T g_dshs (rows 48..63 of the image are zero)
+      masked_bits<2, false>(g, t, cur.bits[2]);
     }
     act_store<HID, 2, false>(g, a.ws + 3 * PS, 0, p0, npts, lane);
-    act_load<HID, 2>(m, a.stash + 0 * PS, 0, p0, npts, lane);  // hidden (raw): mask of the two relu(hidden) consumers
-    gemm_reg_t<2, 2>(WSLAB(3), 65, g, acc, lane);               // + S1^T  (same relu(hidden) mask as P1^T)
-    masked<2, true>(ghid, acc, m);
+    gemm_reg_t<2, 2>(WSLAB(3), 65, g, acc, lane);                 // + S1^T  (same relu(hidden) mask as P1^T)
+    masked_bits<2, true>(ghid, acc, cur.bits[0]);
     act_store<HID, 2, false>(ghid, a.ws + 4 * PS, 0, p0, npts, lane);
     // ---- feature_out: g_x[:, half] = W0[:, half]^T ghid ----
     acc_zero<2>(acc);
@@ -313,6 +411,8 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_backward_kernel(const MlpBwdAr
     acc_zero<2>(acc);
     gemm_reg_t<2, 2>(WSLAB(1), 65, ghid, acc, lane);
     act_store<FEAT, 2, false>(acc, a.g_x, 64, p0, npts, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
   }
 }
 #undef WSLAB
@@ -531,9 +631,10 @@ static int launch_wgrad(const float* G, const float* A, float* dW, float* db, in
 
 using namespace s3g;
 
-// stash = [packed weight slabs + biases (PACK_FLOATS)] [5 x P x 64 activations]
+// stash = [packed weight slabs + biases (PACK_FLOATS)] [5 x P x 64 activations] [tiles x 5 x 64 ReLU mask words]
+static size_t mask_words(int P) { return (size_t)((P > 0 ? P : 0) + MT - 1) / MT * 5 * 64; }
 extern "C" size_t s3g_deform_mlp_stash_bytes(int P) {
-  return ((size_t)PACK_FLOATS + (size_t)5 * (size_t)(P > 0 ? P : 0) * HID) * sizeof(float);
+  return ((size_t)PACK_FLOATS + (size_t)5 * (size_t)(P > 0 ? P : 0) * HID + mask_words(P)) * sizeof(float);
 }
 extern "C" size_t s3g_deform_mlp_pack_bytes(void) { return (size_t)PACK_FLOATS * sizeof(float); }
 
@@ -559,6 +660,7 @@ extern "C" int s3g_deform_mlp_forward(const s3g_mlp_params* w, int P, const floa
   MlpFwdArgs a;
   a.P = P; a.x = features; a.packed = stash; a.dx = dx; a.dshs = dshs; a.feat = feat;
   a.stash = save_activations ? stash + PACK_FLOATS : nullptr;
+  a.maskbits = save_activations ? reinterpret_cast<uint32_t*>(stash + PACK_FLOATS + (size_t)5 * P * HID) : nullptr;
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
   profile_begin(S3G_PROFILE_MLP_FORWARD, stream);
@@ -580,7 +682,7 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   hipStream_t stream = (hipStream_t)stream_;
   const float* stash = stash_ + PACK_FLOATS;  // activations; the packed weight slabs of the forward sit in front
   MlpBwdArgs b;
-  b.P = P; b.packed = stash_; b.stash = stash; b.g_dx = g_dx; b.g_dshs = g_dshs; b.g_feat = g_feat; b.g_x = g_features; b.ws = workspace;
+  b.P = P; b.packed = stash_; b.maskbits = reinterpret_cast<const uint32_t*>(stash + (size_t)5 * P * HID); b.g_dx = g_dx; b.g_dshs = g_dshs; b.g_feat = g_feat; b.g_x = g_features; b.ws = workspace;
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
   profile_begin(S3G_PROFILE_MLP_BACKWARD, stream);
