@@ -330,39 +330,64 @@ __device__ __forceinline__ void foot_flush(const Foot& f, float* __restrict__ gp
   if (f.flags & 2) atomicAdd(&gp[(size_t)(f.key + W) * HEXC + c], f.a10);
   if ((f.flags & 3) == 3) atomicAdd(&gp[(size_t)(f.key + W + 1) * HEXC + c], f.a11);
 }
-// Two-entry footprint cache (A = most recent).  align_corners grids of different levels do not nest, so inside one
-// finest-level cell the points alternate between two (sometimes four) coarse footprints; remembering the previous one
-// as well removes most of those flushes.
+// Two-entry footprint cache.  align_corners grids of different levels do not nest, so inside one finest-level cell the
+// points alternate between two (sometimes four) coarse footprints; remembering the previous one as well removes most of
+// those flushes.
 struct PackedTap {  // what the scatter needs of a Tap: 8 floats in LDS
   int key, flags;
   float w00, w01, w10, w11;
 };
-__device__ __forceinline__ void foot_add(Foot& A, Foot& B, const PackedTap& t, float g, float* __restrict__ gp, int W, int c) {
-  if (t.key != A.key) {
-    if (t.key == B.key) {
-      const Foot tmp = A;
-      A = B;
-      B = tmp;
-    } else {
-      foot_flush(B, gp, W, c);
-      B = A;
-      A.key = t.key;
-      A.flags = t.flags;
-      A.a00 = A.a01 = A.a10 = A.a11 = 0.f;
+// Entries stay where they are (no MRU swap) and the hit path is BRANCH-FREE: both entries take an fma whose multiplicand is
+// the gradient or 0.  The scatter kernel used to be instruction-bound on this function: the two half-waves of a wave walk
+// different segments, so every data-dependent branch of the old hit-A / hit-B-swap / miss cascade ran both sides under
+// complementary exec masks (~100 instructions per call, 32 calls per group of four points).  Only the miss -- about one
+// call in four -- still branches: it flushes the entry that was NOT used last and installs the new footprint in its place.
+struct Foot2 {
+  int key0, key1, fl0, fl1, mru;
+  float a0[4], a1[4];
+};
+__device__ __forceinline__ void foot2_init(Foot2& F) {
+  F.key0 = F.key1 = -1;
+  F.fl0 = F.fl1 = F.mru = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) F.a0[k] = F.a1[k] = 0.f;
+}
+__device__ __forceinline__ void foot2_flush_all(const Foot2& F, float* __restrict__ gp, int W, int c) {
+  foot_flush(Foot{F.key0, F.fl0, F.a0[0], F.a0[1], F.a0[2], F.a0[3]}, gp, W, c);
+  foot_flush(Foot{F.key1, F.fl1, F.a1[0], F.a1[1], F.a1[2], F.a1[3]}, gp, W, c);
+}
+__device__ __forceinline__ void foot2_add(Foot2& F, const PackedTap& t, float g, float* __restrict__ gp, int W, int c) {
+  bool h0 = t.key == F.key0, h1 = t.key == F.key1;
+  if (!(h0 || h1)) {  // miss (uniform inside the half-wave): evict the entry that is not the most recent one
+    const bool v1 = F.mru == 0;
+    foot_flush(Foot{v1 ? F.key1 : F.key0, v1 ? F.fl1 : F.fl0, v1 ? F.a1[0] : F.a0[0], v1 ? F.a1[1] : F.a0[1],
+                    v1 ? F.a1[2] : F.a0[2], v1 ? F.a1[3] : F.a0[3]}, gp, W, c);
+    F.key1 = v1 ? t.key : F.key1;  F.key0 = v1 ? F.key0 : t.key;
+    F.fl1 = v1 ? t.flags : F.fl1;  F.fl0 = v1 ? F.fl0 : t.flags;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      F.a1[k] = v1 ? 0.f : F.a1[k];
+      F.a0[k] = v1 ? F.a0[k] : 0.f;
     }
+    h1 = v1;
+    h0 = !v1;
   }
-  A.a00 += g * t.w00;
-  A.a01 += g * t.w01;
-  A.a10 += g * t.w10;
-  A.a11 += g * t.w11;
+  const float g0 = h0 ? g : 0.f, g1 = h1 ? g : 0.f;
+  F.a0[0] = __builtin_fmaf(g0, t.w00, F.a0[0]); F.a0[1] = __builtin_fmaf(g0, t.w01, F.a0[1]);
+  F.a0[2] = __builtin_fmaf(g0, t.w10, F.a0[2]); F.a0[3] = __builtin_fmaf(g0, t.w11, F.a0[3]);
+  F.a1[0] = __builtin_fmaf(g1, t.w00, F.a1[0]); F.a1[1] = __builtin_fmaf(g1, t.w01, F.a1[1]);
+  F.a1[2] = __builtin_fmaf(g1, t.w10, F.a1[2]); F.a1[3] = __builtin_fmaf(g1, t.w11, F.a1[3]);
+  F.mru = h1 ? 1 : 0;
 }
 
 // A half-wave (32 lanes = the 32 channels) walks SEG consecutive points of the sorted order.  The kernel used to be
 // VALU-bound on make_tap, which all 32 lanes repeated for each of the 8 (level, plane) taps of a point; now the 32 lanes
 // compute the 8 taps of FOUR points at once (lane = point q x tap j), park them in LDS, and every lane reads them back
 // with broadcast loads while it accumulates its channel.
+constexpr int SCATTER_LG = 2;          // levels handled per walk of a segment
+constexpr int SCATTER_WG_PER_CU = 4;   // 4 waves per SIMD: the walk is bound by per-wave issue latency (IPC ~0.2), not by VALU throughput
 constexpr int TAPF = 8;  // floats per packed tap in LDS (6 used; 32-byte slots keep the 16-byte reads aligned)
-__global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
+__global__ void __launch_bounds__(256, SCATTER_WG_PER_CU) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
                                                                const uint32_t* __restrict__ order_all) {
   __shared__ __attribute__((aligned(16))) float tapbuf[8][2][4][8][TAPF];  // [half-wave][double buffer][point][tap]
   const int o = blockIdx.y;
@@ -376,18 +401,15 @@ __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, 
   const int i0 = PLA[o], i1 = PLT[o];
   const int ip = (j & 1) ? i1 : i0;                   // the plane of this lane's tap
   const int axw = PAIR0[ip], axh = PAIR1[ip];
-  constexpr int LG = 4;  // levels handled together: 4 levels x 2 planes x 2 footprints live in registers
+  constexpr int LG = SCATTER_LG;  // levels handled together: LG levels x 2 planes x 2 footprints live in registers
   for (int l0 = 0; l0 < a.d.levels; l0 += LG) {
-    Foot fa[LG][2], fb[LG][2];
+    Foot2 ft[LG][2];
 #pragma unroll
     for (int l = 0; l < LG; l++)
 #pragma unroll
-      for (int m = 0; m < 2; m++) {
-        fa[l][m] = Foot{-1, 0, 0.f, 0.f, 0.f, 0.f};
-        fb[l][m] = Foot{-1, 0, 0.f, 0.f, 0.f, 0.f};
-      }
+      for (int m = 0; m < 2; m++) foot2_init(ft[l][m]);
     const int lt = l0 + (j >> 1);                     // level of this lane's tap
-    const bool tap_on = lt < a.d.levels;
+    const bool tap_on = (j >> 1) < LG && lt < a.d.levels;
     const int Wt = tap_on ? a.d.res[lt][axw] : 2, Ht = tap_on ? a.d.res[lt][axh] : 2;
     // Three-stage software pipeline per lane role (point q of a group, tap j): the sorted index of group g+2, the
     // coordinates of group g+1 and the taps of group g+1 are produced while group g is accumulated, so neither the
@@ -422,9 +444,11 @@ __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, 
         const size_t k = (size_t)min(kb + qq, k1 - 1);
 #pragma unroll
         for (int l = 0; l < LG; l++) {
-          const bool on = l0 + l < a.d.levels;
-          g[qq][l][0] = (on && a.gplanes[l0 + l][i0]) ? G[(size_t)((o * a.d.levels + l0 + l) * 2 + 0) * PL + k * HEXC + c] : 0.f;
-          g[qq][l][1] = (on && a.gplanes[l0 + l][i1]) ? G[(size_t)((o * a.d.levels + l0 + l) * 2 + 1) * PL + k * HEXC + c] : 0.f;
+          // unconditional (level clamped; slabs exist for every plane): a load behind a uniform branch costs two branch
+          // instructions and splits the basic block the scheduler could have filled
+          const int lv = min(l0 + l, a.d.levels - 1);
+          g[qq][l][0] = G[(size_t)((o * a.d.levels + lv) * 2 + 0) * PL + k * HEXC + c];
+          g[qq][l][1] = G[(size_t)((o * a.d.levels + lv) * 2 + 1) * PL + k * HEXC + c];
         }
       }
       // 2. the NEXT group's taps from coordinates loaded one iteration ago; then advance the two prefetch stages
@@ -452,7 +476,7 @@ __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, 
             PackedTap t;
             t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
             t.w00 = lo.z; t.w01 = lo.w; t.w10 = hi.x; t.w11 = hi.y;
-            foot_add(fa[l][m], fb[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
+            foot2_add(ft[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
           }
         }
       }
@@ -465,8 +489,7 @@ __global__ void __launch_bounds__(256) hexplane_scatter_kernel(const HexArgs a, 
         float* gp = a.gplanes[l0 + l][m ? i1 : i0];
         if (gp == nullptr) continue;
         const int W = a.d.res[l0 + l][PAIR0[m ? i1 : i0]];
-        foot_flush(fa[l][m], gp, W, c);
-        foot_flush(fb[l][m], gp, W, c);
+        foot2_flush_all(ft[l][m], gp, W, c);
       }
     }
   }
