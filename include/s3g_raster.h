@@ -173,6 +173,11 @@ int s3g_raster_backward2_accum(const s3g_raster_inputs* in, const float* colors2
 void s3g_raster_set_exact_cull(int on);
 int s3g_raster_get_exact_cull(void);
 
+/* Tile grids of more than 38 000 tiles (beyond 4K images) do not fit the binning pass's LDS histogram and are binned in
+ * bands of consecutive tiles, one pair of launches per band; results are identical.  Testing hook: force a smaller band
+ * (returns the previous size; tiles <= 0 restores the default) so the band path can be exercised on small images. */
+int s3g_raster_set_bin_band(int tiles);
+
 /* present[P] (uint8 0/1) = in_frustum (auxiliary.h:139-164: view-space z > 0.2). */
 int s3g_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);

@@ -37,6 +37,7 @@ void set_error(const char* fmt, ...) {
 // Exact (tile, Gaussian) culling at binning time (geom_math.hpp::tile_can_contribute); on by default, switchable so the
 // instance lists can be compared bit for bit with the reference's bounding-square binning.
 static bool g_exact_cull = true;
+static int g_max_tiles_lds = MAX_TILES_LDS;  // band size of the binning histogram; lowered only by the tests (s3g_raster_set_bin_band)
 
 // ---- in-library kernel timing -----------------------------------------------------------------------------
 struct ProfRec { hipEvent_t a, b; double instances, pixels; };
@@ -202,12 +203,15 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreprocessArgs a)
 //                stored at a private slot.  Also emits gauss_off[g] = exclusive scan of tiles_touched (Gaussian order),
 //                the address of g's slots in the instance->position map used by the backward gather.
 //    Rects wider than BIG_RECT tiles are walked by the whole wave instead of one lane.
+//    Tile grids larger than the LDS histogram (MAX_TILES_LDS) are processed in BANDS of consecutive tiles: both walks are
+//    launched once per band and only handle the instances whose tile lies in it (an 8K image is 4 bands).
 //    (*) order inside a tile is arbitrary here; the per-tile sort fixes it.
 // =========================================================================================================
 constexpr int BIN_THREADS = 256;
 
 struct BinArgs {
   int P, gx, tiles, chunk;         // chunk = Gaussians per workgroup (multiple of BIN_THREADS)
+  int tile_lo, tile_n;             // the band of tiles this launch handles: [tile_lo, tile_lo + tile_n)
   const ushort4* rect;
   const float* depths;
   uint32_t* table;                 // [NB][tiles]
@@ -226,10 +230,11 @@ template <bool WRITE>
 __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [tiles] histogram / cursors, then 8 words of scratch
   uint32_t* cell = lds;
-  uint32_t* wsum = lds + a.tiles;  // [4] wave totals + [1] carry
+  uint32_t* wsum = lds + a.tile_n;  // [4] wave totals + [1] carry
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t* trow = a.table + (size_t)blockIdx.x * a.tiles;
-  for (int i = tid; i < a.tiles; i += BIN_THREADS) cell[i] = WRITE ? a.ranges[i].x + trow[i] : 0u;
+  for (int i = tid; i < a.tile_n; i += BIN_THREADS) cell[i] = WRITE ? a.ranges[a.tile_lo + i].x + trow[a.tile_lo + i] : 0u;
+  const bool first_band = a.tile_lo == 0;  // per-Gaussian outputs (gauss_off, chunk totals) are produced once
   uint32_t carry = WRITE ? a.chunk_total[blockIdx.x] : 0u;  // exclusive prefix of previous workgroups' instances
   uint32_t my_total = 0;
   __syncthreads();
@@ -261,7 +266,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
         if (k < wave) wbase += v;
         tot += v;
       }
-      if (g < g1) a.gauss_off[g] = carry + wbase + incl - area;
+      if (g < g1 && first_band) a.gauss_off[g] = carry + wbase + incl - area;
       carry += tot;
       __syncthreads();  // wsum reused next iteration
       if (area) key = ((uint64_t)__float_as_uint(a.depths[g]) << 32) | (uint32_t)g;
@@ -274,7 +279,9 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
       for (int y = r.y; y < r.w; y++)
         for (int x = r.x; x < r.z; x++, bit <<= 1) {
           if (!(mask & bit)) continue;
-          const uint32_t pos = atomicAdd(&cell[y * a.gx + x], 1u);
+          const uint32_t tb = (uint32_t)(y * a.gx + x - a.tile_lo);
+          if (tb >= (uint32_t)a.tile_n) continue;
+          const uint32_t pos = atomicAdd(&cell[tb], 1u);
           if (WRITE) a.keys[pos] = key;
         }
     }
@@ -291,8 +298,10 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
       bt.my = __shfl(tc.my, src); bt.verdict = __shfl(tc.verdict, src);
       for (uint32_t k = lane; k < barea; k += 64) {
         const int ty = by + (int)(k / (uint32_t)bw), tx = bx + (int)(k % (uint32_t)bw);
+        const uint32_t tb = (uint32_t)(ty * a.gx + tx - a.tile_lo);
+        if (tb >= (uint32_t)a.tile_n) continue;
         if (a.cull && !tile_can_contribute(bt, tx, ty, a.W, a.H)) continue;
-        const uint32_t pos = atomicAdd(&cell[ty * a.gx + tx], 1u);
+        const uint32_t pos = atomicAdd(&cell[tb], 1u);
         if (WRITE) a.keys[pos] = ((uint64_t)khi << 32) | klo;
       }
     }
@@ -300,11 +309,11 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
   if (!WRITE) {
     __syncthreads();
     uint32_t* row = a.table + (size_t)blockIdx.x * a.tiles;
-    for (int i = tid; i < a.tiles; i += BIN_THREADS) row[i] = cell[i];
+    for (int i = tid; i < a.tile_n; i += BIN_THREADS) row[a.tile_lo + i] = cell[i];
     for (int off = 32; off >= 1; off >>= 1) my_total += (uint32_t)__shfl_xor((int)my_total, off);
     if (lane == 0) wsum[wave] = my_total;
     __syncthreads();
-    if (tid == 0) a.chunk_total[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0 && first_band) a.chunk_total[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
   }
 }
 
@@ -697,10 +706,8 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   }
   const bool debug = in->debug != 0;
 
-  if (tiles > MAX_TILES_LDS) {
-    set_error("image of %d tiles exceeds the %d tiles the LDS multisplit handles", tiles, MAX_TILES_LDS);
-    return S3G_ERR_INVALID_ARG;
-  }
+  // tile grids beyond the LDS histogram are binned in bands of consecutive tiles (see bin_kernel)
+  const int band = g_max_tiles_lds < tiles ? g_max_tiles_lds : tiles;
   const int nb = bin_blocks(P), chunk = bin_chunk(P);
 
   size_t geom_bytes = 0, img_bytes = 0;
@@ -731,7 +738,7 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   S3G_KERNEL_CHECK(stream, debug);
 
   // atomic-free binning, counting half
-  const size_t bin_lds = ((size_t)tiles + 8) * sizeof(uint32_t);
+  const size_t bin_lds = ((size_t)band + 8) * sizeof(uint32_t);
   static std::atomic<uint64_t> bin_attr_set{0};
   if (first_call_on_this_device(bin_attr_set)) {
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)bin_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -744,8 +751,11 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   ba.table = im.table; ba.chunk_total = im.chunk_total; ba.ranges = im.ranges; ba.keys = nullptr; ba.gauss_off = g.gauss_off;
   ba.cull = g_exact_cull ? 1 : 0; ba.W = W; ba.H = H; ba.means2D = g.means2D; ba.conic_opacity = g.conic_opacity;
   ba.tile_mask = g.tile_mask;
-  hipLaunchKernelGGL(bin_kernel<false>, dim3(nb), dim3(BIN_THREADS), bin_lds, stream, ba);
-  S3G_KERNEL_CHECK(stream, debug);
+  for (int lo = 0; lo < tiles; lo += band) {
+    ba.tile_lo = lo; ba.tile_n = tiles - lo < band ? tiles - lo : band;
+    hipLaunchKernelGGL(bin_kernel<false>, dim3(nb), dim3(BIN_THREADS), bin_lds, stream, ba);
+    S3G_KERNEL_CHECK(stream, debug);
+  }
   hipLaunchKernelGGL(bin_scan_kernel, dim3((tiles + 255) / 256), dim3(256), 0, stream, tiles, nb, im.table, im.tile_count);
   S3G_KERNEL_CHECK(stream, debug);
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, tiles, im.tile_count, im.ranges, im.ctrl, nb,
@@ -781,8 +791,11 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   const uint32_t tile_blocks = round_up8((uint32_t)tiles);
   if (R > 0) {
     ba.keys = b.keys;
-    hipLaunchKernelGGL(bin_kernel<true>, dim3(nb), dim3(BIN_THREADS), bin_lds, stream, ba);
-    S3G_KERNEL_CHECK(stream, debug);
+    for (int lo = 0; lo < tiles; lo += band) {
+      ba.tile_lo = lo; ba.tile_n = tiles - lo < band ? tiles - lo : band;
+      hipLaunchKernelGGL(bin_kernel<true>, dim3(nb), dim3(BIN_THREADS), bin_lds, stream, ba);
+      S3G_KERNEL_CHECK(stream, debug);
+    }
     // short lists: <= 32 KiB of LDS per workgroup (5 workgroups/CU); long lists: up to 128 KiB, beyond that in global
     constexpr uint32_t SMALL = 4096, LARGE = 16384;
     const uint32_t small_cap = max_tile < SMALL ? max_tile : SMALL;
@@ -891,6 +904,11 @@ extern "C" int s3g_raster_forward_decompose(const s3g_raster_inputs* in, int R, 
 }
 
 extern "C" void s3g_raster_set_exact_cull(int on) { g_exact_cull = on != 0; }
+extern "C" int s3g_raster_set_bin_band(int tiles) {  // testing hook: returns the previous band size; <= 0 restores the default
+  const int prev = g_max_tiles_lds;
+  g_max_tiles_lds = (tiles <= 0 || tiles > MAX_TILES_LDS) ? MAX_TILES_LDS : tiles;
+  return prev;
+}
 extern "C" int s3g_raster_get_exact_cull(void) { return g_exact_cull ? 1 : 0; }
 
 extern "C" void s3g_profile_enable(int on) { g_prof_on = on != 0; }

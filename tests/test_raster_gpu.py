@@ -460,3 +460,64 @@ def test_exact_tile_culling_changes_nothing_but_the_lists(gpu_device, scene):
     assert l1 <= l0 and R1 == len(l1) and R0 == len(l0)
     if scene != "round":
         assert R1 < 0.8 * R0, (R1, R0)     # the cull actually removes instances
+
+
+@pytest.mark.parametrize("band", [1, 7, 29])
+def test_banded_binning_is_identical_to_the_single_pass(gpu_device, band):
+    """Tile grids beyond the LDS histogram are binned in bands of consecutive tiles (include/s3g_raster.h); forcing a small
+    band on a small image must not change one bit of the lists, images or gradients."""
+    import ctypes
+    from diff_gaussian_rasterization import _C
+    from s3gaussian_amd import _debug, _lib
+    L = _lib.lib()
+    L.s3g_raster_set_bin_band.restype = ctypes.c_int
+    W, H, P = 96, 80, 2500
+    s = tiny_scene(P=P, W=W, H=H, seed=31, scale=0.1)
+    s["scales"][:40] *= 12.0                      # some rects larger than 32 tiles: the wave-cooperative walk
+    dev = gpu_device
+    cam = s["cam"]
+    e = torch.Tensor([])
+    gc, gd = grad_pair(H, W)
+
+    def run():
+        d = lambda k: s[k].to(dev)
+        args = (s["bg"].to(dev), d("means3D"), d("colors_precomp"), d("opacities"), d("scales"), d("rotations"), 1.0, e,
+                cam["viewmatrix"].to(dev), cam["projmatrix"].to(dev), cam["tanfovx"], cam["tanfovy"], H, W, e, 0, cam["campos"].to(dev),
+                False, False)
+        R, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(*args)
+        grads = _C.rasterize_gaussians_backward(args[0], args[1], radii, args[2], args[4], args[5], 1.0, e, args[8], args[9],
+                                                cam["tanfovx"], cam["tanfovy"], gc.to(dev), gd.to(dev), e, 0, args[16], geom, R, binning,
+                                                img, False)
+        im, b = _debug.decode_image(img, W, H), _debug.decode_binning(binning, R)
+        return [torch.tensor(R), color, depth, radii, im["ranges"].clone(), b["point_list"].clone(), im["n_contrib"].clone()] + list(grads)
+
+    prev = L.s3g_raster_set_bin_band(band)
+    try:
+        banded = run()
+    finally:
+        L.s3g_raster_set_bin_band(prev)
+    single = run()
+    for a, b in zip(banded, single):
+        assert torch.equal(a, b)
+
+
+def test_image_beyond_the_lds_histogram_matches_the_oracle(gpu_device, oracle, reference_binning):
+    """4096 x 2400 = 38 400 tiles > the 38 000 the binning histogram holds in LDS: two bands."""
+    from diff_gaussian_rasterization import _C
+    from s3gaussian_amd import _debug
+    W, H, P = 4096, 2400, 3000
+    s = tiny_scene(P=P, W=W, H=H, seed=41, scale=0.05)
+    dev = gpu_device
+    cam = s["cam"]
+    e = torch.Tensor([])
+    R, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
+        s["bg"].to(dev), s["means3D"].to(dev), s["colors_precomp"].to(dev), s["opacities"].to(dev), s["scales"].to(dev),
+        s["rotations"].to(dev), 1.0, e, cam["viewmatrix"].to(dev), cam["projmatrix"].to(dev), cam["tanfovx"], cam["tanfovy"],
+        H, W, e, 0, cam["campos"].to(dev), False, False)
+    ref = oracle_forward(oracle, s)
+    assert R == ref["num_rendered"]
+    np.testing.assert_array_equal(radii.cpu().numpy(), ref["radii"])
+    pl = _debug.decode_binning(binning, R)["point_list"].cpu().numpy().astype(np.uint32)
+    np.testing.assert_array_equal(pl, ref["state"]["point_list"])
+    bad = np.abs(color.cpu().numpy() - ref["color"]).max(0) > COLOR_TOL
+    assert bad.mean() <= OUTLIER_FRAC
