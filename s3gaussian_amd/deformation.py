@@ -2,17 +2,56 @@
 (`deform_network` :179-235, `Deformation` :16-178) so checkpoints, `get_mlp_parameters` / `get_grid_parameters`
 (name filter "grid") and the Adam groups of scene/gaussian_model.py:170-201 keep working.
 
-Supported configuration = the reference defaults (arguments/__init__.py:202-236): grid_pe=0, no_grid=False,
-static_mlp=False, empty_voxel=False, apply_rotation=False; the no_dx/no_ds/no_dr/no_do/no_dshs/feat_head switches
-are honoured.  The HexPlane encoder is the fused HIP sampler (s3gaussian_amd/hexplane.py).
+The reference's default configuration (arguments/__init__.py:202-236) runs as two fused HIP operators (HexPlane sampler +
+MFMA MLP).  Every other switch of scene/deformation.py:16-178 is honoured too -- no_dx / no_ds / no_dr / no_do / no_dshs /
+feat_head, grid_pe (sin/cos embedding of the grid feature, :84-86), no_grid (:79-80), static_mlp and empty_voxel (the
+per-point mask of :108-114, DenseGrid of scene/grid.py:15-42), apply_rotation (:140-141) -- on the same fused sampler with
+the heads as PyTorch-ROCm library GEMMs (GPU only; nothing here runs on the CPU).
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
+import torch.nn.functional as F
+
 from .hexplane import HexPlaneField
 from .mlp import deform_mlp
+
+
+def poc_fre(input_data, poc_buf):
+    """scene/deformation.py:244-250."""
+    emb = (input_data.unsqueeze(-1) * poc_buf).flatten(-2)
+    return torch.cat([input_data, emb.sin(), emb.cos()], -1)
+
+
+def batch_quaternion_multiply(q1, q2):
+    """utils/graphics_utils.py:154-177 (product, then normalisation)."""
+    w = q1[:, 0] * q2[:, 0] - q1[:, 1] * q2[:, 1] - q1[:, 2] * q2[:, 2] - q1[:, 3] * q2[:, 3]
+    x = q1[:, 0] * q2[:, 1] + q1[:, 1] * q2[:, 0] + q1[:, 2] * q2[:, 3] - q1[:, 3] * q2[:, 2]
+    y = q1[:, 0] * q2[:, 2] - q1[:, 1] * q2[:, 3] + q1[:, 2] * q2[:, 0] + q1[:, 3] * q2[:, 1]
+    z = q1[:, 0] * q2[:, 3] + q1[:, 1] * q2[:, 2] - q1[:, 2] * q2[:, 1] + q1[:, 3] * q2[:, 0]
+    q3 = torch.stack((w, x, y, z), dim=1)
+    return q3 / torch.norm(q3, dim=1, keepdim=True)
+
+
+class DenseGrid(nn.Module):
+    """scene/grid.py:15-54: a [1,C,X,Y,Z] voxel grid sampled trilinearly (the `empty_voxel` mask)."""
+
+    def __init__(self, channels, world_size):
+        super().__init__()
+        self.channels, self.world_size = channels, world_size
+        self.grid = nn.Parameter(torch.ones([1, channels, *world_size]))
+
+    def set_aabb(self, xyz_max, xyz_min):
+        self.register_buffer('xyz_min', torch.tensor(xyz_min, dtype=torch.float32, device=self.grid.device))
+        self.register_buffer('xyz_max', torch.tensor(xyz_max, dtype=torch.float32, device=self.grid.device))
+
+    def forward(self, xyz):
+        shape = xyz.shape[:-1]
+        ind_norm = ((xyz.reshape(1, 1, 1, -1, 3) - self.xyz_min) / (self.xyz_max - self.xyz_min)).flip((-1,)) * 2 - 1
+        out = F.grid_sample(self.grid, ind_norm, mode='bilinear', align_corners=True)
+        return out.reshape(self.channels, -1).T.reshape(*shape, self.channels)
 
 
 def _head(W, out):
@@ -22,17 +61,17 @@ def _head(W, out):
 class Deformation(nn.Module):
     def __init__(self, D=8, W=256, input_ch=27, input_ch_time=9, grid_pe=0, skips=(), args=None):
         super().__init__()
-        for flag in ("no_grid", "static_mlp", "empty_voxel", "apply_rotation"):
-            if getattr(args, flag, False):
-                raise NotImplementedError(f"{flag}=True is not on the accelerated path")
-        if grid_pe != 0:
-            raise NotImplementedError("grid_pe != 0 is not on the accelerated path")
         self.D, self.W, self.args, self.grid_pe = D, W, args, grid_pe
         self.input_ch, self.input_ch_time, self.skips = input_ch, input_ch_time, list(skips)
         self.no_grid = args.no_grid
         self.grid = HexPlaneField(args.bounds, args.kplanes_config, args.multires)
+        if getattr(args, "empty_voxel", False):
+            self.empty_voxel = DenseGrid(channels=1, world_size=[64, 64, 64])
+        if getattr(args, "static_mlp", False):
+            self.static_mlp = nn.Sequential(nn.ReLU(), nn.Linear(W, W), nn.ReLU(), nn.Linear(W, 1))
         self.ratio = 0
-        layers = [nn.Linear(self.grid.feat_dim, W)]
+        grid_out_dim = self.grid.feat_dim * 3 if grid_pe != 0 else self.grid.feat_dim     # deformation.py:47-51
+        layers = [nn.Linear(4 if self.no_grid else grid_out_dim, W)]
         for _ in range(D - 1):
             layers += [nn.ReLU(), nn.Linear(W, W)]
         self.feature_out = nn.Sequential(*layers)
@@ -50,24 +89,39 @@ class Deformation(nn.Module):
 
     def set_aabb(self, xyz_max, xyz_min):
         self.grid.set_aabb(xyz_max, xyz_min)
+        if getattr(self.args, "empty_voxel", False):
+            self.empty_voxel.set_aabb(xyz_max, xyz_min)
 
     @property
     def get_empty_ratio(self):
         return self.ratio
 
     def query_time(self, rays_pts_emb, scales_emb, rotations_emb, time_feature, time_emb):
-        return self.feature_out(self.grid(rays_pts_emb[:, :3], time_emb[:, :1]))
+        """scene/deformation.py:78-94."""
+        if self.no_grid:
+            hidden = torch.cat([rays_pts_emb[:, :3], time_emb[:, :1]], -1)
+        else:
+            hidden = self.grid(rays_pts_emb[:, :3], time_emb[:, :1])
+            if self.grid_pe > 1:
+                hidden = poc_fre(hidden, self.grid_pe)
+        return self.feature_out(hidden)
+
+    def forward_static(self, rays_pts_emb):
+        """scene/deformation.py:102-105 (needs static_mlp; like the reference, the field is sampled without a time)."""
+        raise NotImplementedError("forward_static samples the 4-D field without a timestamp, which the reference's "
+                                  "HexPlaneField cannot do either (scene/hexplane.py:151-164 concatenates timestamps)")
 
     def forward(self, rays_pts_emb, scales_emb=None, rotations_emb=None, opacity=None, shs_emb=None, time_feature=None,
                 time_emb=None):
         if time_emb is None:
-            raise NotImplementedError("forward_static needs static_mlp, which the reference defaults disable")
+            return self.forward_static(rays_pts_emb[:, :3])
         return self.forward_dynamic(rays_pts_emb, scales_emb, rotations_emb, opacity, shs_emb, time_feature, time_emb)
 
     def _fused_ok(self):
         a = self.args
-        return (self.D == 1 and self.W == 64 and self.grid.feat_dim == 128 and not a.no_dx and not a.no_dshs and a.no_ds
-                and a.no_dr and a.no_do and a.feat_head)
+        plain = not (self.no_grid or self.grid_pe != 0 or getattr(a, "static_mlp", False) or getattr(a, "empty_voxel", False))
+        return (plain and self.D == 1 and self.W == 64 and self.grid.feat_dim == 128 and not a.no_dx and not a.no_dshs
+                and a.no_ds and a.no_dr and a.no_do and a.feat_head)
 
     def deform_heads(self, xyz, time, uniform_time=None, reg_weights=None, need_feat=True):
         """(dx [P,3], dshs [P,16,3], feat [P,3]) only -- the part of forward_dynamic that is not a pass-through in the
@@ -92,20 +146,30 @@ class Deformation(nn.Module):
             dshs = dshs.reshape([shs_emb.shape[0], 16, 3])
             return (rays_pts_emb[:, :3] + dx, scales_emb[:, :3], rotations_emb[:, :4], opacity_emb[:, :1], shs_emb + dshs,
                     dx, feat, dshs)
-        # other switch combinations: HexPlane sampler + library GEMMs
+        # other switch combinations: fused HexPlane sampler + library GEMMs, scene/deformation.py:106-166 line by line
         hidden = self.query_time(rays_pts_emb, scales_emb, rotations_emb, time_feature, time_emb)
+        if getattr(a, "static_mlp", False):
+            mask = self.static_mlp(hidden)
+        elif getattr(a, "empty_voxel", False):
+            mask = self.empty_voxel(rays_pts_emb[:, :3])
+        else:
+            mask = torch.ones_like(opacity_emb[:, 0]).unsqueeze(-1)
         dx = dshs = feat = None
         pts = rays_pts_emb[:, :3]
         if not a.no_dx:
             dx = self.pos_deform(hidden)
-            pts = rays_pts_emb[:, :3] + dx            # mask == 1 in the default configuration (deformation.py:117)
-        scales = scales_emb[:, :3] if a.no_ds else scales_emb[:, :3] + self.scales_deform(hidden)
-        rotations = rotations_emb[:, :4] if a.no_dr else rotations_emb[:, :4] + self.rotations_deform(hidden)
-        opacity = opacity_emb[:, :1] if a.no_do else opacity_emb[:, :1] + self.opacity_deform(hidden)
+            pts = rays_pts_emb[:, :3] * mask + dx
+        scales = scales_emb[:, :3] if a.no_ds else scales_emb[:, :3] * mask + self.scales_deform(hidden)
+        if a.no_dr:
+            rotations = rotations_emb[:, :4]
+        else:
+            dr = self.rotations_deform(hidden)
+            rotations = batch_quaternion_multiply(rotations_emb, dr) if getattr(a, "apply_rotation", False) else rotations_emb[:, :4] + dr
+        opacity = opacity_emb[:, :1] if a.no_do else opacity_emb[:, :1] * mask + self.opacity_deform(hidden)
         shs = shs_emb
         if not a.no_dshs:
             dshs = self.shs_deform(hidden).reshape([shs_emb.shape[0], 16, 3])
-            shs = shs_emb + dshs
+            shs = shs_emb * mask.unsqueeze(-1) + dshs
         if a.feat_head:
             feat = self.dino_head(hidden)
         return pts, scales, rotations, opacity, shs, dx, feat, dshs

@@ -25,6 +25,24 @@ REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+SWITCH_VARIANTS = {
+    # no_grid=True cannot be pinned: the reference itself raises UnboundLocalError there (scene/deformation.py:79-91 assigns
+    # `h` and then reads `hidden`)
+    "grid_pe": dict(grid_pe=2),
+    "static_mlp": dict(static_mlp=True, no_ds=False, no_do=False),
+    "empty_voxel": dict(empty_voxel=True, no_ds=False),
+    "apply_rotation": dict(no_dr=False, apply_rotation=True),
+    "all_heads": dict(no_ds=False, no_dr=False, no_do=False),
+    "no_dx_no_dshs": dict(no_dx=True, no_dshs=True, feat_head=False),
+}
+
+
+def empty_voxel_pattern():
+    """Deterministic non-trivial content for DenseGrid.grid [1,1,64,64,64] (regenerated identically by the test)."""
+    a = torch.linspace(0, 3.0, 64)
+    return (1.0 + 0.3 * torch.sin(a[:, None, None] * 1.3 + a[None, :, None] * 0.7 - a[None, None, :]))[None, None]
+
+
 def import_reference():
     # stub modules the reference imports for side effects only (SURVEY.md 7 "hard parts" vii)
     tk = types.ModuleType("tkinter"); tk.W = "w"; sys.modules["tkinter"] = tk
@@ -117,6 +135,39 @@ def main():
     dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
     cols = torch.clamp_min(m["utils.sh_utils"].eval_sh(3, shs_view, dir_pp) + 0.5, 0.0)
     np.savez_compressed(os.path.join(HERE, "glue.npz"), campos=campos.numpy(), colors=cols.numpy())
+
+    # ---- non-default switches of scene/deformation.py (grid_pe, no_grid, static_mlp, empty_voxel, apply_rotation, all heads)
+    sw = {}
+    for tag, over in SWITCH_VARIANTS.items():
+        torch.manual_seed(99)
+        hy = SimpleNamespace(**{**vars(hyper), "kplanes_config": {"grid_dimensions": 2, "input_coordinate_dim": 4,
+                                                                  "output_coordinate_dim": 32, "resolution": [4, 4, 4, 3]}, **over})
+        netv = m["scene.deformation"].deform_network(hy)
+        gv = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for pp in netv.deformation_net.grid.grids.parameters():
+                pp.add_(0.2 * torch.randn(pp.shape, generator=gv))
+            if over.get("empty_voxel"):
+                netv.deformation_net.empty_voxel.grid.copy_(empty_voxel_pattern())
+        netv.deformation_net.set_aabb([2.0, 1.5, 1.0], [-1.0, -1.5, -0.5])
+        Pv = 64
+        xv = (torch.rand(Pv, 3, generator=gv) * torch.tensor([2.6, 2.6, 1.2]) + torch.tensor([-0.8, -1.3, -0.4])).requires_grad_(True)
+        sv, rv, ov = torch.randn(Pv, 3, generator=gv), torch.randn(Pv, 4, generator=gv), torch.randn(Pv, 1, generator=gv)
+        shv = torch.randn(Pv, 16, 3, generator=gv)
+        tv = torch.full((Pv, 1), 0.61)
+        outs = netv(xv, sv, rv, ov, shv, tv)
+        wv = [None if o is None else torch.randn(o.shape, generator=gv) for o in outs]
+        sum((o * wi).sum() for o, wi in zip(outs, wv) if o is not None).backward()
+        sw[tag + "::xyz"], sw[tag + "::scales"], sw[tag + "::rotations"] = xv.detach().numpy(), sv.numpy(), rv.numpy()
+        sw[tag + "::opacity"], sw[tag + "::shs"], sw[tag + "::time"] = ov.numpy(), shv.numpy(), tv.numpy()
+        sw[tag + "::grad_xyz"] = xv.grad.numpy()
+        for n, o, wi in zip(names, outs, wv):
+            if o is not None:
+                sw[f"{tag}::out_{n}"] = o.detach().numpy(); sw[f"{tag}::w_{n}"] = wi.numpy()
+        for k, v in netv.state_dict().items():
+            if "empty_voxel" not in k:       # regenerated from empty_voxel_pattern() by the test
+                sw[f"{tag}::sd::{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "deform_switches.npz"), **sw)
     print("golden fixtures written to", HERE)
 
 

@@ -169,3 +169,45 @@ def test_regulariser_on_the_sampler_node_matches_separate_nodes(gpu_device, use)
             continue
         assert a.is_contiguous(memory_format=torch.channels_last)
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("variant", ["grid_pe", "static_mlp", "empty_voxel", "apply_rotation", "all_heads", "no_dx_no_dshs"])
+def test_non_default_deformation_switches_match_reference_golden(gpu_device, variant):
+    """grid_pe / static_mlp / empty_voxel / apply_rotation / every head on / dx+dshs off: outputs and dL/dxyz of
+    s3gaussian_amd.deformation against tests/golden/deform_switches.npz, produced by the reference's own
+    scene/deformation.py (tests/golden/make_golden.py).  These configurations run the fused HexPlane sampler with
+    library GEMMs for the heads."""
+    import importlib.util
+    from s3gaussian_amd.deformation import deform_network
+    from s3gaussian_amd.pipeline import default_hyper
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "deform_switches.npz"))
+    over = mg.SWITCH_VARIANTS[variant]
+    hyper = default_hyper(kplanes_config=dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32,
+                                              resolution=[4, 4, 4, 3]), multires=[1, 2], **over)
+    net = deform_network(hyper)
+    sd = {k.split("::sd::")[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(variant + "::sd::")}
+    if over.get("empty_voxel"):
+        sd["deformation_net.empty_voxel.grid"] = mg.empty_voxel_pattern()
+    net.deformation_net.set_aabb([2.0, 1.5, 1.0], [-1.0, -1.5, -0.5])
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all("empty_voxel.xyz" in k for k in missing), (missing, unexpected)
+    net = net.to(gpu_device)
+    if over.get("empty_voxel"):
+        net.deformation_net.set_aabb([2.0, 1.5, 1.0], [-1.0, -1.5, -0.5])   # buffers on the device
+    t = lambda k: torch.from_numpy(z[f"{variant}::{k}"]).to(gpu_device)
+    xyz = t("xyz").clone().requires_grad_(True)
+    outs = net(xyz, t("scales"), t("rotations"), t("opacity"), t("shs"), t("time"))
+    names = ["means3D", "scales", "rotations", "opacity", "shs", "dx", "feat", "dshs"]
+    loss = 0
+    for n, o in zip(names, outs):
+        key = f"{variant}::out_{n}"
+        if o is None:
+            assert key not in z.files, n
+            continue
+        np.testing.assert_allclose(o.detach().cpu().numpy(), z[key], rtol=1e-4, atol=3e-5, err_msg=n)
+        loss = loss + (o * t("w_" + n)).sum()
+    loss.backward()
+    assert rel_l2(xyz.grad.cpu().numpy(), z[f"{variant}::grad_xyz"]) < 1e-4
