@@ -49,11 +49,18 @@ int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, co
 
 /* dL_dfeatures [P, levels*32] -> dL_dxyz [P,3] (written) and dL_dplanes[l][i] (same layout as planes; ACCUMULATED,
  * the caller zero-fills them; a NULL entry skips that plane).  `workspace`: device scratch of
- * s3g_hexplane_backward_workspace_bytes(d, P) bytes (3 KB per point: per-plane sample gradients + sort buffers, plus the
- * row tables and their gradients when uniform_time), uninitialised. */
-size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P);
+ * s3g_hexplane_backward_workspace_bytes(d, P, features != NULL) bytes (sort buffers, per-orientation dL/dxyz partials, the
+ * row tables and their gradients when uniform_time; + 3 KB per point of per-plane sample gradients on the features == NULL
+ * path), uninitialised. */
+size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P, int have_features);
 int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
-                          const float* dL_dfeatures, float* dL_dxyz, float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6],
+                          const float* dL_dfeatures,
+                          const float* features /* [P, levels*32]: the OUTPUT of the matching s3g_hexplane_forward (same
+                          planes, xyz, time).  With it dL/d(sample_i) = dL/dfeature * feature / sample_i needs only the one
+                          sample each scatter walk re-derives from its local texels, and the workspace is 30 bytes per point;
+                          NULL selects the older two-pass algorithm, which stores dL/d(sample) for all 24 plane-levels
+                          (3 KB per point). */,
+                          float* dL_dxyz, float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6],
                           void* workspace,
                           unsigned int* sort_state /* [6*P] device or NULL: the three spatial orders of the points followed
                           by their inverse permutations.  They only steer HOW the work is walked (texel reuse, run-length

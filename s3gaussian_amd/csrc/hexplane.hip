@@ -323,12 +323,20 @@ struct Foot {
   int key, flags;
   float a00, a01, a10, a11;
 };
+// Offsets are 32-bit BYTE offsets off a uniform base pointer (`base + zext(u32)` selects the scalar-base + VGPR-offset
+// addressing mode: no 64-bit address arithmetic per atomic; a plane is at most 2^24 texels).  The corner tests stay
+// branches on purpose: an unconditional atomic of an exact zero to a clamped address was measured 6x SLOWER for the whole
+// pass -- every empty entry and every out-of-range corner then lands on the same few lines (texel 0 of each plane, the nw
+// texel again), and same-address atomics serialise at ~10 ns each.
 __device__ __forceinline__ void foot_flush(const Foot& f, float* __restrict__ gp, int W, int c) {
   if (f.key < 0) return;
-  atomicAdd(&gp[(size_t)f.key * HEXC + c], f.a00);
-  if (f.flags & 1) atomicAdd(&gp[(size_t)(f.key + 1) * HEXC + c], f.a01);
-  if (f.flags & 2) atomicAdd(&gp[(size_t)(f.key + W) * HEXC + c], f.a10);
-  if ((f.flags & 3) == 3) atomicAdd(&gp[(size_t)(f.key + W + 1) * HEXC + c], f.a11);
+  const uint32_t k = ((uint32_t)f.key * HEXC + (uint32_t)c) * 4u;
+  const uint32_t dy = (uint32_t)W * (HEXC * 4u);
+  char* base = reinterpret_cast<char*>(gp);
+  atomicAdd(reinterpret_cast<float*>(base + k), f.a00);
+  if (f.flags & 1) atomicAdd(reinterpret_cast<float*>(base + (k + HEXC * 4u)), f.a01);
+  if (f.flags & 2) atomicAdd(reinterpret_cast<float*>(base + (k + dy)), f.a10);
+  if ((f.flags & 3) == 3) atomicAdd(reinterpret_cast<float*>(base + (k + dy + HEXC * 4u)), f.a11);
 }
 // Two-entry footprint cache.  align_corners grids of different levels do not nest, so inside one finest-level cell the
 // points alternate between two (sometimes four) coarse footprints; remembering the previous one as well removes most of
@@ -495,6 +503,303 @@ __global__ void __launch_bounds__(256, SCATTER_WG_PER_CU) hexplane_scatter_kerne
   }
 }
 
+// =========================================================================================================================
+// Backward WITHOUT the per-plane gradient slab ("walk" kernel).
+//
+// dL/ds_i = g * prod_{j != i} s_j.  The product over ALL six samples is the forward's output feature f = prod_j s_j, which
+// is still in memory (it is the MLP's saved input), so with R = g * f
+//                                   dL/ds_i = R / s_i
+// needs only the ONE sample the pass is about to scatter anyway -- and in the sorted order of orientation o the texels of its
+// spatial plane and of its time table are exactly the footprint the walk is accumulating (L1-resident).  The same texels give
+// ds/d(ix), ds/d(iy), hence this orientation's share of dL/dxyz.  So each of the three orientation walks reads, per point and
+// level, two 128-byte rows by index (g, f) and six local texels, and the per-point pass that wrote 3 KB of dL/ds per point
+// (and this pass reading them back: 7.4 GB per iteration) is gone, together with its 72 non-local texel gathers per point.
+//
+// Division safety: R / s_i is exact to ~2 ulp when |s_i| is a normal number of ordinary size.  If ANY channel of a point's
+// sample is tiny, zero or not finite (|s| <= 1e-18 -- a plane region that is exactly zero, say) the walk contributes NOTHING
+// for that (point, level, plane) and sets a bit in a per-(orientation, point) mask; hexplane_backward_fixup_kernel then forms
+// the product of the OTHER five samples from their texels for exactly those entries (20 non-local gathers and direct atomics
+// each -- slow but exact), so the result is defined for every input the reference accepts.  With no bit set the fix-up pass
+// reads 6 bytes per point and returns.
+// =========================================================================================================================
+constexpr int WALK_LG = 2;          // levels per walk of a segment
+constexpr int WALK_WG_PER_CU = 3;   // waves per SIMD the register budget is set for
+constexpr float WALK_SAFE = 1e-18f;
+
+struct WalkTap {  // 6 floats in LDS: nw texel offset, flags (bit0 ne/se column in range, bit1 sw/se row in range, bit2 d(ix)/du
+  int key, flags;  // != 0, bit3 d(iy)/du != 0), 1-D weights x1-ix, ix-x0, y1-iy, iy-y0
+  float wx0, wx1, wy0, wy1;
+};
+__device__ __forceinline__ WalkTap walk_tap_read(const float* src) {
+  const float4 lo = *reinterpret_cast<const float4*>(src);
+  const float2 hi = *reinterpret_cast<const float2*>(src + 4);
+  WalkTap t;
+  t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
+  t.wx0 = lo.z; t.wx1 = lo.w; t.wy0 = hi.x; t.wy1 = hi.y;
+  return t;
+}
+// one sample of plane i of level l at point coordinates u, channel c (exact path of the division-safety fallback)
+__device__ __forceinline__ float walk_sample(const HexArgs& a, int l, int i, const float* u, int c) {
+  const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
+  const Tap t = make_tap(u[PAIR0[i]], u[PAIR1[i]], W, H);
+  const float* pl = a.d.planes[l][i];
+  float acc = fetch(pl, t.o00, c) * t.w00;
+  acc = acc + fetch(pl, t.o01, c) * t.w01;
+  acc = acc + fetch(pl, t.o10, c) * t.w10;
+  acc = acc + fetch(pl, t.o11, c) * t.w11;
+  return acc;
+}
+__global__ void __launch_bounds__(256, WALK_WG_PER_CU)
+hexplane_backward_walk_kernel(const HexArgs a, const float* __restrict__ feat, const uint32_t* __restrict__ order_all,
+                              float* __restrict__ dup /* [3][P][2] partial dL/du per orientation */,
+                              uint16_t* __restrict__ badmask /* [3][P], zero-filled: bit 2*level + kind */) {
+  constexpr int LG = WALK_LG;
+  __shared__ __attribute__((aligned(16))) float tapbuf[8][2][4][8][TAPF];  // [half-wave][double buffer][point][tap]
+  // g / f rows of a group of four points, DMA-copied global -> LDS one group ahead (no registers held across the wait):
+  // [wave][double buffer][point][level][g | f][64 lanes = the two half-waves' rows side by side]
+  __shared__ __attribute__((aligned(16))) float rowbuf[4][2][4][LG][2][64];
+  const int o = blockIdx.y;
+  const int c = threadIdx.x & 31, hw = threadIdx.x >> 5, wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
+  const int half_base = threadIdx.x & 32;  // first lane of this half-wave inside its wave
+  const int q = c >> 3, j = c & 7;  // tap-phase role: point q of the group of four, tap j = (level j >> 1, kind j & 1)
+  const int seg = blockIdx.x * 8 + hw;
+  const int k0 = seg * SEG, k1 = min(a.P, k0 + SEG);
+  if (k0 >= a.P) return;  // whole half-waves drop out; LDS traffic and shuffles below stay inside a half-wave
+  const uint32_t* order = order_all + (size_t)o * a.P;
+  const int F = a.d.levels * HEXC;
+  const int i0 = PLA[o], i1 = PLT[o];
+  const int ip = (j & 1) ? i1 : i0;                   // the plane of this lane's tap
+  const int axw = PAIR0[ip], axh = PAIR1[ip];
+  // dL/du slots of this orientation: slot 0 = axis PAIR0[i0], slot 1 = axis PAIR1[i0]; the time table's spatial axis
+  // (PAIR0[i1] = the major axis o) is one of the two
+  const bool table_in_slot0 = PAIR0[i1] == PAIR0[i0];
+  for (int l0 = 0; l0 < a.d.levels; l0 += LG) {
+    Foot2 ft[LG][2];
+#pragma unroll
+    for (int l = 0; l < LG; l++)
+#pragma unroll
+      for (int m = 0; m < 2; m++) foot2_init(ft[l][m]);
+    const int lt = l0 + (j >> 1);                     // level of this lane's tap
+    const bool tap_on = (j >> 1) < LG && lt < a.d.levels;
+    const int Wt = tap_on ? a.d.res[lt][axw] : 2, Ht = tap_on ? a.d.res[lt][axh] : 2;
+    auto load_index = [&](int kb) { return (int)order[min(kb + q, k1 - 1)]; };
+    auto store_taps = [&](const float* u, int buf) {
+      const Tap t = make_tap(u[axw], u[axh], Wt, Ht);
+      float4 lo;
+      lo.x = __int_as_float(t.o00);
+      lo.y = __int_as_float((t.o01 >= 0 ? 1 : 0) | (t.o10 >= 0 ? 2 : 0) | (t.mx != 0.f ? 4 : 0) | (t.my != 0.f ? 8 : 0));
+      lo.z = t.x1f - t.ix;
+      lo.w = t.ix - t.x0f;
+      float* dst = &tapbuf[hw][buf][q][j][0];
+      *reinterpret_cast<float4*>(dst) = lo;
+      *reinterpret_cast<float2*>(dst + 4) = make_float2(t.y1f - t.iy, t.iy - t.y0f);
+    };
+    // rows of the group whose role lanes hold `pidx`: 4 points x LG levels x {g, f}, one 4-byte DMA per lane and row
+    auto dma_rows = [&](int pidx, int buf) {
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) {
+        const size_t prow = (size_t)__shfl(pidx, half_base + 8 * qq) * F + c;
+#pragma unroll
+        for (int l = 0; l < LG; l++) {
+          const size_t off = prow + min(l0 + l, a.d.levels - 1) * HEXC;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.gfeat + off),
+                                           (__attribute__((address_space(3))) void*)&rowbuf[wave][buf][qq][l][0][0], 4, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(feat + off),
+                                           (__attribute__((address_space(3))) void*)&rowbuf[wave][buf][qq][l][1][0], 4, 0, 0);
+        }
+      }
+    };
+    // the eight texels (plane a: nw ne sw se, table t: nw ne sw se) of point qq for every level of the group; corners out of
+    // range have weight 0 (the clip puts ix on the last column / row), their offsets are clamped to the nw texel
+    auto load_texels = [&](int buf, int qq, float (&v)[LG][8]) {
+#pragma unroll
+      for (int l = 0; l < LG; l++) {
+        const int lv = min(l0 + l, a.d.levels - 1);
+        const float2 ka = *reinterpret_cast<const float2*>(&tapbuf[hw][buf][qq][l * 2 + 0][0]);
+        const float2 kt = *reinterpret_cast<const float2*>(&tapbuf[hw][buf][qq][l * 2 + 1][0]);
+        const int keya = __float_as_int(ka.x), fla = __float_as_int(ka.y), keyt = __float_as_int(kt.x), flt = __float_as_int(kt.y);
+        // uniform base pointer + 32-bit BYTE offset per lane (scalar-base addressing, no 64-bit address arithmetic)
+        const char* pa = reinterpret_cast<const char*>(a.d.planes[lv][i0]);
+        const char* pt = reinterpret_cast<const char*>(a.d.planes[lv][i1]);
+        const uint32_t Wa = (uint32_t)a.d.res[lv][PAIR0[i0]], Wtt = (uint32_t)a.d.res[lv][PAIR0[i1]];
+        const uint32_t ka0 = ((uint32_t)keya * HEXC + (uint32_t)c) * 4u, kt0 = ((uint32_t)keyt * HEXC + (uint32_t)c) * 4u;
+        const uint32_t ax1 = (fla & 1) ? HEXC * 4u : 0u, ay1 = (fla & 2) ? Wa * (HEXC * 4u) : 0u;
+        const uint32_t tx1 = (flt & 1) ? HEXC * 4u : 0u, ty1 = (flt & 2) ? Wtt * (HEXC * 4u) : 0u;
+        auto ld = [](const char* b, uint32_t off) { return *reinterpret_cast<const float*>(b + off); };
+        v[l][0] = ld(pa, ka0); v[l][1] = ld(pa, ka0 + ax1); v[l][2] = ld(pa, ka0 + ay1); v[l][3] = ld(pa, ka0 + ax1 + ay1);
+        v[l][4] = ld(pt, kt0); v[l][5] = ld(pt, kt0 + tx1); v[l][6] = ld(pt, kt0 + ty1); v[l][7] = ld(pt, kt0 + tx1 + ty1);
+      }
+    };
+    // three-stage pipeline per lane role: index of group g+2; coordinates, taps and g / f rows of group g+1; accumulation of g
+    int pc = load_index(k0), pn, pnn;
+    float un[4];
+    {
+      float u0[4];
+      point_coords(a, pc, u0);
+      store_taps(u0, 0);
+    }
+    dma_rows(pc, 0);
+    pn = load_index(k0 + 4);
+    point_coords(a, pn, un);
+    pnn = load_index(k0 + 8);
+    int buf = 0;
+    for (int kb = k0; kb < k1; kb += 4, buf ^= 1) {
+      // 0. the rows of THIS group (requested one iteration ago) have landed once every outstanding memory operation has
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // 1. next group: rows by DMA, taps from the coordinates loaded one iteration ago; advance the prefetch stages
+      dma_rows(pn, buf ^ 1);
+      store_taps(un, buf ^ 1);
+      const int pc_next = pn;
+      pn = pnn;
+      point_coords(a, pn, un);
+      pnn = load_index(kb + 12);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // 2. point by point (a rolled loop: one copy of the body); the texels of the next point are in flight while the
+      //    current one is worked on
+      const int nq = min(4, k1 - kb);
+      float vc[LG][8], vn[LG][8];
+      load_texels(buf, 0, vc);
+#pragma unroll 1
+      for (int qq = 0; qq < nq; qq++) {
+        load_texels(buf, min(qq + 1, 3), vn);
+        const int pthis = __shfl(pc, half_base + 8 * qq);
+        float du0 = 0.f, du1 = 0.f;
+        uint32_t badbits = 0;
+#pragma unroll
+        for (int l = 0; l < LG; l++) {
+          if (l0 + l >= a.d.levels) break;
+          const int lv = l0 + l;
+          const WalkTap ta = walk_tap_read(&tapbuf[hw][buf][qq][l * 2 + 0][0]);
+          const WalkTap tt = walk_tap_read(&tapbuf[hw][buf][qq][l * 2 + 1][0]);
+          const int Wa = a.d.res[lv][PAIR0[i0]], Wtt = a.d.res[lv][PAIR0[i1]];
+          const float a00 = vc[l][0], a01 = vc[l][1], a10 = vc[l][2], a11 = vc[l][3];
+          const float t00 = vc[l][4], t01 = vc[l][5], t10 = vc[l][6], t11 = vc[l][7];
+          PackedTap fa, fb;
+          fa.key = ta.key; fa.flags = ta.flags & 3;
+          fa.w00 = ta.wx0 * ta.wy0; fa.w01 = ta.wx1 * ta.wy0; fa.w10 = ta.wx0 * ta.wy1; fa.w11 = ta.wx1 * ta.wy1;
+          fb.key = tt.key; fb.flags = tt.flags & 3;
+          fb.w00 = tt.wx0 * tt.wy0; fb.w01 = tt.wx1 * tt.wy0; fb.w10 = tt.wx0 * tt.wy1; fb.w11 = tt.wx1 * tt.wy1;
+          float sa = a00 * fa.w00; sa = sa + a01 * fa.w01; sa = sa + a10 * fa.w10; sa = sa + a11 * fa.w11;
+          float st = t00 * fb.w00; st = st + t01 * fb.w01; st = st + t10 * fb.w10; st = st + t11 * fb.w11;
+          const float g = rowbuf[wave][buf][qq][l][0][lane64], R = g * rowbuf[wave][buf][qq][l][1][lane64];
+          float ga = R * __builtin_amdgcn_rcpf(sa), gt = R * __builtin_amdgcn_rcpf(st);
+          const bool bad_a = !(fabsf(sa) > WALK_SAFE) || !(fabsf(sa) < 1e18f);
+          const bool bad_t = !(fabsf(st) > WALK_SAFE) || !(fabsf(st) < 1e18f);
+          if ((__ballot(bad_a || bad_t) >> half_base) & 0xffffffffull) {   // any channel of THIS half-wave: leave it to the fix-up
+            if ((__ballot(bad_a) >> half_base) & 0xffffffffull) { ga = 0.f; badbits |= 1u << (2 * lv); }
+            if ((__ballot(bad_t) >> half_base) & 0xffffffffull) { gt = 0.f; badbits |= 2u << (2 * lv); }
+          }
+          // this orientation's share of dL/du: ds/dix = (ne - nw)(y1 - iy) + (se - sw)(iy - y0), ds/diy likewise
+          const float dXa = (a01 - a00) * ta.wy0 + (a11 - a10) * ta.wy1;
+          const float dYa = (a10 - a00) * ta.wx0 + (a11 - a01) * ta.wx1;
+          const float dXt = (t01 - t00) * tt.wy0 + (t11 - t10) * tt.wy1;
+          const float mxa = (ta.flags & 4) ? (float)(Wa - 1) / 2.f : 0.f;
+          const float mya = (ta.flags & 8) ? (float)(a.d.res[lv][PAIR1[i0]] - 1) / 2.f : 0.f;
+          const float mxt = (tt.flags & 4) ? (float)(Wtt - 1) / 2.f : 0.f;
+          const float tterm = mxt * (dXt * gt);
+          du0 += mxa * (dXa * ga) + (table_in_slot0 ? tterm : 0.f);
+          du1 += mya * (dYa * ga) + (table_in_slot0 ? 0.f : tterm);
+          float* gpa = a.gplanes[lv][i0];
+          float* gpt = a.gplanes[lv][i1];
+          if (gpa != nullptr) foot2_add(ft[l][0], fa, ga, gpa, Wa, c);
+          if (gpt != nullptr) foot2_add(ft[l][1], fb, gt, gpt, Wtt, c);
+        }
+        // dL/du: sum over the 32 channels; lanes 0 and 1 add slots 0 and 1 to this orientation's partials
+        for (int off = 16; off >= 1; off >>= 1) {
+          du0 += __shfl_xor(du0, off);
+          du1 += __shfl_xor(du1, off);
+        }
+        if (c < 2) {
+          float* dst = dup + ((size_t)o * a.P + pthis) * 2 + c;
+          *dst = (l0 == 0 ? 0.f : *dst) + (c == 0 ? du0 : du1);   // the same half-wave revisits the point in the next level group
+        }
+        if (badbits != 0 && c == 0) badmask[(size_t)o * a.P + pthis] |= (uint16_t)badbits;
+#pragma unroll
+        for (int l = 0; l < LG; l++)
+#pragma unroll
+          for (int k = 0; k < 8; k++) vc[l][k] = vn[l][k];
+      }
+      pc = pc_next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (clamped) prefetch must not land in a buffer the next level group reuses
+#pragma unroll
+    for (int l = 0; l < LG; l++) {
+      if (l0 + l >= a.d.levels) break;
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        float* gp = a.gplanes[l0 + l][m ? i1 : i0];
+        if (gp == nullptr) continue;
+        foot2_flush_all(ft[l][m], gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
+      }
+    }
+  }
+}
+
+// Exact contributions of the (orientation, point, level, plane) entries the walk skipped.  One half-wave per flagged
+// (orientation, point); lanes = channels; direct atomics (the entries are rare by construction).
+__global__ void __launch_bounds__(256) hexplane_backward_fixup_kernel(const HexArgs a, const uint16_t* __restrict__ badmask,
+                                                                      float* __restrict__ dup) {
+  const int o = blockIdx.y, c = threadIdx.x & 31;
+  const int F = a.d.levels * HEXC;
+  const bool table_in_slot0 = PAIR0[PLT[o]] == PAIR0[PLA[o]];
+  for (int p = blockIdx.x * 8 + (threadIdx.x >> 5); p < a.P; p += gridDim.x * 8) {
+    const uint32_t bits = badmask[(size_t)o * a.P + p];
+    if (bits == 0) continue;   // uniform inside the half-wave
+    float u[4];
+    point_coords(a, p, u);
+    float du0 = 0.f, du1 = 0.f;
+    for (int l = 0; l < a.d.levels; l++)
+      for (int m = 0; m < 2; m++) {
+        if (!((bits >> (2 * l + m)) & 1u)) continue;
+        const int i = m ? PLT[o] : PLA[o];
+        // g * prod_{j != i} s_j in autograd's order: prefix product left to right, suffix factors from the right
+        float pre = 1.f, suf = a.gfeat[(size_t)p * F + l * HEXC + c];
+        for (int k = 5; k > i; k--) suf = suf * walk_sample(a, l, k, u, c);
+        for (int k = 0; k < i; k++) pre = pre * walk_sample(a, l, k, u, c);
+        const float gi = suf * pre;
+        const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
+        const Tap t = make_tap(u[PAIR0[i]], u[PAIR1[i]], W, H);
+        const float* pl = a.d.planes[l][i];
+        const float v00 = fetch(pl, t.o00, c), v01 = fetch(pl, t.o01, c), v10 = fetch(pl, t.o10, c), v11 = fetch(pl, t.o11, c);
+        const float dX = (v01 - v00) * (t.y1f - t.iy) + (v11 - v10) * (t.iy - t.y0f);
+        const float dY = (v10 - v00) * (t.x1f - t.ix) + (v11 - v01) * (t.ix - t.x0f);
+        if (m == 0) {
+          du0 += t.mx * (dX * gi);
+          du1 += t.my * (dY * gi);
+        } else {
+          (table_in_slot0 ? du0 : du1) += t.mx * (dX * gi);
+        }
+        float* gp = a.gplanes[l][i];
+        if (gp != nullptr) {
+          atomicAdd(&gp[(size_t)t.o00 * HEXC + c], gi * t.w00);
+          if (t.o01 >= 0) atomicAdd(&gp[(size_t)t.o01 * HEXC + c], gi * t.w01);
+          if (t.o10 >= 0) atomicAdd(&gp[(size_t)t.o10 * HEXC + c], gi * t.w10);
+          if (t.o11 >= 0) atomicAdd(&gp[(size_t)t.o11 * HEXC + c], gi * t.w11);
+        }
+      }
+    for (int off = 16; off >= 1; off >>= 1) {
+      du0 += __shfl_xor(du0, off);
+      du1 += __shfl_xor(du1, off);
+    }
+    if (c < 2) dup[((size_t)o * a.P + p) * 2 + c] += c == 0 ? du0 : du1;
+  }
+}
+
+// dL/dxyz = (sum of the orientations' shares) * d(u)/d(xyz): axis 0 <- (o0, slot0) + (o2, slot0), axis 1 <- (o0, slot1) +
+// (o1, slot0), axis 2 <- (o1, slot1) + (o2, slot1)
+__global__ void __launch_bounds__(256) hexplane_dxyz_kernel(const HexArgs a, const float* __restrict__ dup) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.P) return;
+  const size_t P = (size_t)a.P;
+  const float2 d0 = reinterpret_cast<const float2*>(dup)[p], d1 = reinterpret_cast<const float2*>(dup)[P + p];
+  const float2 d2 = reinterpret_cast<const float2*>(dup)[2 * P + p];
+  const float du[3] = {d0.x + d2.x, d0.y + d1.x, d1.y + d2.y};
+#pragma unroll
+  for (int k = 0; k < 3; k++) a.gxyz[3 * (size_t)p + k] = du[k] * (2.0f / (a.d.aabb_min[k] - a.d.aabb_max[k]));
+}
+
 // ---- uniform time: the (axis, t) planes collapse to 1-D row tables ---------------------------------------------------
 // When every point carries the same t, the t half of the bilinear footprint is the same for all of them:
 //   R[x][c] = P[y0][x][c] * (y1 - iy) + P[y1][x][c] * (iy - y0)       (iy from time[0], exactly as make_tap computes it)
@@ -618,22 +923,35 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
   return S3G_OK;
 }
 
-extern "C" size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P) {
+static void carve_backward(Carver& c, const s3g_hexplane_desc* d, int P, bool walk, float** G, float** tables, SortWork* w,
+                           float** dup, uint16_t** badmask) {
+  const size_t n = (size_t)P;
+  float* g = walk ? nullptr : c.take<float>((size_t)d->levels * 6 * n * HEXC);   // legacy path: per-plane gradient slab
+  float* tb = d->uniform_time ? c.take<float>(2 * time_table_floats(d)) : nullptr;
+  SortWork s;
+  s.table = c.take<uint32_t>((size_t)3 * SORT_NB * SORT_BINS);
+  s.seg_start = c.take<uint32_t>((size_t)3 * (SORT_BINS + 1));
+  s.tmp = c.take<uint32_t>(3 * n);
+  s.order = c.take<uint32_t>(3 * n);
+  s.rank = c.take<uint32_t>(3 * n);
+  float* du = walk ? c.take<float>(6 * n) : nullptr;
+  uint16_t* bm = walk ? c.take<uint16_t>(3 * n) : nullptr;
+  if (G) *G = g;
+  if (tables) *tables = tb;
+  if (w) *w = s;
+  if (dup) *dup = du;
+  if (badmask) *badmask = bm;
+}
+
+extern "C" size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P, int have_features) {
   if (!d || d->levels < 1 || d->levels > S3G_HEX_MAX_LEVELS || P < 0) return 0;
-  const int levels = d->levels;
   Carver c(nullptr);
-  c.take<float>((size_t)levels * 6 * P * HEXC);
-  if (d->uniform_time) c.take<float>(2 * time_table_floats(d));
-  c.take<uint32_t>((size_t)3 * SORT_NB * SORT_BINS);
-  c.take<uint32_t>((size_t)3 * (SORT_BINS + 1));
-  c.take<uint32_t>((size_t)3 * P);
-  c.take<uint32_t>((size_t)3 * P);
-  c.take<uint32_t>((size_t)3 * P);
+  carve_backward(c, d, P, have_features != 0, nullptr, nullptr, nullptr, nullptr, nullptr);
   return c.bytes();
 }
 
 extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
-                                     const float* dL_dfeatures, float* dL_dxyz,
+                                     const float* dL_dfeatures, const float* features, float* dL_dxyz,
                                      float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* workspace,
                                      uint32_t* sort_state, int sort_reuse, void* stream_) {
   if (int e = check_desc(d)) return e;
@@ -644,26 +962,23 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
   }
   if (P == 0) return S3G_OK;
   hipStream_t stream = (hipStream_t)stream_;
+  const bool walk = features != nullptr;
   HexArgs a;
   memset(&a, 0, sizeof a);
   a.d = *d; a.P = P; a.xyz = xyz; a.time = time; a.gfeat = dL_dfeatures; a.gxyz = dL_dxyz;
   for (int l = 0; l < d->levels; l++)
     for (int i = 0; i < 6; i++) a.gplanes[l][i] = dL_dplanes[l][i];
   Carver c(workspace);
-  float* G = c.take<float>((size_t)d->levels * 6 * P * HEXC);
-  float* tables = d->uniform_time ? c.take<float>(2 * time_table_floats(d)) : nullptr;
+  float *G, *tables, *dup;
+  uint16_t* badmask;
   SortWork w;
-  w.table = c.take<uint32_t>((size_t)3 * SORT_NB * SORT_BINS);
-  w.seg_start = c.take<uint32_t>((size_t)3 * (SORT_BINS + 1));
-  w.tmp = c.take<uint32_t>((size_t)3 * P);
-  w.order = c.take<uint32_t>((size_t)3 * P);
-  w.rank = c.take<uint32_t>((size_t)3 * P);
+  carve_backward(c, d, P, walk, &G, &tables, &w, &dup, &badmask);
   if (sort_state) {  // caller-owned, persistent
     w.order = sort_state;
     w.rank = sort_state + (size_t)3 * P;
   }
 
-  // 1. three spatial orders (2-level LDS counting sorts) and their inverse permutations
+  // 1. three spatial orders (2-level LDS counting sorts); the legacy path also needs their inverse permutations
   if (!sort_reuse) {
     const int chunk = (((P + SORT_NB - 1) / SORT_NB + 255) / 256) * 256;
     hipLaunchKernelGGL(hexsort_major_kernel<false>, dim3(SORT_NB, 3), dim3(256), 0, stream, a, w, chunk);
@@ -673,7 +988,6 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.rank);
     S3G_HIP_CHECK(hipGetLastError());
   }
-  // 2. per-point pass, walking the points in (x,y) order so neighbouring half-waves share texels
   //    (the sorts above used the real resolutions; from here on the time planes are height-1 row tables if uniform_time)
   TimeRows rows;
   if (d->uniform_time) {
@@ -681,16 +995,29 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     S3G_HIP_CHECK(hipMemsetAsync(tables + nt, 0, nt * sizeof(float), stream));
     use_time_rows(a, rows, tables, tables + nt, stream);
   }
-  a.proc_order = w.order;
-  const int blocks = (P + 31) / 32;
-  profile_begin(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream);
-  hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3(blocks), dim3(256), 0, stream, a, G, w.rank);
-  profile_end(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream, (double)P, (double)d->levels);
-  S3G_HIP_CHECK(hipGetLastError());
   const int nseg = (P + SEG - 1) / SEG;
-  profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
-  hipLaunchKernelGGL(hexplane_scatter_kernel, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, G, w.order);
-  profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
+  if (walk) {
+    // 2. one walk per orientation over the sorted points: dL/ds = g f / s from local texels (no per-plane gradient slab),
+    //    then the rare exact fix-ups and the assembly of dL/dxyz
+    S3G_HIP_CHECK(hipMemsetAsync(badmask, 0, (size_t)3 * P * sizeof(uint16_t), stream));
+    profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
+    hipLaunchKernelGGL(hexplane_backward_walk_kernel, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, features, w.order, dup,
+                       badmask);
+    profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
+    hipLaunchKernelGGL(hexplane_backward_fixup_kernel, dim3(min((P + 7) / 8, 2048), 3), dim3(256), 0, stream, a, badmask, dup);
+    hipLaunchKernelGGL(hexplane_dxyz_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a, dup);
+  } else {
+    // 2'. legacy: per-point pass writing dL/ds of all 24 plane-levels to G, then the scatter walk reading it back
+    a.proc_order = w.order;
+    const int blocks = (P + 31) / 32;
+    profile_begin(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream);
+    hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3(blocks), dim3(256), 0, stream, a, G, w.rank);
+    profile_end(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream, (double)P, (double)d->levels);
+    S3G_HIP_CHECK(hipGetLastError());
+    profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
+    hipLaunchKernelGGL(hexplane_scatter_kernel, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, G, w.order);
+    profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
+  }
   if (d->uniform_time) {
     int maxW = 0;
     for (int l = 0; l < d->levels; l++)

@@ -211,3 +211,74 @@ def test_non_default_deformation_switches_match_reference_golden(gpu_device, var
         loss = loss + (o * t("w_" + n)).sum()
     loss.backward()
     assert rel_l2(xyz.grad.cpu().numpy(), z[f"{variant}::grad_xyz"]) < 1e-4
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+@pytest.mark.parametrize("tmode", ["per_point", 0.37])
+def test_exact_zero_samples_take_the_exact_fallback(gpu_device, tmode, legacy, monkeypatch):
+    """The backward forms dL/d(sample_i) as dL/dfeature * feature / sample_i.  Samples that are exactly zero (a zeroed plane
+    region, a whole zero plane, a zero time plane) or tiny cannot be divided by: those (point, level, plane) entries must
+    come out of the exact fix-up pass with the same gradients as autograd gives the reference.  legacy=True runs the
+    slab algorithm (features == NULL at the C ABI, the default) on the same data."""
+    from oracle import hexplane_ref as hr
+    from s3gaussian_amd.hexplane import HexPlaneField
+    from s3gaussian_amd import hexplane as hx
+    monkeypatch.setattr(hx, "BACKWARD_MODE", "slab" if legacy else "walk")
+    torch.manual_seed(11)
+    cfg = dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32, resolution=[16, 16, 16, 6])
+    ref = hr.HexPlaneField(1.6, cfg, [1, 2, 4, 8])
+    with torch.no_grad():
+        for p in ref.grids.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+        ref.grids[0][0][:, :, 3:9, 2:11] = 0.0         # a zero block in the (x,y) plane of level 0
+        ref.grids[1][3].zero_()                         # the whole (y,z) plane of level 1
+        ref.grids[2][4][:, 5:9].zero_()                 # four channels of the (y,t) plane of level 2
+        ref.grids[3][1][:, :, ::2, :] *= 1e-25          # tiny but non-zero samples: division is not trusted there either
+    mine = HexPlaneField(1.6, cfg, [1, 2, 4, 8])
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(gpu_device)
+    P = 4000
+    xyz = torch.rand(P, 3) * 3.6 - 1.8
+    time = torch.rand(P, 1) if tmode == "per_point" else torch.full((P, 1), float(tmode))
+    w = torch.randn(P, 128)
+    xr = xyz.clone().requires_grad_(True)
+    (ref(xr, time) * w).sum().backward()
+    xg = xyz.to(gpu_device).requires_grad_(True)
+    fg = mine(xg, time.to(gpu_device))
+    (fg * w.to(gpu_device)).sum().backward()
+    assert torch.isfinite(xg.grad).all()
+    assert rel_l2(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1e-4
+    for (k, pr), (_, pg) in zip(ref.named_parameters(), mine.named_parameters()):
+        if pr.grad is not None:
+            assert torch.isfinite(pg.grad).all(), k
+            assert rel_l2(pg.grad.cpu().numpy(), pr.grad.numpy()) < 1e-5, k
+
+
+@pytest.mark.parametrize("tmode", ["per_point", 0.37, 1.0])
+def test_walk_backward_matches_the_slab_backward(gpu_device, tmode, monkeypatch):
+    """The two backward algorithms (include/s3g_hexplane.h: `features` given or NULL) on the default-resolution field:
+    same dL/dxyz and plane gradients to fp32 round-off (1e-5 relative; the walk divides by one re-derived sample)."""
+    from s3gaussian_amd import hexplane as hx
+    torch.manual_seed(5)
+    cfg = dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32, resolution=[64, 64, 64, 25])
+    f = hx.HexPlaneField(1.6, cfg, [1, 2, 4, 8])
+    with torch.no_grad():
+        for p in f.parameters():
+            if p.requires_grad:
+                p.add_(0.3 * torch.randn_like(p))
+    f = f.to(gpu_device)
+    P = 50_000
+    xyz = (torch.rand(P, 3) * 3.6 - 1.8).to(gpu_device)
+    time = (torch.rand(P, 1) if tmode == "per_point" else torch.full((P, 1), float(tmode))).to(gpu_device)
+    w = torch.randn(P, 128).to(gpu_device)
+    res = {}
+    for mode in ("slab", "walk"):
+        monkeypatch.setattr(hx, "BACKWARD_MODE", mode)
+        for p in f.parameters():
+            p.grad = None
+        x = xyz.clone().requires_grad_(True)
+        (f(x, time) * w).sum().backward()
+        res[mode] = (x.grad.clone(), [p.grad.clone() for p in f.parameters() if p.requires_grad])
+    assert rel_l2(res["walk"][0].cpu().numpy(), res["slab"][0].cpu().numpy()) < 1e-5
+    for a, b in zip(res["walk"][1], res["slab"][1]):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5

@@ -45,3 +45,4 @@ for i, name in ((2, "hexplane_forward"), (3, "hexplane_backward_point"), (4, "he
     n = L.s3g_profile_read(i, C.byref(ms), None, None)
     print(f"{name}: {ms.value / max(n, 1):.4f} ms avg over {n}")
 L.s3g_profile_enable(0)
+print("S3G_HEX_BACKWARD =", os.environ.get("S3G_HEX_BACKWARD", "slab"))
