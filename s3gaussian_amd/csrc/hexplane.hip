@@ -40,6 +40,7 @@ struct HexArgs {
   float* feat;
   float* gxyz;
   const uint32_t* proc_order;  // optional: process point proc_order[i] at step i (spatially sorted -> texel reuse in L1/L2)
+  int seg_len;                 // scatter walks: sorted points per half-wave
 };
 
 struct Tap {         // one bilinear footprint
@@ -315,7 +316,9 @@ __global__ void __launch_bounds__(256) hexsort_rank_kernel(int P, const uint32_t
 }
 
 // ---- pass B: scatter in sorted order with register run-length combining ----
-constexpr int SEG = 128;  // sorted points walked by one half-wave
+// sorted points walked by one half-wave (HexArgs::seg_len): longer segments flush fewer footprints at their ends, shorter ones
+// give more half-waves; 256 measured best at 1.2 M points (1.21 vs 1.30 ms), 128 below a million
+static inline int segment_length(int P) { return P >= 1000000 ? 256 : 128; }
 
 // One bilinear footprint being accumulated in registers: key = texel offset of its nw corner (-1 = empty), flags bit0 =
 // ne/se column in range, bit1 = sw/se row in range (the other three corners follow from key, flags and the plane width).
@@ -360,20 +363,24 @@ __device__ __forceinline__ void foot2_init(Foot2& F) {
 #pragma unroll
   for (int k = 0; k < 4; k++) F.a0[k] = F.a1[k] = 0.f;
 }
+// ROW = true: the plane is a height-1 row table (uniform time): only the nw / ne corners exist, the sw / se halves of
+// the footprint (weights exactly 0, flag bit 1 clear) are compiled out -- half the fmas, selects and flush atomics.
+template <bool ROW = false>
 __device__ __forceinline__ void foot2_flush_all(const Foot2& F, float* __restrict__ gp, int W, int c) {
-  foot_flush(Foot{F.key0, F.fl0, F.a0[0], F.a0[1], F.a0[2], F.a0[3]}, gp, W, c);
-  foot_flush(Foot{F.key1, F.fl1, F.a1[0], F.a1[1], F.a1[2], F.a1[3]}, gp, W, c);
+  foot_flush(Foot{F.key0, ROW ? (F.fl0 & 1) : F.fl0, F.a0[0], F.a0[1], ROW ? 0.f : F.a0[2], ROW ? 0.f : F.a0[3]}, gp, W, c);
+  foot_flush(Foot{F.key1, ROW ? (F.fl1 & 1) : F.fl1, F.a1[0], F.a1[1], ROW ? 0.f : F.a1[2], ROW ? 0.f : F.a1[3]}, gp, W, c);
 }
+template <bool ROW = false>
 __device__ __forceinline__ void foot2_add(Foot2& F, const PackedTap& t, float g, float* __restrict__ gp, int W, int c) {
   bool h0 = t.key == F.key0, h1 = t.key == F.key1;
   if (!(h0 || h1)) {  // miss (uniform inside the half-wave): evict the entry that is not the most recent one
     const bool v1 = F.mru == 0;
-    foot_flush(Foot{v1 ? F.key1 : F.key0, v1 ? F.fl1 : F.fl0, v1 ? F.a1[0] : F.a0[0], v1 ? F.a1[1] : F.a0[1],
-                    v1 ? F.a1[2] : F.a0[2], v1 ? F.a1[3] : F.a0[3]}, gp, W, c);
+    foot_flush(Foot{v1 ? F.key1 : F.key0, ROW ? ((v1 ? F.fl1 : F.fl0) & 1) : (v1 ? F.fl1 : F.fl0), v1 ? F.a1[0] : F.a0[0],
+                    v1 ? F.a1[1] : F.a0[1], ROW ? 0.f : (v1 ? F.a1[2] : F.a0[2]), ROW ? 0.f : (v1 ? F.a1[3] : F.a0[3])}, gp, W, c);
     F.key1 = v1 ? t.key : F.key1;  F.key0 = v1 ? F.key0 : t.key;
     F.fl1 = v1 ? t.flags : F.fl1;  F.fl0 = v1 ? F.fl0 : t.flags;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < (ROW ? 2 : 4); k++) {
       F.a1[k] = v1 ? 0.f : F.a1[k];
       F.a0[k] = v1 ? F.a0[k] : 0.f;
     }
@@ -382,19 +389,22 @@ __device__ __forceinline__ void foot2_add(Foot2& F, const PackedTap& t, float g,
   }
   const float g0 = h0 ? g : 0.f, g1 = h1 ? g : 0.f;
   F.a0[0] = __builtin_fmaf(g0, t.w00, F.a0[0]); F.a0[1] = __builtin_fmaf(g0, t.w01, F.a0[1]);
-  F.a0[2] = __builtin_fmaf(g0, t.w10, F.a0[2]); F.a0[3] = __builtin_fmaf(g0, t.w11, F.a0[3]);
   F.a1[0] = __builtin_fmaf(g1, t.w00, F.a1[0]); F.a1[1] = __builtin_fmaf(g1, t.w01, F.a1[1]);
-  F.a1[2] = __builtin_fmaf(g1, t.w10, F.a1[2]); F.a1[3] = __builtin_fmaf(g1, t.w11, F.a1[3]);
+  if (!ROW) {
+    F.a0[2] = __builtin_fmaf(g0, t.w10, F.a0[2]); F.a0[3] = __builtin_fmaf(g0, t.w11, F.a0[3]);
+    F.a1[2] = __builtin_fmaf(g1, t.w10, F.a1[2]); F.a1[3] = __builtin_fmaf(g1, t.w11, F.a1[3]);
+  }
   F.mru = h1 ? 1 : 0;
 }
 
-// A half-wave (32 lanes = the 32 channels) walks SEG consecutive points of the sorted order.  The kernel used to be
+// A half-wave (32 lanes = the 32 channels) walks seg_len consecutive points of the sorted order.  The kernel used to be
 // VALU-bound on make_tap, which all 32 lanes repeated for each of the 8 (level, plane) taps of a point; now the 32 lanes
 // compute the 8 taps of FOUR points at once (lane = point q x tap j), park them in LDS, and every lane reads them back
 // with broadcast loads while it accumulates its channel.
 constexpr int SCATTER_LG = 2;          // levels handled per walk of a segment
-constexpr int SCATTER_WG_PER_CU = 4;   // 4 waves per SIMD: the walk is bound by per-wave issue latency (IPC ~0.2), not by VALU throughput
+constexpr int SCATTER_WG_PER_CU = 5;   // 5 waves per SIMD: the walk is bound by per-wave issue latency (IPC ~0.2), not by VALU throughput
 constexpr int TAPF = 8;  // floats per packed tap in LDS (6 used; 32-byte slots keep the 16-byte reads aligned)
+template <bool UT>   // UT: uniform time -- the (axis, t) planes are height-1 row tables
 __global__ void __launch_bounds__(256, SCATTER_WG_PER_CU) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
                                                                const uint32_t* __restrict__ order_all) {
   __shared__ __attribute__((aligned(16))) float tapbuf[8][2][4][8][TAPF];  // [half-wave][double buffer][point][tap]
@@ -402,7 +412,7 @@ __global__ void __launch_bounds__(256, SCATTER_WG_PER_CU) hexplane_scatter_kerne
   const int c = threadIdx.x & 31, hw = threadIdx.x >> 5;
   const int q = c >> 3, j = c & 7;  // tap-phase role: point q of the group of four, tap j = (level j >> 1, kind j & 1)
   const int seg = blockIdx.x * 8 + hw;
-  const int k0 = seg * SEG, k1 = min(a.P, k0 + SEG);
+  const int k0 = seg * a.seg_len, k1 = min(a.P, k0 + a.seg_len);
   if (k0 >= a.P) return;  // whole half-waves drop out; the LDS traffic below is private to a half-wave (wave-ordered)
   const uint32_t* order = order_all + (size_t)o * a.P;
   const size_t PL = (size_t)a.P * HEXC;
@@ -484,7 +494,8 @@ __global__ void __launch_bounds__(256, SCATTER_WG_PER_CU) hexplane_scatter_kerne
             PackedTap t;
             t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
             t.w00 = lo.z; t.w01 = lo.w; t.w10 = hi.x; t.w11 = hi.y;
-            foot2_add(ft[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
+            if (UT && m == 1) foot2_add<true>(ft[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[i1]], c);
+            else foot2_add<false>(ft[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
           }
         }
       }
@@ -497,7 +508,8 @@ __global__ void __launch_bounds__(256, SCATTER_WG_PER_CU) hexplane_scatter_kerne
         float* gp = a.gplanes[l0 + l][m ? i1 : i0];
         if (gp == nullptr) continue;
         const int W = a.d.res[l0 + l][PAIR0[m ? i1 : i0]];
-        foot2_flush_all(ft[l][m], gp, W, c);
+        if (UT && m == 1) foot2_flush_all<true>(ft[l][m], gp, W, c);
+        else foot2_flush_all<false>(ft[l][m], gp, W, c);
       }
     }
   }
@@ -563,7 +575,7 @@ hexplane_backward_walk_kernel(const HexArgs a, const float* __restrict__ feat, c
   const int half_base = threadIdx.x & 32;  // first lane of this half-wave inside its wave
   const int q = c >> 3, j = c & 7;  // tap-phase role: point q of the group of four, tap j = (level j >> 1, kind j & 1)
   const int seg = blockIdx.x * 8 + hw;
-  const int k0 = seg * SEG, k1 = min(a.P, k0 + SEG);
+  const int k0 = seg * a.seg_len, k1 = min(a.P, k0 + a.seg_len);
   if (k0 >= a.P) return;  // whole half-waves drop out; LDS traffic and shuffles below stay inside a half-wave
   const uint32_t* order = order_all + (size_t)o * a.P;
   const int F = a.d.levels * HEXC;
@@ -995,7 +1007,8 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     S3G_HIP_CHECK(hipMemsetAsync(tables + nt, 0, nt * sizeof(float), stream));
     use_time_rows(a, rows, tables, tables + nt, stream);
   }
-  const int nseg = (P + SEG - 1) / SEG;
+  a.seg_len = segment_length(P);
+  const int nseg = (P + a.seg_len - 1) / a.seg_len;
   if (walk) {
     // 2. one walk per orientation over the sorted points: dL/ds = g f / s from local texels (no per-plane gradient slab),
     //    then the rare exact fix-ups and the assembly of dL/dxyz
@@ -1015,7 +1028,10 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     profile_end(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream, (double)P, (double)d->levels);
     S3G_HIP_CHECK(hipGetLastError());
     profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
-    hipLaunchKernelGGL(hexplane_scatter_kernel, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, G, w.order);
+    if (d->uniform_time)
+      hipLaunchKernelGGL(hexplane_scatter_kernel<true>, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, G, w.order);
+    else
+      hipLaunchKernelGGL(hexplane_scatter_kernel<false>, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, G, w.order);
     profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
   }
   if (d->uniform_time) {

@@ -118,7 +118,7 @@ def test_training_on_the_gpu_path_reaches_the_psnr_of_the_oracle_path(gpu_device
                                            hyper.plane_tv_weight))
         surrogate.backward()
         adam.step()
-        return float(loss)
+        return float(loss.detach())
 
     losses_gpu, losses_orc = [], []
     for v in order:
