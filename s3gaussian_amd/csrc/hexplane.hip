@@ -402,10 +402,10 @@ __device__ __forceinline__ void foot2_add(Foot2& F, const PackedTap& t, float g,
 // compute the 8 taps of FOUR points at once (lane = point q x tap j), park them in LDS, and every lane reads them back
 // with broadcast loads while it accumulates its channel.
 constexpr int SCATTER_LG = 2;          // levels handled per walk of a segment
-constexpr int SCATTER_WG_PER_CU = 5;   // 5 waves per SIMD: the walk is bound by per-wave issue latency (IPC ~0.2), not by VALU throughput
+constexpr int SCATTER_WG_PER_CU = 5;   // 5 waves per SIMD with row-table footprints (4 for general per-point time): the walk is bound by per-wave issue latency (IPC ~0.2), not by VALU throughput
 constexpr int TAPF = 8;  // floats per packed tap in LDS (6 used; 32-byte slots keep the 16-byte reads aligned)
 template <bool UT>   // UT: uniform time -- the (axis, t) planes are height-1 row tables
-__global__ void __launch_bounds__(256, SCATTER_WG_PER_CU) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
+__global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_CU - 1) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
                                                                const uint32_t* __restrict__ order_all) {
   __shared__ __attribute__((aligned(16))) float tapbuf[8][2][4][8][TAPF];  // [half-wave][double buffer][point][tap]
   const int o = blockIdx.y;
