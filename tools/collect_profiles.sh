@@ -1,0 +1,26 @@
+#!/bin/bash
+# Final evidence of a round, run ON THE GPU BOX (gpurun): bench line, kernel stats, PMC traffic, sync gap, 2-rank functional run.
+#   gpurun -- 'bash tools/collect_profiles.sh r02'
+# Everything lands under gpurun_out/<tag>_*; copy what should be judged into profiles/.
+set -uo pipefail
+TAG="${1:-rNN}"
+ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
+OUT="$ROOT/gpurun_out"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+python "$ROOT/bench.py" > "$OUT/${TAG}_bench_line.json" 2> "$OUT/${TAG}_bench_line.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- python "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-alt-paths > /dev/null 2>&1
+f=$(find "$OUT/prof_stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_bench_kernel_stats.csv"
+python "$ROOT/tools/sync_gap.py" "$OUT/prof_stats" > "$OUT/${TAG}_sync_gap.txt" 2>&1
+rm -rf "$OUT/prof_stats"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-alt-paths > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-alt-paths > /dev/null 2>&1
+python "$ROOT/tools/pmc_traffic.py" /tmp/pmc_f /tmp/pmc_w "$OUT/${TAG}_pmc" > "$OUT/${TAG}_pmc_traffic.txt" 2>&1
+# two ranks on the one GPU of the lease: functional check of the view-parallel path (gloo; RCCL refuses two ranks on one device)
+cd "$ROOT"
+S3G_DIST_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+    bench.py --gpus 2 --steps 3 --warmup 1 --P 300000 > "$OUT/${TAG}_two_ranks_gloo.json" 2> "$OUT/${TAG}_two_ranks_gloo.err"
+timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 \
+    bench.py --gpus 2 --steps 2 --warmup 1 --P 100000 > "$OUT/${TAG}_two_ranks_rccl.json" 2> "$OUT/${TAG}_two_ranks_rccl.err"
+tail -2 "$OUT/${TAG}_two_ranks_rccl.err" > "$OUT/${TAG}_two_ranks_rccl_tail.txt"
+echo done

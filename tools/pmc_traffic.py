@@ -1,5 +1,5 @@
 """Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, MI355X_MICROARCH.md "HBM") of bench.py into
-profiles/r01_bench_pmc_fetch_write.csv and profiles/kernel_traffic.json (HBM bytes per launch of every s3g kernel).
+profiles/rNN_bench_pmc_fetch_write.csv and profiles/kernel_traffic.json (HBM bytes per launch of every s3g kernel).
 
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
@@ -42,12 +42,14 @@ def main():
         f, w = fetch.get(k, (0, 0.0))[1], write.get(k, (0, 0.0))[1]
         rows.append((k, n, f, w))
         traffic[k] = int(round((2.0 * f + w) * 1024.0))
-    with open(os.path.join(out, "r01_bench_pmc_fetch_write.csv"), "w") as fh:
+    with open(os.path.join(out, "bench_pmc_fetch_write.csv"), "w") as fh:
         fh.write("kernel,launches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg\n")
         for k, n, f, w in rows:
             fh.write(f"{k},{n},{f:.1f},{w:.1f}\n")
+    launches = {"s3g::mlp_wgrad_kernel": 9}   # launches inside bench.py's hipEvent bracket for that id
     json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 3 --warmup 1 "
-                          "--no-cpu-baseline (two passes)",
+                          "--no-cpu-baseline --no-alt-paths (two passes, tools/collect_profiles.sh)",
+               "launches_per_bracket": launches,
                "formula": "hbm_bytes = (2 * FETCH_SIZE_KB + WRITE_SIZE_KB) * 1024  (gfx950 FETCH_SIZE correction, "
                           "MI355X_MICROARCH.md 'HBM'); wgrad: average over its template instances",
                "hbm_bytes_per_launch": traffic}, open(os.path.join(out, "kernel_traffic.json"), "w"), indent=1)
