@@ -17,19 +17,25 @@ from collections import defaultdict
 
 
 def collect(d, counter):
-    acc = defaultdict(lambda: [0, 0.0])
+    """-> {kernel: (launches used, mean counter value)}.  bench.py also runs inference renders (no activation stash, one
+    image) through the same kernels; a kernel's TRAINING launches are its heaviest ones, so the mean is taken over the
+    `steps` launches with the largest counter value (steps = number of adam_kernel launches; wgrad: 9 per step)."""
+    vals = defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
             name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
             name = re.sub(r"<.*", "", name)
-            if not name.startswith("s3g::"):
-                continue
-            a = acc[name]
-            a[0] += 1
-            a[1] += float(r["Counter_Value"])
-    return {k: (n, v / n) for k, (n, v) in acc.items()}
+            if name.startswith("s3g::"):
+                vals[name].append(float(r["Counter_Value"]))
+    steps = max(len(vals.get("s3g::adam_kernel", [])), 1)
+    out = {}
+    for k, v in vals.items():
+        n = min(len(v), steps * (9 if k == "s3g::mlp_wgrad_kernel" else 1))
+        top = sorted(v, reverse=True)[:n]
+        out[k] = (n, sum(top) / n)
+    return out
 
 
 def main():
