@@ -6,6 +6,9 @@
 
 namespace s3g {
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr bool ADAM_NONTEMPORAL = true;   // streaming loads / stores: 0.605 -> 0.534 ms (every element is touched exactly once per step)
+
 struct AdamArgs {
   s3g_adam_tensor t[S3G_ADAM_MAX_TENSORS];
   float beta1, beta2, w1, w2;  // w_k = 1 - beta_k rounded from DOUBLE, like torch's python-side `1 - beta`
@@ -31,10 +34,20 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
     p = p - step_size * (m / denom);           // param.addcdiv_(exp_avg, denom, value = -step_size)
   };
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    float4 p = p4[i], m = m4[i], v = v4[i];
-    const float4 g = g4[i];
+    float4 p, m, v, g;
+    if (ADAM_NONTEMPORAL) {
+      auto ld = [](const float4* q) { const f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(q)); return make_float4(x.x, x.y, x.z, x.w); };
+      p = ld(p4 + i); m = ld(m4 + i); v = ld(v4 + i); g = ld(g4 + i);
+    } else {
+      p = p4[i]; m = m4[i]; v = v4[i]; g = g4[i];
+    }
     upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
-    p4[i] = p; m4[i] = m; v4[i] = v;
+    if (ADAM_NONTEMPORAL) {
+      auto st = [](float4* q, float4 x) { f4v y = {x.x, x.y, x.z, x.w}; __builtin_nontemporal_store(y, reinterpret_cast<f4v*>(q)); };
+      st(p4 + i, p); st(m4 + i, m); st(v4 + i, v);
+    } else {
+      p4[i] = p; m4[i] = m; v4[i] = v;
+    }
   }
   for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < t.numel; i += (size_t)gridDim.x * 256)
     upd(t.param[i], t.grad[i], t.exp_avg[i], t.exp_avg_sq[i]);  // the numel % 4 tail, or everything when unaligned

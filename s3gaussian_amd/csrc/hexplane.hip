@@ -31,6 +31,8 @@ namespace s3g {
 constexpr int HEXC = S3G_HEX_CHANNELS;
 typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr bool G_NONTEMPORAL = true;         // streaming stores of the gradient slab: point pass 1.83 -> 1.60 ms
+constexpr bool FEAT_NONTEMPORAL = true;      // forward's feature rows
+constexpr bool GFEAT_NONTEMPORAL = true;     // point pass: dL/dfeature rows (read once)
 constexpr bool G_NONTEMPORAL_LOAD = true;    // and streaming loads in the scatter: 1.28 -> 1.23 ms
 
 struct HexArgs {
@@ -123,7 +125,12 @@ __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) 
         s = s + fetch4(pl, t.o11, c4) * t.w11;
         prod = prod * s;
       }
-      *reinterpret_cast<float4*>(a.feat + (size_t)p * F + l * HEXC + c4) = prod;
+      if (FEAT_NONTEMPORAL) {
+        f4v v = {prod.x, prod.y, prod.z, prod.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(a.feat + (size_t)p * F + l * HEXC + c4));
+      } else {
+        *reinterpret_cast<float4*>(a.feat + (size_t)p * F + l * HEXC + c4) = prod;
+      }
     }
   }
 }
@@ -176,7 +183,15 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
         mx[i] = t.mx;
         my[i] = t.my;
       }
-      const float4 g = live ? *reinterpret_cast<const float4*>(a.gfeat + (size_t)p * F + l * HEXC + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) {
+        if (GFEAT_NONTEMPORAL) {
+          const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.gfeat + (size_t)p * F + l * HEXC + c4));
+          g = make_float4(v.x, v.y, v.z, v.w);
+        } else {
+          g = *reinterpret_cast<const float4*>(a.gfeat + (size_t)p * F + l * HEXC + c4);
+        }
+      }
       // product rule in the order autograd applies it to ((((1*s0)*s1)*s2)*s3)*s4)*s5: pre[i] = prod_{j<i} s_j, suffix by recursion
       float4 pre[6];
       pre[0] = make_float4(1.f, 1.f, 1.f, 1.f);

@@ -468,6 +468,9 @@ __device__ __forceinline__ void row_load(float (&v)[RowSplit<W>::VEC], const flo
 // the full memory latency once per tile that way: ~9 us per tile for 1.7 us of MFMA work).  The one ragged tile at the end
 // of the array is handled separately with masked loads.
 constexpr int WG_WAVES = 8;  // waves per wgrad workgroup (one persistent workgroup per CU)
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+constexpr bool WGRAD_NONTEMPORAL = false;   // streaming operand loads: measured slower (1.19 -> 1.27 ms), the shared `hidden` plane is re-read by three launches
 
 // raw (select-free) operand loads of a FULL tile: columns are clamped statically so lanes beyond the row's width re-read
 // valid data (their MFMA rows are discarded at the flush)
@@ -477,10 +480,14 @@ __device__ __forceinline__ void row_load_full(float (&v)[RowSplit<W>::VEC], cons
   const int col = VEC * i < W ? VEC * i : W - VEC;
   const float* src = g + (size_t)p * STRIDE + col;
   if constexpr (VEC == 4) {
-    const float4 x = *reinterpret_cast<const float4*>(src);
+    float4 x;
+    if (WGRAD_NONTEMPORAL) { const f4v q = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(src)); x = make_float4(q.x, q.y, q.z, q.w); }
+    else x = *reinterpret_cast<const float4*>(src);
     v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
   } else if constexpr (VEC == 2) {
-    const float2 x = *reinterpret_cast<const float2*>(src);
+    float2 x;
+    if (WGRAD_NONTEMPORAL) { const f2v q = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(src)); x = make_float2(q.x, q.y); }
+    else x = *reinterpret_cast<const float2*>(src);
     v[0] = x.x; v[1] = x.y;
   } else {
     v[0] = src[0];
