@@ -17,25 +17,35 @@ from collections import defaultdict
 
 
 def collect(d, counter):
-    """-> {kernel: (launches used, mean counter value)}.  bench.py also runs inference renders (no activation stash, one
-    image) through the same kernels; a kernel's TRAINING launches are its heaviest ones, so the mean is taken over the
-    `steps` launches with the largest counter value (steps = number of adam_kernel launches; wgrad: 9 per step)."""
-    vals = defaultdict(list)
+    """-> {kernel: (training steps used, mean counter value per launch)} over the TRAINING iterations only.
+    bench.py also runs inference renders through the same kernels (no activation stash, one image, warm or cold caches).
+    Dispatches are walked in order and cut into segments at every adam_kernel (the end of a training step); inside a segment
+    the training step is everything from the LAST hexplane_forward launch on.  The first step (cold caches, first sort) is
+    dropped when there are more."""
+    rows = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
             name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
             name = re.sub(r"<.*", "", name)
+            rows.append((int(r["Dispatch_Id"]), name, float(r["Counter_Value"])))
+    rows.sort()
+    steps, seg = [], []
+    for _, name, v in rows:
+        seg.append((name, v))
+        if name == "s3g::adam_kernel":
+            last_fwd = max((i for i, (n, _) in enumerate(seg) if n == "s3g::hexplane_forward_kernel"), default=0)
+            steps.append(seg[last_fwd:])
+            seg = []
+    if len(steps) > 1:
+        steps = steps[1:]
+    acc = defaultdict(list)
+    for st in steps:
+        for name, v in st:
             if name.startswith("s3g::"):
-                vals[name].append(float(r["Counter_Value"]))
-    steps = max(len(vals.get("s3g::adam_kernel", [])), 1)
-    out = {}
-    for k, v in vals.items():
-        n = min(len(v), steps * (9 if k == "s3g::mlp_wgrad_kernel" else 1))
-        top = sorted(v, reverse=True)[:n]
-        out[k] = (n, sum(top) / n)
-    return out
+                acc[name].append(v)
+    return {k: (len(steps), sum(v) / len(v)) for k, v in acc.items()}
 
 
 def main():
