@@ -16,6 +16,7 @@ rm -rf "$OUT/prof_stats"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-alt-paths > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-alt-paths > /dev/null 2>&1
 python "$ROOT/tools/pmc_traffic.py" /tmp/pmc_f /tmp/pmc_w "$OUT/${TAG}_pmc" > "$OUT/${TAG}_pmc_traffic.txt" 2>&1
+for k in f w; do c=$(find /tmp/pmc_$k -name "*counter_collection.csv" | head -1); [ -n "$c" ] && cp "$c" "$OUT/${TAG}_pmc/raw_$k.csv"; done
 # two ranks on the one GPU of the lease: functional check of the view-parallel path (gloo; RCCL refuses two ranks on one device)
 cd "$ROOT"
 S3G_DIST_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
