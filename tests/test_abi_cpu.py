@@ -125,10 +125,11 @@ def test_product_package_never_imports_oracle():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r01_bench_line.json is what `python bench.py` printed on the MI355X: one JSON object with the driver's
-    fields, the roofline of the dominant kernel (measured live, PMC traffic attached) and the CPU baseline."""
+    """profiles/r02_bench_line.json is what `python bench.py` printed on the MI355X: one JSON object with the driver's
+    fields, the roofline of the dominant kernel (hipEvent times measured live; strict algorithmic vs implementation bytes;
+    PMC traffic labelled with its source) and the CPU baseline (two-term fit + the north_star's point-splat variant)."""
     import json
-    line = open(os.path.join(ROOT, "profiles", "r01_bench_line.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", "r02_bench_line.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -138,10 +139,19 @@ def test_committed_bench_line_follows_the_contract():
     assert isinstance(base, dict)
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - d["n_gpus"] * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
+    c = d["config"]
+    assert c["path"] == "fused" and set(c["paths"]) == {"fused", "import_swap", "zero_diff"}
+    assert c["paths"]["zero_diff"]["iters_per_s"] < c["paths"]["import_swap"]["iters_per_s"] < c["paths"]["fused"]["iters_per_s"]
+    assert c["instances_R_per_view"] > 0 and c["visible_V_per_view"] > 0 and c["mean_tile_list_length"] > 0
+    assert abs(c["psnr_delta_vs_oracle_db"]) <= 0.1
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] is not None
+    assert "NOT collected in this run" in r["traffic_source"]
     dom = max(r["kernels"], key=lambda k: k["ms_per_step"])
     assert dom["kernel"] == r["kernel"]
-    c = d["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    for k in r["kernels"]:
+        assert k["algorithmic_bytes_per_launch"] <= k["implementation_bytes_per_launch"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"] and "pixel_term_s" in cb["model"]
+    assert cb["point_splat"]["kind"] == "point_splat" and cb["point_splat"]["value"] > 0

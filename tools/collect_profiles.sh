@@ -8,7 +8,6 @@ ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-python "$ROOT/bench.py" > "$OUT/${TAG}_bench_line.json" 2> "$OUT/${TAG}_bench_line.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- python "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-alt-paths > /dev/null 2>&1
 f=$(find "$OUT/prof_stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_bench_kernel_stats.csv"
 python "$ROOT/tools/sync_gap.py" "$OUT/prof_stats" > "$OUT/${TAG}_sync_gap.txt" 2>&1
@@ -17,6 +16,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- p
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-alt-paths > /dev/null 2>&1
 python "$ROOT/tools/pmc_traffic.py" /tmp/pmc_f /tmp/pmc_w "$OUT/${TAG}_pmc" > "$OUT/${TAG}_pmc_traffic.txt" 2>&1
 for k in f w; do c=$(find /tmp/pmc_$k -name "*counter_collection.csv" | head -1); [ -n "$c" ] && cp "$c" "$OUT/${TAG}_pmc/raw_$k.csv"; done
+# the bench line last, so that its `traffic` fields are the PMC bytes collected a minute earlier on this very box
+cp "$OUT/${TAG}_pmc/kernel_traffic.json" "$ROOT/profiles/kernel_traffic.json" 2>/dev/null
+cd /tmp
+python "$ROOT/bench.py" > "$OUT/${TAG}_bench_line.json" 2> "$OUT/${TAG}_bench_line.err"
 # two ranks on the one GPU of the lease: functional check of the view-parallel path (gloo; RCCL refuses two ranks on one device)
 cd "$ROOT"
 S3G_DIST_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
