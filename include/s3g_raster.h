@@ -86,9 +86,12 @@ int s3g_raster_forward_reuse(const s3g_raster_inputs* in, int R, const void* geo
  * Gaussians: one extra blend pass over the full sorted lists with one transmittance chain per class, instead of two more
  * complete rasterizations of boolean-masked copies.  Images are bit-identical to those (a subset's tile list is the full
  * list minus the other class, in the same order).  The arenas are only read.  Colours: in->colors_precomp, or the
- * forward's own SH colours when NULL.  is_dynamic: uint8 [P], device.  Outputs [3,H,W] / [1,H,W], fully written. */
+ * forward's own SH colours when NULL.  is_dynamic: uint8 [P], device.  class_counts: device int64 [2] = number of static
+ * and of dynamic Gaussians, or NULL: a class with count 0 renders as zeros WITHOUT background, like the reference's P == 0
+ * early-out (read on the device: no host sync).  Outputs [3,H,W] / [1,H,W], fully written. */
 int s3g_raster_forward_decompose(const s3g_raster_inputs* in, int R, const void* geometry_arena, const void* binning_arena,
-                                 const void* image_arena, const uint8_t* is_dynamic, float* out_color_d, float* out_depth_d,
+                                 const void* image_arena, const uint8_t* is_dynamic, const long long* class_counts,
+                                 float* out_color_d, float* out_depth_d,
                                  float* out_color_s, float* out_depth_s, void* stream);
 
 /* Forward of TWO images from one geometry in one blend pass: colours in->colors_precomp -> out_color (+ out_depth) and

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("S3G_LIB_PATH") or os.path.join(_HERE, "lib", "libs3g.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -83,7 +83,7 @@ def lib() -> C.CDLL:
     L.s3g_mark_visible.restype = C.c_int
     L.s3g_mark_visible.argtypes = [C.c_int, vp, vp, vp, vp, vp]
     L.s3g_raster_forward_decompose.restype = C.c_int
-    L.s3g_raster_forward_decompose.argtypes = [C.POINTER(RasterInputs), C.c_int] + [vp] * 9
+    L.s3g_raster_forward_decompose.argtypes = [C.POINTER(RasterInputs), C.c_int] + [vp] * 10
     L.s3g_raster_backward_accum.restype = C.c_int
     L.s3g_raster_backward_accum.argtypes = [C.POINTER(RasterInputs), C.c_int] + [vp] * 17 + [C.POINTER(DensifyAccum), vp]
     L.s3g_raster_backward2_accum.restype = C.c_int

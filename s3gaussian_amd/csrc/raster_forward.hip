@@ -583,6 +583,7 @@ blend_decompose_kernel(int W, int H, int gx, int tiles, const uint2* __restrict_
                        const uint32_t* __restrict__ point_list, const float2* __restrict__ means2D,
                        const float4* __restrict__ conic_opacity, const float* __restrict__ colors,
                        const float* __restrict__ depths, const float* __restrict__ bg, const uint8_t* __restrict__ cls,
+                       const long long* __restrict__ class_counts /* [2]: static, dynamic; NULL = both non-empty */,
                        float* __restrict__ out_color_d, float* __restrict__ out_depth_d, float* __restrict__ out_color_s,
                        float* __restrict__ out_depth_s) {
   __shared__ StagedGaussian sg[256];
@@ -639,13 +640,15 @@ blend_decompose_kernel(int W, int H, int gx, int tiles, const uint2* __restrict_
   }
   if (inside) {
     const size_t pix = (size_t)py * W + px, N = (size_t)H * W;
-    out_color_s[pix] = Cr[0] + T[0] * bg[0];
-    out_color_s[N + pix] = Cg[0] + T[0] * bg[1];
-    out_color_s[2 * N + pix] = Cb[0] + T[0] * bg[2];
+    // an EMPTY class renders as zeros WITHOUT background, like the reference's P == 0 early-out (rasterize_points.cu:81-116)
+    const float ks = (class_counts && class_counts[0] == 0) ? 0.f : 1.f, kd = (class_counts && class_counts[1] == 0) ? 0.f : 1.f;
+    out_color_s[pix] = ks * (Cr[0] + T[0] * bg[0]);
+    out_color_s[N + pix] = ks * (Cg[0] + T[0] * bg[1]);
+    out_color_s[2 * N + pix] = ks * (Cb[0] + T[0] * bg[2]);
     out_depth_s[pix] = D[0];
-    out_color_d[pix] = Cr[1] + T[1] * bg[0];
-    out_color_d[N + pix] = Cg[1] + T[1] * bg[1];
-    out_color_d[2 * N + pix] = Cb[1] + T[1] * bg[2];
+    out_color_d[pix] = kd * (Cr[1] + T[1] * bg[0]);
+    out_color_d[N + pix] = kd * (Cg[1] + T[1] * bg[1]);
+    out_color_d[2 * N + pix] = kd * (Cb[1] + T[1] * bg[2]);
     out_depth_d[pix] = D[1];
   }
 }
@@ -666,7 +669,7 @@ static inline uint32_t round_up8(uint32_t v) { return (v + 7u) & ~7u; }
 using namespace s3g;
 
 extern "C" const char* s3g_last_error(void) { return g_err; }
-extern "C" int s3g_abi_version(void) { return 5; }
+extern "C" int s3g_abi_version(void) { return 6; }
 
 static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2, float* out_color2,
                                s3g_resize_fn geometry_buffer, void* geometry_user, s3g_resize_fn binning_buffer,
@@ -881,7 +884,7 @@ extern "C" int s3g_raster_forward_reuse(const s3g_raster_inputs* in, int R, cons
 
 extern "C" int s3g_raster_forward_decompose(const s3g_raster_inputs* in, int R, const void* geometry_arena,
                                             const void* binning_arena, const void* image_arena, const uint8_t* is_dynamic,
-                                            float* out_color_d, float* out_depth_d, float* out_color_s, float* out_depth_s,
+                                            const long long* class_counts, float* out_color_d, float* out_depth_d, float* out_color_s, float* out_depth_s,
                                             void* stream_) {
   g_err[0] = 0;
   hipStream_t stream = (hipStream_t)stream_;
@@ -898,7 +901,7 @@ extern "C" int s3g_raster_forward_decompose(const s3g_raster_inputs* in, int R, 
   const float* color_ptr = in->colors_precomp ? in->colors_precomp : g.rgb;   // SH path: the forward's own colours
   hipLaunchKernelGGL(blend_decompose_kernel, dim3(round_up8((uint32_t)tiles)), dim3(256), 0, stream, W, H, gx, tiles,
                      im.ranges, b.point_list, g.means2D, g.conic_opacity, color_ptr, g.depths, in->background, is_dynamic,
-                     out_color_d, out_depth_d, out_color_s, out_depth_s);
+                     class_counts, out_color_d, out_depth_d, out_color_s, out_depth_s);
   S3G_KERNEL_CHECK(stream, in->debug != 0);
   return S3G_OK;
 }

@@ -165,13 +165,15 @@ def rasterize_decomposition(background, colors, is_dynamic, tan_fovx, tan_fovy, 
     H, W = int(image_height), int(image_width)
     out = [torch.empty((c, H, W), dtype=torch.float32, device=dev) for c in (NUM_CHANNELS, 1, NUM_CHANNELS, 1)]
     keep = [_f32(background, "bg"), _f32(colors, "colors_precomp"), is_dynamic.to(torch.uint8).contiguous()]
+    n_dyn = keep[2].sum(dtype=torch.int64)
+    counts = torch.stack([P - n_dyn, n_dyn])          # [static, dynamic], read by the kernel: an empty class renders as zeros
     if keep[2].numel() != P or not keep[2].is_cuda:
         raise RuntimeError("is_dynamic must be a GPU mask with one entry per Gaussian")
     inp = _inputs(P, 0, 0, W, H, keep[0], None, None, keep[1], None, None, 1.0, None, None, None, None, tan_fovx, tan_fovy,
                   None, False, debug)
     with torch.cuda.device(dev):
         code = L.s3g_raster_forward_decompose(C.byref(inp), int(R), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
-                                              keep[2].data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                              keep[2].data_ptr(), counts.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
                                               out[3].data_ptr(), torch.cuda.current_stream().cuda_stream)
     _lib.check(code)
     return tuple(out)

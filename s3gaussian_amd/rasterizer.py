@@ -178,11 +178,6 @@ class GaussianRasterizer(nn.Module):
             return dict(render=color, radii=radii, depth=depth, render_d=z3, depth_d=z1, render_s=z3.clone(), depth_s=z1.clone())
         cd, dd, cs, ds = _C.rasterize_decomposition(rs.bg, n(colors_precomp), dynamic_mask, rs.tanfovx, rs.tanfovy,
                                                     rs.image_height, rs.image_width, P, R, geom, binning, img, rs.debug)
-        n_dyn = int(dynamic_mask.sum())     # an EMPTY subset renders as zeros without background (rasterize_points.cu:81-116)
-        if n_dyn == 0:
-            cd.zero_(), dd.zero_()
-        if n_dyn == P:
-            cs.zero_(), ds.zero_()
         return dict(render=color, radii=radii, depth=depth, render_d=cd, depth_d=dd, render_s=cs, depth_s=ds)
 
     def forward_pair(self, means3D, means2D, opacities, colors_a, colors_b, scales=None, rotations=None, cov3D_precomp=None,

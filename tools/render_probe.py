@@ -23,3 +23,19 @@ for feat in (False, True, False, True):
             render(cams[i % len(cams)], pc, pipe, bg, stage="fine", render_feat=feat)
         torch.cuda.synchronize()
     print(f"render_feat={feat}: {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms/frame")
+
+# evaluation path (gaussian_renderer/__init__.py:168-204): full + dynamic-only + static-only renders
+with torch.no_grad():   # non-trivial dx so that both classes are populated
+    for p in pc._deformation.deformation_net.pos_deform.parameters():
+        p.add_(0.05 * torch.randn_like(p))
+for fused in (True, False, True, False):
+    pipe_d = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False, fused_decomposition=fused)
+    with torch.no_grad():
+        for i in range(3):
+            render(cams[i], pc, pipe_d, bg, stage="fine", return_decomposition=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(30):
+            render(cams[i % len(cams)], pc, pipe_d, bg, stage="fine", return_decomposition=True)
+        torch.cuda.synchronize()
+    print(f"return_decomposition, shared geometry={fused}: {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms/frame")
