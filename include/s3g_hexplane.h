@@ -52,6 +52,7 @@ int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, co
  * s3g_hexplane_backward_workspace_bytes(d, P, features != NULL) bytes (sort buffers, per-orientation dL/dxyz partials, the
  * row tables and their gradients when uniform_time; + 3 KB per point of per-plane sample gradients on the features == NULL
  * path), uninitialised. */
+#define S3G_HEX_SORT_STATE_WORDS 7
 size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P, int have_features);
 int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
                           const float* dL_dfeatures,
@@ -62,12 +63,12 @@ int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, c
                           (3 KB per point). */,
                           float* dL_dxyz, float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6],
                           void* workspace,
-                          unsigned int* sort_state /* [6*P] device or NULL: the three spatial orders of the points followed
-                          by their inverse permutations.  They only steer HOW the work is walked (texel reuse, run-length
+                          unsigned int* sort_state /* [S3G_HEX_SORT_STATE_WORDS * P] device or NULL: the three spatial orders
+                          of the points, their inverse permutations, and the 3-D blocked processing order.  They only steer HOW the work is walked (texel reuse, run-length
                           combining), never the result, so a caller may keep them across iterations while the points move
                           slowly: sort_reuse != 0 = `sort_state` holds the orders of an earlier call with the same P and the
-                          sorts are skipped; sort_reuse == 0 = they are recomputed and left there.  sort_state[0..P) is the
-                          (x,y) order, usable as proc_order of later forwards. */,
+                          sorts are skipped; sort_reuse == 0 = they are recomputed and left there.  sort_state[6P..7P) is the
+                          blocked order, usable as proc_order of later forwards. */,
                           int sort_reuse, void* stream);
 
 #ifdef __cplusplus

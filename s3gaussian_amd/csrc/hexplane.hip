@@ -35,6 +35,15 @@ constexpr bool FEAT_NONTEMPORAL = true;      // forward's feature rows
 constexpr bool GFEAT_NONTEMPORAL = true;     // point pass: dL/dfeature rows (read once)
 constexpr bool G_NONTEMPORAL_LOAD = true;    // and streaming loads in the scatter: 1.28 -> 1.23 ms
 
+// Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8) and every XCD has its own L2.  With the points in
+// spatial order, giving XCD k the k-th CONTIGUOUS eighth of the groups keeps each texel line in one L2 instead of eight.
+constexpr bool XCD_CONTIGUOUS = true;
+__device__ __forceinline__ int xcd_group(int b, int nb) {
+  if (!XCD_CONTIGUOUS) return b;
+  const int per = nb >> 3;
+  return b < (per << 3) ? (b & 7) * per + (b >> 3) : b;
+}
+
 struct HexArgs {
   s3g_hexplane_desc d;
   float* gplanes[S3G_HEX_MAX_LEVELS][6];
@@ -103,33 +112,109 @@ __device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_fl
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-// EIGHT lanes own one point, four channels each (one 16-byte load per texel and lane; the 8 lanes read its 128-byte
-// line): the kernel is VALU-bound on the tap arithmetic, which every lane of a point repeats -- 8 copies instead of 32.
+// ---- per-point passes (forward, backward pass A) ----
+// EIGHT lanes own one point, four channels each (one 16-byte load per texel and lane; the 8 lanes read its 128-byte line).
+// These kernels are bound by VALU ISSUE (a wave64 instruction occupies its 16-lane SIMD for 4 cycles: 537 G wave-instructions
+// per second for the whole chip at 2.1 GHz), not by memory: replacing every texel address by one hot line changed nothing
+// (1.51 -> 1.49 ms), and instruction count x 4 cycles predicts the measured times to 10 %.  So instructions are what is saved:
+//   * the bilinear tap of a (level, plane) is computed ONCE per point -- lane j < 6 of the point's eight computes plane j of
+//     every level -- and shared through LDS as 16 bytes (packed nw key + flags, ix - x0, iy - y0); the r1 kernels repeated
+//     make_tap in all eight lanes (6 x ~45 instructions per level and lane);
+//   * texel loads are branch-free: an out-of-range corner (only possible on the last column / row, where its weight is
+//     exactly 0) reads the nw texel instead of selecting zeros behind an exec-mask branch (24 branches + 96 v_mov per level);
+//   * texel addresses are a uniform base pointer + a 32-bit byte offset (planes are at most 2^24 texels: check_desc);
+//   * uniform time: the (axis, t) row tables have two corners, not four (compile-time: template UT).
+// x1 - ix is recomputed as 1 - (ix - x0): ix - x0 is exact (Sterbenz; x0 = 0 trivially), so both expressions are the correct
+// rounding of the same real number -- bit-identical weights.
+struct PointTap {  // as read back from LDS
+  uint32_t off;    // byte offset of the nw texel's channel 0
+  uint32_t dx, dy; // byte distance to the ne / sw texel, 0 when that corner is out of range
+  float fx, fy, gx, gy;   // ix - x0, iy - y0, x1 - ix, y1 - iy
+  float mx, my;    // d(ix)/d(u), d(iy)/d(u) incl. the border-clip mask
+};
+constexpr int TAP_SLOTS = 8;   // 16-byte tap slots per (point, level): 6 used
+
+// lane role j < 6: plane j of every level for the lane's point -> tapbuf[slot][l][j]
+__device__ __forceinline__ void produce_taps(const HexArgs& a, const float* u, int j, float4* __restrict__ taps /* [levels][TAP_SLOTS] of this point */) {
+  if (j >= 6) return;
+  // plane j = axes (a0, a1) in itertools.combinations order: (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); selects on lane-role
+  // predicates (an indexed u[] / res[] would go through scratch memory)
+  const bool a0_is0 = j < 3, a0_is1 = j == 3 || j == 4;
+  const bool a1_is1 = j == 0, a1_is2 = j == 1 || j == 3;
+  const float ua = a0_is0 ? u[0] : (a0_is1 ? u[1] : u[2]);
+  const float ub = a1_is1 ? u[1] : (a1_is2 ? u[2] : u[3]);
+  for (int l = 0; l < a.d.levels; l++) {
+    const int r0 = a.d.res[l][0], r1 = a.d.res[l][1], r2 = a.d.res[l][2], r3 = a.d.res[l][3];
+    const int W = a0_is0 ? r0 : (a0_is1 ? r1 : r2), H = a1_is1 ? r1 : (a1_is2 ? r2 : r3);
+    const Tap t = make_tap(ua, ub, W, H);
+    const uint32_t flags = (t.o01 >= 0 ? 1u : 0u) | (t.o10 >= 0 ? 2u : 0u) | (t.mx != 0.f ? 4u : 0u) | (t.my != 0.f ? 8u : 0u);
+    taps[l * TAP_SLOTS + j] = make_float4(__uint_as_float(((uint32_t)t.o00 << 4) | flags), t.ix - t.x0f, t.iy - t.y0f, 0.f);
+  }
+}
+template <bool ROW>
+__device__ __forceinline__ PointTap read_tap(const float4* __restrict__ taps, int l, int i, int W, int H, int c4) {
+  const float4 v = taps[l * TAP_SLOTS + i];
+  const uint32_t pk = __float_as_uint(v.x);
+  PointTap t;
+  t.off = (pk >> 4) * (HEXC * 4u) + (uint32_t)c4 * 4u;
+  t.dx = (pk & 1u) ? HEXC * 4u : 0u;
+  t.dy = (!ROW && (pk & 2u)) ? (uint32_t)W * (HEXC * 4u) : 0u;
+  t.fx = v.y; t.gx = 1.f - v.y;
+  t.fy = ROW ? 0.f : v.z; t.gy = ROW ? 1.f : 1.f - v.z;
+  t.mx = (pk & 4u) ? (float)(W - 1) / 2.f : 0.f;
+  t.my = (pk & 8u) ? (float)(H - 1) / 2.f : 0.f;
+  return t;
+}
+__device__ __forceinline__ float4 texel4(const float* __restrict__ plane, uint32_t byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(plane) + byte_off);
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ constexpr bool IS_TIME_PLANE[6] = {false, false, true, false, true, true};
+
+template <bool UT>
 __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) {
-  const int c4 = (threadIdx.x & 7) * 4, slot = threadIdx.x >> 3;
+  extern __shared__ float4 tapbuf[];   // [32 points][levels][TAP_SLOTS]
+  const int j = threadIdx.x & 7, c4 = j * 4, slot = threadIdx.x >> 3;
   const int F = a.d.levels * HEXC;
-  for (int pi = blockIdx.x * 32 + slot; pi < a.P; pi += gridDim.x * 32) {
-    const int p = a.proc_order ? (int)a.proc_order[pi] : pi;
+  float4* taps = tapbuf + (size_t)slot * a.d.levels * TAP_SLOTS;
+  for (int p0 = xcd_group(blockIdx.x, gridDim.x) * 32; p0 < a.P; p0 += gridDim.x * 32) {
+    const int pi = p0 + slot;
+    const bool live = pi < a.P;
+    const int p = live ? (a.proc_order ? (int)a.proc_order[pi] : pi) : 0;
     float u[4];
     point_coords(a, p, u);
+    wave_lds_sync();   // the previous point's taps have been read
+    produce_taps(a, u, j, taps);
+    wave_lds_sync();
     for (int l = 0; l < a.d.levels; l++) {
       float4 prod = make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
-        const Tap t = make_tap(u[PAIR0[i]], u[PAIR1[i]], W, H);
         const float* pl = a.d.planes[l][i];
-        float4 s = fetch4(pl, t.o00, c4) * t.w00;
-        s = s + fetch4(pl, t.o01, c4) * t.w01;
-        s = s + fetch4(pl, t.o10, c4) * t.w10;
-        s = s + fetch4(pl, t.o11, c4) * t.w11;
+        float4 s;
+        if (UT && IS_TIME_PLANE[i]) {
+          const PointTap t = read_tap<true>(taps, l, i, W, H, c4);
+          s = texel4(pl, t.off) * t.gx;
+          s = s + texel4(pl, t.off + t.dx) * t.fx;
+        } else {
+          const PointTap t = read_tap<false>(taps, l, i, W, H, c4);
+          s = texel4(pl, t.off) * (t.gx * t.gy);
+          s = s + texel4(pl, t.off + t.dx) * (t.fx * t.gy);
+          s = s + texel4(pl, t.off + t.dy) * (t.gx * t.fy);
+          s = s + texel4(pl, t.off + t.dy + t.dx) * (t.fx * t.fy);
+        }
         prod = prod * s;
       }
-      if (FEAT_NONTEMPORAL) {
+      if (live) {
         f4v v = {prod.x, prod.y, prod.z, prod.w};
-        __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(a.feat + (size_t)p * F + l * HEXC + c4));
-      } else {
-        *reinterpret_cast<float4*>(a.feat + (size_t)p * F + l * HEXC + c4) = prod;
+        f4v* dst = reinterpret_cast<f4v*>(a.feat + (size_t)p * F + l * HEXC + c4);
+        if (FEAT_NONTEMPORAL) __builtin_nontemporal_store(v, dst);
+        else *dst = v;
       }
     }
   }
@@ -143,77 +228,119 @@ __device__ constexpr int KIND_OF[6] = {0, 0, 1, 0, 1, 1};  // 0 = spatial plane 
 
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-// Same lane mapping as the forward (8 lanes per point, 4 channels each).  Per plane only the sample s and its two
-// coordinate derivatives are kept:  ds/dix = (ne - nw)(y1 - iy) + (se - sw)(iy - y0),  ds/diy = (sw - nw)(x1 - ix) +
-// (se - ne)(ix - x0)  (the four terms of torch's grid_sampler_2d_backward, grouped).
+// Same lane mapping and tap sharing as the forward.  Per plane only the sample s and its two coordinate derivatives are kept:
+// ds/dix = (ne - nw)(y1 - iy) + (se - sw)(iy - y0),  ds/diy = (sw - nw)(x1 - ix) + (se - ne)(ix - x0)  (the four terms of
+// torch's grid_sampler_2d_backward, grouped).
+//
+// Measured dead ends (cfg3, 1.2 M points; the kernel takes 1.5 ms, 1.07 ms without its G stores): halving the VALU work (shared
+// taps, below) changed nothing; neither did pointing every texel load at one hot line, nor a blocked processing order with
+// XCD-contiguous groups (the forward gains 8 % from it); a persistent-workgroup version that prefetches the next level's
+// texels into a second register set and the next group's index / coordinates / taps was SLOWER (1.86 ms at 256 VGPRs with
+// spills, 1.58 ms with the group prefetch alone).
+struct LevelIn {       // texels of one level's planes (uniform time: the three spatial planes only) + the dL/dfeature row
+  float4 v[6][4];
+  float4 g;
+};
+template <bool UT>
+__device__ __forceinline__ void issue_level(const HexArgs& a, const float4* __restrict__ taps, int l, int c4, const float* __restrict__ grow, LevelIn& in) {
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
+    const float* pl = a.d.planes[l][i];
+    if (UT && IS_TIME_PLANE[i]) {
+      // row tables (a few hundred KB in total, L1 / L2 resident) are read where they are used
+    } else {
+      const PointTap t = read_tap<false>(taps, l, i, W, H, c4);
+      in.v[i][0] = texel4(pl, t.off);
+      in.v[i][1] = texel4(pl, t.off + t.dx);
+      in.v[i][2] = texel4(pl, t.off + t.dy);
+      in.v[i][3] = texel4(pl, t.off + t.dy + t.dx);
+    }
+  }
+  const f4v* src = reinterpret_cast<const f4v*>(grow + l * HEXC);
+  const f4v v = GFEAT_NONTEMPORAL ? __builtin_nontemporal_load(src) : *src;
+  in.g = make_float4(v.x, v.y, v.z, v.w);
+}
+// the arithmetic of one level: product rule, six G rows (when `store`), this level's share of dL/du
+template <bool UT>
+__device__ __forceinline__ void consume_level(const HexArgs& a, const float4* __restrict__ taps, int l, int c4, const LevelIn& in, bool store,
+                                              float* __restrict__ G, size_t PL, const uint32_t* rk, float* du) {
+  float4 s[6], dX[6], dY[6];
+  float mx[6], my[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
+    if (UT && IS_TIME_PLANE[i]) {
+      const PointTap t = read_tap<true>(taps, l, i, W, H, c4);
+      const float* pl = a.d.planes[l][i];
+      const float4 v00 = texel4(pl, t.off), v01 = texel4(pl, t.off + t.dx);
+      s[i] = v00 * t.gx;
+      s[i] = s[i] + v01 * t.fx;
+      dX[i] = v01 - v00;
+      dY[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      mx[i] = t.mx; my[i] = 0.f;
+    } else {
+      const PointTap t = read_tap<false>(taps, l, i, W, H, c4);
+      const float4 v00 = in.v[i][0], v01 = in.v[i][1], v10 = in.v[i][2], v11 = in.v[i][3];
+      float4 acc = v00 * (t.gx * t.gy);
+      acc = acc + v01 * (t.fx * t.gy);
+      acc = acc + v10 * (t.gx * t.fy);
+      acc = acc + v11 * (t.fx * t.fy);
+      s[i] = acc;
+      // a corner that is out of range is the nw / ne / sw texel again: its difference terms are then multiplied by an
+      // exactly-zero mask (mx or my) below, as the reference's are by the border clip
+      dX[i] = (v01 - v00) * t.gy + (v11 - v10) * t.fy;
+      dY[i] = (v10 - v00) * t.gx + (v11 - v01) * t.fx;
+      mx[i] = t.mx; my[i] = t.my;
+    }
+  }
+  // product rule in the order autograd applies it to ((((1*s0)*s1)*s2)*s3)*s4)*s5: pre[i] = prod_{j<i} s_j, suffix by recursion
+  float4 pre[6];
+  pre[0] = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+  for (int i = 1; i < 6; i++) pre[i] = pre[i - 1] * s[i - 1];
+  float4 gs = in.g;  // dL/d(prefix product through plane i)
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    const float4 gi = gs * pre[i];  // dL/ds_i
+    gs = gs * s[i];
+    if (store) {
+      f4v v = {gi.x, gi.y, gi.z, gi.w};
+      f4v* grow = reinterpret_cast<f4v*>(G + (size_t)((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * PL + ((size_t)rk[ORI_OF[i]] * HEXC + c4));
+      if (G_NONTEMPORAL) __builtin_nontemporal_store(v, grow);   // written once, read once by the scatter pass much later
+      else *grow = v;
+      if (PAIR0[i] < 3) du[PAIR0[i]] += mx[i] * dot4(dX[i], gi);
+      if (PAIR1[i] < 3) du[PAIR1[i]] += my[i] * dot4(dY[i], gi);
+    }
+  }
+}
+
+template <bool UT>
 __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexArgs a, float* __restrict__ G,
                                                                       const uint32_t* __restrict__ rank_all) {
-  const int c4 = (threadIdx.x & 7) * 4, slot = threadIdx.x >> 3;
+  extern __shared__ float4 tapbuf[];   // [32 points][levels][TAP_SLOTS]
+  const int j = threadIdx.x & 7, c4 = j * 4, slot = threadIdx.x >> 3;
   const int F = a.d.levels * HEXC;
   const size_t PL = (size_t)a.P * HEXC;  // one slab of G
-  for (int p0 = blockIdx.x * 32; p0 < a.P; p0 += gridDim.x * 32) {  // uniform trip count: shuffles below need all lanes
+  float4* taps = tapbuf + (size_t)slot * a.d.levels * TAP_SLOTS;
+  for (int p0 = xcd_group(blockIdx.x, gridDim.x) * 32; p0 < a.P; p0 += gridDim.x * 32) {  // uniform trip count: shuffles below need all lanes
     const int pi = p0 + slot;
     const bool live = pi < a.P;
     const int p = live ? (a.proc_order ? (int)a.proc_order[pi] : pi) : 0;
-    uint32_t rk[3] = {0u, 0u, 0u};
-    if (live)
+    uint32_t rk[3];   // this point's row in the slabs of the three orientations
 #pragma unroll
-      for (int o = 0; o < 3; o++) rk[o] = rank_all[(size_t)o * a.P + p];
-    float u[4] = {0.f, 0.f, 0.f, 0.f};
-    if (live) point_coords(a, p, u);
+    for (int o = 0; o < 3; o++) rk[o] = rank_all[(size_t)o * a.P + p];
+    float u[4];
+    point_coords(a, p, u);
+    wave_lds_sync();
+    produce_taps(a, u, j, taps);
+    wave_lds_sync();
+    const float* grow = a.gfeat + (size_t)p * F + c4;
     float du[3] = {0.f, 0.f, 0.f};
     for (int l = 0; l < a.d.levels; l++) {
-      float4 s[6], dX[6], dY[6];
-      float mx[6], my[6];
-#pragma unroll
-      for (int i = 0; i < 6; i++) {
-        const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
-        const Tap t = make_tap(u[PAIR0[i]], u[PAIR1[i]], W, H);
-        const float* pl = a.d.planes[l][i];
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 v00 = live ? fetch4(pl, t.o00, c4) : z, v01 = live ? fetch4(pl, t.o01, c4) : z;
-        const float4 v10 = live ? fetch4(pl, t.o10, c4) : z, v11 = live ? fetch4(pl, t.o11, c4) : z;
-        float4 acc = v00 * t.w00;
-        acc = acc + v01 * t.w01;
-        acc = acc + v10 * t.w10;
-        acc = acc + v11 * t.w11;
-        s[i] = acc;
-        dX[i] = (v01 - v00) * (t.y1f - t.iy) + (v11 - v10) * (t.iy - t.y0f);
-        dY[i] = (v10 - v00) * (t.x1f - t.ix) + (v11 - v01) * (t.ix - t.x0f);
-        mx[i] = t.mx;
-        my[i] = t.my;
-      }
-      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live) {
-        if (GFEAT_NONTEMPORAL) {
-          const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.gfeat + (size_t)p * F + l * HEXC + c4));
-          g = make_float4(v.x, v.y, v.z, v.w);
-        } else {
-          g = *reinterpret_cast<const float4*>(a.gfeat + (size_t)p * F + l * HEXC + c4);
-        }
-      }
-      // product rule in the order autograd applies it to ((((1*s0)*s1)*s2)*s3)*s4)*s5: pre[i] = prod_{j<i} s_j, suffix by recursion
-      float4 pre[6];
-      pre[0] = make_float4(1.f, 1.f, 1.f, 1.f);
-#pragma unroll
-      for (int i = 1; i < 6; i++) pre[i] = pre[i - 1] * s[i - 1];
-      float4 gs = g;  // dL/d(prefix product through plane i)
-#pragma unroll
-      for (int i = 5; i >= 0; i--) {
-        const float4 gi = gs * pre[i];  // dL/ds_i
-        gs = gs * s[i];
-        if (live) {
-          float* grow = G + (size_t)((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * PL + (size_t)rk[ORI_OF[i]] * HEXC + c4;
-          if (G_NONTEMPORAL) {   // written once, read once by the scatter pass much later: keep it out of the texels' way in L2
-            f4v v = {gi.x, gi.y, gi.z, gi.w};
-            __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(grow));
-          } else {
-            *reinterpret_cast<float4*>(grow) = gi;
-          }
-          if (PAIR0[i] < 3) du[PAIR0[i]] += mx[i] * dot4(dX[i], gi);
-          if (PAIR1[i] < 3) du[PAIR1[i]] += my[i] * dot4(dY[i], gi);
-        }
-      }
+      LevelIn X;
+      issue_level<UT>(a, taps, l, c4, grow, X);
+      consume_level<UT>(a, taps, l, c4, X, live, G, PL, rk, du);
     }
     // sum over the 32 channels (the 8 lanes of this point), then undo the aabb normalisation
 #pragma unroll
@@ -222,8 +349,7 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
       for (int off = 4; off >= 1; off >>= 1) v += __shfl_xor(v, off);
       du[k] = v;
     }
-    const int c = threadIdx.x & 7;
-    if (live && c < 3) a.gxyz[3 * (size_t)p + c] = (c == 0 ? du[0] : (c == 1 ? du[1] : du[2])) * (2.0f / (a.d.aabb_min[c] - a.d.aabb_max[c]));
+    if (live && j < 3) a.gxyz[3 * (size_t)p + j] = (j == 0 ? du[0] : (j == 1 ? du[1] : du[2])) * (2.0f / (a.d.aabb_min[j] - a.d.aabb_max[j]));
   }
 }
 
@@ -248,13 +374,33 @@ __device__ __forceinline__ int sort_cell(const HexArgs& a, int p, int axis) {
   return min(SORT_BINS - 1, max(0, cidx));
 }
 
+// Order 3 is the PROCESSING order of the per-point passes (forward, backward pass A): a two-level 3-D blocking -- major key
+// = the 8 x 8 x 8 grid of blocks of the volume, minor key = the 8 x 8 x 8 sub-blocks of a block -- so that consecutive
+// points are close in x, y AND z and all three spatial planes' texels stay in the L2 of the XCD that works on the block.
+// (In an (x, y) order every tap of the (y, z) plane missed: 2.5 GB of 128-byte fetches per pass at 1.2 M points.)
+constexpr int N_ORDERS = 4;
+__device__ __forceinline__ int block_key(const HexArgs& a, int p, int shift) {
+  int key = 0;
+#pragma unroll
+  for (int axis = 0; axis < 3; axis++) {
+    const int Wc = min(a.d.res[a.d.levels - 1][axis], SORT_BINS);
+    const int c = sort_cell(a, p, axis);
+    key = key * 8 + (min(63, (c * 64) / Wc) >> shift & 7);
+  }
+  return key;
+}
+__device__ __forceinline__ int major_key(const HexArgs& a, int p, int o) { return o < 3 ? sort_cell(a, p, MAJ[o]) : block_key(a, p, 3); }
+__device__ __forceinline__ int minor_key(const HexArgs& a, int p, int o) { return o < 3 ? sort_cell(a, p, MIN_[o]) : block_key(a, p, 0); }
+
 struct SortWork {
-  uint32_t* table;      // [3][SORT_NB][SORT_BINS]
-  uint32_t* seg_start;  // [3][SORT_BINS + 1]
-  uint32_t* tmp;        // [3][P]  indices grouped by major cell
-  uint32_t* order;      // [3][P]  final order
-  uint32_t* rank;       // [3][P]  inverse permutation: rank[o][order[o][k]] = k
+  uint32_t* table;      // [4][SORT_NB][SORT_BINS]
+  uint32_t* seg_start;  // [4][SORT_BINS + 1]
+  uint32_t* tmp;        // [4][P]  indices grouped by major key
+  uint32_t* order;      // [3][P]  final orders of the three orientation walks
+  uint32_t* rank;       // [3][P]  inverse permutations: rank[o][order[o][k]] = k
+  uint32_t* proc;       // [P]     order 3: processing order of the per-point passes
 };
+__device__ __forceinline__ uint32_t* order_of(const SortWork& w, int o, int P) { return o < 3 ? w.order + (size_t)o * P : w.proc; }
 
 template <bool WRITE>
 __global__ void __launch_bounds__(256) hexsort_major_kernel(const HexArgs a, const SortWork w, int chunk) {
@@ -265,7 +411,7 @@ __global__ void __launch_bounds__(256) hexsort_major_kernel(const HexArgs a, con
   __syncthreads();
   const int g0 = blockIdx.x * chunk, g1 = min(a.P, g0 + chunk);
   for (int g = g0 + threadIdx.x; g < g1; g += 256) {
-    const uint32_t pos = atomicAdd(&cell[sort_cell(a, g, MAJ[o])], 1u);
+    const uint32_t pos = atomicAdd(&cell[major_key(a, g, o)], 1u);
     if (WRITE) w.tmp[(size_t)o * a.P + pos] = (uint32_t)g;
   }
   if (!WRITE) {
@@ -305,10 +451,10 @@ __global__ void __launch_bounds__(256) hexsort_minor_kernel(const HexArgs a, con
   const uint32_t s0 = w.seg_start[o * (SORT_BINS + 1) + bin], s1 = w.seg_start[o * (SORT_BINS + 1) + bin + 1];
   if (s1 == s0) return;
   const uint32_t* tmp = w.tmp + (size_t)o * a.P;
-  uint32_t* order = w.order + (size_t)o * a.P;
+  uint32_t* order = order_of(w, o, a.P);
   for (int i = tid; i < SORT_BINS; i += 256) cnt[i] = 0u;
   __syncthreads();
-  for (uint32_t k = s0 + tid; k < s1; k += 256) atomicAdd(&cnt[sort_cell(a, (int)tmp[k], MIN_[o])], 1u);
+  for (uint32_t k = s0 + tid; k < s1; k += 256) atomicAdd(&cnt[minor_key(a, (int)tmp[k], o)], 1u);
   __syncthreads();
   // exclusive scan of 512 counters: each thread owns two consecutive bins
   const uint32_t c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
@@ -329,7 +475,7 @@ __global__ void __launch_bounds__(256) hexsort_minor_kernel(const HexArgs a, con
   __syncthreads();
   for (uint32_t k = s0 + tid; k < s1; k += 256) {
     const uint32_t g = tmp[k];
-    order[atomicAdd(&cnt[sort_cell(a, (int)g, MIN_[o])], 1u)] = g;
+    order[atomicAdd(&cnt[minor_key(a, (int)g, o)], 1u)] = g;
   }
 }
 
@@ -345,24 +491,44 @@ static inline int segment_length(int P) { return P >= 1000000 ? 256 : 128; }
 
 // One bilinear footprint being accumulated in registers: key = texel offset of its nw corner (-1 = empty), flags bit0 =
 // ne/se column in range, bit1 = sw/se row in range (the other three corners follow from key, flags and the plane width).
-struct Foot {
+// A lane owns CPL adjacent channels: T = float (CPL = 1, 32 lanes per walker) or f2v (CPL = 2, 16 lanes per walker: every key
+// compare, select and cache-management instruction then serves two channels and the accumulation is v_pk_fma_f32 -- the walk
+// is bound by VALU issue, 4 cycles per wave64 instruction).
+constexpr bool FOOT_SHIFT = true;
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <typename T> struct lanes_of;
+template <> struct lanes_of<float> { static constexpr int CPL = 1; };
+template <> struct lanes_of<f2v> { static constexpr int CPL = 2; };
+__device__ __forceinline__ float vzero(float) { return 0.f; }
+__device__ __forceinline__ f2v vzero(f2v) { return f2v{0.f, 0.f}; }
+__device__ __forceinline__ float vfma(float g, float w, float acc) { return __builtin_fmaf(g, w, acc); }
+__device__ __forceinline__ f2v vfma(f2v g, float w, f2v acc) { return __builtin_elementwise_fma(g, f2v{w, w}, acc); }
+__device__ __forceinline__ void vatomic(char* base, uint32_t k, float v) { atomicAdd(reinterpret_cast<float*>(base + k), v); }
+__device__ __forceinline__ void vatomic(char* base, uint32_t k, f2v v) {
+  atomicAdd(reinterpret_cast<float*>(base + k), v.x);
+  atomicAdd(reinterpret_cast<float*>(base + (k + 4u)), v.y);
+}
+template <typename T>
+struct FootT {
   int key, flags;
-  float a00, a01, a10, a11;
+  T a00, a01, a10, a11;
 };
+using Foot = FootT<float>;
 // Offsets are 32-bit BYTE offsets off a uniform base pointer (`base + zext(u32)` selects the scalar-base + VGPR-offset
 // addressing mode: no 64-bit address arithmetic per atomic; a plane is at most 2^24 texels).  The corner tests stay
 // branches on purpose: an unconditional atomic of an exact zero to a clamped address was measured 6x SLOWER for the whole
 // pass -- every empty entry and every out-of-range corner then lands on the same few lines (texel 0 of each plane, the nw
-// texel again), and same-address atomics serialise at ~10 ns each.
-__device__ __forceinline__ void foot_flush(const Foot& f, float* __restrict__ gp, int W, int c) {
+// texel again), and same-address atomics serialise at ~10 ns each.  c = first channel of the lane.
+template <typename T>
+__device__ __forceinline__ void foot_flush(const FootT<T>& f, float* __restrict__ gp, int W, int c) {
   if (f.key < 0) return;
   const uint32_t k = ((uint32_t)f.key * HEXC + (uint32_t)c) * 4u;
   const uint32_t dy = (uint32_t)W * (HEXC * 4u);
   char* base = reinterpret_cast<char*>(gp);
-  atomicAdd(reinterpret_cast<float*>(base + k), f.a00);
-  if (f.flags & 1) atomicAdd(reinterpret_cast<float*>(base + (k + HEXC * 4u)), f.a01);
-  if (f.flags & 2) atomicAdd(reinterpret_cast<float*>(base + (k + dy)), f.a10);
-  if ((f.flags & 3) == 3) atomicAdd(reinterpret_cast<float*>(base + (k + dy + HEXC * 4u)), f.a11);
+  vatomic(base, k, f.a00);
+  if (f.flags & 1) vatomic(base, k + HEXC * 4u, f.a01);
+  if (f.flags & 2) vatomic(base, k + dy, f.a10);
+  if ((f.flags & 3) == 3) vatomic(base, k + dy + HEXC * 4u, f.a11);
 }
 // Two-entry footprint cache.  align_corners grids of different levels do not nest, so inside one finest-level cell the
 // points alternate between two (sometimes four) coarse footprints; remembering the previous one as well removes most of
@@ -372,85 +538,125 @@ struct PackedTap {  // what the scatter needs of a Tap: 8 floats in LDS
   float w00, w01, w10, w11;
 };
 // Entries stay where they are (no MRU swap) and the hit path is BRANCH-FREE: both entries take an fma whose multiplicand is
-// the gradient or 0.  The scatter kernel used to be instruction-bound on this function: the two half-waves of a wave walk
+// the gradient or 0.  The scatter kernel used to be instruction-bound on this function: the walkers sharing a wave walk
 // different segments, so every data-dependent branch of the old hit-A / hit-B-swap / miss cascade ran both sides under
 // complementary exec masks (~100 instructions per call, 32 calls per group of four points).  Only the miss -- about one
 // call in four -- still branches: it flushes the entry that was NOT used last and installs the new footprint in its place.
-struct Foot2 {
+template <typename T>
+struct Foot2T {
   int key0, key1, fl0, fl1, mru;
-  float a0[4], a1[4];
+  T a0[4], a1[4];
 };
-__device__ __forceinline__ void foot2_init(Foot2& F) {
+using Foot2 = Foot2T<float>;
+template <typename T>
+__device__ __forceinline__ void foot2_init(Foot2T<T>& F) {
   F.key0 = F.key1 = -1;
   F.fl0 = F.fl1 = F.mru = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) F.a0[k] = F.a1[k] = 0.f;
+  for (int k = 0; k < 4; k++) F.a0[k] = F.a1[k] = vzero(T{});
 }
 // ROW = true: the plane is a height-1 row table (uniform time): only the nw / ne corners exist, the sw / se halves of
 // the footprint (weights exactly 0, flag bit 1 clear) are compiled out -- half the fmas, selects and flush atomics.
-template <bool ROW = false>
-__device__ __forceinline__ void foot2_flush_all(const Foot2& F, float* __restrict__ gp, int W, int c) {
-  foot_flush(Foot{F.key0, ROW ? (F.fl0 & 1) : F.fl0, F.a0[0], F.a0[1], ROW ? 0.f : F.a0[2], ROW ? 0.f : F.a0[3]}, gp, W, c);
-  foot_flush(Foot{F.key1, ROW ? (F.fl1 & 1) : F.fl1, F.a1[0], F.a1[1], ROW ? 0.f : F.a1[2], ROW ? 0.f : F.a1[3]}, gp, W, c);
+template <bool ROW = false, typename T>
+__device__ __forceinline__ void foot2_flush_all(const Foot2T<T>& F, float* __restrict__ gp, int W, int c) {
+  const T z = vzero(T{});
+  foot_flush(FootT<T>{F.key0, ROW ? (F.fl0 & 1) : F.fl0, F.a0[0], F.a0[1], ROW ? z : F.a0[2], ROW ? z : F.a0[3]}, gp, W, c);
+  foot_flush(FootT<T>{F.key1, ROW ? (F.fl1 & 1) : F.fl1, F.a1[0], F.a1[1], ROW ? z : F.a1[2], ROW ? z : F.a1[3]}, gp, W, c);
 }
-template <bool ROW = false>
-__device__ __forceinline__ void foot2_add(Foot2& F, const PackedTap& t, float g, float* __restrict__ gp, int W, int c) {
+// Miss path, one code shape for both cases (a second set of divergent branches cost more scalar registers than the kernel has):
+//   evict  the entry that was NOT used last is flushed (up to 4 atomics) and restarts empty with the new footprint;
+//   shift  the new footprint is one row BELOW / one column RIGHT of the most recent one -- the usual step of a walk along the
+//          minor axis.  Two of its texels are already being summed in that entry: only the row / column left behind is
+//          flushed (2 atomics instead of 4 -- the walk is bound by the rate of atomic line-ops) and the other two sums move up.
+template <bool ROW = false, typename T>
+__device__ __forceinline__ void foot2_add(Foot2T<T>& F, const PackedTap& t, T g, float* __restrict__ gp, int W, int c) {
+  const T z = vzero(T{});
   bool h0 = t.key == F.key0, h1 = t.key == F.key1;
-  if (!(h0 || h1)) {  // miss (uniform inside the half-wave): evict the entry that is not the most recent one
-    const bool v1 = F.mru == 0;
-    foot_flush(Foot{v1 ? F.key1 : F.key0, ROW ? ((v1 ? F.fl1 : F.fl0) & 1) : (v1 ? F.fl1 : F.fl0), v1 ? F.a1[0] : F.a0[0],
-                    v1 ? F.a1[1] : F.a0[1], ROW ? 0.f : (v1 ? F.a1[2] : F.a0[2]), ROW ? 0.f : (v1 ? F.a1[3] : F.a0[3])}, gp, W, c);
-    F.key1 = v1 ? t.key : F.key1;  F.key0 = v1 ? F.key0 : t.key;
-    F.fl1 = v1 ? t.flags : F.fl1;  F.fl0 = v1 ? F.fl0 : t.flags;
-#pragma unroll
-    for (int k = 0; k < (ROW ? 2 : 4); k++) {
-      F.a1[k] = v1 ? 0.f : F.a1[k];
-      F.a0[k] = v1 ? F.a0[k] : 0.f;
+  if (!(h0 || h1)) {  // miss (uniform inside the walker's lanes)
+    const bool m1 = F.mru != 0;                       // most recent entry
+    const int mkey = m1 ? F.key1 : F.key0, mfl = m1 ? F.fl1 : F.fl0;
+    const bool down = FOOT_SHIFT && !ROW && mkey >= 0 && t.key == mkey + W;
+    const bool right = FOOT_SHIFT && mkey >= 0 && t.key == mkey + 1 && (mfl & 1);
+    const bool shift = down || right;
+    const bool w1 = shift ? m1 : !m1;                 // entry that is flushed (partly) and rewritten
+    const int K = w1 ? F.key1 : F.key0, FL = w1 ? F.fl1 : F.fl0;
+    const T A0 = w1 ? F.a1[0] : F.a0[0], A1 = w1 ? F.a1[1] : F.a0[1];
+    const T A2 = ROW ? z : (w1 ? F.a1[2] : F.a0[2]), A3 = ROW ? z : (w1 ? F.a1[3] : F.a0[3]);
+    if (K >= 0) {
+      const uint32_t k = ((uint32_t)K * HEXC + (uint32_t)c) * 4u;
+      const uint32_t dy = (uint32_t)W * (HEXC * 4u);
+      char* base = reinterpret_cast<char*>(gp);
+      vatomic(base, k, A0);                                                    // nw leaves in every case
+      if ((FL & 1) && !right) vatomic(base, k + HEXC * 4u, A1);               // ne stays when shifting right
+      if (!ROW && (FL & 2) && !down) vatomic(base, k + dy, A2);               // sw stays when shifting down
+      if (!ROW && (FL & 3) == 3 && !shift) vatomic(base, k + dy + HEXC * 4u, A3);
     }
-    h1 = v1;
-    h0 = !v1;
+    // new contents: shift down (nw, ne, sw, se) <- (sw, se, 0, 0); shift right <- (ne, 0, se, 0); evict <- 0
+    const T n0 = down ? A2 : (right ? A1 : z), n1 = down ? A3 : z, n2 = right ? A3 : z;
+    F.a1[0] = w1 ? n0 : F.a1[0];  F.a0[0] = w1 ? F.a0[0] : n0;
+    F.a1[1] = w1 ? n1 : F.a1[1];  F.a0[1] = w1 ? F.a0[1] : n1;
+    if (!ROW) {
+      F.a1[2] = w1 ? n2 : F.a1[2];  F.a0[2] = w1 ? F.a0[2] : n2;
+      F.a1[3] = w1 ? z : F.a1[3];   F.a0[3] = w1 ? F.a0[3] : z;
+    }
+    F.key1 = w1 ? t.key : F.key1;  F.key0 = w1 ? F.key0 : t.key;
+    F.fl1 = w1 ? t.flags : F.fl1;  F.fl0 = w1 ? F.fl0 : t.flags;
+    h1 = w1;
+    h0 = !w1;
   }
-  const float g0 = h0 ? g : 0.f, g1 = h1 ? g : 0.f;
-  F.a0[0] = __builtin_fmaf(g0, t.w00, F.a0[0]); F.a0[1] = __builtin_fmaf(g0, t.w01, F.a0[1]);
-  F.a1[0] = __builtin_fmaf(g1, t.w00, F.a1[0]); F.a1[1] = __builtin_fmaf(g1, t.w01, F.a1[1]);
+  const T g0 = h0 ? g : z, g1 = h1 ? g : z;
+  F.a0[0] = vfma(g0, t.w00, F.a0[0]); F.a0[1] = vfma(g0, t.w01, F.a0[1]);
+  F.a1[0] = vfma(g1, t.w00, F.a1[0]); F.a1[1] = vfma(g1, t.w01, F.a1[1]);
   if (!ROW) {
-    F.a0[2] = __builtin_fmaf(g0, t.w10, F.a0[2]); F.a0[3] = __builtin_fmaf(g0, t.w11, F.a0[3]);
-    F.a1[2] = __builtin_fmaf(g1, t.w10, F.a1[2]); F.a1[3] = __builtin_fmaf(g1, t.w11, F.a1[3]);
+    F.a0[2] = vfma(g0, t.w10, F.a0[2]); F.a0[3] = vfma(g0, t.w11, F.a0[3]);
+    F.a1[2] = vfma(g1, t.w10, F.a1[2]); F.a1[3] = vfma(g1, t.w11, F.a1[3]);
   }
   F.mru = h1 ? 1 : 0;
 }
 
-// A half-wave (32 lanes = the 32 channels) walks seg_len consecutive points of the sorted order.  The kernel used to be
-// VALU-bound on make_tap, which all 32 lanes repeated for each of the 8 (level, plane) taps of a point; now the 32 lanes
-// compute the 8 taps of FOUR points at once (lane = point q x tap j), park them in LDS, and every lane reads them back
-// with broadcast loads while it accumulates its channel.
+// A WALKER = 32 / CPL lanes (each owning CPL adjacent channels) walks seg_len consecutive points of the sorted order.  The
+// kernel used to be VALU-bound on make_tap, which every lane repeated for each (level, plane) tap of a point; now the walker's
+// lanes compute the taps of FOUR points at once (lane = point q x tap j), park them in LDS, and every lane reads them back
+// with broadcast loads while it accumulates its channels.
 constexpr int SCATTER_LG = 2;          // levels handled per walk of a segment
-constexpr int SCATTER_WG_PER_CU = 5;   // 5 waves per SIMD with row-table footprints (4 for general per-point time): the walk is bound by per-wave issue latency (IPC ~0.2), not by VALU throughput
+constexpr int SCATTER_CPL = 1;         // channels per lane (2 = v_pk_fma accumulation, but twice the flush atomics: 2.07 vs 1.14 ms -- the walk is bound by atomic line-ops)
+constexpr int SCATTER_WG_PER_CU = SCATTER_CPL == 2 ? 3 : 4;   // waves per SIMD the register budget is set for (5 = 96 VGPRs: the shift path spills, 1.57 vs 1.00 ms)
 constexpr int TAPF = 8;  // floats per packed tap in LDS (6 used; 32-byte slots keep the 16-byte reads aligned)
-template <bool UT>   // UT: uniform time -- the (axis, t) planes are height-1 row tables
+template <typename T> __device__ __forceinline__ T load_g(const float* p);
+template <> __device__ __forceinline__ float load_g<float>(const float* p) { return G_NONTEMPORAL_LOAD ? __builtin_nontemporal_load(p) : *p; }
+template <> __device__ __forceinline__ f2v load_g<f2v>(const float* p) {
+  const f2v* q = reinterpret_cast<const f2v*>(p);
+  return G_NONTEMPORAL_LOAD ? __builtin_nontemporal_load(q) : *q;
+}
+template <bool UT, typename T>   // UT: uniform time -- the (axis, t) planes are height-1 row tables
 __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_CU - 1) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
                                                                const uint32_t* __restrict__ order_all) {
-  __shared__ __attribute__((aligned(16))) float tapbuf[8][2][4][8][TAPF];  // [half-wave][double buffer][point][tap]
+  constexpr int CPL = lanes_of<T>::CPL, LANES = HEXC / CPL, WALKERS = 256 / LANES;
+  constexpr int LG = SCATTER_LG;      // levels handled together: LG levels x 2 planes x 2 footprints live in registers
+  constexpr int NTAP = 2 * LG;        // taps per point and walk
+  static_assert(LANES >= 4 * NTAP, "tap phase: one lane per (point of the group of four, tap)");
+  __shared__ __attribute__((aligned(16))) float tapbuf[WALKERS][2][4][NTAP][TAPF];  // [walker][double buffer][point][tap]
   const int o = blockIdx.y;
-  const int c = threadIdx.x & 31, hw = threadIdx.x >> 5;
-  const int q = c >> 3, j = c & 7;  // tap-phase role: point q of the group of four, tap j = (level j >> 1, kind j & 1)
-  const int seg = blockIdx.x * 8 + hw;
+  const int ln = threadIdx.x & (LANES - 1), hw = threadIdx.x / LANES;
+  const int c = ln * CPL;             // first channel of this lane
+  const int q = (ln / NTAP) & 3, j = ln % NTAP;  // tap-phase role: point q of the group of four, tap j = (level j >> 1, kind j & 1)
+  const bool tap_lane = ln < 4 * NTAP;
+  const int seg = blockIdx.x * WALKERS + hw;
   const int k0 = seg * a.seg_len, k1 = min(a.P, k0 + a.seg_len);
-  if (k0 >= a.P) return;  // whole half-waves drop out; the LDS traffic below is private to a half-wave (wave-ordered)
+  if (k0 >= a.P) return;  // whole walkers drop out; the LDS traffic below is private to a walker (wave-ordered)
   const uint32_t* order = order_all + (size_t)o * a.P;
   const size_t PL = (size_t)a.P * HEXC;
   const int i0 = PLA[o], i1 = PLT[o];
   const int ip = (j & 1) ? i1 : i0;                   // the plane of this lane's tap
   const int axw = PAIR0[ip], axh = PAIR1[ip];
-  constexpr int LG = SCATTER_LG;  // levels handled together: LG levels x 2 planes x 2 footprints live in registers
   for (int l0 = 0; l0 < a.d.levels; l0 += LG) {
-    Foot2 ft[LG][2];
+    Foot2T<T> ft[LG][2];
 #pragma unroll
     for (int l = 0; l < LG; l++)
 #pragma unroll
       for (int m = 0; m < 2; m++) foot2_init(ft[l][m]);
     const int lt = l0 + (j >> 1);                     // level of this lane's tap
-    const bool tap_on = (j >> 1) < LG && lt < a.d.levels;
+    const bool tap_on = lt < a.d.levels;
     const int Wt = tap_on ? a.d.res[lt][axw] : 2, Ht = tap_on ? a.d.res[lt][axh] : 2;
     // Three-stage software pipeline per lane role (point q of a group, tap j): the sorted index of group g+2, the
     // coordinates of group g+1 and the taps of group g+1 are produced while group g is accumulated, so neither the
@@ -464,9 +670,11 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
       lo.y = __int_as_float((t.o01 >= 0 ? 1 : 0) | (t.o10 >= 0 ? 2 : 0));
       lo.z = t.w00;
       lo.w = t.w01;
-      float* dst = &tapbuf[hw][buf][q][j][0];
-      *reinterpret_cast<float4*>(dst) = lo;
-      *reinterpret_cast<float2*>(dst + 4) = make_float2(t.w10, t.w11);
+      if (tap_lane) {
+        float* dst = &tapbuf[hw][buf][q][j][0];
+        *reinterpret_cast<float4*>(dst) = lo;
+        *reinterpret_cast<float2*>(dst + 4) = make_float2(t.w10, t.w11);
+      }
     };
     float un[4];                       // coordinates of the NEXT group's point
     {
@@ -478,8 +686,8 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
     int pnn = load_index(k0 + 8);      // index of the group after next
     int buf = 0;
     for (int kb = k0; kb < k1; kb += 4, buf ^= 1) {
-      // 1. this group's G rows: 4 points x 8 rows requested at once (the walk is latency-bound, not bandwidth-bound)
-      float g[4][LG][2];
+      // 1. this group's G rows: 4 points x 2 LG rows requested at once
+      T g[4][LG][2];
 #pragma unroll
       for (int qq = 0; qq < 4; qq++) {
         const size_t k = (size_t)min(kb + qq, k1 - 1);
@@ -488,10 +696,8 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
           // unconditional (level clamped; slabs exist for every plane): a load behind a uniform branch costs two branch
           // instructions and splits the basic block the scheduler could have filled
           const int lv = min(l0 + l, a.d.levels - 1);
-          const float* g0p = &G[(size_t)((o * a.d.levels + lv) * 2 + 0) * PL + k * HEXC + c];
-          const float* g1p = &G[(size_t)((o * a.d.levels + lv) * 2 + 1) * PL + k * HEXC + c];
-          g[qq][l][0] = G_NONTEMPORAL_LOAD ? __builtin_nontemporal_load(g0p) : *g0p;
-          g[qq][l][1] = G_NONTEMPORAL_LOAD ? __builtin_nontemporal_load(g1p) : *g1p;
+          g[qq][l][0] = load_g<T>(&G[(size_t)((o * a.d.levels + lv) * 2 + 0) * PL + k * HEXC + c]);
+          g[qq][l][1] = load_g<T>(&G[(size_t)((o * a.d.levels + lv) * 2 + 1) * PL + k * HEXC + c]);
         }
       }
       // 2. the NEXT group's taps from coordinates loaded one iteration ago; then advance the two prefetch stages
@@ -910,6 +1116,7 @@ static void use_time_rows(HexArgs& a, TimeRows& r, float* tables, float* gtables
   hipLaunchKernelGGL(hexplane_time_rows_kernel<false>, dim3((maxW * HEXC + 255) / 256, 3, a.d.levels), dim3(256), 0, stream, r);
 }
 
+static const int PAIR0_HOST[6] = {0, 0, 0, 1, 1, 2}, PAIR1_HOST[6] = {1, 2, 3, 2, 3, 3};
 static int check_desc(const s3g_hexplane_desc* d) {
   if (!d || d->levels < 1 || d->levels > S3G_HEX_MAX_LEVELS) {
     set_error("hexplane: bad descriptor (levels)");
@@ -919,6 +1126,11 @@ static int check_desc(const s3g_hexplane_desc* d) {
     for (int k = 0; k < 4; k++)
       if (d->res[l][k] < 2) {
         set_error("hexplane: resolution must be >= 2");
+        return S3G_ERR_INVALID_ARG;
+      }
+    for (int i = 0; i < 6; i++)
+      if ((long long)d->res[l][PAIR0_HOST[i]] * d->res[l][PAIR1_HOST[i]] > (1ll << 24)) {
+        set_error("hexplane: a plane has more than 2^24 texels (32-bit texel byte offsets)");
         return S3G_ERR_INVALID_ARG;
       }
     for (int i = 0; i < 6; i++)
@@ -954,7 +1166,9 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
   if (d->uniform_time) use_time_rows(a, rows, (float*)workspace, nullptr, (hipStream_t)stream_);
   const int blocks = (P + 31) / 32;  // one group of 32 points per workgroup measured best (0.567 -> 0.535 ms vs a 4096 cap)
   profile_begin(S3G_PROFILE_HEXPLANE_FORWARD, (hipStream_t)stream_);
-  hipLaunchKernelGGL(hexplane_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
+  const size_t lds = (size_t)32 * d->levels * TAP_SLOTS * sizeof(float4);
+  if (d->uniform_time) hipLaunchKernelGGL(hexplane_forward_kernel<true>, dim3(blocks), dim3(256), lds, (hipStream_t)stream_, a);
+  else hipLaunchKernelGGL(hexplane_forward_kernel<false>, dim3(blocks), dim3(256), lds, (hipStream_t)stream_, a);
   profile_end(S3G_PROFILE_HEXPLANE_FORWARD, (hipStream_t)stream_, (double)P, (double)d->levels);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
@@ -966,11 +1180,12 @@ static void carve_backward(Carver& c, const s3g_hexplane_desc* d, int P, bool wa
   float* g = walk ? nullptr : c.take<float>((size_t)d->levels * 6 * n * HEXC);   // legacy path: per-plane gradient slab
   float* tb = d->uniform_time ? c.take<float>(2 * time_table_floats(d)) : nullptr;
   SortWork s;
-  s.table = c.take<uint32_t>((size_t)3 * SORT_NB * SORT_BINS);
-  s.seg_start = c.take<uint32_t>((size_t)3 * (SORT_BINS + 1));
-  s.tmp = c.take<uint32_t>(3 * n);
+  s.table = c.take<uint32_t>((size_t)N_ORDERS * SORT_NB * SORT_BINS);
+  s.seg_start = c.take<uint32_t>((size_t)N_ORDERS * (SORT_BINS + 1));
+  s.tmp = c.take<uint32_t>(N_ORDERS * n);
   s.order = c.take<uint32_t>(3 * n);
   s.rank = c.take<uint32_t>(3 * n);
+  s.proc = c.take<uint32_t>(n);
   float* du = walk ? c.take<float>(6 * n) : nullptr;
   uint16_t* bm = walk ? c.take<uint16_t>(3 * n) : nullptr;
   if (G) *G = g;
@@ -1013,15 +1228,16 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
   if (sort_state) {  // caller-owned, persistent
     w.order = sort_state;
     w.rank = sort_state + (size_t)3 * P;
+    w.proc = sort_state + (size_t)6 * P;
   }
 
   // 1. three spatial orders (2-level LDS counting sorts); the legacy path also needs their inverse permutations
   if (!sort_reuse) {
     const int chunk = (((P + SORT_NB - 1) / SORT_NB + 255) / 256) * 256;
-    hipLaunchKernelGGL(hexsort_major_kernel<false>, dim3(SORT_NB, 3), dim3(256), 0, stream, a, w, chunk);
-    hipLaunchKernelGGL(hexsort_scan_kernel, dim3(3), dim3(512), 0, stream, w, P);
-    hipLaunchKernelGGL(hexsort_major_kernel<true>, dim3(SORT_NB, 3), dim3(256), 0, stream, a, w, chunk);
-    hipLaunchKernelGGL(hexsort_minor_kernel, dim3(SORT_BINS, 3), dim3(256), 0, stream, a, w);
+    hipLaunchKernelGGL(hexsort_major_kernel<false>, dim3(SORT_NB, N_ORDERS), dim3(256), 0, stream, a, w, chunk);
+    hipLaunchKernelGGL(hexsort_scan_kernel, dim3(N_ORDERS), dim3(512), 0, stream, w, P);
+    hipLaunchKernelGGL(hexsort_major_kernel<true>, dim3(SORT_NB, N_ORDERS), dim3(256), 0, stream, a, w, chunk);
+    hipLaunchKernelGGL(hexsort_minor_kernel, dim3(SORT_BINS, N_ORDERS), dim3(256), 0, stream, a, w);
     hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.rank);
     S3G_HIP_CHECK(hipGetLastError());
   }
@@ -1046,17 +1262,21 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     hipLaunchKernelGGL(hexplane_dxyz_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a, dup);
   } else {
     // 2'. legacy: per-point pass writing dL/ds of all 24 plane-levels to G, then the scatter walk reading it back
-    a.proc_order = w.order;
+    a.proc_order = w.proc;
     const int blocks = (P + 31) / 32;
     profile_begin(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream);
-    hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3(blocks), dim3(256), 0, stream, a, G, w.rank);
+    const size_t lds = (size_t)32 * d->levels * TAP_SLOTS * sizeof(float4);
+    if (d->uniform_time) hipLaunchKernelGGL(hexplane_backward_point_kernel<true>, dim3(blocks), dim3(256), lds, stream, a, G, w.rank);
+    else hipLaunchKernelGGL(hexplane_backward_point_kernel<false>, dim3(blocks), dim3(256), lds, stream, a, G, w.rank);
     profile_end(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream, (double)P, (double)d->levels);
     S3G_HIP_CHECK(hipGetLastError());
     profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
+    using ScatterT = std::conditional<SCATTER_CPL == 2, f2v, float>::type;
+    constexpr int walkers = 256 / (HEXC / SCATTER_CPL);
     if (d->uniform_time)
-      hipLaunchKernelGGL(hexplane_scatter_kernel<true>, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, G, w.order);
+      hipLaunchKernelGGL((hexplane_scatter_kernel<true, ScatterT>), dim3((nseg + walkers - 1) / walkers, 3), dim3(256), 0, stream, a, G, w.order);
     else
-      hipLaunchKernelGGL(hexplane_scatter_kernel<false>, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, G, w.order);
+      hipLaunchKernelGGL((hexplane_scatter_kernel<false, ScatterT>), dim3((nseg + walkers - 1) / walkers, 3), dim3(256), 0, stream, a, G, w.order);
     profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
   }
   if (d->uniform_time) {

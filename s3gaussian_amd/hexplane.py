@@ -22,6 +22,7 @@ from . import _lib
 
 MAX_LEVELS, CHANNELS = 8, 32
 SORT_REFRESH = 8   # backward passes between two re-sorts of the points (see _HexPlaneSample.backward)
+SORT_STATE_WORDS = 7   # S3G_HEX_SORT_STATE_WORDS (include/s3g_hexplane.h): 3 orders + 3 ranks + the blocked processing order
 # Backward algorithm (include/s3g_hexplane.h): "slab" = per-point pass writes dL/d(sample) of all 24 plane-levels (3 KB per
 # point), three sorted scatter walks read them back -- the faster one today (2.96 ms at 1.2 M points); "walk" = no slab: each
 # scatter walk forms dL/d(sample) = dL/dfeature * feature / sample from the forward's output and the texels it is about to
@@ -156,8 +157,8 @@ class _HexPlaneSample(torch.autograd.Function):
         state, reuse = None, 0
         if cache is not None:
             state = cache.get("sort_state")
-            if state is None or state.numel() != 6 * P or state.device != xyz_c.device:
-                state = torch.empty(6 * P, dtype=torch.int32, device=xyz_c.device)
+            if state is None or state.numel() != SORT_STATE_WORDS * P or state.device != xyz_c.device:
+                state = torch.empty(SORT_STATE_WORDS * P, dtype=torch.int32, device=xyz_c.device)
                 cache["sort_state"], cache["sort_age"] = state, 0
             else:
                 cache["sort_age"] = cache.get("sort_age", 0) + 1
@@ -172,7 +173,7 @@ class _HexPlaneSample(torch.autograd.Function):
                                                state.data_ptr() if state is not None else None, reuse,
                                                torch.cuda.current_stream().cuda_stream))
         if cache is not None:
-            cache["order"] = state[:P]  # (x,y) processing order for the forwards
+            cache["order"] = state[6 * P:7 * P]  # 3-D blocked processing order for the forwards
         return (gxyz if ctx.needs_input_grad[0] else None, None, None, *gplanes)
 
 
