@@ -30,6 +30,7 @@ namespace s3g {
 
 constexpr int HEXC = S3G_HEX_CHANNELS;
 typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr bool G_POINT_MAJOR = true;         // G rows of a point contiguous, points in PROCESSING order (pass A streams its stores)
 constexpr bool G_NONTEMPORAL = true;         // streaming stores of the gradient slab: point pass 1.83 -> 1.60 ms
 constexpr bool FEAT_NONTEMPORAL = true;      // forward's feature rows
 constexpr bool GFEAT_NONTEMPORAL = true;     // point pass: dL/dfeature rows (read once)
@@ -232,17 +233,39 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a
 // ds/dix = (ne - nw)(y1 - iy) + (se - sw)(iy - y0),  ds/diy = (sw - nw)(x1 - ix) + (se - ne)(ix - x0)  (the four terms of
 // torch's grid_sampler_2d_backward, grouped).
 //
-// Measured dead ends (cfg3, 1.2 M points; the kernel takes 1.5 ms, 1.07 ms without its G stores): halving the VALU work (shared
-// taps, below) changed nothing; neither did pointing every texel load at one hot line, nor a blocked processing order with
-// XCD-contiguous groups (the forward gains 8 % from it); a persistent-workgroup version that prefetches the next level's
-// texels into a second register set and the next group's index / coordinates / taps was SLOWER (1.86 ms at 256 VGPRs with
-// spills, 1.58 ms with the group prefetch alone).
+// What bounds pass A (cfg3, 1.2 M points, 1.43 ms; PMC pass in profiles/r02_hexplane_sq_pmc.txt): its waves sit parked on
+// s_waitcnt 63 % of their resident time and issue VALU 18 % of it (288 M wave-instructions = 0.5 ms of pure issue) -- at two
+// waves per SIMD (172 registers: six samples and their derivatives have to be live for the product rule) nothing hides a
+// memory round trip, and vmcnt being ONE in-order counter, a wait for level l+1's texels also waits for level l's store
+// acknowledgements (1.07 ms with the stores compiled out).  Everything tried against that made it slower, because each costs
+// registers and this kernel has none to give: a second texel register set prefetching the next level (persistent workgroups,
+// next group's index / coordinates / taps prefetched as well): 1.86 ms at 256 VGPRs with spills; the same unrolled so that
+// no set crosses a loop back-edge, next level's loads issued between samples() and this level's stores: 1.94 ms (285 VGPRs,
+// or 256 with spills); launch_bounds for three waves: 1.69 ms (spills).  Without effect: halving the VALU work (shared taps),
+// pointing every texel load at one hot line, the blocked order / XCD-contiguous groups (the forward gains 8 % from those).
+// Point-major G (24 rows of a point contiguous, points in processing order -> streaming stores): 1.50 -> 1.43 ms.
+// V = the channels one lane owns: f4v (8 lanes per point) or f2v (16 lanes per point: half the live registers per lane --
+// the six samples and their derivatives -- hence twice the waves per SIMD to hide the round trips, for ~20 % more VALU work).
+typedef float f2v_ __attribute__((ext_vector_type(2)));
+template <typename V> struct vec_of;
+template <> struct vec_of<f4v> { static constexpr int N = 4; };
+template <> struct vec_of<f2v_> { static constexpr int N = 2; };
+template <typename V> __device__ __forceinline__ V vsplat(float x);
+template <> __device__ __forceinline__ f4v vsplat<f4v>(float x) { return f4v{x, x, x, x}; }
+template <> __device__ __forceinline__ f2v_ vsplat<f2v_>(float x) { return f2v_{x, x}; }
+__device__ __forceinline__ float vdot(f4v a, f4v b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float vdot(f2v_ a, f2v_ b) { return a.x * b.x + a.y * b.y; }
+template <typename V>
+__device__ __forceinline__ V texelv(const float* __restrict__ plane, uint32_t byte_off) {
+  return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(plane) + byte_off);
+}
+template <typename V>
 struct LevelIn {       // texels of one level's planes (uniform time: the three spatial planes only) + the dL/dfeature row
-  float4 v[6][4];
-  float4 g;
+  V v[6][4];
+  V g;
 };
-template <bool UT>
-__device__ __forceinline__ void issue_level(const HexArgs& a, const float4* __restrict__ taps, int l, int c4, const float* __restrict__ grow, LevelIn& in) {
+template <bool UT, typename V>
+__device__ __forceinline__ void issue_level(const HexArgs& a, const float4* __restrict__ taps, int l, int c0, const float* __restrict__ grow, LevelIn<V>& in) {
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
@@ -250,103 +273,119 @@ __device__ __forceinline__ void issue_level(const HexArgs& a, const float4* __re
     if (UT && IS_TIME_PLANE[i]) {
       // row tables (a few hundred KB in total, L1 / L2 resident) are read where they are used
     } else {
-      const PointTap t = read_tap<false>(taps, l, i, W, H, c4);
-      in.v[i][0] = texel4(pl, t.off);
-      in.v[i][1] = texel4(pl, t.off + t.dx);
-      in.v[i][2] = texel4(pl, t.off + t.dy);
-      in.v[i][3] = texel4(pl, t.off + t.dy + t.dx);
+      const PointTap t = read_tap<false>(taps, l, i, W, H, c0);
+      in.v[i][0] = texelv<V>(pl, t.off);
+      in.v[i][1] = texelv<V>(pl, t.off + t.dx);
+      in.v[i][2] = texelv<V>(pl, t.off + t.dy);
+      in.v[i][3] = texelv<V>(pl, t.off + t.dy + t.dx);
     }
   }
-  const f4v* src = reinterpret_cast<const f4v*>(grow + l * HEXC);
-  const f4v v = GFEAT_NONTEMPORAL ? __builtin_nontemporal_load(src) : *src;
-  in.g = make_float4(v.x, v.y, v.z, v.w);
+  const V* src = reinterpret_cast<const V*>(grow + l * HEXC);
+  in.g = GFEAT_NONTEMPORAL ? __builtin_nontemporal_load(src) : *src;
 }
-// the arithmetic of one level: product rule, six G rows (when `store`), this level's share of dL/du
-template <bool UT>
-__device__ __forceinline__ void consume_level(const HexArgs& a, const float4* __restrict__ taps, int l, int c4, const LevelIn& in, bool store,
-                                              float* __restrict__ G, size_t PL, const uint32_t* rk, float* du) {
-  float4 s[6], dX[6], dY[6];
+// The arithmetic of one level in two halves:
+//   samples()  texels -> s, ds/dix, ds/diy per plane (the texel registers are dead afterwards);
+//   finish()   product rule -> six G rows (stored when `store`) and this level's share of dL/du.
+template <typename V>
+struct LevelS {
+  V s[6], dX[6], dY[6];
   float mx[6], my[6];
+};
+template <bool UT, typename V>
+__device__ __forceinline__ void samples_level(const HexArgs& a, const float4* __restrict__ taps, int l, int c0, const LevelIn<V>& in, LevelS<V>& S) {
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
     if (UT && IS_TIME_PLANE[i]) {
-      const PointTap t = read_tap<true>(taps, l, i, W, H, c4);
+      const PointTap t = read_tap<true>(taps, l, i, W, H, c0);
       const float* pl = a.d.planes[l][i];
-      const float4 v00 = texel4(pl, t.off), v01 = texel4(pl, t.off + t.dx);
-      s[i] = v00 * t.gx;
-      s[i] = s[i] + v01 * t.fx;
-      dX[i] = v01 - v00;
-      dY[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      mx[i] = t.mx; my[i] = 0.f;
+      const V v00 = texelv<V>(pl, t.off), v01 = texelv<V>(pl, t.off + t.dx);
+      S.s[i] = v00 * t.gx;
+      S.s[i] = S.s[i] + v01 * t.fx;
+      S.dX[i] = v01 - v00;
+      S.dY[i] = vsplat<V>(0.f);
+      S.mx[i] = t.mx; S.my[i] = 0.f;
     } else {
-      const PointTap t = read_tap<false>(taps, l, i, W, H, c4);
-      const float4 v00 = in.v[i][0], v01 = in.v[i][1], v10 = in.v[i][2], v11 = in.v[i][3];
-      float4 acc = v00 * (t.gx * t.gy);
+      const PointTap t = read_tap<false>(taps, l, i, W, H, c0);
+      const V v00 = in.v[i][0], v01 = in.v[i][1], v10 = in.v[i][2], v11 = in.v[i][3];
+      V acc = v00 * (t.gx * t.gy);
       acc = acc + v01 * (t.fx * t.gy);
       acc = acc + v10 * (t.gx * t.fy);
       acc = acc + v11 * (t.fx * t.fy);
-      s[i] = acc;
+      S.s[i] = acc;
       // a corner that is out of range is the nw / ne / sw texel again: its difference terms are then multiplied by an
       // exactly-zero mask (mx or my) below, as the reference's are by the border clip
-      dX[i] = (v01 - v00) * t.gy + (v11 - v10) * t.fy;
-      dY[i] = (v10 - v00) * t.gx + (v11 - v01) * t.fx;
-      mx[i] = t.mx; my[i] = t.my;
+      S.dX[i] = (v01 - v00) * t.gy + (v11 - v10) * t.fy;
+      S.dY[i] = (v10 - v00) * t.gx + (v11 - v01) * t.fx;
+      S.mx[i] = t.mx; S.my[i] = t.my;
     }
   }
+}
+template <typename V>
+__device__ __forceinline__ void finish_level(const HexArgs& a, int l, int c0, const LevelS<V>& S, V g, bool store,
+                                             float* __restrict__ G, size_t PL, const uint32_t* rk, size_t gbase, float* du) {
   // product rule in the order autograd applies it to ((((1*s0)*s1)*s2)*s3)*s4)*s5: pre[i] = prod_{j<i} s_j, suffix by recursion
-  float4 pre[6];
-  pre[0] = make_float4(1.f, 1.f, 1.f, 1.f);
+  V pre[6];
+  pre[0] = vsplat<V>(1.f);
 #pragma unroll
-  for (int i = 1; i < 6; i++) pre[i] = pre[i - 1] * s[i - 1];
-  float4 gs = in.g;  // dL/d(prefix product through plane i)
+  for (int i = 1; i < 6; i++) pre[i] = pre[i - 1] * S.s[i - 1];
+  V gs = g;  // dL/d(prefix product through plane i)
 #pragma unroll
   for (int i = 5; i >= 0; i--) {
-    const float4 gi = gs * pre[i];  // dL/ds_i
-    gs = gs * s[i];
+    const V gi = gs * pre[i];  // dL/ds_i
+    gs = gs * S.s[i];
     if (store) {
-      f4v v = {gi.x, gi.y, gi.z, gi.w};
-      f4v* grow = reinterpret_cast<f4v*>(G + (size_t)((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * PL + ((size_t)rk[ORI_OF[i]] * HEXC + c4));
-      if (G_NONTEMPORAL) __builtin_nontemporal_store(v, grow);   // written once, read once by the scatter pass much later
-      else *grow = v;
-      if (PAIR0[i] < 3) du[PAIR0[i]] += mx[i] * dot4(dX[i], gi);
-      if (PAIR1[i] < 3) du[PAIR1[i]] += my[i] * dot4(dY[i], gi);
+      V* grow = G_POINT_MAJOR
+                    ? reinterpret_cast<V*>(G + gbase + (size_t)(((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * HEXC + c0))
+                    : reinterpret_cast<V*>(G + (size_t)((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * PL + ((size_t)rk[ORI_OF[i]] * HEXC + c0));
+      if (G_NONTEMPORAL) __builtin_nontemporal_store(gi, grow);   // written once, read once by the scatter pass much later
+      else *grow = gi;
+      if (PAIR0[i] < 3) du[PAIR0[i]] += S.mx[i] * vdot(S.dX[i], gi);
+      if (PAIR1[i] < 3) du[PAIR1[i]] += S.my[i] * vdot(S.dY[i], gi);
     }
   }
 }
 
-template <bool UT>
+using PointV = f4v;    // channels per lane of pass A (f2v_: 106 VGPRs = 4 waves per SIMD, but 1.73 vs 1.53 ms)
+template <bool UT, typename V, int LV>   // LV > 0: level count at compile time (unrolled: the per-level plane pointers and resolutions are fetched up front instead of four dependent scalar loads per level)
 __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexArgs a, float* __restrict__ G,
                                                                       const uint32_t* __restrict__ rank_all) {
-  extern __shared__ float4 tapbuf[];   // [32 points][levels][TAP_SLOTS]
-  const int j = threadIdx.x & 7, c4 = j * 4, slot = threadIdx.x >> 3;
-  const int F = a.d.levels * HEXC;
+  constexpr int CPL = vec_of<V>::N, LPP = HEXC / CPL, PPW = 256 / LPP;   // channels per lane, lanes per point, points per workgroup
+  extern __shared__ float4 tapbuf[];   // [PPW points][levels][TAP_SLOTS]
+  const int j = threadIdx.x & (LPP - 1), c0 = j * CPL, slot = threadIdx.x / LPP;
+  const int L = LV > 0 ? LV : a.d.levels;
+  const int F = L * HEXC;
   const size_t PL = (size_t)a.P * HEXC;  // one slab of G
-  float4* taps = tapbuf + (size_t)slot * a.d.levels * TAP_SLOTS;
-  for (int p0 = xcd_group(blockIdx.x, gridDim.x) * 32; p0 < a.P; p0 += gridDim.x * 32) {  // uniform trip count: shuffles below need all lanes
+  float4* taps = tapbuf + (size_t)slot * L * TAP_SLOTS;
+  for (int p0 = xcd_group(blockIdx.x, gridDim.x) * PPW; p0 < a.P; p0 += gridDim.x * PPW) {  // uniform trip count: shuffles below need all lanes
     const int pi = p0 + slot;
     const bool live = pi < a.P;
     const int p = live ? (a.proc_order ? (int)a.proc_order[pi] : pi) : 0;
-    uint32_t rk[3];   // this point's row in the slabs of the three orientations
+    uint32_t rk[3] = {0u, 0u, 0u};   // slab layout: this point's row in the slabs of the three orientations
+    if (!G_POINT_MAJOR)
 #pragma unroll
-    for (int o = 0; o < 3; o++) rk[o] = rank_all[(size_t)o * a.P + p];
+      for (int o = 0; o < 3; o++) rk[o] = rank_all[(size_t)o * a.P + p];
+    const size_t gbase = (size_t)pi * (size_t)(6 * L * HEXC);   // point-major layout: 24 rows of this PROCESSING position
     float u[4];
     point_coords(a, p, u);
     wave_lds_sync();
     produce_taps(a, u, j, taps);
     wave_lds_sync();
-    const float* grow = a.gfeat + (size_t)p * F + c4;
+    const float* grow = a.gfeat + (size_t)p * F + c0;
     float du[3] = {0.f, 0.f, 0.f};
-    for (int l = 0; l < a.d.levels; l++) {
-      LevelIn X;
-      issue_level<UT>(a, taps, l, c4, grow, X);
-      consume_level<UT>(a, taps, l, c4, X, live, G, PL, rk, du);
+#pragma unroll LV > 0 ? LV : 1
+    for (int l = 0; l < L; l++) {
+      LevelIn<V> X;
+      LevelS<V> S;
+      issue_level<UT>(a, taps, l, c0, grow, X);
+      samples_level<UT>(a, taps, l, c0, X, S);
+      finish_level(a, l, c0, S, X.g, live, G, PL, rk, gbase, du);
     }
-    // sum over the 32 channels (the 8 lanes of this point), then undo the aabb normalisation
+    // sum over the 32 channels (the lanes of this point), then undo the aabb normalisation
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       float v = du[k];
-      for (int off = 4; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      for (int off = LPP / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
       du[k] = v;
     }
     if (live && j < 3) a.gxyz[3 * (size_t)p + j] = (j == 0 ? du[0] : (j == 1 ? du[1] : du[2])) * (2.0f / (a.d.aabb_min[j] - a.d.aabb_max[j]));
@@ -397,7 +436,8 @@ struct SortWork {
   uint32_t* seg_start;  // [4][SORT_BINS + 1]
   uint32_t* tmp;        // [4][P]  indices grouped by major key
   uint32_t* order;      // [3][P]  final orders of the three orientation walks
-  uint32_t* rank;       // [3][P]  inverse permutations: rank[o][order[o][k]] = k
+  uint32_t* rank;       // [3][P]  slab layout: inverse permutations, rank[o][order[o][k]] = k; point-major G: comp[o][k] =
+                        //         position of point order[o][k] in the processing order
   uint32_t* proc;       // [P]     order 3: processing order of the per-point passes
 };
 __device__ __forceinline__ uint32_t* order_of(const SortWork& w, int o, int P) { return o < 3 ? w.order + (size_t)o * P : w.proc; }
@@ -482,6 +522,12 @@ __global__ void __launch_bounds__(256) hexsort_minor_kernel(const HexArgs a, con
 __global__ void __launch_bounds__(256) hexsort_rank_kernel(int P, const uint32_t* __restrict__ order, uint32_t* __restrict__ rank) {
   const int k = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
   if (k < P) rank[(size_t)o * P + order[(size_t)o * P + k]] = (uint32_t)k;
+}
+// point-major G: where in the PROCESSING order is the k-th point of orientation o's order?  comp[o][k] = procrank[order[o][k]]
+__global__ void __launch_bounds__(256) hexsort_compose_kernel(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ procrank,
+                                                              uint32_t* __restrict__ comp) {
+  const int k = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
+  if (k < P) comp[(size_t)o * P + k] = procrank[order[(size_t)o * P + k]];
 }
 
 // ---- pass B: scatter in sorted order with register run-length combining ----
@@ -630,7 +676,7 @@ template <> __device__ __forceinline__ f2v load_g<f2v>(const float* p) {
 }
 template <bool UT, typename T>   // UT: uniform time -- the (axis, t) planes are height-1 row tables
 __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_CU - 1) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
-                                                               const uint32_t* __restrict__ order_all) {
+                                                               const uint32_t* __restrict__ order_all, const uint32_t* __restrict__ comp_all) {
   constexpr int CPL = lanes_of<T>::CPL, LANES = HEXC / CPL, WALKERS = 256 / LANES;
   constexpr int LG = SCATTER_LG;      // levels handled together: LG levels x 2 planes x 2 footprints live in registers
   constexpr int NTAP = 2 * LG;        // taps per point and walk
@@ -645,7 +691,9 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   const int k0 = seg * a.seg_len, k1 = min(a.P, k0 + a.seg_len);
   if (k0 >= a.P) return;  // whole walkers drop out; the LDS traffic below is private to a walker (wave-ordered)
   const uint32_t* order = order_all + (size_t)o * a.P;
+  const uint32_t* comp = comp_all + (size_t)o * a.P;
   const size_t PL = (size_t)a.P * HEXC;
+  const size_t GP = (size_t)(6 * a.d.levels * HEXC);   // point-major layout: floats per point
   const int i0 = PLA[o], i1 = PLT[o];
   const int ip = (j & 1) ? i1 : i0;                   // the plane of this lane's tap
   const int axw = PAIR0[ip], axh = PAIR1[ip];
@@ -684,8 +732,18 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
     }
     load_coords(load_index(k0 + 4), un);
     int pnn = load_index(k0 + 8);      // index of the group after next
+    // point-major G: processing positions of this group's four points, fetched a group ahead (G's addresses depend on them)
+    uint32_t cpos[4] = {0u, 0u, 0u, 0u}, cpos_n[4] = {0u, 0u, 0u, 0u};
+    if (G_POINT_MAJOR) {
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) cpos[qq] = comp[min(k0 + qq, k1 - 1)];
+    }
     int buf = 0;
     for (int kb = k0; kb < k1; kb += 4, buf ^= 1) {
+      if (G_POINT_MAJOR) {
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) cpos_n[qq] = comp[min(kb + 4 + qq, k1 - 1)];
+      }
       // 1. this group's G rows: 4 points x 2 LG rows requested at once
       T g[4][LG][2];
 #pragma unroll
@@ -696,10 +754,18 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
           // unconditional (level clamped; slabs exist for every plane): a load behind a uniform branch costs two branch
           // instructions and splits the basic block the scheduler could have filled
           const int lv = min(l0 + l, a.d.levels - 1);
-          g[qq][l][0] = load_g<T>(&G[(size_t)((o * a.d.levels + lv) * 2 + 0) * PL + k * HEXC + c]);
-          g[qq][l][1] = load_g<T>(&G[(size_t)((o * a.d.levels + lv) * 2 + 1) * PL + k * HEXC + c]);
+          if (G_POINT_MAJOR) {
+            const float* row = G + (size_t)cpos[qq] * GP + (size_t)(((o * a.d.levels + lv) * 2) * HEXC + c);
+            g[qq][l][0] = load_g<T>(row);
+            g[qq][l][1] = load_g<T>(row + HEXC);
+          } else {
+            g[qq][l][0] = load_g<T>(&G[(size_t)((o * a.d.levels + lv) * 2 + 0) * PL + k * HEXC + c]);
+            g[qq][l][1] = load_g<T>(&G[(size_t)((o * a.d.levels + lv) * 2 + 1) * PL + k * HEXC + c]);
+          }
         }
       }
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) cpos[qq] = cpos_n[qq];
       // 2. the NEXT group's taps from coordinates loaded one iteration ago; then advance the two prefetch stages
       store_taps(un, buf ^ 1);
       load_coords(pnn, un);
@@ -1238,7 +1304,12 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     hipLaunchKernelGGL(hexsort_scan_kernel, dim3(N_ORDERS), dim3(512), 0, stream, w, P);
     hipLaunchKernelGGL(hexsort_major_kernel<true>, dim3(SORT_NB, N_ORDERS), dim3(256), 0, stream, a, w, chunk);
     hipLaunchKernelGGL(hexsort_minor_kernel, dim3(SORT_BINS, N_ORDERS), dim3(256), 0, stream, a, w);
-    hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.rank);
+    if (G_POINT_MAJOR) {   // w.rank holds comp[o][k]; the inverse of the processing order goes through w.tmp (free after the sorts)
+      hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 1), dim3(256), 0, stream, P, w.proc, w.tmp);
+      hipLaunchKernelGGL(hexsort_compose_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.tmp, w.rank);
+    } else {
+      hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.rank);
+    }
     S3G_HIP_CHECK(hipGetLastError());
   }
   //    (the sorts above used the real resolutions; from here on the time planes are height-1 row tables if uniform_time)
@@ -1263,20 +1334,22 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
   } else {
     // 2'. legacy: per-point pass writing dL/ds of all 24 plane-levels to G, then the scatter walk reading it back
     a.proc_order = w.proc;
-    const int blocks = (P + 31) / 32;
     profile_begin(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream);
-    const size_t lds = (size_t)32 * d->levels * TAP_SLOTS * sizeof(float4);
-    if (d->uniform_time) hipLaunchKernelGGL(hexplane_backward_point_kernel<true>, dim3(blocks), dim3(256), lds, stream, a, G, w.rank);
-    else hipLaunchKernelGGL(hexplane_backward_point_kernel<false>, dim3(blocks), dim3(256), lds, stream, a, G, w.rank);
+    constexpr int ppw = 256 / (HEXC / vec_of<PointV>::N);   // points per workgroup
+    const int pblocks = (P + ppw - 1) / ppw;
+    const size_t lds = (size_t)ppw * d->levels * TAP_SLOTS * sizeof(float4);
+    if (d->uniform_time && d->levels == 4) hipLaunchKernelGGL((hexplane_backward_point_kernel<true, PointV, 4>), dim3(pblocks), dim3(256), lds, stream, a, G, w.rank);
+    else if (d->uniform_time) hipLaunchKernelGGL((hexplane_backward_point_kernel<true, PointV, 0>), dim3(pblocks), dim3(256), lds, stream, a, G, w.rank);
+    else hipLaunchKernelGGL((hexplane_backward_point_kernel<false, PointV, 0>), dim3(pblocks), dim3(256), lds, stream, a, G, w.rank);
     profile_end(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream, (double)P, (double)d->levels);
     S3G_HIP_CHECK(hipGetLastError());
     profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
     using ScatterT = std::conditional<SCATTER_CPL == 2, f2v, float>::type;
     constexpr int walkers = 256 / (HEXC / SCATTER_CPL);
     if (d->uniform_time)
-      hipLaunchKernelGGL((hexplane_scatter_kernel<true, ScatterT>), dim3((nseg + walkers - 1) / walkers, 3), dim3(256), 0, stream, a, G, w.order);
+      hipLaunchKernelGGL((hexplane_scatter_kernel<true, ScatterT>), dim3((nseg + walkers - 1) / walkers, 3), dim3(256), 0, stream, a, G, w.order, w.rank);
     else
-      hipLaunchKernelGGL((hexplane_scatter_kernel<false, ScatterT>), dim3((nseg + walkers - 1) / walkers, 3), dim3(256), 0, stream, a, G, w.order);
+      hipLaunchKernelGGL((hexplane_scatter_kernel<false, ScatterT>), dim3((nseg + walkers - 1) / walkers, 3), dim3(256), 0, stream, a, G, w.order, w.rank);
     profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
   }
   if (d->uniform_time) {
