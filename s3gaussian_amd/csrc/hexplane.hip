@@ -134,6 +134,9 @@ struct PointTap {  // as read back from LDS
   float mx, my;    // d(ix)/d(u), d(iy)/d(u) incl. the border-clip mask
 };
 constexpr int TAP_SLOTS = 8;   // 16-byte tap slots per (point, level): 6 used
+// float4 slots per point: one slot of padding, so that the points of a wave (who read the same tap index at once, each point's
+// lanes the same address) start 4 banks apart instead of on the same bank (SQ_LDS_BANK_CONFLICT was 6 cycles per LDS instruction)
+__host__ __device__ constexpr int tap_stride(int levels) { return levels * TAP_SLOTS + 1; }
 
 // lane role j < 6: plane j of every level for the lane's point -> tapbuf[slot][l][j]
 __device__ __forceinline__ void produce_taps(const HexArgs& a, const float* u, int j, float4* __restrict__ taps /* [levels][TAP_SLOTS] of this point */) {
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) 
   extern __shared__ float4 tapbuf[];   // [32 points][levels][TAP_SLOTS]
   const int j = threadIdx.x & 7, c4 = j * 4, slot = threadIdx.x >> 3;
   const int F = a.d.levels * HEXC;
-  float4* taps = tapbuf + (size_t)slot * a.d.levels * TAP_SLOTS;
+  float4* taps = tapbuf + (size_t)slot * tap_stride(a.d.levels);
   for (int p0 = xcd_group(blockIdx.x, gridDim.x) * 32; p0 < a.P; p0 += gridDim.x * 32) {
     const int pi = p0 + slot;
     const bool live = pi < a.P;
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
   const int L = LV > 0 ? LV : a.d.levels;
   const int F = L * HEXC;
   const size_t PL = (size_t)a.P * HEXC;  // one slab of G
-  float4* taps = tapbuf + (size_t)slot * L * TAP_SLOTS;
+  float4* taps = tapbuf + (size_t)slot * tap_stride(L);
   for (int p0 = xcd_group(blockIdx.x, gridDim.x) * PPW; p0 < a.P; p0 += gridDim.x * PPW) {  // uniform trip count: shuffles below need all lanes
     const int pi = p0 + slot;
     const bool live = pi < a.P;
@@ -1232,7 +1235,7 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
   if (d->uniform_time) use_time_rows(a, rows, (float*)workspace, nullptr, (hipStream_t)stream_);
   const int blocks = (P + 31) / 32;  // one group of 32 points per workgroup measured best (0.567 -> 0.535 ms vs a 4096 cap)
   profile_begin(S3G_PROFILE_HEXPLANE_FORWARD, (hipStream_t)stream_);
-  const size_t lds = (size_t)32 * d->levels * TAP_SLOTS * sizeof(float4);
+  const size_t lds = (size_t)32 * tap_stride(d->levels) * sizeof(float4);
   if (d->uniform_time) hipLaunchKernelGGL(hexplane_forward_kernel<true>, dim3(blocks), dim3(256), lds, (hipStream_t)stream_, a);
   else hipLaunchKernelGGL(hexplane_forward_kernel<false>, dim3(blocks), dim3(256), lds, (hipStream_t)stream_, a);
   profile_end(S3G_PROFILE_HEXPLANE_FORWARD, (hipStream_t)stream_, (double)P, (double)d->levels);
@@ -1337,7 +1340,7 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     profile_begin(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream);
     constexpr int ppw = 256 / (HEXC / vec_of<PointV>::N);   // points per workgroup
     const int pblocks = (P + ppw - 1) / ppw;
-    const size_t lds = (size_t)ppw * d->levels * TAP_SLOTS * sizeof(float4);
+    const size_t lds = (size_t)ppw * tap_stride(d->levels) * sizeof(float4);
     if (d->uniform_time && d->levels == 4) hipLaunchKernelGGL((hexplane_backward_point_kernel<true, PointV, 4>), dim3(pblocks), dim3(256), lds, stream, a, G, w.rank);
     else if (d->uniform_time) hipLaunchKernelGGL((hexplane_backward_point_kernel<true, PointV, 0>), dim3(pblocks), dim3(256), lds, stream, a, G, w.rank);
     else hipLaunchKernelGGL((hexplane_backward_point_kernel<false, PointV, 0>), dim3(pblocks), dim3(256), lds, stream, a, G, w.rank);

@@ -70,7 +70,11 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
   constexpr int SLOTS = 16;       // 4 waves x 4 rows of 16 lanes
   __shared__ StagedGaussian sg[BATCH];
   __shared__ float4 sg2[NX ? BATCH : 1];  // second image's colour
-  __shared__ float acc[SLOTS][NR][BATCH];  // one slot per (wave, row): combined in fixed order -> bit-reproducible sums
+  // one slot per (wave, row): combined in fixed order -> bit-reproducible sums.  Slots are padded by 16 floats: the four row
+  // leaders of a wave store the same [value][Gaussian] element of their four slots at once, and NR * BATCH floats is a
+  // multiple of the 64 banks (a 4-way conflict on each of the 13 stores: SQ_LDS_BANK_CONFLICT 1.8 cycles per LDS instruction)
+  constexpr int SLOT_FLOATS = NR * BATCH + 16;
+  __shared__ float acc[SLOTS][SLOT_FLOATS];
 
   const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= (uint32_t)tiles) return;
@@ -110,7 +114,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
   for (uint32_t done_cnt = 0; done_cnt < hi; done_cnt += BATCH) {
     const uint32_t cnt = min(BATCH, hi - done_cnt);
     __syncthreads();  // previous batch fully consumed (sg, acc)
-    for (uint32_t e = tid; e < SLOTS * NR * BATCH; e += 256) (&acc[0][0][0])[e] = 0.f;
+    for (uint32_t e = tid; e < SLOTS * SLOT_FLOATS; e += 256) (&acc[0][0])[e] = 0.f;
     if ((uint32_t)tid < cnt) {
       const uint32_t pos = hi - 1 - (done_cnt + tid);  // back to front
       const uint32_t id = point_list[rg.x + pos];
@@ -176,7 +180,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
       sxx = row_sum_lane15(sxx); sxy = row_sum_lane15(sxy); syy = row_sum_lane15(syy);
       if (NX) { p2_r = row_sum_lane15(p2_r); p2_g = row_sum_lane15(p2_g); p2_b = row_sum_lane15(p2_b); }
       if ((lane & 15) == 15) {
-        float* aw = &acc[wave * 4 + (lane >> 4)][0][j];
+        float* aw = &acc[wave * 4 + (lane >> 4)][j];
         aw[0 * BATCH] = p_r; aw[1 * BATCH] = p_g; aw[2 * BATCH] = p_b; aw[3 * BATCH] = p_d; aw[4 * BATCH] = s0;
         aw[5 * BATCH] = sx; aw[6 * BATCH] = sy; aw[7 * BATCH] = sxx; aw[8 * BATCH] = sxy; aw[9 * BATCH] = syy;
         if (NX) { aw[10 * BATCH] = p2_r; aw[11 * BATCH] = p2_g; aw[12 * BATCH] = p2_b; }
@@ -189,11 +193,11 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
       float2* rec = reinterpret_cast<float2*>(records + (size_t)(rg.x + pos) * NR);
 #pragma unroll
       for (int k = 0; k < NR / 2; k++) {
-        float lo = acc[0][2 * k][tid], hi2 = acc[0][2 * k + 1][tid];
+        float lo = acc[0][2 * k * BATCH + tid], hi2 = acc[0][(2 * k + 1) * BATCH + tid];
 #pragma unroll
         for (int q = 1; q < SLOTS; q++) {  // fixed order: rows of wave 0, then wave 1, ...
-          lo += acc[q][2 * k][tid];
-          hi2 += acc[q][2 * k + 1][tid];
+          lo += acc[q][2 * k * BATCH + tid];
+          hi2 += acc[q][(2 * k + 1) * BATCH + tid];
         }
         rec[k] = make_float2(lo, hi2);
       }
