@@ -64,7 +64,9 @@ int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, c
                           float* dL_dxyz, float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6],
                           void* workspace,
                           unsigned int* sort_state /* [S3G_HEX_SORT_STATE_WORDS * P] device or NULL: the three spatial orders
-                          of the points, their inverse permutations, and the 3-D blocked processing order.  They only steer HOW the work is walked (texel reuse, run-length
+                          of the points [0,3P), for each of them the position of its k-th point in the processing order
+                          [3P,6P) (where that point's dL/d(sample) rows are), and the 3-D blocked processing order itself
+                          [6P,7P).  They only steer HOW the work is walked (texel reuse, run-length
                           combining), never the result, so a caller may keep them across iterations while the points move
                           slowly: sort_reuse != 0 = `sort_state` holds the orders of an earlier call with the same P and the
                           sorts are skipped; sort_reuse == 0 = they are recomputed and left there.  sort_state[6P..7P) is the
