@@ -41,11 +41,15 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 // Sum within each row of 16 lanes only (4 DPP adds; lane 15 of every row holds its row's total).  The blend backward stops
 // here and parks the four row totals in LDS: the two row_bcast steps that finish a wave total cost three instructions each
 // (zero, v_mov_dpp, add) per value -- 78 of the ~240 VALU instructions of a (Gaussian, wave) visit in a VALU-bound kernel.
+// The empty asm pins the last add in the straight-line block: its only use is the row leader's LDS store, so the compiler sank
+// it into that branch, where it cannot be fused with the DPP move any more (v_mov_b32_dpp + v_add_f32: 13 extra VALU
+// instructions per visit in a kernel that is bound by VALU issue).
 __device__ __forceinline__ float row_sum_lane15(float v) {
   v = dpp_add<0x111, 0xf>(v);  // row_shr:1
   v = dpp_add<0x112, 0xf>(v);  // row_shr:2
   v = dpp_add<0x114, 0xf>(v);  // row_shr:4
   v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  asm volatile("" : "+v"(v));
   return v;
 }
 
