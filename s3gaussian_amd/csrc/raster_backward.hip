@@ -53,6 +53,47 @@ __device__ __forceinline__ float row_sum_lane15(float v) {
   return v;
 }
 
+// ---- transpose-reduce: NV values summed over the 16 lanes of a row with 29 DPP adds instead of 4 NV = 52 ----
+// A plain reduction sums every value in every lane.  Here each step also splits the values between the two partners:
+//   A  lane i <-> i ^ 8 (row_ror:8):        lanes 0-7 go on with values 0-7, lanes 8-15 with values 8-15;
+//   B  lane i <-> 7 - i (row_half_mirror):  banks (groups of four lanes) 0 / 2 keep the low four of their eight, banks 1 / 3 the high four;
+//   C, D  quad_perm butterflies inside a bank: every lane of bank b ends with the row totals of values 4b .. 4b+3.
+// "keep these, take the partner's" needs no selects: a DPP instruction writes only the lanes its bank_mask enables (bank =
+// four consecutive lanes of a row), so `v_add_f32_dpp r, x, x bank_mask:0x3` followed by `v_add_f32_dpp r, y, y bank_mask:0xc`
+// leaves x + x' in lanes 0-7 and y + y' in lanes 8-15 of the same register.  Inline asm because the builtin (update_dpp + add)
+// cannot express an add whose WRITE is masked; the s_nop covers the VALU-write -> DPP-read hazard (2 wait states) that the
+// compiler does not track through inline asm.  Lanes of a bank whose values do not exist (>= NV) hold finite garbage that is
+// never stored.
+// first write of a register (its other lanes are overwritten by the S3G_DPP_ACC that follows, or never read)
+#define S3G_DPP_SET(dst, src, ctrl, bank) \
+  asm volatile("v_add_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:" bank : "=v"(dst) : "v"(src))
+#define S3G_DPP_ACC(dst, src, ctrl, bank) \
+  asm volatile("v_add_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:" bank : "+v"(dst) : "v"(src))
+#define S3G_DPP_SELF(dst, ctrl) asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(dst))
+template <int NV>
+__device__ __forceinline__ void row_transpose_reduce(const float* v /* [NV] */, float* q /* [4] */) {
+  static_assert(NV > 8 && NV <= 16, "values per visit");
+  float r[8];
+  asm volatile("s_nop 1");
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    S3G_DPP_SET(r[i], v[i], "row_ror:8", "0x3");
+    if (i + 8 < NV) S3G_DPP_ACC(r[i], v[i + 8], "row_ror:8", "0xc");
+  }
+  asm volatile("s_nop 1");
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    S3G_DPP_SET(q[i], r[i], "row_half_mirror", "0x5");
+    S3G_DPP_ACC(q[i], r[i + 4], "row_half_mirror", "0xa");
+  }
+  asm volatile("s_nop 1");
+#pragma unroll
+  for (int i = 0; i < 4; i++) S3G_DPP_SELF(q[i], "quad_perm:[1,0,3,2]");
+  asm volatile("s_nop 1");
+#pragma unroll
+  for (int i = 0; i < 4; i++) S3G_DPP_SELF(q[i], "quad_perm:[2,3,0,1]");
+}
+
 // record layout (NREC floats): dcolor r,g,b | ddepth | S0 | Sx | Sy | Sxx | Sxy | Syy   [| dcolor2 r,g,b | pad]
 //
 // NX = 3: TWO images blended from the same geometry (the RGB+depth render and the feature render of one iteration,
@@ -77,7 +118,8 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
   // one slot per (wave, row): combined in fixed order -> bit-reproducible sums.  Slots are padded by 16 floats: the four row
   // leaders of a wave store the same [value][Gaussian] element of their four slots at once, and NR * BATCH floats is a
   // multiple of the 64 banks (a 4-way conflict on each of the 13 stores: SQ_LDS_BANK_CONFLICT 1.8 cycles per LDS instruction)
-  constexpr int SLOT_FLOATS = NR * BATCH + 16;
+  constexpr int NV = NX ? NREC + 3 : NREC;   // sums per visit
+  constexpr int SLOT_FLOATS = 16 * BATCH + 16;   // 16 value rows: the transpose-reduce stores four rows per bank, unconditionally
   __shared__ float acc[SLOTS][SLOT_FLOATS];
 
   const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -178,16 +220,13 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
         const float vx = v * dx, vy = v * dy;
         s0 = v; sx = vx; sy = vy; sxx = vx * dx; sxy = vx * dy; syy = vy * dy;
       }
-      // wave-uniform from here: all 64 lanes take part in the DPP reductions (within rows of 16 lanes)
-      p_r = row_sum_lane15(p_r); p_g = row_sum_lane15(p_g); p_b = row_sum_lane15(p_b); p_d = row_sum_lane15(p_d);
-      s0 = row_sum_lane15(s0); sx = row_sum_lane15(sx); sy = row_sum_lane15(sy);
-      sxx = row_sum_lane15(sxx); sxy = row_sum_lane15(sxy); syy = row_sum_lane15(syy);
-      if (NX) { p2_r = row_sum_lane15(p2_r); p2_g = row_sum_lane15(p2_g); p2_b = row_sum_lane15(p2_b); }
-      if ((lane & 15) == 15) {
-        float* aw = &acc[wave * 4 + (lane >> 4)][j];
-        aw[0 * BATCH] = p_r; aw[1 * BATCH] = p_g; aw[2 * BATCH] = p_b; aw[3 * BATCH] = p_d; aw[4 * BATCH] = s0;
-        aw[5 * BATCH] = sx; aw[6 * BATCH] = sy; aw[7 * BATCH] = sxx; aw[8 * BATCH] = sxy; aw[9 * BATCH] = syy;
-        if (NX) { aw[10 * BATCH] = p2_r; aw[11 * BATCH] = p2_g; aw[12 * BATCH] = p2_b; }
+      // wave-uniform from here: all 64 lanes take part in the DPP reductions (within rows of 16 lanes); values in record order
+      const float vals[13] = {p_r, p_g, p_b, p_d, s0, sx, sy, sxx, sxy, syy, p2_r, p2_g, p2_b};
+      float q4[4];
+      row_transpose_reduce<NV>(vals, q4);
+      if ((lane & 3) == 0) {   // the first lane of bank b stores the row totals of values 4b .. 4b+3 (rows >= NV: never read)
+        float* aw = &acc[wave * 4 + (lane >> 4)][(lane & 12) * BATCH + j];
+        aw[0 * BATCH] = q4[0]; aw[1 * BATCH] = q4[1]; aw[2 * BATCH] = q4[2]; aw[3 * BATCH] = q4[3];
       }
     }
     __syncthreads();
@@ -203,7 +242,7 @@ blend_backward_kernel(int W, int H, int gx, int tiles, const uint2* __restrict__
           lo += acc[q][2 * k * BATCH + tid];
           hi2 += acc[q][(2 * k + 1) * BATCH + tid];
         }
-        rec[k] = make_float2(lo, hi2);
+        rec[k] = make_float2(lo, 2 * k + 1 < NV ? hi2 : 0.f);   // the pad float of a 14-float record stays 0
       }
     }
   }
