@@ -239,14 +239,15 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a
 // What bounds pass A (cfg3, 1.2 M points, 1.43 ms; PMC pass in profiles/r02_hexplane_sq_pmc.txt): its waves sit parked on
 // s_waitcnt 63 % of their resident time and issue VALU 18 % of it (288 M wave-instructions = 0.5 ms of pure issue) -- at two
 // waves per SIMD (172 registers: six samples and their derivatives have to be live for the product rule) nothing hides a
-// memory round trip, and vmcnt being ONE in-order counter, a wait for level l+1's texels also waits for level l's store
-// acknowledgements (1.07 ms with the stores compiled out).  Everything tried against that made it slower, because each costs
-// registers and this kernel has none to give: a second texel register set prefetching the next level (persistent workgroups,
+// memory round trip (1.07 ms with the G stores compiled out; issuing the next level's loads BEFORE this level's stores -- vmcnt
+// is one in-order counter for loads and stores -- changed nothing: 1.437 vs 1.435 ms).  Everything tried against the latency
+// made it slower or did nothing, because each costs registers and this kernel has none to give: a second texel register set prefetching the next level (persistent workgroups,
 // next group's index / coordinates / taps prefetched as well): 1.86 ms at 256 VGPRs with spills; the same unrolled so that
 // no set crosses a loop back-edge, next level's loads issued between samples() and this level's stores: 1.94 ms (285 VGPRs,
 // or 256 with spills); launch_bounds for three waves: 1.69 ms (spills).  Without effect: halving the VALU work (shared taps),
 // pointing every texel load at one hot line, the blocked order / XCD-contiguous groups (the forward gains 8 % from those).
-// Point-major G (24 rows of a point contiguous, points in processing order -> streaming stores): 1.50 -> 1.43 ms.
+// Point-major G (24 rows of a point contiguous, points in processing order -> streaming stores): 1.50 -> 1.43 ms; padding the
+// tap slots against LDS bank conflicts: 1.42 -> 1.33 ms; more waves (16 lanes per point: 4 per SIMD) 1.73 ms.
 // V = the channels one lane owns: f4v (8 lanes per point) or f2v (16 lanes per point: half the live registers per lane --
 // the six samples and their derivatives -- hence twice the waves per SIMD to hide the round trips, for ~20 % more VALU work).
 typedef float f2v_ __attribute__((ext_vector_type(2)));
