@@ -11,6 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- python "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-alt-paths > /dev/null 2>&1
 f=$(find "$OUT/prof_stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_bench_kernel_stats.csv"
 python "$ROOT/tools/sync_gap.py" "$OUT/prof_stats" > "$OUT/${TAG}_sync_gap.txt" 2>&1
+python "$ROOT/tools/step_trace.py" "$OUT/prof_stats" > "$OUT/${TAG}_step_trace.txt" 2>&1
 rm -rf "$OUT/prof_stats"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-alt-paths > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-alt-paths > /dev/null 2>&1
