@@ -375,11 +375,11 @@ def main():
     for i in range(9):
         L.s3g_profile_read(i, None, None, None)
     L.s3g_profile_enable(1)
-    vis_acc = torch.zeros((), device=device, dtype=torch.float64)
+    vis_masks = []     # summed after the timed region (workload statistics are not part of the step)
     t0 = time.perf_counter()
     for i in range(a.warmup, a.warmup + a.steps):
         loss, pkg = step(i)
-        vis_acc += pkg["visibility_filter"].sum()
+        vis_masks.append(pkg["visibility_filter"])
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -408,7 +408,7 @@ def main():
     if rank == 0:
         # ---- roofline leg: every hot kernel timed in-library with hipEvents on the launch stream (include/s3g_raster.h),
         # priced against its ALGORITHMIC bytes / flops (DESIGN.md section 7 states each model) -----------------------------
-        V = float(vis_acc.item()) / max(a.steps, 1)    # mean visible Gaussians per step (both raster calls share them)
+        V = float(sum(int(m.sum()) for m in vis_masks)) / max(a.steps, 1)    # mean visible Gaussians per step (both raster calls share them)
         P = float(a.P)
         net = pc._deformation.deformation_net
         planes = [p for p in net.grid.grids.parameters()] if hasattr(net.grid, "grids") else []
