@@ -317,18 +317,20 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
   }
 }
 
-// One thread per tile: exclusive prefix over workgroups (coalesced across tiles), 8 independent loads in flight.
+// One thread per tile: exclusive prefix over workgroups (coalesced across tiles).  Only tiles / 256 workgroups exist (27 at
+// 1066 x 1600), so the kernel is a chain of dependent round trips: 32 independent loads in flight per thread (8: 44 us).
 __global__ void __launch_bounds__(256) bin_scan_kernel(int tiles, int nb, uint32_t* __restrict__ table,
                                                        uint32_t* __restrict__ tile_count) {
+  constexpr int INFLIGHT = 32;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= tiles) return;
   uint32_t run = 0;
-  for (int b = 0; b < nb; b += 8) {
-    uint32_t v[8];
+  for (int b = 0; b < nb; b += INFLIGHT) {
+    uint32_t v[INFLIGHT];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = (b + k < nb) ? table[(size_t)(b + k) * tiles + t] : 0u;
+    for (int k = 0; k < INFLIGHT; k++) v[k] = (b + k < nb) ? table[(size_t)(b + k) * tiles + t] : 0u;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < INFLIGHT; k++) {
       if (b + k < nb) table[(size_t)(b + k) * tiles + t] = run;
       run += v[k];
     }
