@@ -408,6 +408,39 @@ def psnr(img1, img2):
     return 20 * torch.log10(1.0 / torch.sqrt(mse))
 
 
+_weight_cache: Dict = {}
+
+
+class _WeightedTerms(torch.autograd.Function):
+    """sum_i w_i * term_i  +  w_dx * mean|dx|   in three launches forward (L1 norm, stack, dot) and three backward (scale, sign,
+    multiply) instead of the ~19 five-microsecond launches the same expression costs term by term (train.py:404-425 adds the
+    regularisers one `loss = loss + ...` at a time; that section of the iteration is bound by the host's launch rate)."""
+
+    @staticmethod
+    def forward(ctx, dx, w_dx, weights, *terms):
+        vals = list(terms)
+        w = list(weights)
+        if dx is not None:
+            vals.append(torch.linalg.vector_norm(dx, ord=1))
+            w.append(w_dx / dx.numel())
+        key = (tuple(w), vals[0].device)
+        wt = _weight_cache.get(key)
+        if wt is None:     # the weights are constants of the run (the dx weight changes with P): one upload each
+            if len(_weight_cache) > 64:
+                _weight_cache.clear()
+            wt = _weight_cache[key] = torch.tensor(w, dtype=torch.float32, device=vals[0].device)
+        ctx.save_for_backward(wt, dx if dx is not None else wt)
+        ctx.has_dx, ctx.n = dx is not None, len(terms)
+        return torch.dot(torch.stack([v.reshape(()).float() for v in vals]), wt)
+
+    @staticmethod
+    def backward(ctx, g):
+        wt, dx = ctx.saved_tensors
+        gw = g * wt
+        g_dx = torch.sign(dx) * gw[-1] if ctx.has_dx else None
+        return (g_dx, None, None, *gw[:ctx.n].unbind(0))
+
+
 def training_loss(pc: GaussianParams, pkg: Dict, gt_image, gt_depth, gt_feat, hyper, opt, stage="fine", fused_pixel_terms=True):
     """train.py:395-425 for a batch of one view.  The per-pixel terms (L1, depth L2, DSSIM, feature L2) run as one fused
     pass (losses.photometric_loss); fused_pixel_terms=False evaluates them step by step like the reference."""
@@ -427,15 +460,30 @@ def training_loss(pc: GaussianParams, pkg: Dict, gt_image, gt_depth, gt_feat, hy
             loss = loss + opt.lambda_dssim * (1.0 - fused_ssim(image, gt))
         if use_feat:
             loss = loss + l2_loss(pkg["feat"], gt_feat) * opt.lambda_feat
-    if fine and not hyper.no_dx and opt.lambda_dx != 0:
-        loss = loss + torch.mean(torch.abs(pkg["dx"])) * opt.lambda_dx
-    if fine and not hyper.no_dshs and opt.lambda_dshs != 0:
-        dshs_l1 = pkg["dshs_l1"] if "dshs_l1" in pkg else torch.mean(torch.abs(pkg["dshs"]))
-        loss = loss + dshs_l1 * opt.lambda_dshs
-    if stage == "fine" and hyper.time_smoothness_weight != 0:
-        loss = loss + (pkg["plane_reg"] if pkg.get("plane_reg") is not None else
-                       pc.compute_regulation(hyper.time_smoothness_weight, hyper.l1_time_planes, hyper.plane_tv_weight))
-    return loss
+    want_dx = fine and not hyper.no_dx and opt.lambda_dx != 0
+    want_dshs = fine and not hyper.no_dshs and opt.lambda_dshs != 0
+    want_reg = stage == "fine" and hyper.time_smoothness_weight != 0
+    if not fused_pixel_terms:    # the reference's own sequence, one term at a time
+        if want_dx:
+            loss = loss + torch.mean(torch.abs(pkg["dx"])) * opt.lambda_dx
+        if want_dshs:
+            dshs_l1 = pkg["dshs_l1"] if "dshs_l1" in pkg else torch.mean(torch.abs(pkg["dshs"]))
+            loss = loss + dshs_l1 * opt.lambda_dshs
+        if want_reg:
+            loss = loss + (pkg["plane_reg"] if pkg.get("plane_reg") is not None else
+                           pc.compute_regulation(hyper.time_smoothness_weight, hyper.l1_time_planes, hyper.plane_tv_weight))
+        return loss
+    terms, weights = [loss], [1.0]
+    if want_dshs:
+        terms.append(pkg["dshs_l1"] if "dshs_l1" in pkg else torch.mean(torch.abs(pkg["dshs"])))
+        weights.append(float(opt.lambda_dshs))
+    if want_reg:
+        terms.append(pkg["plane_reg"] if pkg.get("plane_reg") is not None else
+                     pc.compute_regulation(hyper.time_smoothness_weight, hyper.l1_time_planes, hyper.plane_tv_weight))
+        weights.append(1.0)
+    if len(terms) == 1 and not want_dx:
+        return loss
+    return _WeightedTerms.apply(pkg["dx"] if want_dx else None, float(opt.lambda_dx), tuple(weights), *terms)
 
 
 def training_step(pc: GaussianParams, cam: Dict, gt_image, gt_depth, gt_feat, hyper, opt, bg, stage="fine",
