@@ -607,7 +607,8 @@ __global__ void __launch_bounds__(WG_WAVES * 64) mlp_wgrad_kernel(const WgradArg
   }
   // acc[m][n][r] of lane l is dW[GV * row + m][AV * col + n], row = acc_row(r, l), col = l & 31.  The waves add their blocks
   // into `red` ONE AFTER THE OTHER with plain read-modify-writes (the lanes of a wave own distinct elements): ds_add_f32 costs
-  // ~145 cycles per wave instruction on this chip, and 64 of them per wave were 13 % of every launch (1.27 -> 1.10 ms for the
+  // 192 cycles per wave instruction on this chip, serialised across the waves of the CU (tools/ubench/lds_atomics.hip), and 64
+  // of them per wave were 13 % of every launch (1.27 -> 1.10 ms for the
   // nine launches).  The order is fixed, so a workgroup's partial sums are reproducible.
   for (int w = 0; w < WG_WAVES; w++) {
     if (wave == w) {
