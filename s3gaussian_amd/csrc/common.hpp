@@ -20,19 +20,6 @@ inline bool first_call_on_this_device(std::atomic<uint64_t>& seen) {
   return (seen.fetch_or(bit) & bit) == 0;
 }
 
-// compute units of the current device (persistent-kernel grid sizing); cached per device ordinal
-inline int device_cu_count() {
-  static std::atomic<int> cached[64];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  int n = cached[dev & 63].load(std::memory_order_relaxed);
-  if (n <= 0) {
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cached[dev & 63].store(n, std::memory_order_relaxed);
-  }
-  return n;
-}
-
 constexpr int TILE_X = 16;  // reference BLOCK_X/BLOCK_Y, RAST/cuda_rasterizer/config.h:16-17
 constexpr int TILE_Y = 16;
 constexpr int TILE_PIX = TILE_X * TILE_Y;
