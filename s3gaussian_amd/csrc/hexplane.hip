@@ -4,23 +4,24 @@
 // [P,32] tensor, then 20 elementwise products and a concat; autograd replays the same 24 in backward.
 //
 // Planes are stored channel-last, so one texel = 32 channels = one 128-byte line.  Forward and the per-point backward give
-// a point to EIGHT lanes (4 channels each, one 16-byte load per texel): these kernels are VALU-bound on the bilinear-tap
-// arithmetic, which every lane of a point repeats -- 8 copies instead of 32.  The product over planes never leaves
-// registers.  Arithmetic follows torch's grid_sampler_2d (bilinear, border, align_corners=True) op for op; contraction
-// is off.  When all points share one timestamp (desc.uniform_time) the three (axis, t) planes of a level are first
-// collapsed to 1-D row tables (see "uniform time" below).
+// a point to EIGHT lanes (4 channels each, one 16-byte load per texel); the bilinear taps are computed once per point and
+// shared through LDS; points are processed in a 3-D blocked order, groups dealt to the XCDs in contiguous eighths.  The
+// product over planes never leaves registers.  Arithmetic follows torch's grid_sampler_2d (bilinear, border,
+// align_corners=True) op for op; contraction is off.  When all points share one timestamp (desc.uniform_time) the three
+// (axis, t) planes of a level are first collapsed to 1-D row tables (see "uniform time" below).
 //
 // Backward without an atomic storm.  A direct scatter is 96 line-coalesced float atomics per point; MI355X retires
 // ~10 G such line-ops/s whatever the contention (tools/ubench/atomic_lines.hip), i.e. 11.5 ms at 1.2 M points.  So:
-//   pass A  (point order)   re-gathers the taps, applies the product rule, writes dL/ds for all 24 plane-levels to a
-//                           scratch slab G[24][P][32] (3 KB per point -- HBM is 288 GB) and finishes dL/dxyz;
-//   sort    three 2-level counting sorts of the point indices by (major, minor) finest-level texel cell, one per plane
-//           orientation, with LDS histograms (no global atomics, no library sort); the orders only steer the walk, so the
-//           caller may keep them for several iterations (sort_state / sort_reuse);
+//   pass A  (blocked order) re-gathers the taps, applies the product rule, writes dL/ds for all 24 plane-levels to the
+//                           scratch G[P][24][32] (point-major: 3 KB per point, streamed -- HBM is 288 GB) and finishes dL/dxyz;
+//   sort    four 2-level counting sorts of the point indices -- by (major, minor) finest-level texel cell, one per plane
+//           orientation, and the blocked processing order -- with LDS histograms (no global atomics, no library sort); the
+//           orders only steer the walks, so the caller may keep them for several iterations (sort_state / sort_reuse);
 //   pass B  (sorted order, one launch for the three orientations = 2 plane kinds x all levels each): a half-wave (32
 //           lanes = the 32 channels) walks a run of spatially consecutive points keeping two bilinear footprints per
-//           (level, plane) in registers and only issues atomics when a footprint is evicted -- consecutive points share
-//           texels, so the 96 line-ops per point drop to ~7.  Taps are computed cooperatively (lane = point x tap) and
+//           (level, plane) in registers and only issues atomics when a footprint is evicted (two instead of four when the
+//           walk just steps to the neighbouring footprint) -- consecutive points share texels, so the 96 line-ops per point
+//           drop to ~5.  Taps are computed cooperatively (lane = point x tap) and
 //           shared through LDS; index, coordinate and tap computation run one to two groups ahead of the accumulation.
 #include "common.hpp"
 
@@ -105,19 +106,16 @@ __device__ __forceinline__ void point_coords(const HexArgs& a, int p, float* u) 
 __device__ constexpr int PAIR0[6] = {0, 0, 0, 1, 1, 2};
 __device__ constexpr int PAIR1[6] = {1, 2, 3, 2, 3, 3};
 
-__device__ __forceinline__ float4 fetch4(const float* __restrict__ plane, int off, int c4) {
-  return off >= 0 ? *reinterpret_cast<const float4*>(plane + (size_t)off * HEXC + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
 __device__ __forceinline__ float4 operator*(float4 a, float b) { return make_float4(a.x * b, a.y * b, a.z * b, a.w * b); }
 __device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
 // ---- per-point passes (forward, backward pass A) ----
 // EIGHT lanes own one point, four channels each (one 16-byte load per texel and lane; the 8 lanes read its 128-byte line).
-// These kernels are bound by VALU ISSUE (a wave64 instruction occupies its 16-lane SIMD for 4 cycles: 537 G wave-instructions
-// per second for the whole chip at 2.1 GHz), not by memory: replacing every texel address by one hot line changed nothing
-// (1.51 -> 1.49 ms), and instruction count x 4 cycles predicts the measured times to 10 %.  So instructions are what is saved:
+// The r1 kernels spent most of their instructions on work every lane of a point repeated; this version issues half of them
+// (forward 512 -> 268 VALU instructions per level, pass A 907 -> 585).  That did NOT make them faster by itself -- the forward is
+// bound by the rate the L1 takes 128-byte lines plus its feature stores, pass A by memory latency at two waves per SIMD (SQ
+// counters: DESIGN.md 6) -- but it is what the SIMDs no longer burn:
 //   * the bilinear tap of a (level, plane) is computed ONCE per point -- lane j < 6 of the point's eight computes plane j of
 //     every level -- and shared through LDS as 16 bytes (packed nw key + flags, ix - x0, iy - y0); the r1 kernels repeated
 //     make_tap in all eight lanes (6 x ~45 instructions per level and lane);
@@ -230,7 +228,6 @@ __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) 
 __device__ constexpr int ORI_OF[6] = {0, 2, 0, 1, 1, 2};   // plane i -> orientation pass that scatters it
 __device__ constexpr int KIND_OF[6] = {0, 0, 1, 0, 1, 1};  // 0 = spatial plane of the pass, 1 = its time plane
 
-__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
 // Same lane mapping and tap sharing as the forward.  Per plane only the sample s and its two coordinate derivatives are kept:
 // ds/dix = (ne - nw)(y1 - iy) + (se - sw)(iy - y0),  ds/diy = (sw - nw)(x1 - ix) + (se - ne)(ix - x0)  (the four terms of
