@@ -139,15 +139,23 @@ __host__ __device__ constexpr int tap_stride(int levels) { return levels * TAP_S
 // lane role j < 6: plane j of every level for the lane's point -> tapbuf[slot][l][j]
 __device__ __forceinline__ void produce_taps(const HexArgs& a, const float* u, int j, float4* __restrict__ taps /* [levels][TAP_SLOTS] of this point */) {
   if (j >= 6) return;
-  // plane j = axes (a0, a1) in itertools.combinations order: (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); selects on lane-role
-  // predicates (an indexed u[] / res[] would go through scratch memory)
+  // plane j = axes (a0, a1) in itertools.combinations order: (0,1) (0,2) (0,3) (1,2) (1,3) (2,3).  The lane's two resolutions
+  // are picked out of the level's four by SHIFTS of two packed 64-bit values: an indexed res[] -- and a chain of selects, which
+  // the compiler turns back into one -- goes through scratch memory, a serial memory round trip at the head of every group.
+  const int a0 = j < 3 ? 0 : (j < 5 ? 1 : 2), a1 = j < 3 ? j + 1 : (j < 5 ? j - 1 : 3);
   const bool a0_is0 = j < 3, a0_is1 = j == 3 || j == 4;
   const bool a1_is1 = j == 0, a1_is2 = j == 1 || j == 3;
-  const float ua = a0_is0 ? u[0] : (a0_is1 ? u[1] : u[2]);
-  const float ub = a1_is1 ? u[1] : (a1_is2 ? u[2] : u[3]);
+  // (the same for the coordinates: selects between loads of one private array are rewritten by the compiler into ONE load
+  // with a selected index, i.e. the array is spilled to scratch and read back; the empty asm makes them plain registers)
+  float u0 = u[0], u1 = u[1], u2 = u[2], u3 = u[3];
+  asm volatile("" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));
+  const float ua = a0_is0 ? u0 : (a0_is1 ? u1 : u2);
+  const float ub = a1_is1 ? u1 : (a1_is2 ? u2 : u3);
   for (int l = 0; l < a.d.levels; l++) {
-    const int r0 = a.d.res[l][0], r1 = a.d.res[l][1], r2 = a.d.res[l][2], r3 = a.d.res[l][3];
-    const int W = a0_is0 ? r0 : (a0_is1 ? r1 : r2), H = a1_is1 ? r1 : (a1_is2 ? r2 : r3);
+    const uint64_t lo = (uint64_t)(uint32_t)a.d.res[l][0] | ((uint64_t)(uint32_t)a.d.res[l][1] << 32);
+    const uint64_t hi = (uint64_t)(uint32_t)a.d.res[l][2] | ((uint64_t)(uint32_t)a.d.res[l][3] << 32);
+    const int W = (int)(uint32_t)((a0 < 2 ? lo : hi) >> (32 * (a0 & 1)));
+    const int H = (int)(uint32_t)((a1 < 2 ? lo : hi) >> (32 * (a1 & 1)));
     const Tap t = make_tap(ua, ub, W, H);
     const uint32_t flags = (t.o01 >= 0 ? 1u : 0u) | (t.o10 >= 0 ? 2u : 0u) | (t.mx != 0.f ? 4u : 0u) | (t.my != 0.f ? 8u : 0u);
     taps[l * TAP_SLOTS + j] = make_float4(__uint_as_float(((uint32_t)t.o00 << 4) | flags), t.ix - t.x0f, t.iy - t.y0f, 0.f);
