@@ -420,6 +420,8 @@ class _WeightedTerms(torch.autograd.Function):
     def forward(ctx, dx, w_dx, weights, *terms):
         vals = list(terms)
         w = list(weights)
+        if dx is not None and dx.numel() == 0:   # no Gaussians: mean|dx| of the reference is NaN; it contributes nothing here
+            dx = None
         if dx is not None:
             vals.append(torch.linalg.vector_norm(dx, ord=1))
             w.append(w_dx / dx.numel())
@@ -437,7 +439,7 @@ class _WeightedTerms(torch.autograd.Function):
     def backward(ctx, g):
         wt, dx = ctx.saved_tensors
         gw = g * wt
-        g_dx = torch.sign(dx) * gw[-1] if ctx.has_dx else None
+        g_dx = torch.sign(dx) * gw[-1] if ctx.has_dx else None   # (None also for an empty dx: no gradient to give)
         return (g_dx, None, None, *gw[:ctx.n].unbind(0))
 
 

@@ -36,3 +36,10 @@ def test_weights_are_uploaded_once_per_configuration():
     for _ in range(3):
         _WeightedTerms.apply(None, 0.0, (1.0, 0.25), a, b)
     assert len(pipeline._weight_cache) == 1
+
+
+def test_empty_dx_contributes_nothing():
+    a = torch.tensor(0.5, requires_grad=True)
+    out = _WeightedTerms.apply(torch.zeros(0, 3, requires_grad=True), 0.01, (2.0,), a)
+    out.backward()
+    assert float(out) == 1.0 and float(a.grad) == 2.0
