@@ -31,7 +31,6 @@ namespace s3g {
 
 constexpr int HEXC = S3G_HEX_CHANNELS;
 typedef float f4v __attribute__((ext_vector_type(4)));
-constexpr bool G_POINT_MAJOR = true;         // G rows of a point contiguous, points in PROCESSING order (pass A streams its stores)
 constexpr bool G_NONTEMPORAL = true;         // streaming stores of the gradient slab: point pass 1.83 -> 1.60 ms
 constexpr bool FEAT_NONTEMPORAL = true;      // forward's feature rows
 constexpr bool GFEAT_NONTEMPORAL = true;     // point pass: dL/dfeature rows (read once)
@@ -231,8 +230,9 @@ __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) 
 }
 
 // ---- pass A: per point, dL/ds for every plane-level -> G, and dL/dxyz ----
-// G layout: slab (orientation o, level l, kind q) = G + (((o * levels + l) * 2 + q) * P + rank_o[p]) * 32, i.e. every
-// orientation's rows are stored in THAT orientation's sorted order, so pass B streams them sequentially.
+// G layout (point-major): the 24 rows of a point are contiguous, points in PROCESSING order, so pass A streams its stores:
+// row (orientation o, level l, kind q) of processing position pi = G + ((pi * 3 + o) * levels + l) * 2 + q) * 32; pass B reads
+// the 1 KB of an orientation by the position comp[o][k] of its k-th point.
 __device__ constexpr int ORI_OF[6] = {0, 2, 0, 1, 1, 2};   // plane i -> orientation pass that scatters it
 __device__ constexpr int KIND_OF[6] = {0, 0, 1, 0, 1, 1};  // 0 = spatial plane of the pass, 1 = its time plane
 
@@ -332,7 +332,7 @@ __device__ __forceinline__ void samples_level(const HexArgs& a, const float4* __
 }
 template <typename V>
 __device__ __forceinline__ void finish_level(const HexArgs& a, int l, int c0, const LevelS<V>& S, V g, bool store,
-                                             float* __restrict__ G, size_t PL, const uint32_t* rk, size_t gbase, float* du) {
+                                             float* __restrict__ G, size_t gbase, float* du) {
   // product rule in the order autograd applies it to ((((1*s0)*s1)*s2)*s3)*s4)*s5: pre[i] = prod_{j<i} s_j, suffix by recursion
   V pre[6];
   pre[0] = vsplat<V>(1.f);
@@ -344,9 +344,8 @@ __device__ __forceinline__ void finish_level(const HexArgs& a, int l, int c0, co
     const V gi = gs * pre[i];  // dL/ds_i
     gs = gs * S.s[i];
     if (store) {
-      V* grow = G_POINT_MAJOR
-                    ? reinterpret_cast<V*>(G + gbase + (size_t)(((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * HEXC + c0))
-                    : reinterpret_cast<V*>(G + (size_t)((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * PL + ((size_t)rk[ORI_OF[i]] * HEXC + c0));
+      // point-major G: row (orientation, level, kind) of this point's block, gbase = processing position * 24 rows
+      V* grow = reinterpret_cast<V*>(G + gbase + (size_t)(((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * HEXC + c0));
       if (G_NONTEMPORAL) __builtin_nontemporal_store(gi, grow);   // written once, read once by the scatter pass much later
       else *grow = gi;
       if (PAIR0[i] < 3) du[PAIR0[i]] += S.mx[i] * vdot(S.dX[i], gi);
@@ -357,23 +356,17 @@ __device__ __forceinline__ void finish_level(const HexArgs& a, int l, int c0, co
 
 using PointV = f4v;    // channels per lane of pass A (f2v_: 106 VGPRs = 4 waves per SIMD, but 1.73 vs 1.53 ms)
 template <bool UT, typename V, int LV>   // LV > 0: level count at compile time (unrolled: the per-level plane pointers and resolutions are fetched up front instead of four dependent scalar loads per level)
-__global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexArgs a, float* __restrict__ G,
-                                                                      const uint32_t* __restrict__ rank_all) {
+__global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexArgs a, float* __restrict__ G) {
   constexpr int CPL = vec_of<V>::N, LPP = HEXC / CPL, PPW = 256 / LPP;   // channels per lane, lanes per point, points per workgroup
   extern __shared__ float4 tapbuf[];   // [PPW points][levels][TAP_SLOTS]
   const int j = threadIdx.x & (LPP - 1), c0 = j * CPL, slot = threadIdx.x / LPP;
   const int L = LV > 0 ? LV : a.d.levels;
   const int F = L * HEXC;
-  const size_t PL = (size_t)a.P * HEXC;  // one slab of G
   float4* taps = tapbuf + (size_t)slot * tap_stride(L);
   for (int p0 = xcd_group(blockIdx.x, gridDim.x) * PPW; p0 < a.P; p0 += gridDim.x * PPW) {  // uniform trip count: shuffles below need all lanes
     const int pi = p0 + slot;
     const bool live = pi < a.P;
     const int p = live ? (a.proc_order ? (int)a.proc_order[pi] : pi) : 0;
-    uint32_t rk[3] = {0u, 0u, 0u};   // slab layout: this point's row in the slabs of the three orientations
-    if (!G_POINT_MAJOR)
-#pragma unroll
-      for (int o = 0; o < 3; o++) rk[o] = rank_all[(size_t)o * a.P + p];
     const size_t gbase = (size_t)pi * (size_t)(6 * L * HEXC);   // point-major layout: 24 rows of this PROCESSING position
     float u[4];
     point_coords(a, p, u);
@@ -388,7 +381,7 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
       LevelS<V> S;
       issue_level<UT>(a, taps, l, c0, grow, X);
       samples_level<UT>(a, taps, l, c0, X, S);
-      finish_level(a, l, c0, S, X.g, live, G, PL, rk, gbase, du);
+      finish_level(a, l, c0, S, X.g, live, G, gbase, du);
     }
     // sum over the 32 channels (the lanes of this point), then undo the aabb normalisation
 #pragma unroll
@@ -445,8 +438,7 @@ struct SortWork {
   uint32_t* seg_start;  // [4][SORT_BINS + 1]
   uint32_t* tmp;        // [4][P]  indices grouped by major key
   uint32_t* order;      // [3][P]  final orders of the three orientation walks
-  uint32_t* rank;       // [3][P]  slab layout: inverse permutations, rank[o][order[o][k]] = k; point-major G: comp[o][k] =
-                        //         position of point order[o][k] in the processing order
+  uint32_t* comp;       // [3][P]  comp[o][k] = position of point order[o][k] in the processing order (where its G rows are)
   uint32_t* proc;       // [P]     order 3: processing order of the per-point passes
 };
 __device__ __forceinline__ uint32_t* order_of(const SortWork& w, int o, int P) { return o < 3 ? w.order + (size_t)o * P : w.proc; }
@@ -701,7 +693,6 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   if (k0 >= a.P) return;  // whole walkers drop out; the LDS traffic below is private to a walker (wave-ordered)
   const uint32_t* order = order_all + (size_t)o * a.P;
   const uint32_t* comp = comp_all + (size_t)o * a.P;
-  const size_t PL = (size_t)a.P * HEXC;
   const size_t GP = (size_t)(6 * a.d.levels * HEXC);   // point-major layout: floats per point
   const int i0 = PLA[o], i1 = PLT[o];
   const int ip = (j & 1) ? i1 : i0;                   // the plane of this lane's tap
@@ -742,35 +733,25 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
     load_coords(load_index(k0 + 4), un);
     int pnn = load_index(k0 + 8);      // index of the group after next
     // point-major G: processing positions of this group's four points, fetched a group ahead (G's addresses depend on them)
-    uint32_t cpos[4] = {0u, 0u, 0u, 0u}, cpos_n[4] = {0u, 0u, 0u, 0u};
-    if (G_POINT_MAJOR) {
+    uint32_t cpos[4], cpos_n[4];
 #pragma unroll
-      for (int qq = 0; qq < 4; qq++) cpos[qq] = comp[min(k0 + qq, k1 - 1)];
-    }
+    for (int qq = 0; qq < 4; qq++) cpos[qq] = comp[min(k0 + qq, k1 - 1)];
     int buf = 0;
     for (int kb = k0; kb < k1; kb += 4, buf ^= 1) {
-      if (G_POINT_MAJOR) {
 #pragma unroll
-        for (int qq = 0; qq < 4; qq++) cpos_n[qq] = comp[min(kb + 4 + qq, k1 - 1)];
-      }
+      for (int qq = 0; qq < 4; qq++) cpos_n[qq] = comp[min(kb + 4 + qq, k1 - 1)];
       // 1. this group's G rows: 4 points x 2 LG rows requested at once
       T g[4][LG][2];
 #pragma unroll
       for (int qq = 0; qq < 4; qq++) {
-        const size_t k = (size_t)min(kb + qq, k1 - 1);
 #pragma unroll
         for (int l = 0; l < LG; l++) {
-          // unconditional (level clamped; slabs exist for every plane): a load behind a uniform branch costs two branch
+          // unconditional (level clamped; rows exist for every plane): a load behind a uniform branch costs two branch
           // instructions and splits the basic block the scheduler could have filled
           const int lv = min(l0 + l, a.d.levels - 1);
-          if (G_POINT_MAJOR) {
-            const float* row = G + (size_t)cpos[qq] * GP + (size_t)(((o * a.d.levels + lv) * 2) * HEXC + c);
-            g[qq][l][0] = load_g<T>(row);
-            g[qq][l][1] = load_g<T>(row + HEXC);
-          } else {
-            g[qq][l][0] = load_g<T>(&G[(size_t)((o * a.d.levels + lv) * 2 + 0) * PL + k * HEXC + c]);
-            g[qq][l][1] = load_g<T>(&G[(size_t)((o * a.d.levels + lv) * 2 + 1) * PL + k * HEXC + c]);
-          }
+          const float* row = G + (size_t)cpos[qq] * GP + (size_t)(((o * a.d.levels + lv) * 2) * HEXC + c);
+          g[qq][l][0] = load_g<T>(row);
+          g[qq][l][1] = load_g<T>(row + HEXC);
         }
       }
 #pragma unroll
@@ -1259,7 +1240,7 @@ static void carve_backward(Carver& c, const s3g_hexplane_desc* d, int P, bool wa
   s.seg_start = c.take<uint32_t>((size_t)N_ORDERS * (SORT_BINS + 1));
   s.tmp = c.take<uint32_t>(N_ORDERS * n);
   s.order = c.take<uint32_t>(3 * n);
-  s.rank = c.take<uint32_t>(3 * n);
+  s.comp = c.take<uint32_t>(3 * n);
   s.proc = c.take<uint32_t>(n);
   float* du = walk ? c.take<float>(6 * n) : nullptr;
   uint16_t* bm = walk ? c.take<uint16_t>(3 * n) : nullptr;
@@ -1302,7 +1283,7 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
   carve_backward(c, d, P, walk, &G, &tables, &w, &dup, &badmask);
   if (sort_state) {  // caller-owned, persistent
     w.order = sort_state;
-    w.rank = sort_state + (size_t)3 * P;
+    w.comp = sort_state + (size_t)3 * P;
     w.proc = sort_state + (size_t)6 * P;
   }
 
@@ -1313,12 +1294,9 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     hipLaunchKernelGGL(hexsort_scan_kernel, dim3(N_ORDERS), dim3(512), 0, stream, w, P);
     hipLaunchKernelGGL(hexsort_major_kernel<true>, dim3(SORT_NB, N_ORDERS), dim3(256), 0, stream, a, w, chunk);
     hipLaunchKernelGGL(hexsort_minor_kernel, dim3(SORT_BINS, N_ORDERS), dim3(256), 0, stream, a, w);
-    if (G_POINT_MAJOR) {   // w.rank holds comp[o][k]; the inverse of the processing order goes through w.tmp (free after the sorts)
-      hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 1), dim3(256), 0, stream, P, w.proc, w.tmp);
-      hipLaunchKernelGGL(hexsort_compose_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.tmp, w.rank);
-    } else {
-      hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.rank);
-    }
+    // comp[o][k]; the inverse of the processing order goes through w.tmp (free after the sorts)
+    hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 1), dim3(256), 0, stream, P, w.proc, w.tmp);
+    hipLaunchKernelGGL(hexsort_compose_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.tmp, w.comp);
     S3G_HIP_CHECK(hipGetLastError());
   }
   //    (the sorts above used the real resolutions; from here on the time planes are height-1 row tables if uniform_time)
@@ -1347,18 +1325,18 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     constexpr int ppw = 256 / (HEXC / vec_of<PointV>::N);   // points per workgroup
     const int pblocks = (P + ppw - 1) / ppw;
     const size_t lds = (size_t)ppw * tap_stride(d->levels) * sizeof(float4);
-    if (d->uniform_time && d->levels == 4) hipLaunchKernelGGL((hexplane_backward_point_kernel<true, PointV, 4>), dim3(pblocks), dim3(256), lds, stream, a, G, w.rank);
-    else if (d->uniform_time) hipLaunchKernelGGL((hexplane_backward_point_kernel<true, PointV, 0>), dim3(pblocks), dim3(256), lds, stream, a, G, w.rank);
-    else hipLaunchKernelGGL((hexplane_backward_point_kernel<false, PointV, 0>), dim3(pblocks), dim3(256), lds, stream, a, G, w.rank);
+    if (d->uniform_time && d->levels == 4) hipLaunchKernelGGL((hexplane_backward_point_kernel<true, PointV, 4>), dim3(pblocks), dim3(256), lds, stream, a, G);
+    else if (d->uniform_time) hipLaunchKernelGGL((hexplane_backward_point_kernel<true, PointV, 0>), dim3(pblocks), dim3(256), lds, stream, a, G);
+    else hipLaunchKernelGGL((hexplane_backward_point_kernel<false, PointV, 0>), dim3(pblocks), dim3(256), lds, stream, a, G);
     profile_end(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream, (double)P, (double)d->levels);
     S3G_HIP_CHECK(hipGetLastError());
     profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
     using ScatterT = std::conditional<SCATTER_CPL == 2, f2v, float>::type;
     constexpr int walkers = 256 / (HEXC / SCATTER_CPL);
     if (d->uniform_time)
-      hipLaunchKernelGGL((hexplane_scatter_kernel<true, ScatterT>), dim3((nseg + walkers - 1) / walkers, 3), dim3(256), 0, stream, a, G, w.order, w.rank);
+      hipLaunchKernelGGL((hexplane_scatter_kernel<true, ScatterT>), dim3((nseg + walkers - 1) / walkers, 3), dim3(256), 0, stream, a, G, w.order, w.comp);
     else
-      hipLaunchKernelGGL((hexplane_scatter_kernel<false, ScatterT>), dim3((nseg + walkers - 1) / walkers, 3), dim3(256), 0, stream, a, G, w.order, w.rank);
+      hipLaunchKernelGGL((hexplane_scatter_kernel<false, ScatterT>), dim3((nseg + walkers - 1) / walkers, 3), dim3(256), 0, stream, a, G, w.order, w.comp);
     profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
   }
   if (d->uniform_time) {
