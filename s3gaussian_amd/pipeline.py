@@ -127,6 +127,51 @@ class GaussianParams(nn.Module):
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         return self.optimizer
 
+    # ---- optional maintenance: keep the Gaussians in a spatially coherent order ------------------------------------------
+    @torch.no_grad()
+    def reorder_spatially(self, cells: int = 1024):
+        """Permute the Gaussians into the Morton (3-D blocked) order of their positions: every per-Gaussian parameter, its Adam
+        moments, the densification accumulators and the deformation table move together, the Parameter objects stay the same
+        (optimizer groups and data-parallel reducers keep working).  The index of a Gaussian has no meaning in the reference
+        (densify / prune reshuffle them, scene/gaussian_model.py:397-494), so this changes no result beyond the tie-break of
+        exactly equal depths; what it buys is locality: neighbouring lanes then read neighbouring texels, tiles and rows
+        WITHOUT a processing-order indirection.  Not called by training_step / bench.py.
+        Returns the permutation: new[i] = old[perm[i]]."""
+        xyz = self._xyz.detach()
+        lo, hi = xyz.min(dim=0).values, xyz.max(dim=0).values
+        q = ((xyz - lo) / (hi - lo).clamp_min(1e-12) * (cells - 1)).long().clamp_(0, cells - 1)
+
+        def spread(v):   # 10 bits -> every third bit
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+
+        key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        perm = torch.argsort(key, stable=True)
+        params = [self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity]
+        opt = getattr(self, "optimizer", None)
+        for p in params:
+            p.data = p.data[perm].contiguous()
+            torch.autograd.graph.increment_version(p)
+            st = opt.state.get(p) if opt is not None else None
+            if st:
+                for name in ("exp_avg", "exp_avg_sq"):
+                    if name in st:
+                        st[name] = st[name][perm].contiguous()
+        for name in ("max_radii2D", "xyz_gradient_accum", "denom", "_deformation_table"):
+            t_ = getattr(self, name, None)
+            if isinstance(t_, torch.Tensor) and t_.shape[:1] == perm.shape:
+                setattr(self, name, t_[perm].contiguous())
+        # cached spatial orders of the sampler hold point indices of the old order; the rasterizer's geometry cache likewise
+        grid = getattr(self._deformation.deformation_net, "grid", None)
+        if grid is not None and hasattr(grid, "_order_cache"):
+            grid._order_cache.clear()
+        if self._xyz.is_cuda:
+            from . import raster_C
+            raster_C.invalidate_geometry_cache()
+        return perm
+
     # ---- checkpoint / point-cloud I/O with the reference's formats (SURVEY 8f row 4) -------------------------------------
     def capture(self):
         """The 14-tuple of scene/gaussian_model.py:71-88 (what train.py saves with torch.save)."""
