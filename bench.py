@@ -309,6 +309,18 @@ def time_alt_paths(pc, cams, views, targets, tkeys, hyper, opt, bg, steps=4, war
     return out
 
 
+def workload_label(a):
+    """Name of the workload, derived from the arguments: a BASELINE.json config name only when the run IS that config."""
+    std = (a.width, a.height, a.frames, a.scale_mult) == (1600, 1066, 50, 1.0)
+    if std and a.P == 1_200_000:
+        return "BASELINE cfg3 (configs[2])" if a.gpus == 1 else f"BASELINE cfg4 (configs[3]: cfg3 view-parallel over {a.gpus} ranks)"
+    if std and a.P == 600_000:
+        return "BASELINE cfg2 (configs[1])"
+    if std and a.P == 2_500_000:
+        return "BASELINE cfg5 size (configs[4], densified count)"
+    return f"synthetic street scene, NOT a BASELINE config (scale_mult {a.scale_mult})"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,6 +334,9 @@ def main():
     ap.add_argument("--no-alt-paths", action="store_true", help="skip timing the zero_diff / import_swap call paths")
     ap.add_argument("--scale-mult", type=float, default=1.0,
                     help="multiply every Gaussian's scale: larger splats -> more (tile, Gaussian) instances R per view (R-sweep)")
+    ap.add_argument("--reorder", action="store_true",
+                    help="keep the Gaussians themselves in Morton order (GaussianParams.reorder_spatially() once after the scene is "
+                         "built; a real run repeats it after every densification)")
     a = ap.parse_args()
 
     from s3gaussian_amd import _lib, dp
@@ -337,6 +352,8 @@ def main():
     L.s3g_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
 
     pc, cams, hyper, opt, bg = build_scene(a.P, a.width, a.height, a.frames, device, scale_mult=a.scale_mult)
+    if a.reorder:
+        pc.reorder_spatially()
     my_views = dp.shard_views(len(cams), rank, world, seed=0)
     n_needed = a.steps + a.warmup
     views = [my_views[i % len(my_views)] for i in range(n_needed)]
@@ -508,10 +525,10 @@ def main():
             "metric": "train_iters_per_sec", "value": round(world * a.steps / dt, 3), "unit": "iters/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE cfg3: {a.P} Gaussians, {a.height}x{a.width}, 3 cams x {a.frames} frames, fine stage "
+            "config": {"workload": workload_label(a) + f": {a.P} Gaussians, {a.height}x{a.width}, 3 cams x {a.frames} frames, fine stage "
                                    "(hexplane+deformation ON), RGB+depth render + feature render, L1+DSSIM+depthL2+featL2+regs, Adam",
                        "path": "fused", "gaussians": a.P, "image": [a.height, a.width], "views_per_step_per_rank": 1,
-                       "scale_mult": a.scale_mult, "instances_R_per_view": round(R_mean), "visible_V_per_view": round(V),
+                       "scale_mult": a.scale_mult, "gaussians_in_morton_order": bool(a.reorder), "instances_R_per_view": round(R_mean), "visible_V_per_view": round(V),
                        "mean_tile_list_length": round(R_mean / (((a.width + 15) // 16) * ((a.height + 15) // 16)), 1),
                        "densify_bookkeeping_in_step": True,
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",

@@ -31,8 +31,9 @@ if [ ! -d "$RAST/cuda_rasterizer" ]; then
     echo "build_ref: $RAST not present, keeping prebuilt oracle/_ref" >&2
     exit 0
 fi
-if [ -f "$OUT/libref_raster.so" ] && [ -f "$OUT/libref_raster_fma.so" ] && [ "${1:-}" != "-f" ] \
-   && [ "$OUT/libref_raster.so" -nt "$HERE/ref_shim.cpp" ] && [ "$OUT/libref_raster.so" -nt "$HERE/build_ref.sh" ]; then
+if [ -f "$OUT/libref_raster.so" ] && [ -f "$OUT/libref_raster_fma.so" ] && [ -f "$OUT/libref_knn.so" ] && [ "${1:-}" != "-f" ] \
+   && [ "$OUT/libref_raster.so" -nt "$HERE/ref_shim.cpp" ] && [ "$OUT/libref_raster.so" -nt "$HERE/build_ref.sh" ] \
+   && [ "$OUT/libref_knn.so" -nt "$HERE/ref_knn_shim.cpp" ] && [ "$OUT/libref_knn.so" -nt "$HERE/build_ref.sh" ]; then
     exit 0
 fi
 
@@ -65,4 +66,16 @@ build_one() {   # $1 = output name, rest = extra flags
 }
 build_one libref_raster.so -ffp-contract=off
 build_one libref_raster_fma.so
-echo "build_ref: wrote $OUT/libref_raster.so $OUT/libref_raster_fma.so"
+
+# ---- simple-knn (distCUDA2): submodules/simple-knn/simple_knn.{cu,h} -> rocthrust / hipcub via hipify-perl, same recipe ----------
+#   oracle/_ref/libref_knn.so   -ffp-contract=off (squared distances are three products + two adds: comparable bit for bit)
+KNN="${S3G_REFERENCE:-/root/reference}/submodules/simple-knn"
+mkdir -p "$TMP/knn"
+"$HIPIFY" "$KNN/simple_knn.cu" 2>/dev/null \
+  | sed -e '/#include ""/d' -e '/cooperative_groups\/reduce.h/d' -e '/device_radix_sort/d' -e '/#define __CUDACC__/d' \
+        -e 's/<< </<<</g' -e 's/>> >/>>>/g' > "$TMP/knn/simple_knn.hip"
+"$HIPIFY" "$KNN/simple_knn.h" 2>/dev/null > "$TMP/knn/simple_knn.h"
+"$HIPCC" --offload-arch="$ARCH" -O3 -std=c++17 -fPIC -w -ffp-contract=off -include cfloat -I"$TMP/knn" -c "$TMP/knn/simple_knn.hip" -o "$TMP/knn/simple_knn.o"
+"$HIPCC" --offload-arch="$ARCH" -O3 -std=c++17 -fPIC -w -I"$TMP/knn" -x hip -c "$HERE/ref_knn_shim.cpp" -o "$TMP/knn/shim.o"
+"$HIPCC" --offload-arch="$ARCH" -shared -fPIC "$TMP/knn/simple_knn.o" "$TMP/knn/shim.o" -o "$OUT/libref_knn.so"
+echo "build_ref: wrote $OUT/libref_raster.so $OUT/libref_raster_fma.so $OUT/libref_knn.so"

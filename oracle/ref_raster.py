@@ -140,3 +140,23 @@ class _Handle:
         if self.h:
             self.lib.ref_free(self.h)
             self.h = None
+
+
+def knn_available() -> bool:
+    return os.path.exists(os.path.join(REF_DIR, "libref_knn.so"))
+
+
+def ref_knn_mean_dist2(points: np.ndarray) -> np.ndarray:
+    """The REFERENCE's own SimpleKNN::knn (simple_knn.cu:185-221, oracle/_ref/libref_knn.so via oracle/ref_knn_shim.cpp) on the
+    GPU of the box: float32 [P,3] -> float32 [P] (what `distCUDA2` returns, spatial.cu:15-26)."""
+    path = os.path.join(REF_DIR, "libref_knn.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} missing: run oracle/build_ref.sh where /root/reference exists")
+    lib = C.CDLL(path)
+    lib.ref_knn_mean_dist2.restype = C.c_int
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    out = np.zeros(pts.shape[0], np.float32)
+    rc = lib.ref_knn_mean_dist2(int(pts.shape[0]), pts.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != 0:
+        raise RuntimeError(f"ref_knn_mean_dist2 failed ({rc})")
+    return out

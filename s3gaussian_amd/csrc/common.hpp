@@ -12,12 +12,19 @@
 namespace s3g {
 
 // hipFuncSetAttribute is per DEVICE: a process that drives several GPUs (one Python process, two `cuda:k` tensors) must
-// raise the dynamic-LDS limit on each of them.  True the first time it is called with `seen` on the current device.
-inline bool first_call_on_this_device(std::atomic<uint64_t>& seen) {
+// raise the dynamic-LDS limit on each of them.  Protocol: `if (device_needs_setup(seen)) { ...S3G_HIP_CHECK(set attrs)...;
+// device_setup_done(seen); }` -- the bit is set only AFTER every attribute call succeeded (a failed attempt is retried by the
+// next call instead of leaving the limit low for good), two host threads racing here both set the (idempotent) attributes
+// before either launches, and device ids >= 64 simply repeat the cheap attribute calls every time instead of aliasing.
+inline bool device_needs_setup(const std::atomic<uint64_t>& seen) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const uint64_t bit = 1ull << (dev & 63);
-  return (seen.fetch_or(bit) & bit) == 0;
+  return dev >= 64 || (seen.load(std::memory_order_acquire) & (1ull << dev)) == 0;
+}
+inline void device_setup_done(std::atomic<uint64_t>& seen) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 64) seen.fetch_or(1ull << dev, std::memory_order_release);
 }
 
 constexpr int TILE_X = 16;  // reference BLOCK_X/BLOCK_Y, RAST/cuda_rasterizer/config.h:16-17

@@ -287,9 +287,10 @@ extern "C" int s3g_knn_mean_dist2(int P, const float* points, float* meanDists, 
   const int nb = KNN_SPLIT_BLOCKS;
   const int chunk = (((P + nb - 1) / nb + 1023) / 1024) * 1024;
   static std::atomic<uint64_t> attr_set{0};
-  if (first_call_on_this_device(attr_set)) {
+  if (device_needs_setup(attr_set)) {
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)knn_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KNN_CELLS * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)knn_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KNN_CELLS * 4));
+    device_setup_done(attr_set);
   }
   hipLaunchKernelGGL(knn_minmax_kernel, dim3(nb), dim3(256), 0, stream, P, points, w.partial);
   hipLaunchKernelGGL(knn_minmax_final_kernel, dim3(1), dim3(64), 0, stream, nb, w.partial, w.mm);

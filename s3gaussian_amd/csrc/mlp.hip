@@ -654,9 +654,10 @@ extern "C" size_t s3g_deform_mlp_pack_bytes(void) { return (size_t)PACK_FLOATS *
 
 static int mlp_set_attrs() {
   static std::atomic<uint64_t> done{0};
-  if (first_call_on_this_device(done)) {
+  if (device_needs_setup(done)) {
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
+    device_setup_done(done);
   }
   return S3G_OK;
 }

@@ -745,11 +745,12 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   // atomic-free binning, counting half
   const size_t bin_lds = ((size_t)band + 8) * sizeof(uint32_t);
   static std::atomic<uint64_t> bin_attr_set{0};
-  if (first_call_on_this_device(bin_attr_set)) {
+  if (device_needs_setup(bin_attr_set)) {
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)bin_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (MAX_TILES_LDS + 8) * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)bin_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (MAX_TILES_LDS + 8) * 4));
+    device_setup_done(bin_attr_set);
   }
   BinArgs ba;
   ba.P = P; ba.gx = gx; ba.tiles = tiles; ba.chunk = chunk; ba.rect = g.rect; ba.depths = g.depths;
@@ -810,9 +811,10 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
     if (max_tile > SMALL) {
       const uint32_t large_cap = max_tile < LARGE ? max_tile : LARGE;
       static std::atomic<uint64_t> attr_set{0};
-      if (first_call_on_this_device(attr_set)) {
+      if (device_needs_setup(attr_set)) {
         S3G_HIP_CHECK(hipFuncSetAttribute((const void*)sort_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           LARGE * 8));
+        device_setup_done(attr_set);
       }
       hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)large_cap * 8, stream, tiles, gx,
                          im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, b.slot_pos, SMALL, 0xffffffffu, large_cap);

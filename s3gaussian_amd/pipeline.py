@@ -153,6 +153,8 @@ class GaussianParams(nn.Module):
         opt = getattr(self, "optimizer", None)
         for p in params:
             p.data = p.data[perm].contiguous()
+            if p.grad is not None:      # a pending gradient (called between backward and step) follows its Gaussian
+                p.grad = p.grad[perm].contiguous()
             torch.autograd.graph.increment_version(p)
             st = opt.state.get(p) if opt is not None else None
             if st:
@@ -192,6 +194,9 @@ class GaussianParams(nn.Module):
         self.training_setup(training_args)
         self.xyz_gradient_accum, self.denom = xyz_gradient_accum, denom
         self.optimizer.load_state_dict(opt_dict)
+        for st in self.optimizer.state.values():   # torch.load(map_location="cuda") puts the step counters on the GPU, where
+            if torch.is_tensor(st.get("step")):    # reading them would cost one host sync per parameter and step
+                st["step"] = st["step"].cpu()
 
     def construct_list_of_attributes(self):
         """scene/gaussian_model.py:220-234."""
@@ -363,13 +368,17 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
                                                    shs=shs_final, colors_precomp=colors_precomp, scales=scales_final,
                                                    rotations=rotations_final, cov3D_precomp=cov3D_precomp)
     pair = want_feat and colors_precomp is not None and means3D_final.is_cuda and getattr(pipe, "fused_pair", True)
+    # the bookkeeping rides in the pair node's backward only when that node really is the fused one (forward_pair falls back to
+    # two ordinary nodes for P == 0 or debug snapshots); otherwise training_step runs the separate pass (optim.densify_stats)
+    fuse_stats = bool(densify_accum is not None and pair and means3D_final.shape[0] > 0 and not rs.debug)
     if decomposed is not None:
         rendered_image, radii, depth = decomposed["render"], decomposed["radii"], decomposed["depth"]
     elif pair:
         # RGB + feature image from one node: shared geometry forward, ONE fused backward (rasterizer.forward_pair)
         rendered_image, radii, depth, rendered_image2 = rasterizer.forward_pair(
             means3D=means3D_final, means2D=means2D, opacities=opacity, colors_a=colors_precomp, colors_b=feat,
-            scales=scales_final, rotations=rotations_final, cov3D_precomp=cov3D_precomp, densify_accum=densify_accum)
+            scales=scales_final, rotations=rotations_final, cov3D_precomp=cov3D_precomp,
+            densify_accum=densify_accum if fuse_stats else None)
     else:
         rendered_image, radii, depth = rasterizer(means3D=means3D_final, means2D=means2D, shs=shs_final,
                                                   colors_precomp=colors_precomp, opacities=opacity, scales=scales_final,
@@ -377,7 +386,7 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
     out = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
            "radii": radii, "depth": depth}
     if densify_accum is not None:
-        out["densify_stats_fused"] = bool(pair and means3D_final.shape[0] > 0 and not rs.debug)
+        out["densify_stats_fused"] = fuse_stats
     if want_feat:
         if not pair:
             rendered_image2, _, _ = rasterizer(means3D=means3D_final, means2D=means2D, shs=None, colors_precomp=feat,
@@ -478,6 +487,7 @@ class _WeightedTerms(torch.autograd.Function):
             wt = _weight_cache[key] = torch.tensor(w, dtype=torch.float32, device=vals[0].device)
         ctx.save_for_backward(wt, dx if dx is not None else wt)
         ctx.has_dx, ctx.n = dx is not None, len(terms)
+        ctx.term_shapes = [tuple(v.shape) for v in terms]   # a [1]-shaped term must get a [1]-shaped gradient back
         return torch.dot(torch.stack([v.reshape(()).float() for v in vals]), wt)
 
     @staticmethod
@@ -485,7 +495,7 @@ class _WeightedTerms(torch.autograd.Function):
         wt, dx = ctx.saved_tensors
         gw = g * wt
         g_dx = torch.sign(dx) * gw[-1] if ctx.has_dx else None   # (None also for an empty dx: no gradient to give)
-        return (g_dx, None, None, *gw[:ctx.n].unbind(0))
+        return (g_dx, None, None, *(gi.reshape(sh) for gi, sh in zip(gw[:ctx.n].unbind(0), ctx.term_shapes)))
 
 
 def training_loss(pc: GaussianParams, pkg: Dict, gt_image, gt_depth, gt_feat, hyper, opt, stage="fine", fused_pixel_terms=True):
@@ -538,8 +548,9 @@ def training_step(pc: GaussianParams, cam: Dict, gt_image, gt_depth, gt_feat, hy
     """One iteration of train.py for one view: render -> loss -> backward -> Adam step.  `grad_hook(pc, pkg)` runs
     between backward and the optimizer step (used by the data-parallel wrapper for the RCCL all-reduce).
     densify_stats=True also does the bookkeeping of train.py:489-493 (max_radii2D, xyz_gradient_accum, denom) for this
-    single-view batch: inside the rasterizer's per-Gaussian backward when the iteration has one raster node, else as one
-    fused pass over the viewspace gradient (optim.densify_stats).  Data-parallel runs reduce the statistics first
+    single-view batch: inside the rasterizer's per-Gaussian backward when the RGB + feature pair runs as ONE two-image node
+    (the default fine-stage configuration), else -- coarse stage, pipe.fused_pair=False, debug snapshots, P == 0 -- as one fused
+    pass over the viewspace gradient afterwards (optim.densify_stats).  Data-parallel runs reduce the statistics first
     (dp.reduce_densification_stats) and must leave this off."""
     pipe = pipe or SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
     acc = (pc.xyz_gradient_accum, pc.denom, pc.max_radii2D) if densify_stats else None
@@ -549,7 +560,10 @@ def training_step(pc: GaussianParams, cam: Dict, gt_image, gt_depth, gt_feat, hy
     loss.backward()
     if densify_stats and not pkg.get("densify_stats_fused", False):
         from .optim import densify_stats as _densify_stats
-        _densify_stats(pc.xyz_gradient_accum, pc.denom, pc.max_radii2D, pkg["viewspace_points"].grad, pkg["radii"])
+        vg = pkg["viewspace_points"].grad
+        if vg is None:     # no gradient reached the screen-space points (nothing visible): the statistics do not move
+            vg = torch.zeros_like(pkg["viewspace_points"])
+        _densify_stats(pc.xyz_gradient_accum, pc.denom, pc.max_radii2D, vg, pkg["radii"])
     if grad_hook is not None:
         grad_hook(pc, pkg)
     pc.optimizer.step()

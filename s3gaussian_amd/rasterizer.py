@@ -203,7 +203,7 @@ class GaussianRasterizer(nn.Module):
             b, _, _ = self.forward(means3D, means2D, opacities, colors_precomp=colors_b, scales=scales if scales.numel() else None,
                                    rotations=rotations if rotations.numel() else None,
                                    cov3D_precomp=cov3D_precomp if cov3D_precomp.numel() else None)
-            if densify_accum is not None:
+            if densify_accum is not None:   # direct callers only: pipeline.render() decides before calling
                 raise RuntimeError("densify_accum needs the fused two-image node (P > 0, debug off)")
             return a, radii, depth, b
         return _RasterizeGaussiansPair.apply(means3D, means2D, colors_a, colors_b, opacities, scales, rotations, cov3D_precomp,

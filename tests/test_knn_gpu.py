@@ -19,6 +19,29 @@ def test_distcuda2_matches_oracle(gpu_device, P):
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("P", [4, 7, 1000, 1025, 30_000, 1_200_000])
+def test_knn_oracle_and_distcuda2_are_pinned_by_the_reference_build(gpu_device, P):
+    """oracle/_ref/libref_knn.so = the reference's own simple_knn.cu (hipify-perl + hipcc, oracle/build_ref.sh).  It pins
+    oracle/knn_oracle.c (which until round 3 was pinned by brute force only) and the product, incl. the 1.2 M street scene.
+    The reference's boxMeanDist visits candidates in a thread-dependent order but the three smallest squared distances are a
+    set property: results must agree to fp32 round-off of one mean (rtol 1e-6), duplicates included."""
+    from oracle import ref_raster
+    from oracle.oracle import knn_mean_dist2
+    from simple_knn._C import distCUDA2
+    if not ref_raster.knn_available():
+        pytest.fail("oracle/_ref/libref_knn.so missing: run oracle/build_ref.sh (needs /root/reference) before gpurun")
+    if P == 1_200_000:
+        from s3gaussian_amd import synth
+        pts = synth.street_scene(P=P, seed=0, n_frames=2)["gaussians"]["xyz"].numpy()
+    else:
+        g = np.random.default_rng(P)
+        pts = (g.normal(size=(P, 3)) * np.array([30, 10, 2])).astype(np.float32)
+        pts[: P // 8] = pts[P // 8: 2 * (P // 8)]       # exact duplicates: distance 0 neighbours count (self excluded by index)
+    want = ref_raster.ref_knn_mean_dist2(pts)
+    np.testing.assert_allclose(knn_mean_dist2(pts), want, rtol=1e-6, atol=0)
+    np.testing.assert_allclose(distCUDA2(torch.from_numpy(pts).to(gpu_device)).cpu().numpy(), want, rtol=1e-6, atol=0)
+
+
 def test_distcuda2_duplicates_and_clusters(gpu_device):
     from oracle.oracle import knn_mean_dist2
     from simple_knn._C import distCUDA2

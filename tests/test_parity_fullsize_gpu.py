@@ -1,0 +1,293 @@
+"""Oracle parity of the deformation half of the path AT BASELINE SIZE (cfg2 = 600 k, cfg3 = 1.2 M Gaussians, plus 70 k = two
+32-point tiles per MLP wave): HexPlane sampler, fused MFMA MLP, the whole deform_network, render glue, kNN.
+
+Checker = oracle/hexplane_ref.py (the restatement pinned by the goldens generated from the reference's own modules,
+tests/golden/make_golden.py) evaluated in FLOAT64 with plain torch ops on the GPU of the box -- the same code the CPU tests
+pin, only the device and dtype differ (no product kernel is involved on the checker side: F.grid_sample, nn.Linear, exp,
+normalize, sigmoid).  kNN: oracle/knn_oracle.c (OpenMP) at 1.2 M points.
+
+Follows scene/hexplane.py:73-106, scene/deformation.py:78-166, gaussian_renderer/__init__.py:99-115,
+submodules/simple-knn/simple_knn.cu:185-221.
+
+Tolerances (written where asserted): features / heads rtol 2e-5; dL/dxyz rel-L2 <= 1e-4; every plane gradient rel-L2 <= 1e-5;
+all 18 weight / bias gradients rel-L2 <= 2e-5 (K = 1.2 M summation); glue outputs rtol 2e-5, gradients rel-L2 1e-5; kNN rtol 1e-6.
+Every comparison appends its observed numbers to gpurun_out/parity_stats_r03.jsonl (copied to profiles/r03_parity_stats.jsonl)."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIZES = [70_000, 600_000, 1_200_000]
+CFG = dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32, resolution=[64, 64, 64, 25])
+
+
+def _record(**kw):
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_stats_r03.jsonl"), "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+
+
+def _rel(a, b):
+    """rel-L2 of a (product, fp32) against b (checker, fp64), evaluated on the device in fp64."""
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def _max_rel(a, b, atol):
+    """max |a-b| / (atol + rtol-free |b|): the smallest rtol np.testing.assert_allclose(a, b, rtol, atol) would accept."""
+    a, b = a.detach().double(), b.detach().double()
+    return float(((a - b).abs() - atol).clamp_min(0).div(b.abs().clamp_min(1e-300)).max())
+
+
+@pytest.fixture(scope="module")
+def street(gpu_device):
+    """The cfg2/cfg3 street scene: positions of the first P Gaussians of the 1.2 M scene, its hexplane aabb."""
+    from s3gaussian_amd import synth
+    sc = synth.street_scene(P=1_200_000, seed=0, n_frames=4)
+    return dict(xyz=sc["gaussians"]["xyz"].to(gpu_device), aabb=sc["aabb"], gs=sc["gaussians"], cam=sc["cameras"][4])
+
+
+def _kink_free(xyz64, aabb, tol=1e-4):
+    """[P,1] mask: 1 where no spatial coordinate lies within `tol` texels of a grid line of any level.  Bilinear interpolation
+    is piecewise linear: a point within fp32 round-off (~3e-5 texels at 512 texels) of a line may land in the neighbouring cell
+    in fp32, which changes nothing continuous (features, plane gradients) but switches dL/dxyz to the other cell's slope.  Such
+    points (~0.3 %) get zero loss weight on BOTH sides; the fp32-vs-fp32 tests at small P compare them bit for bit."""
+    hi, lo = (torch.tensor(a, dtype=torch.float64, device=xyz64.device) for a in aabb)
+    pn = (xyz64 - hi) * (2.0 / (lo - hi)) - 1.0
+    ok = torch.ones(xyz64.shape[0], dtype=torch.bool, device=xyz64.device)
+    for m in (1, 2, 4, 8):
+        ix = (pn + 1.0) * 0.5 * (64 * m - 1)
+        fr = ix - torch.floor(ix)
+        ok &= (torch.minimum(fr, 1.0 - fr) > tol).all(dim=1)
+    return ok[:, None]
+
+
+def _fields(dev, aabb, seed):
+    """Default-resolution field [64,64,64,25] x [1,2,4,8]: fp64 checker on the GPU + the product module with equal planes."""
+    from oracle import hexplane_ref as hr
+    from s3gaussian_amd.hexplane import HexPlaneField
+    torch.manual_seed(seed)
+    ref = hr.HexPlaneField(1.6, CFG, [1, 2, 4, 8])
+    with torch.no_grad():
+        for p in ref.grids.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    ref.set_aabb(*aabb)
+    mine = HexPlaneField(1.6, CFG, [1, 2, 4, 8])
+    mine.set_aabb(*aabb)
+    mine.load_state_dict(ref.state_dict())
+    return ref.double().to(dev), mine.to(dev)
+
+
+@pytest.mark.parametrize("backward", ["slab", "walk"])
+@pytest.mark.parametrize("tmode", ["uniform", "per_point"])
+@pytest.mark.parametrize("P", SIZES)
+def test_hexplane_sampler_at_baseline_size(gpu_device, street, monkeypatch, P, tmode, backward):
+    """P = 1.2 M takes the 256-point scatter segments, the multi-workgroup counting sorts, the blocked order with XCD dealing and
+    the point-major G slab at 3.7 GB; the second backward reuses the cached spatial orders (sort_age 1)."""
+    import s3gaussian_amd.hexplane as hx
+    if P == 600_000 and backward == "walk":
+        pytest.skip("600 k covers the slab default; walk is checked at 70 k and 1.2 M")
+    monkeypatch.setattr(hx, "BACKWARD_MODE", backward)
+    dev = gpu_device
+    ref, mine = _fields(dev, street["aabb"], seed=P % 1000)
+    g = torch.Generator().manual_seed(P + 7)
+    xyz = street["xyz"][:P].clone()
+    xyz[::97] += torch.tensor([150.0, -60.0, 20.0], device=dev) * (torch.rand(xyz[::97].shape[0], 1, generator=g).to(dev) - 0.5)  # some outside the aabb
+    time = (torch.rand(P, 1, generator=g) * 1.2 - 0.1).to(dev) if tmode == "per_point" else torch.full((P, 1), 0.37, device=dev)
+    keep = _kink_free(xyz.double(), street["aabb"])
+    w = torch.randn(P, 128, generator=g).to(dev) * keep.float()
+    xr = xyz.double().requires_grad_(True)
+    fr = ref(xr, time.double())
+    (fr * w.double()).sum().backward()
+    stats = dict(test="hexplane", P=P, time=tmode, backward=backward, kink_points_masked=int((~keep).sum()))
+    for rep in range(2):          # rep 1: stale-order reuse path (sort_state cached, reuse = 1)
+        for p in mine.parameters():
+            p.grad = None
+        xg = xyz.clone().requires_grad_(True)
+        fg = mine(xg, time, uniform_time=(tmode == "uniform"))
+        (fg * w).sum().backward()
+        torch.cuda.synchronize()
+        assert mine._order_cache.get("sort_age", 0) == rep
+        feat_rtol = _max_rel(fg, fr, atol=1e-6)
+        gx = _rel(xg.grad, xr.grad)
+        gp = {k: _rel(pg.grad, pr.grad) for (k, pr), (_, pg) in zip(ref.named_parameters(), mine.named_parameters()) if pr.grad is not None}
+        stats[f"rep{rep}"] = dict(features_max_rtol=feat_rtol, dxyz_rel_l2=gx, plane_grad_rel_l2_max=max(gp.values()),
+                                  plane_grad_rel_l2_worst=max(gp, key=gp.get))
+        assert feat_rtol <= 2e-5, feat_rtol                                   # features rtol 2e-5 (atol 1e-6)
+        assert gx <= 1e-4, gx                                                 # dL/dxyz rel-L2
+        assert len(gp) == 24 and max(gp.values()) <= 1e-5, gp                 # every plane gradient rel-L2
+    _record(**stats)
+
+
+def _mlp_modules(seed):
+    from oracle import hexplane_ref as hr
+    torch.manual_seed(seed)
+    net = hr.deform_network(hr.default_hyper(kplanes_config=dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32,
+                                                                  resolution=[4, 4, 4, 3])))
+    d = net.deformation_net
+    for m in d.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.normal_(m.bias, std=0.1)
+    return d
+
+
+def _min_abs_preactivation(d, x):
+    """Per point: smallest |input| of any ReLU of the stack (fp64).  A point within fp32 round-off of a kink may take the other
+    branch in fp32; it gets zero loss weight on both sides (scene/deformation.py:53-76 has five ReLUs on the active heads)."""
+    with torch.no_grad():
+        hidden = d.feature_out(x)
+        worst = torch.full((x.shape[0],), float("inf"), dtype=x.dtype, device=x.device)
+        for head in (d.pos_deform, d.shs_deform, d.dino_head):
+            t = hidden
+            for m in head:
+                if isinstance(m, torch.nn.ReLU):
+                    worst = torch.minimum(worst, t.abs().min(dim=1).values)
+                t = m(t)
+    return worst
+
+
+MLP_HEADS = ("feature_out", "pos_deform", "shs_deform", "dino_head")
+
+
+@pytest.mark.parametrize("P", SIZES)
+def test_fused_mlp_at_baseline_size(gpu_device, P):
+    """P > 65 536: every wave of mlp_forward / mlp_backward runs its `cur = nxt` software pipeline for more than one tile and
+    mlp_wgrad its clamped prefetch + ragged tail (P is not a multiple of 32 x 8 x 256)."""
+    from s3gaussian_amd.mlp import deform_mlp
+    dev = gpu_device
+    P = P + 13                      # ragged tail
+    d64 = _mlp_modules(P % 977).double().to(dev)
+    dg = copy.deepcopy(d64).float()
+    g = torch.Generator().manual_seed(P + 1)
+    x = torch.randn(P, 128, generator=g).to(dev)
+    w = [torch.randn(P, n, generator=g).to(dev) for n in (3, 48, 3)]
+    keep = (_min_abs_preactivation(d64, x.double()) > 1e-5).float()[:, None]
+    w = [wi * keep for wi in w]
+    x64 = x.double().requires_grad_(True)
+    hidden = d64.feature_out(x64)
+    outs64 = (d64.pos_deform(hidden), d64.shs_deform(hidden), d64.dino_head(hidden))
+    sum((o * wi.double()).sum() for o, wi in zip(outs64, w)).backward()
+    xg = x.clone().requires_grad_(True)
+    outs = deform_mlp(xg, dg.feature_out, dg.pos_deform, dg.shs_deform, dg.dino_head)
+    sum((o * wi).sum() for o, wi in zip(outs, w)).backward()
+    torch.cuda.synchronize()
+    heads = [max(_max_rel(o, r, atol=2e-5), 0.0) for o, r in zip(outs, outs64)]
+    gx = _rel(xg.grad, x64.grad)
+    ref_params = dict(d64.named_parameters())
+    gw = {n: _rel(p.grad, ref_params[n].grad) for n, p in dg.named_parameters() if n.startswith(MLP_HEADS)}
+    _record(test="mlp", P=P, kink_points_masked=int((keep == 0).sum()), heads_max_rtol=heads, dfeatures_rel_l2=gx,
+            weight_grad_rel_l2_max=max(gw.values()), weight_grad_rel_l2=gw)
+    assert max(heads) <= 2e-5, heads                                          # heads rtol 2e-5 (atol 2e-5)
+    assert gx <= 1e-5, gx
+    assert len(gw) == 18 and max(gw.values()) <= 2e-5, gw                     # 9 weights + 9 biases
+
+
+@pytest.mark.parametrize("P", [70_000, 1_200_000])
+def test_deform_network_at_baseline_size(gpu_device, street, P):
+    """HexPlane (uniform time, as render() calls it) + MLP heads + `xyz + dx`, `shs + dshs` end to end through
+    s3gaussian_amd.deformation.deform_network vs the fp64 restatement: outputs, dL/dxyz, dL/dshs and EVERY parameter gradient
+    (24 planes + 18 MLP tensors)."""
+    from oracle import hexplane_ref as hr
+    from s3gaussian_amd.deformation import deform_network
+    dev = gpu_device
+    torch.manual_seed(P % 991)
+    ref = hr.deform_network(hr.default_hyper())
+    with torch.no_grad():
+        for p in ref.deformation_net.grid.grids.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+        for m in ref.deformation_net.modules():
+            if isinstance(m, torch.nn.Linear):
+                torch.nn.init.normal_(m.bias, std=0.05)
+    ref.deformation_net.grid.set_aabb(*street["aabb"])
+    mine = deform_network(hr.default_hyper())
+    mine.deformation_net.set_aabb(*street["aabb"])
+    mine.load_state_dict(ref.state_dict())
+    ref, mine = ref.double().to(dev), mine.to(dev)
+    assert mine.deformation_net._fused_ok()
+    gs = street["gs"]
+    xyz, shs = street["xyz"][:P], gs["shs"][:P].to(dev)
+    sc, rot, op = gs["log_scales"][:P].to(dev), gs["rotations_raw"][:P].to(dev), gs["opacity_logit"][:P].to(dev)
+    t = torch.full((P, 1), 0.61, device=dev)
+    xr, sr = xyz.double().requires_grad_(True), shs.double().requires_grad_(True)
+    outs_r = ref(xr, sc.double(), rot.double(), op.double(), sr, t.double())
+    with torch.no_grad():
+        keep = (_min_abs_preactivation(ref.deformation_net, ref.deformation_net.grid(xr.detach(), t.double())) > 1e-5)
+        keep = (keep & _kink_free(xr.detach(), street["aabb"])[:, 0]).double()
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn(o.shape, generator=g).to(dev) * keep.view(-1, *([1] * (o.dim() - 1))).float() for o in outs_r]
+    sum((o * w.double()).sum() for o, w in zip(outs_r, ws)).backward()
+    xg, sg = xyz.clone().requires_grad_(True), shs.clone().requires_grad_(True)
+    outs_g = mine(xg, sc, rot, op, sg, t)
+    sum((o * w).sum() for o, w in zip(outs_g, ws)).backward()
+    torch.cuda.synchronize()
+    names = ["means3D", "scales", "rotations", "opacity", "shs", "dx", "feat", "dshs"]
+    out_rtol = {n: _max_rel(a, b, atol=2e-5) for n, a, b in zip(names, outs_g, outs_r)}
+    gx, gshs = _rel(xg.grad, xr.grad), _rel(sg.grad, sr.grad)
+    gr = dict(ref.named_parameters())
+    gp = {k: _rel(p.grad, gr[k].grad) for k, p in mine.named_parameters() if gr[k].grad is not None}
+    for k, p in mine.named_parameters():
+        assert (p.grad is None) == (gr[k].grad is None), k
+    worst_plane = max(v for k, v in gp.items() if "grid" in k)
+    worst_mlp = max(v for k, v in gp.items() if "grid" not in k)
+    _record(test="deform_network", P=P, kink_points_masked=int((keep == 0).sum()), outputs_max_rtol=out_rtol, dxyz_rel_l2=gx,
+            dshs_rel_l2=gshs, plane_grad_rel_l2_max=worst_plane, mlp_grad_rel_l2_max=worst_mlp)
+    assert max(out_rtol.values()) <= 1e-4, out_rtol                           # heads through 128-deep fp32 dot products of fp32 features
+    assert gx <= 1e-4 and gshs <= 1e-5, (gx, gshs)
+    assert len(gp) == 24 + 18
+    assert worst_plane <= 2e-5 and worst_mlp <= 2e-5, gp
+
+
+@pytest.mark.parametrize("P", [70_000, 1_200_000])
+def test_glue_at_baseline_size(gpu_device, street, P):
+    """exp / normalize / sigmoid / (shs + dshs) / eval_sh / clamp + the mean|dshs| regulariser, forward and backward, vs the
+    fp64 restatement of gaussian_renderer/__init__.py:99-115 + utils/sh_utils.py:57-112 (dirs from the undeformed xyz)."""
+    from oracle import hexplane_ref as hr
+    from s3gaussian_amd.glue import activations_and_colors
+    dev = gpu_device
+    gs = street["gs"]
+    g = torch.Generator().manual_seed(P + 5)
+    f_dc, f_rest = gs["shs"][:P, :1].contiguous().to(dev), gs["shs"][:P, 1:].contiguous().to(dev)
+    dshs = (0.05 * torch.randn(P, 16, 3, generator=g)).to(dev)
+    xyz, ls, rr, ol = street["xyz"][:P], gs["log_scales"][:P].to(dev), gs["rotations_raw"][:P].to(dev), gs["opacity_logit"][:P].to(dev)
+    campos = street["cam"]["campos"].to(dev)
+    ws = [torch.randn(P, n, generator=g).to(dev) for n in (3, 3, 4, 1)]
+    leaves32 = [t.clone().requires_grad_(True) for t in (f_dc, f_rest, dshs, xyz, ls, rr, ol)]
+    leaves64 = [t.double().requires_grad_(True) for t in (f_dc, f_rest, dshs, xyz, ls, rr, ol)]
+    a, b, d, x, s_, r_, o_ = leaves64
+    pre = hr.eval_sh(3, (torch.cat((a, b), dim=1) + d).transpose(1, 2), torch.nn.functional.normalize(x - campos.double()[None])) + 0.5
+    # a colour channel within round-off of the clamp at 0 may sit on the other side of the kink in fp32: zero weight, both sides
+    live = (pre.detach().abs() > 1e-5).float()
+    ws[0] = ws[0] * live
+    outs_r = (hr.shs_to_colors(3, torch.cat((a, b), dim=1) + d, x, campos.double()), torch.exp(s_),
+              torch.nn.functional.normalize(r_), torch.sigmoid(o_), torch.mean(torch.abs(d)))
+    (sum((o * w.double()).sum() for o, w in zip(outs_r[:4], ws)) + 700.0 * outs_r[4]).backward()
+    a, b, d, x, s_, r_, o_ = leaves32
+    outs = activations_and_colors(3, a, b, d, x, campos, s_, r_, o_, with_dshs_l1=True)
+    (sum((o * w).sum() for o, w in zip(outs[:4], ws)) + 700.0 * outs[4]).backward()
+    torch.cuda.synchronize()
+    out_rtol = [_max_rel(outs[0] * live, outs_r[0] * live.double(), atol=2e-6)] + [_max_rel(o, r, atol=2e-6) for o, r in zip(outs[1:5], outs_r[1:5])]
+    names = ["f_dc", "f_rest", "dshs", "xyz", "log_scales", "rotations", "opacity"]
+    gl = {n: _rel(p.grad, q.grad) for n, p, q in zip(names, leaves32, leaves64)}
+    _record(test="glue", P=P, outputs_max_rtol=out_rtol, grad_rel_l2=gl)
+    assert max(out_rtol) <= 2e-5, out_rtol
+    assert max(gl.values()) <= 1e-5, gl
+
+
+def test_distcuda2_at_baseline_size(gpu_device, street):
+    """distCUDA2 over the 1.2 M positions of cfg3 vs oracle/knn_oracle.c (OpenMP; simple_knn.cu:185-221): rtol 1e-6."""
+    from oracle.oracle import knn_mean_dist2
+    from simple_knn._C import distCUDA2
+    pts = street["xyz"]
+    got = distCUDA2(pts).cpu().numpy()
+    want = knn_mean_dist2(pts.cpu().numpy())
+    err = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
+    _record(test="knn", P=int(pts.shape[0]), max_rel_err=float(err.max()), exact_fraction=float((got == want).mean()))
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)

@@ -25,7 +25,9 @@ def test_reorder_moves_everything_together():
     ids = {id(p) for p in (pc._xyz, pc._opacity, pc._scaling, pc._rotation, pc._features_dc, pc._features_rest)}
     old_xyz = pc._xyz.detach().clone()
     m_before = pc.optimizer.state[pc._opacity]["exp_avg"].clone()
+    pc._scaling.grad = tag[:, None].repeat(1, 3).clone()              # a gradient still pending when the reorder happens
     perm = pc.reorder_spatially()
+    assert torch.equal(pc._scaling.grad[:, 0], tag[perm])              # ... follows its Gaussian
     assert sorted(perm.tolist()) == list(range(P))
     assert {id(p) for p in (pc._xyz, pc._opacity, pc._scaling, pc._rotation, pc._features_dc, pc._features_rest)} == ids
     new_tag = pc._opacity.detach()[:, 0]
