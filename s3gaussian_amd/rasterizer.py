@@ -191,20 +191,18 @@ class GaussianRasterizer(nn.Module):
         has_sr = scales is not None or rotations is not None
         if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        if means3D.shape[0] == 0 or self.raster_settings.debug:
+            # nothing to share / debug snapshots wanted: fall back to two ordinary nodes
+            if densify_accum is not None:   # direct callers only: pipeline.render() decides before calling
+                raise RuntimeError("densify_accum needs the fused two-image node (P > 0, debug off)")
+            a, radii, depth = self.forward(means3D, means2D, opacities, colors_precomp=colors_a, scales=scales, rotations=rotations,
+                                           cov3D_precomp=cov3D_precomp)
+            b, _, _ = self.forward(means3D, means2D, opacities, colors_precomp=colors_b, scales=scales, rotations=rotations,
+                                   cov3D_precomp=cov3D_precomp)
+            return a, radii, depth, b
         empty = torch.Tensor([])
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
-        if means3D.shape[0] == 0 or self.raster_settings.debug:
-            # nothing to share / debug snapshots wanted: fall back to two ordinary nodes
-            a, radii, depth = self.forward(means3D, means2D, opacities, colors_precomp=colors_a, scales=scales if scales.numel() else None,
-                                           rotations=rotations if rotations.numel() else None,
-                                           cov3D_precomp=cov3D_precomp if cov3D_precomp.numel() else None)
-            b, _, _ = self.forward(means3D, means2D, opacities, colors_precomp=colors_b, scales=scales if scales.numel() else None,
-                                   rotations=rotations if rotations.numel() else None,
-                                   cov3D_precomp=cov3D_precomp if cov3D_precomp.numel() else None)
-            if densify_accum is not None:   # direct callers only: pipeline.render() decides before calling
-                raise RuntimeError("densify_accum needs the fused two-image node (P > 0, debug off)")
-            return a, radii, depth, b
         return _RasterizeGaussiansPair.apply(means3D, means2D, colors_a, colors_b, opacities, scales, rotations, cov3D_precomp,
                                              self.raster_settings, densify_accum)

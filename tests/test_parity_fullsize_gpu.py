@@ -2,15 +2,21 @@
 32-point tiles per MLP wave): HexPlane sampler, fused MFMA MLP, the whole deform_network, render glue, kNN.
 
 Checker = oracle/hexplane_ref.py (the restatement pinned by the goldens generated from the reference's own modules,
-tests/golden/make_golden.py) evaluated in FLOAT64 with plain torch ops on the GPU of the box -- the same code the CPU tests
-pin, only the device and dtype differ (no product kernel is involved on the checker side: F.grid_sample, nn.Linear, exp,
-normalize, sigmoid).  kNN: oracle/knn_oracle.c (OpenMP) at 1.2 M points.
+tests/golden/make_golden.py) evaluated with plain torch ops on the GPU of the box -- the same code the CPU tests pin, only the
+device differs (no product kernel is involved on the checker side: F.grid_sample, nn.Linear, exp, normalize, sigmoid):
+  * in FLOAT32 for everything that goes through the HexPlane sampler.  The reference computes in fp32, and its fp32 texel
+    coordinates are only good to ~3e-5 texels at 512 texels per axis, which moves a sample by ~1e-4 relative against exact
+    arithmetic (measured below: the reference's OWN fp32 arithmetic is 1.6e-5 abs / up to 4e-5 rel-L2 in the plane gradients
+    away from fp64, doubling per level).  Parity means reproducing the reference's arithmetic, so the bar is set against fp32;
+  * the FLOAT64 evaluation runs next to it and both distances are recorded: the product is as close to exact as the reference;
+  * in FLOAT64 for the MLP and the glue (dot products and elementwise math: fp32 round-off only).
+kNN: oracle/knn_oracle.c (OpenMP) at 1.2 M points.
 
 Follows scene/hexplane.py:73-106, scene/deformation.py:78-166, gaussian_renderer/__init__.py:99-115,
 submodules/simple-knn/simple_knn.cu:185-221.
 
 Tolerances (written where asserted): features / heads rtol 2e-5; dL/dxyz rel-L2 <= 1e-4; every plane gradient rel-L2 <= 1e-5;
-all 18 weight / bias gradients rel-L2 <= 2e-5 (K = 1.2 M summation); glue outputs rtol 2e-5, gradients rel-L2 1e-5; kNN rtol 1e-6.
+all 16 weight / bias gradients (8 Linear layers) rel-L2 <= 2e-5 (K = 1.2 M summation); glue outputs rtol 2e-5, gradients rel-L2 1e-5; kNN rtol 1e-6.
 Every comparison appends its observed numbers to gpurun_out/parity_stats_r03.jsonl (copied to profiles/r03_parity_stats.jsonl)."""
 import copy
 import json
@@ -97,17 +103,24 @@ def test_hexplane_sampler_at_baseline_size(gpu_device, street, monkeypatch, P, t
         pytest.skip("600 k covers the slab default; walk is checked at 70 k and 1.2 M")
     monkeypatch.setattr(hx, "BACKWARD_MODE", backward)
     dev = gpu_device
-    ref, mine = _fields(dev, street["aabb"], seed=P % 1000)
+    ref64, mine = _fields(dev, street["aabb"], seed=P % 1000)
+    ref32 = copy.deepcopy(ref64).float()
     g = torch.Generator().manual_seed(P + 7)
     xyz = street["xyz"][:P].clone()
     xyz[::97] += torch.tensor([150.0, -60.0, 20.0], device=dev) * (torch.rand(xyz[::97].shape[0], 1, generator=g).to(dev) - 0.5)  # some outside the aabb
     time = (torch.rand(P, 1, generator=g) * 1.2 - 0.1).to(dev) if tmode == "per_point" else torch.full((P, 1), 0.37, device=dev)
     keep = _kink_free(xyz.double(), street["aabb"])
     w = torch.randn(P, 128, generator=g).to(dev) * keep.float()
-    xr = xyz.double().requires_grad_(True)
-    fr = ref(xr, time.double())
-    (fr * w.double()).sum().backward()
-    stats = dict(test="hexplane", P=P, time=tmode, backward=backward, kink_points_masked=int((~keep).sum()))
+    x64 = xyz.double().requires_grad_(True)
+    f64 = ref64(x64, time.double())
+    (f64 * w.double()).sum().backward()
+    xr = xyz.clone().requires_grad_(True)
+    fr = ref32(xr, time)
+    (fr * w).sum().backward()
+    p64 = dict(ref64.named_parameters())
+    stats = dict(test="hexplane", P=P, time=tmode, backward=backward, kink_points_masked=int((~keep).sum()),
+                 reference_fp32_vs_fp64=dict(features_max_abs=float((fr.double() - f64).abs().max()), dxyz_rel_l2=_rel(xr.grad, x64.grad),
+                                             plane_grad_rel_l2_max=max(_rel(p.grad, p64[k].grad) for k, p in ref32.named_parameters() if p.grad is not None)))
     for rep in range(2):          # rep 1: stale-order reuse path (sort_state cached, reuse = 1)
         for p in mine.parameters():
             p.grad = None
@@ -118,12 +131,18 @@ def test_hexplane_sampler_at_baseline_size(gpu_device, street, monkeypatch, P, t
         assert mine._order_cache.get("sort_age", 0) == rep
         feat_rtol = _max_rel(fg, fr, atol=1e-6)
         gx = _rel(xg.grad, xr.grad)
-        gp = {k: _rel(pg.grad, pr.grad) for (k, pr), (_, pg) in zip(ref.named_parameters(), mine.named_parameters()) if pr.grad is not None}
-        stats[f"rep{rep}"] = dict(features_max_rtol=feat_rtol, dxyz_rel_l2=gx, plane_grad_rel_l2_max=max(gp.values()),
-                                  plane_grad_rel_l2_worst=max(gp, key=gp.get))
+        gp = {k: _rel(pg.grad, pr.grad) for (k, pr), (_, pg) in zip(ref32.named_parameters(), mine.named_parameters()) if pr.grad is not None}
+        stats[f"rep{rep}"] = dict(features_max_rtol=feat_rtol, features_max_abs=float((fg - fr).abs().max()), dxyz_rel_l2=gx,
+                                  plane_grad_rel_l2_max=max(gp.values()), plane_grad_rel_l2_worst=max(gp, key=gp.get),
+                                  vs_fp64=dict(features_max_abs=float((fg.double() - f64).abs().max()), dxyz_rel_l2=_rel(xg.grad, x64.grad),
+                                               plane_grad_rel_l2_max=max(_rel(pg.grad, p64[k].grad) for k, pg in mine.named_parameters() if pg.grad is not None)))
         assert feat_rtol <= 2e-5, feat_rtol                                   # features rtol 2e-5 (atol 1e-6)
         assert gx <= 1e-4, gx                                                 # dL/dxyz rel-L2
         assert len(gp) == 24 and max(gp.values()) <= 1e-5, gp                 # every plane gradient rel-L2
+        # and no further from exact arithmetic than the reference's own fp32 evaluation (x1.5 slack for summation order)
+        r = stats["reference_fp32_vs_fp64"]
+        assert stats[f"rep{rep}"]["vs_fp64"]["plane_grad_rel_l2_max"] <= 1.5 * r["plane_grad_rel_l2_max"] + 1e-6
+        assert stats[f"rep{rep}"]["vs_fp64"]["features_max_abs"] <= 1.5 * r["features_max_abs"] + 1e-7
     _record(**stats)
 
 
@@ -187,14 +206,14 @@ def test_fused_mlp_at_baseline_size(gpu_device, P):
             weight_grad_rel_l2_max=max(gw.values()), weight_grad_rel_l2=gw)
     assert max(heads) <= 2e-5, heads                                          # heads rtol 2e-5 (atol 2e-5)
     assert gx <= 1e-5, gx
-    assert len(gw) == 18 and max(gw.values()) <= 2e-5, gw                     # 9 weights + 9 biases
+    assert len(gw) == 16 and max(gw.values()) <= 2e-5, gw                     # 8 Linear layers: weights + biases
 
 
 @pytest.mark.parametrize("P", [70_000, 1_200_000])
 def test_deform_network_at_baseline_size(gpu_device, street, P):
     """HexPlane (uniform time, as render() calls it) + MLP heads + `xyz + dx`, `shs + dshs` end to end through
-    s3gaussian_amd.deformation.deform_network vs the fp64 restatement: outputs, dL/dxyz, dL/dshs and EVERY parameter gradient
-    (24 planes + 18 MLP tensors)."""
+    s3gaussian_amd.deformation.deform_network vs the restatement in the reference's fp32 arithmetic (fp64 alongside): outputs, dL/dxyz, dL/dshs and EVERY parameter gradient
+    (24 planes + 16 MLP tensors)."""
     from oracle import hexplane_ref as hr
     from s3gaussian_amd.deformation import deform_network
     dev = gpu_device
@@ -210,39 +229,48 @@ def test_deform_network_at_baseline_size(gpu_device, street, P):
     mine = deform_network(hr.default_hyper())
     mine.deformation_net.set_aabb(*street["aabb"])
     mine.load_state_dict(ref.state_dict())
-    ref, mine = ref.double().to(dev), mine.to(dev)
+    ref64, mine = ref.double().to(dev), mine.to(dev)
+    ref32 = copy.deepcopy(ref64).float()      # the checker: the reference's fp32 arithmetic (module docstring)
     assert mine.deformation_net._fused_ok()
     gs = street["gs"]
     xyz, shs = street["xyz"][:P], gs["shs"][:P].to(dev)
     sc, rot, op = gs["log_scales"][:P].to(dev), gs["rotations_raw"][:P].to(dev), gs["opacity_logit"][:P].to(dev)
     t = torch.full((P, 1), 0.61, device=dev)
-    xr, sr = xyz.double().requires_grad_(True), shs.double().requires_grad_(True)
-    outs_r = ref(xr, sc.double(), rot.double(), op.double(), sr, t.double())
-    with torch.no_grad():
-        keep = (_min_abs_preactivation(ref.deformation_net, ref.deformation_net.grid(xr.detach(), t.double())) > 1e-5)
-        keep = (keep & _kink_free(xr.detach(), street["aabb"])[:, 0]).double()
+    with torch.no_grad():      # points on a ReLU or bilinear kink (decided in fp64): zero loss weight on every side
+        keep = (_min_abs_preactivation(ref64.deformation_net, ref64.deformation_net.grid(xyz.double(), t.double())) > 1e-5)
+        keep = (keep & _kink_free(xyz.double(), street["aabb"])[:, 0]).float()
     g = torch.Generator().manual_seed(3)
-    ws = [torch.randn(o.shape, generator=g).to(dev) * keep.view(-1, *([1] * (o.dim() - 1))).float() for o in outs_r]
-    sum((o * w.double()).sum() for o, w in zip(outs_r, ws)).backward()
-    xg, sg = xyz.clone().requires_grad_(True), shs.clone().requires_grad_(True)
-    outs_g = mine(xg, sc, rot, op, sg, t)
-    sum((o * w).sum() for o, w in zip(outs_g, ws)).backward()
+    shapes = [(P, 3), (P, 3), (P, 4), (P, 1), (P, 16, 3), (P, 3), (P, 3), (P, 16, 3)]
+    ws = [torch.randn(sh, generator=g).to(dev) * keep.view(-1, *([1] * (len(sh) - 1))) for sh in shapes]
+
+    def run(net, dt):
+        x, sh_ = xyz.detach().to(dt).clone().requires_grad_(True), shs.detach().to(dt).clone().requires_grad_(True)
+        outs = net(x, sc.to(dt), rot.to(dt), op.to(dt), sh_, t.to(dt))
+        sum((o * w.to(dt)).sum() for o, w in zip(outs, ws)).backward()
+        return outs, x.grad, sh_.grad, {k: p.grad for k, p in net.named_parameters()}
+
+    o64, gx64, gs64, gp64 = run(ref64, torch.float64)
+    o32, gx32, gs32, gp32 = run(ref32, torch.float32)
+    og, gxg, gsg, gpg = run(mine, torch.float32)
     torch.cuda.synchronize()
     names = ["means3D", "scales", "rotations", "opacity", "shs", "dx", "feat", "dshs"]
-    out_rtol = {n: _max_rel(a, b, atol=2e-5) for n, a, b in zip(names, outs_g, outs_r)}
-    gx, gshs = _rel(xg.grad, xr.grad), _rel(sg.grad, sr.grad)
-    gr = dict(ref.named_parameters())
-    gp = {k: _rel(p.grad, gr[k].grad) for k, p in mine.named_parameters() if gr[k].grad is not None}
-    for k, p in mine.named_parameters():
-        assert (p.grad is None) == (gr[k].grad is None), k
+    out_rtol = {n: _max_rel(a_, b_, atol=2e-5) for n, a_, b_ in zip(names, og, o32)}
+    gx, gshs = _rel(gxg, gx32), _rel(gsg, gs32)
+    for k in gpg:
+        assert (gpg[k] is None) == (gp32[k] is None), k
+    gp = {k: _rel(v, gp32[k]) for k, v in gpg.items() if v is not None}
     worst_plane = max(v for k, v in gp.items() if "grid" in k)
     worst_mlp = max(v for k, v in gp.items() if "grid" not in k)
+    d64 = lambda grads: (max(_rel(v, gp64[k]) for k, v in grads.items() if v is not None and "grid" in k),
+                         max(_rel(v, gp64[k]) for k, v in grads.items() if v is not None and "grid" not in k))
     _record(test="deform_network", P=P, kink_points_masked=int((keep == 0).sum()), outputs_max_rtol=out_rtol, dxyz_rel_l2=gx,
-            dshs_rel_l2=gshs, plane_grad_rel_l2_max=worst_plane, mlp_grad_rel_l2_max=worst_mlp)
-    assert max(out_rtol.values()) <= 1e-4, out_rtol                           # heads through 128-deep fp32 dot products of fp32 features
+            dshs_rel_l2=gshs, plane_grad_rel_l2_max=worst_plane, mlp_grad_rel_l2_max=worst_mlp,
+            product_vs_fp64=dict(zip(("plane_grad_rel_l2_max", "mlp_grad_rel_l2_max"), d64(gpg)), dxyz_rel_l2=_rel(gxg, gx64)),
+            reference_fp32_vs_fp64=dict(zip(("plane_grad_rel_l2_max", "mlp_grad_rel_l2_max"), d64(gp32)), dxyz_rel_l2=_rel(gx32, gx64)))
+    assert max(out_rtol.values()) <= 2e-5, out_rtol                           # every output, rtol 2e-5 (atol 2e-5)
     assert gx <= 1e-4 and gshs <= 1e-5, (gx, gshs)
-    assert len(gp) == 24 + 18
-    assert worst_plane <= 2e-5 and worst_mlp <= 2e-5, gp
+    assert len(gp) == 24 + 16
+    assert worst_plane <= 1e-5 and worst_mlp <= 2e-5, gp
 
 
 @pytest.mark.parametrize("P", [70_000, 1_200_000])

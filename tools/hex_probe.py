@@ -15,7 +15,19 @@ cfg = dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32, 
 f = HexPlaneField(1.6, cfg, [1, 2, 4, 8])
 f.set_aabb(*sc["aabb"])
 f = f.to(dev)
-xyz = sc["gaussians"]["xyz"].to(dev).requires_grad_(True)
+xyz = sc["gaussians"]["xyz"].to(dev)
+if "morton" in sys.argv[2:]:   # the Gaussians THEMSELVES in Morton order (pipeline.GaussianParams.reorder_spatially's key)
+    lo, hi = xyz.min(dim=0).values, xyz.max(dim=0).values
+    q = ((xyz - lo) / (hi - lo) * 1023).long().clamp_(0, 1023)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+    xyz = xyz[torch.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), stable=True)].contiguous()
+    print("points in Morton order")
+xyz.requires_grad_(True)
 t = torch.full((P, 1), 0.37, device=dev)
 w = torch.randn(P, 128, device=dev)
 for it in range(4):

@@ -7,17 +7,20 @@ set -uo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-: > "$OUT/pmc_memsys.txt"
-pass() {   # pass <tag> <counter> [counter]
+echo "== pmc_memsys PROBE_ARGS='${PROBE_ARGS:-}' PASSES='${PASSES:-all}'" >> "$OUT/pmc_memsys.txt"
+_pass() {   # _pass <tag> <counter> [counter]
   local tag="$1"; shift
   rm -rf "/tmp/pm_$tag"
   if timeout "${PASS_TIMEOUT:-90}" rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "/tmp/pm_$tag" -- \
-       python "$ROOT/tools/hex_probe.py" > "/tmp/pm_$tag.log" 2>&1; then
+       python "$ROOT/tools/hex_probe.py" ${PROBE_ARGS:-} > "/tmp/pm_$tag.log" 2>&1; then
     python "$ROOT/tools/pmc_summary.py" "/tmp/pm_$tag" hexplane_ | grep -v -A2 time_rows >> "$OUT/pmc_memsys.txt"
   else
     echo "pass $tag ($*): timed out or failed" >> "$OUT/pmc_memsys.txt"
   fi
 }
+# PASSES="tlb1 tlb2" selects passes (default: all); PROBE_ARGS="1200000 morton" runs the probe on Morton-ordered points
+want() { [ -z "${PASSES:-}" ] || [[ " $PASSES " == *" $1 "* ]]; }
+pass() { want "$1" && _pass "$@"; }
 pass tlb1 TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum
 pass tlb2 TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_STALL_MULTI_MISS_sum
 pass l1a  TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum
