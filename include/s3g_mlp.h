@@ -53,6 +53,17 @@ int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* feature
                             const float* g_dshs, const float* g_feat, float* g_features, const s3g_mlp_params* gw,
                             float* workspace, void* stream);
 
+/* Inference only (no autograd): HexPlane sampler (+) feature_out + position / SH heads in ONE kernel -- what
+ * deform_network.forward_dynamic computes under torch.no_grad() for a render that does not draw the feature image
+ * (/root/reference/scene/deformation.py:108-166 with the default switches, called from gaussian_renderer/__init__.py:82-97).
+ * xyz [P,3], time [P] -> dx [P,3], dshs [P,48]; the [P,128] feature array is never materialised.  Results are bit-identical to
+ * s3g_hexplane_forward followed by s3g_deform_mlp_forward(feat = NULL).  The descriptor must have 4 levels (4 x 32 = the 128 inputs
+ * of feature_out).  `workspace`: s3g_deform_infer_workspace_bytes(d) bytes, uninitialised.  proc_order as in s3g_hexplane_forward. */
+#include "s3g_hexplane.h"
+size_t s3g_deform_infer_workspace_bytes(const s3g_hexplane_desc* d);
+int s3g_deform_infer(const s3g_hexplane_desc* d, const s3g_mlp_params* w, int P, const float* xyz, const float* time,
+                     const unsigned int* proc_order, float* dx, float* dshs, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

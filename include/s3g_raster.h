@@ -201,7 +201,8 @@ enum {
   S3G_PROFILE_MLP_BACKWARD = 6,
   S3G_PROFILE_MLP_WGRAD = 7,
   S3G_PROFILE_ADAM = 8,
-  S3G_PROFILE_IDS = 9
+  S3G_PROFILE_DEFORM_INFER = 9, /* s3g_deform_infer: HexPlane sampler (+) MLP heads, inference */
+  S3G_PROFILE_IDS = 10
 };
 void s3g_profile_enable(int on);
 int s3g_profile_read(int id, double* total_ms, double* total_instances, double* total_pixels);

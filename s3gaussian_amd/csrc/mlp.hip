@@ -18,6 +18,7 @@
 //                        accumulators in registers, one LDS-combined atomic flush per workgroup; biases alongside.
 // HBM scratch is spent freely (2 x 1280 B per point): 3 GB of the 288 GB, ~1 ms of traffic for ~20 ms saved.
 #include "common.hpp"
+#include "hexplane_dev.hpp"
 
 #include "../../include/s3g_mlp.h"
 
@@ -418,6 +419,126 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_backward_kernel(const MlpBwdAr
 #undef WSLAB
 #undef BIAS
 
+// ---- inference: HexPlane sampler (+) MLP heads in ONE kernel (render(): gaussian_renderer/__init__.py:82-97) --------
+// Under no_grad nothing is stashed and the feature (dino) head is not needed, so the weight image shrinks to the first six slabs
+// (W0 | W0 | P1 | S1 | P2 | S2 = 104 KB) and 46 KB of LDS are left: each wave gets a 32-point x 32-channel staging tile and one
+// level's tap slots.  A wave samples ONE LEVEL of its 32 points the way hexplane_forward_kernel does (8 lanes per point, four
+// rounds of 8 points), writes the float4 it would have stored to HBM into the staging tile instead, re-reads it in the MFMA B
+// operand layout (lane = point, registers = channels) and runs that level's quarter of the feature_out GEMM (K = 32); after the
+// fourth level `hidden` is complete and the two heads follow exactly as in mlp_forward_kernel.  The [P,128] feature array -- 614 MB
+// written by the sampler and read back by the MLP at cfg3 -- never exists; the sampler waves of a CU wait on texel gathers while
+// its other waves keep the matrix pipe busy.  Same arithmetic in the same order as the two separate kernels (the K order of the
+// feature_out GEMM is level 0..3 there too): outputs are bit-identical (tests/test_infer_gpu.py).
+struct InferArgs {
+  HexArgs h;            // sampler side: descriptor (row tables already swapped in when uniform_time), xyz, time, proc_order, P
+  const float* packed;  // mlp_pack_kernel's image
+  float *dx, *dshs;
+};
+constexpr int INF_SLABS = 6;
+constexpr int INF_WFLOATS = INF_SLABS * SLAB + 8 * 64;
+constexpr int STG_LD = 36;                       // floats per staged point: 32 channels + 4 (16 lanes of a ds_read_b128 hit 16 distinct bank groups)
+constexpr int STG_FLOATS = MT * STG_LD;
+constexpr int INF_TAP_STRIDE = TAP_SLOTS + 1;    // float4 per point: 6 taps used, padded like tap_stride()
+constexpr int INF_WAVE_FLOATS = STG_FLOATS + 8 * INF_TAP_STRIDE * 4;
+constexpr int INF_LDS_FLOATS = INF_WFLOATS + NWAVE * INF_WAVE_FLOATS;
+static_assert(INF_LDS_FLOATS * 4 <= 160 * 1024, "inference image + staging must fit the CU's LDS");
+
+template <bool UT>
+__global__ void __launch_bounds__(NWAVE * 64) deform_infer_kernel(const InferArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = wave; c < INF_SLABS * SLAB / 256; c += NWAVE)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.packed + c * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(lds + c * 256), 16, 0, 0);
+  if (wave < 2)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.packed + NSLAB * SLAB + wave * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(lds + INF_SLABS * SLAB + wave * 256), 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  auto wslab = [&](int k) { return lds + k * SLAB; };
+  auto bias = [&](int k) { return lds + INF_SLABS * SLAB + k * 64; };   // b0 | pb1 | sb1 | pb2 | sb2 | ...
+  float* stage = lds + INF_WFLOATS + wave * INF_WAVE_FLOATS;
+  float4* taps = reinterpret_cast<float4*>(stage + STG_FLOATS) + (lane >> 3) * INF_TAP_STRIDE;
+  const int slot = lane >> 3, j8 = lane & 7, c4 = j8 * 4;   // sampler role: point slot, channel quad
+  const int jj = lane & 31, hh = lane >> 5;                 // MFMA role: point column, row half
+  const int P = a.h.P, ntiles = (P + MT - 1) / MT;
+  for (int tile = blockIdx.x * NWAVE + wave; tile < ntiles; tile += gridDim.x * NWAVE) {
+    const int p0 = tile * MT;
+    f32x16 hid[2];
+    acc_bias<2>(hid, bias(0), lane);
+    for (int l = 0; l < 4; l++) {
+      for (int rr = 0; rr < 4; rr++) {
+        const int pos = p0 + 8 * rr + slot;
+        const int p = pos < P ? (a.h.proc_order ? (int)a.h.proc_order[pos] : pos) : 0;
+        float u[4];
+        point_coords(a.h, p, u);
+        wave_lds_sync();   // the previous round's taps have been read
+        produce_taps_level(a.h, u, j8, l, taps);
+        wave_lds_sync();
+        float4 prod = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          const int W = a.h.d.res[l][PAIR0[i]], H = a.h.d.res[l][PAIR1[i]];
+          const float* pl = a.h.d.planes[l][i];
+          float4 s;
+          if (UT && IS_TIME_PLANE[i]) {
+            const PointTap t = read_tap<true>(taps, 0, i, W, H, c4);
+            s = texel4(pl, t.off) * t.gx;
+            s = s + texel4(pl, t.off + t.dx) * t.fx;
+          } else {
+            const PointTap t = read_tap<false>(taps, 0, i, W, H, c4);
+            s = texel4(pl, t.off) * (t.gx * t.gy);
+            s = s + texel4(pl, t.off + t.dx) * (t.fx * t.gy);
+            s = s + texel4(pl, t.off + t.dy) * (t.gx * t.fy);
+            s = s + texel4(pl, t.off + t.dy + t.dx) * (t.fx * t.fy);
+          }
+          prod = prod * s;
+        }
+        *reinterpret_cast<float4*>(stage + (8 * rr + slot) * STG_LD + c4) = prod;
+      }
+      wave_lds_sync();
+      f32x16 x[1];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {   // channels 8q + 4h .. +3 of point jj: the chunk act_load would have read from HBM
+        const float4 v = *reinterpret_cast<const float4*>(stage + jj * STG_LD + 8 * q + 4 * hh);
+        x[0][4 * q + 0] = v.x; x[0][4 * q + 1] = v.y; x[0][4 * q + 2] = v.z; x[0][4 * q + 3] = v.w;
+      }
+      gemm_reg<2, 1, false>(wslab(l >> 1) + 32 * (l & 1) * 65, 65, x, hid, lane);   // K quarter l of feature_out
+    }
+    const int posm = p0 + jj;
+    const bool livem = posm < P;
+    const size_t pm = livem ? (size_t)(a.h.proc_order ? a.h.proc_order[posm] : (uint32_t)posm) : 0;
+    f32x16 act[2], acc[2], o[1];
+    // pos head
+    acc_bias<2>(act, bias(1), lane);
+    gemm_reg<2, 2, true>(wslab(2), 65, hid, act, lane);
+    relu_inplace<2>(act);
+    acc_bias<1>(o, bias(3), lane);
+    gemm_reg<1, 2, false>(wslab(4), 33, act, o, lane);
+    if (livem && hh == 0) {
+      float* row = a.dx + pm * 3;
+      row[0] = o[0][0]; row[1] = o[0][1]; row[2] = o[0][2];
+    }
+    // shs head
+    acc_bias<2>(act, bias(2), lane);
+    gemm_reg<2, 2, true>(wslab(3), 65, hid, act, lane);
+    relu_inplace<2>(act);
+    acc_bias<2>(acc, bias(4), lane);
+    gemm_reg<2, 2, false>(wslab(5), 65, act, acc, lane);
+    if (livem) {
+      float* row = a.dshs + pm * 48 + 4 * hh;
+#pragma unroll
+      for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (32 * mb + 8 * q >= 48) continue;
+          *reinterpret_cast<float4*>(row + 32 * mb + 8 * q) =
+              make_float4(acc[mb][4 * q + 0], acc[mb][4 * q + 1], acc[mb][4 * q + 2], acc[mb][4 * q + 3]);
+        }
+    }
+  }
+}
+
 // dW[o][i] += sum_p G[p][o] * A[p][i];  db[o] += sum_p G[p][o].   An MFMA GEMM whose K dimension is the points, fed
 // straight from HBM: at K step s lane (i, k) supplies point p0 + 2s + k, and -- because the order of the M / N rows of an
 // MFMA is as free as its K order -- row i of block t is feature VEC*i + t, so a lane's operand values for all blocks
@@ -468,9 +589,17 @@ __device__ __forceinline__ void row_load(float (&v)[RowSplit<W>::VEC], const flo
 // the full memory latency once per tile that way: ~9 us per tile for 1.7 us of MFMA work).  The one ragged tile at the end
 // of the array is handled separately with masked loads.
 constexpr int WG_WAVES = 8;  // waves per wgrad workgroup (one persistent workgroup per CU)
+#ifndef S3G_WGRAD_STREAM
+#define S3G_WGRAD_STREAM 0   // streaming loads for the planes a launch reads once: measured SLOWER (0.955 -> 1.01 ms, r3), kept as an A/B switch
+#endif
+#ifndef S3G_WGRAD_PAIRED
+#define S3G_WGRAD_PAIRED 1   // 0: the nine separate launches of round 2 (A/B builds: tools/build_variant.sh)
+#endif
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
-constexpr bool WGRAD_NONTEMPORAL = false;   // streaming operand loads: measured slower (1.19 -> 1.27 ms), the shared `hidden` plane is re-read by three launches
+// streaming operand loads in the single-GEMM launches: r2 measured them slower (1.19 -> 1.27 ms) while `hidden` was re-read by three
+// of those launches; since the paired launches (below) only D2 / P2 / S2 remain here and every plane they read is read once
+constexpr bool WGRAD_NONTEMPORAL = S3G_WGRAD_PAIRED && S3G_WGRAD_STREAM;
 
 // raw (select-free) operand loads of a FULL tile: columns are clamped statically so lanes beyond the row's width re-read
 // valid data (their MFMA rows are discarded at the flush)
@@ -631,6 +760,163 @@ __global__ void __launch_bounds__(WG_WAVES * 64) mlp_wgrad_kernel(const WgradArg
   if (a.db != nullptr && threadIdx.x < GW) atomicAdd(&a.db[threadIdx.x], red[32 * GV * AW + threadIdx.x]);
 }
 
+// ---- weight gradients of GEMMs that SHARE an operand, in one launch ---------------------------------------------------------
+// D0 / P1 / S1 all multiply by `hidden` (P1 and S1 through a ReLU), the two K halves of feature_out share `ghid`; as nine separate
+// launches every shared plane came from HBM once per launch (4.87 GB per iteration for 0.61 GB of algorithmic input).  Here the
+// waves of a persistent workgroup are split by GEMM ("job") and the waves with the same index inside their jobs walk the SAME
+// tile sequence, so the rows of a shared plane are requested by two to three waves of one CU within the same few microseconds and
+// all but the first request hit in the L2 of that XCD (or are merged in the L1).  One code path for every job of the launch -- the
+// shapes (64 x 64, row strides, ReLU on the activation) are runtime values -- because a workgroup whose waves run eight differently
+// unrolled code paths thrashes the instruction cache (all nine GEMMs in one launch, 1.55 -> 1.93 ms).
+struct WJob {
+  const float* G;   // [P][64]
+  const float* A;   // [P][astride], 64 columns used
+  float* dW;        // [64][astride] window
+  float* db;        // [64] or NULL
+  int astride;
+  float relu_lo;    // 0 = ReLU on A, -inf = none: one v_max either way
+};
+struct WMultiArgs {
+  WJob job[4];
+  int wpj;          // waves per job (workgroup = njobs * wpj waves)
+  int P;
+};
+constexpr int WM_RED = 32 * 2 * 64 + 32 * 2;   // floats of LDS per job: its 64 x 64 block + the bias sums
+
+// NT: streaming load for a plane this launch reads exactly once (evict-first in L2, so the SHARED plane's rows survive until the
+// sibling waves have asked for them)
+template <bool NT>
+__device__ __forceinline__ void wide_row(float (&v)[2], const float* __restrict__ g, int p, int stride, int i) {
+  const float* src = g + (size_t)p * stride + 2 * i;
+  if (NT && S3G_WGRAD_STREAM) {
+    const f2v x = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(src));
+    v[0] = x.x; v[1] = x.y;
+  } else {
+    const float2 x = *reinterpret_cast<const float2*>(src);
+    v[0] = x.x; v[1] = x.y;
+  }
+}
+
+template <bool G_NT, bool A_NT>
+__global__ void __launch_bounds__(WG_WAVES * 64) mlp_wgrad_multi_kernel(const WMultiArgs a) {
+  constexpr int STEPS = MT / 2;
+  extern __shared__ __attribute__((aligned(16))) float red_all[];
+  const int nw = blockDim.x >> 6;
+  for (int e = threadIdx.x; e < (nw / a.wpj) * WM_RED; e += blockDim.x) red_all[e] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int jidx = wave / a.wpj, wj = wave % a.wpj;
+  const WJob jb = a.job[jidx];
+  float* red = red_all + jidx * WM_RED;
+  const int i = lane & 31, k = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+  float bsum[2] = {0.f, 0.f};
+  const int nfull = a.P / MT;
+  const int stride = gridDim.x * a.wpj;
+  struct Set {
+    float g[STEPS][2];
+    float v[STEPS][2];
+  };
+  auto issue = [&](Set& S, int tile) {  // requires tile < nfull
+    const int p0 = tile * MT;
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      wide_row<G_NT>(S.g[s], jb.G, p0 + 2 * s + k, HID, i);
+      wide_row<A_NT>(S.v[s], jb.A, p0 + 2 * s + k, jb.astride, i);
+    }
+  };
+  auto consume = [&](const Set& S) {
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      const float b0 = fmaxf(S.v[s][0], jb.relu_lo), b1 = fmaxf(S.v[s][1], jb.relu_lo);
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        bsum[m] += S.g[s][m];
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(S.g[s][m], b0, acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(S.g[s][m], b1, acc[m][1], 0, 0, 0);
+      }
+    }
+  };
+  {
+    Set A, B;   // two alternating register sets, unconditional clamped prefetch: see mlp_wgrad_kernel
+    const int t0 = blockIdx.x * a.wpj + wj;
+    const int cnt = t0 < nfull ? (nfull - t0 + stride - 1) / stride : 0;
+    const int last = nfull - 1;
+    if (cnt > 0) {
+      issue(A, t0);
+      for (int it = 0; it < cnt; it += 2) {
+        issue(B, min(t0 + (it + 1) * stride, last));
+        __builtin_amdgcn_sched_barrier(0);
+        consume(A);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 >= cnt) break;
+        issue(A, min(t0 + (it + 2) * stride, last));
+        __builtin_amdgcn_sched_barrier(0);
+        consume(B);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (a.P % MT != 0 && (nfull % stride) == blockIdx.x * a.wpj + wj) {   // the ragged last tile, masked loads
+    const int p0 = nfull * MT;
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      const int p = p0 + 2 * s + k;
+      float ga[2] = {0.f, 0.f}, ba[2] = {0.f, 0.f};
+      if (p < a.P) {
+        wide_row<false>(ga, jb.G, p, HID, i);
+        wide_row<false>(ba, jb.A, p, jb.astride, i);
+        ba[0] = fmaxf(ba[0], jb.relu_lo); ba[1] = fmaxf(ba[1], jb.relu_lo);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        bsum[m] += ga[m];
+#pragma unroll
+        for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[m], ba[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+  // the waves of a job add their blocks into the job's LDS block one after the other (plain read-modify-writes, fixed order)
+  for (int w = 0; w < a.wpj; w++) {
+    if (wj == w) {
+#pragma unroll
+      for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) red[(2 * acc_row(r, lane) + m) * 64 + 2 * (lane & 31) + n] += acc[m][n][r];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
+        if (k == 0) red[32 * 2 * 64 + 2 * i + m] += tot;
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = wj * 64 + lane; e < 64 * 64; e += a.wpj * 64)
+    atomicAdd(&jb.dW[(size_t)(e >> 6) * jb.astride + (e & 63)], red[e]);
+  if (jb.db != nullptr && wj == 0) atomicAdd(&jb.db[lane], red[32 * 2 * 64 + lane]);
+}
+
+template <bool G_NT, bool A_NT>
+static int launch_wgrad_multi(const WJob* jobs, int njobs, int P, hipStream_t stream) {
+  WMultiArgs a;
+  for (int j = 0; j < 4; j++) a.job[j] = jobs[j < njobs ? j : 0];
+  a.wpj = WG_WAVES / njobs;
+  a.P = P;
+  const int ntiles = (P + MT - 1) / MT;
+  const int blocks = min((ntiles + a.wpj - 1) / a.wpj, 256);
+  hipLaunchKernelGGL((mlp_wgrad_multi_kernel<G_NT, A_NT>), dim3(blocks), dim3(njobs * a.wpj * 64), (size_t)njobs * WM_RED * sizeof(float), stream, a);
+  S3G_HIP_CHECK(hipGetLastError());
+  return S3G_OK;
+}
+
 template <int GW, int AW, bool RELU_A, int ASTRIDE = AW>
 static int launch_wgrad(const float* G, const float* A, float* dW, float* db, int P, hipStream_t stream) {
   WgradArgs a{G, A, dW, db, P};
@@ -657,6 +943,8 @@ static int mlp_set_attrs() {
   if (device_needs_setup(done)) {
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_multi_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WM_RED * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_multi_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WM_RED * 4));
     device_setup_done(done);
   }
   return S3G_OK;
@@ -706,7 +994,26 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   S3G_HIP_CHECK(hipGetLastError());
   profile_begin(S3G_PROFILE_MLP_WGRAD, stream);
   const size_t PS = (size_t)P * HID;
-  if (g_feat != nullptr) {  // NULL: the dino head received no gradient; its six parameter gradients are left untouched
+  const float NONE = -__builtin_huge_valf(), RELU = 0.f;
+  // GEMMs that share an operand run in ONE launch each (see mlp_wgrad_multi_kernel): feature_out's two K halves share ghid ...
+  const WJob w0a{workspace + 4 * PS, features, gw->W0, gw->b0, FEAT, NONE}, w0b{workspace + 4 * PS, features + 64, gw->W0 + 64, nullptr, FEAT, NONE};
+  // ... and D0 / P1 / S1 share `hidden` (stash plane 0); D1 fills the fourth wave pair of the workgroup
+  const WJob d0{workspace + 1 * PS, stash + 0 * PS, gw->D0, gw->db0, HID, NONE}, d1{workspace + 0 * PS, stash + 3 * PS, gw->D1, gw->db1, HID, NONE};
+  const WJob p1{workspace + 2 * PS, stash + 0 * PS, gw->P1, gw->pb1, HID, RELU}, s1{workspace + 3 * PS, stash + 0 * PS, gw->S1, gw->sb1, HID, RELU};
+  if (S3G_WGRAD_PAIRED) {
+    { const WJob jobs[2] = {w0a, w0b}; if (int e = (launch_wgrad_multi<false, true>(jobs, 2, P, stream))) return e; }   // ghid shared, feature halves read once
+    if (g_feat != nullptr) {  // NULL: the dino head received no gradient; its six parameter gradients are left untouched
+      const WJob jobs[4] = {d0, p1, s1, d1};
+      if (int e = (launch_wgrad_multi<true, false>(jobs, 4, P, stream))) return e;   // every G plane read once, `hidden` shared
+      if (int e = launch_wgrad<3, 64, false>(g_feat, stash + 4 * PS, gw->D2, gw->db2, P, stream)) return e;
+    } else {
+      const WJob jobs[2] = {p1, s1};
+      if (int e = (launch_wgrad_multi<true, false>(jobs, 2, P, stream))) return e;
+    }
+    if (int e = launch_wgrad<3, 64, false>(g_dx, stash + 1 * PS, gw->P2, gw->pb2, P, stream)) return e;
+    if (int e = launch_wgrad<48, 64, false>(g_dshs, stash + 2 * PS, gw->S2, gw->sb2, P, stream)) return e;
+  } else {
+  if (g_feat != nullptr) {
     if (int e = launch_wgrad<3, 64, false>(g_feat, stash + 4 * PS, gw->D2, gw->db2, P, stream)) return e;
     if (int e = launch_wgrad<64, 64, false>(workspace + 0 * PS, stash + 3 * PS, gw->D1, gw->db1, P, stream)) return e;
     if (int e = launch_wgrad<64, 64, false>(workspace + 1 * PS, stash + 0 * PS, gw->D0, gw->db0, P, stream)) return e;
@@ -717,6 +1024,49 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   if (int e = launch_wgrad<64, 64, true>(workspace + 3 * PS, stash + 0 * PS, gw->S1, gw->sb1, P, stream)) return e;
   if (int e = launch_wgrad<64, 64, false, 128>(workspace + 4 * PS, features, gw->W0, gw->b0, P, stream)) return e;
   if (int e = launch_wgrad<64, 64, false, 128>(workspace + 4 * PS, features + 64, gw->W0 + 64, nullptr, P, stream)) return e;
+  }
   profile_end(S3G_PROFILE_MLP_WGRAD, stream, (double)P, 0.0);
+  return S3G_OK;
+}
+
+extern "C" size_t s3g_deform_infer_workspace_bytes(const s3g_hexplane_desc* d) {
+  if (!d || d->levels != 4) return 0;
+  return ((size_t)PACK_FLOATS + (d->uniform_time ? time_table_floats(d) : 0)) * sizeof(float);
+}
+
+extern "C" int s3g_deform_infer(const s3g_hexplane_desc* d, const s3g_mlp_params* w, int P, const float* xyz, const float* time,
+                                const unsigned int* proc_order, float* dx, float* dshs, void* workspace, void* stream_) {
+  if (int e = check_desc(d)) return e;
+  if (d->levels != 4) {
+    set_error("s3g_deform_infer: the fused path is built for 4 levels x 32 channels = feature_out's 128 inputs");
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (!w || P < 0 || (P > 0 && (!xyz || !time || !dx || !dshs || !workspace))) {
+    set_error("s3g_deform_infer: bad argument");
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (P == 0) return S3G_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  static std::atomic<uint64_t> done{0};
+  if (device_needs_setup(done)) {
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)deform_infer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, INF_LDS_FLOATS * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)deform_infer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, INF_LDS_FLOATS * 4));
+    device_setup_done(done);
+  }
+  float* packed = (float*)workspace;
+  InferArgs a;
+  memset(&a, 0, sizeof a);
+  a.h.d = *d; a.h.P = P; a.h.xyz = xyz; a.h.time = time; a.h.proc_order = proc_order;
+  a.packed = packed; a.dx = dx; a.dshs = dshs;
+  TimeRows rows;
+  if (d->uniform_time) use_time_rows(a.h, rows, packed + PACK_FLOATS, nullptr, stream);
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(NSLAB + 1), dim3(256), 0, stream, *w, packed);
+  const int ntiles = (P + MT - 1) / MT;
+  const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
+  profile_begin(S3G_PROFILE_DEFORM_INFER, stream);
+  if (d->uniform_time) hipLaunchKernelGGL(deform_infer_kernel<true>, dim3(blocks), dim3(NWAVE * 64), INF_LDS_FLOATS * 4, stream, a);
+  else hipLaunchKernelGGL(deform_infer_kernel<false>, dim3(blocks), dim3(NWAVE * 64), INF_LDS_FLOATS * 4, stream, a);
+  profile_end(S3G_PROFILE_DEFORM_INFER, stream, (double)P, 4.0);
+  S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }

@@ -16,7 +16,12 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .hexplane import HexPlaneField
-from .mlp import deform_mlp
+import os
+
+from .mlp import deform_infer, deform_mlp
+
+# S3G_FUSED_INFERENCE=0: inference renders go through the two separate kernels (sampler, then MLP) like training does
+FUSED_INFERENCE = os.environ.get("S3G_FUSED_INFERENCE", "1") != "0"
 
 
 def poc_fre(input_data, poc_buf):
@@ -127,6 +132,12 @@ class Deformation(nn.Module):
         """(dx [P,3], dshs [P,16,3], feat [P,3]) only -- the part of forward_dynamic that is not a pass-through in the
         reference's default configuration.  Lets a caller that fuses `shs + dshs` downstream (pipeline.render) skip
         materialising the [P,16,3] sum."""
+        if (FUSED_INFERENCE and not torch.is_grad_enabled() and not need_feat and reg_weights is None and xyz.is_cuda
+                and len(self.grid.resolutions) == 4):
+            # inference render without the feature image: sampler (+) heads in one kernel, no [P,128] round trip
+            dx, dshs = deform_infer(self.grid, xyz[:, :3], time[:, :1], self.feature_out, self.pos_deform, self.shs_deform,
+                                    self.dino_head, uniform_time)
+            return dx, dshs.reshape([xyz.shape[0], 16, 3]), None
         reg = None
         if reg_weights is not None:   # plane regulariser evaluated on the sampler's autograd node (hexplane_sample)
             feats, reg = self.grid(xyz[:, :3], time[:, :1], uniform_time, reg_weights)

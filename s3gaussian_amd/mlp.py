@@ -32,6 +32,11 @@ def _bind():
         L.s3g_deform_mlp_pack_bytes.restype = C.c_size_t
         L.s3g_deform_mlp_backward.restype = C.c_int
         L.s3g_deform_mlp_backward.argtypes = [C.POINTER(_Params), C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(_Params), vp, vp]
+        from .hexplane import _HexDesc
+        L.s3g_deform_infer_workspace_bytes.restype = C.c_size_t
+        L.s3g_deform_infer_workspace_bytes.argtypes = [C.POINTER(_HexDesc)]
+        L.s3g_deform_infer.restype = C.c_int
+        L.s3g_deform_infer.argtypes = [C.POINTER(_HexDesc), C.POINTER(_Params), C.c_int, vp, vp, vp, vp, vp, vp, vp]
         _bound = True
     return L
 
@@ -99,12 +104,47 @@ class _DeformMLP(torch.autograd.Function):
         return (gx, None, None, *grads)
 
 
+def _head_params(feature_out, pos_deform, shs_deform, dino_head):
+    return [feature_out[0].weight, feature_out[0].bias, pos_deform[1].weight, pos_deform[1].bias, pos_deform[3].weight,
+            pos_deform[3].bias, shs_deform[1].weight, shs_deform[1].bias, shs_deform[3].weight, shs_deform[3].bias,
+            dino_head[0].weight, dino_head[0].bias, dino_head[2].weight, dino_head[2].bias, dino_head[4].weight,
+            dino_head[4].bias]
+
+
+@torch.no_grad()
+def deform_infer(grid, xyz, time, feature_out, pos_deform, shs_deform, dino_head, uniform_time=None):
+    """Inference only: HexPlane sampler (+) feature_out + position / SH heads in ONE kernel (include/s3g_mlp.h::s3g_deform_infer).
+    xyz [P,3], time [P,1] -> (dx [P,3], dshs [P,48]); bit-identical to `deform_mlp(grid(xyz, time), ..., need_feat=False)[:2]`
+    without ever materialising the [P,128] features.  `grid` is the HexPlaneField (4 levels x 32 channels)."""
+    from .hexplane import _make_desc
+    if not xyz.is_cuda:
+        raise RuntimeError(f"deform_infer: xyz must live on the GPU (got {xyz.device}); no CPU fallback")
+    L = _bind()
+    P, dev = xyz.shape[0], xyz.device
+    xyz_c = xyz.detach().contiguous().float()
+    t_c = time.detach().reshape(-1).contiguous().float()
+    if t_c.numel() != P:
+        raise RuntimeError("time must have one value per point")
+    if uniform_time is None:
+        uniform_time = bool(P > 0 and (t_c == t_c[0]).all().item())
+    d = _make_desc(grid._planes(), grid.resolutions, grid._host_aabb(), bool(uniform_time) and P > 0)
+    order = grid._order_cache.get("order")
+    if order is not None and (order.numel() != P or order.device != dev):
+        order = None
+    dx = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    dshs = torch.empty((P, 48), dtype=torch.float32, device=dev)
+    ws = torch.empty(max(L.s3g_deform_infer_workspace_bytes(C.byref(d)), 4) // 4, dtype=torch.float32, device=dev)
+    w = _pack([p.detach() for p in _head_params(feature_out, pos_deform, shs_deform, dino_head)])
+    with torch.cuda.device(dev):
+        _lib.check(L.s3g_deform_infer(C.byref(d), C.byref(w), P, xyz_c.data_ptr(), t_c.data_ptr(),
+                                      order.data_ptr() if order is not None else None, dx.data_ptr(), dshs.data_ptr(),
+                                      ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return dx, dshs
+
+
 def deform_mlp(features, feature_out, pos_deform, shs_deform, dino_head, need_feat=True):
     """features [P,128] -> (dx [P,3], dshs [P,48], feat [P,3]) with the reference's Sequential modules as parameter
     holders (feature_out = Sequential(Linear); heads = Sequential(ReLU, Linear, ReLU, Linear); dino = Sequential(Linear,
     ReLU, Linear, ReLU, Linear))."""
-    ps = [feature_out[0].weight, feature_out[0].bias, pos_deform[1].weight, pos_deform[1].bias, pos_deform[3].weight,
-          pos_deform[3].bias, shs_deform[1].weight, shs_deform[1].bias, shs_deform[3].weight, shs_deform[3].bias,
-          dino_head[0].weight, dino_head[0].bias, dino_head[2].weight, dino_head[2].bias, dino_head[4].weight,
-          dino_head[4].bias]
+    ps = _head_params(feature_out, pos_deform, shs_deform, dino_head)
     return _DeformMLP.apply(features, need_feat, torch.is_grad_enabled(), *ps)
