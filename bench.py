@@ -389,7 +389,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    for i in range(9):
+    for i in range(10):
         L.s3g_profile_read(i, None, None, None)
     L.s3g_profile_enable(1)
     vis_masks = []     # summed after the timed region (workload statistics are not part of the step)
@@ -415,12 +415,18 @@ def main():
         for i in range(3):
             render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
         torch.cuda.synchronize()
+        L.s3g_profile_read(9, None, None, None)
+        L.s3g_profile_enable(1)
         t1 = time.perf_counter()
         n_frames = 20
         for i in range(n_frames):
             render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
         torch.cuda.synchronize()
         render_ms = 1000.0 * (time.perf_counter() - t1) / n_frames
+        L.s3g_profile_enable(0)
+        _ms = C.c_double()
+        _n = L.s3g_profile_read(9, C.byref(_ms), None, None)
+        infer_kernel_ms = (_ms.value / _n) if _n else None   # s3g::deform_infer_kernel (HexPlane (+) MLP heads), per frame
 
     if rank == 0:
         # ---- roofline leg: every hot kernel timed in-library with hipEvents on the launch stream (include/s3g_raster.h),
@@ -533,7 +539,8 @@ def main():
                        "densify_bookkeeping_in_step": True,
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
                        "blend_forward_avg_ms": fwd["avg_launch_ms"] if fwd else None,
-                       "render_ms_per_frame": round(render_ms, 3)},
+                       "render_ms_per_frame": round(render_ms, 3),
+                       "render_deform_infer_kernel_ms": round(infer_kernel_ms, 4) if infer_kernel_ms else None},
             "roofline": roof,
         }
         if world == 1 and not a.no_alt_paths:

@@ -429,6 +429,11 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_backward_kernel(const MlpBwdAr
 // written by the sampler and read back by the MLP at cfg3 -- never exists; the sampler waves of a CU wait on texel gathers while
 // its other waves keep the matrix pipe busy.  Same arithmetic in the same order as the two separate kernels (the K order of the
 // feature_out GEMM is level 0..3 there too): outputs are bit-identical (tests/test_infer_gpu.py).
+#ifndef S3G_INFER_STAGGER
+#define S3G_INFER_STAGGER 0   // x 127 x 64 cycles (~3.9 us each) of initial delay for waves 4..7: measured without effect (r3)
+#endif
+#define S3G_INFER_PRIO 0   // 1: s_setprio(1) around the MFMA clusters, 2: static priority for waves 4..7
+#define S3G_INFER_EXPERIMENT 0   // 1: no head GEMMs, 2: no texel loads (timing experiments only; results are wrong)
 struct InferArgs {
   HexArgs h;            // sampler side: descriptor (row tables already swapped in when uniform_time), xyz, time, proc_order, P
   const float* packed;  // mlp_pack_kernel's image
@@ -439,7 +444,7 @@ constexpr int INF_WFLOATS = INF_SLABS * SLAB + 8 * 64;
 constexpr int STG_LD = 36;                       // floats per staged point: 32 channels + 4 (16 lanes of a ds_read_b128 hit 16 distinct bank groups)
 constexpr int STG_FLOATS = MT * STG_LD;
 constexpr int INF_TAP_STRIDE = TAP_SLOTS + 1;    // float4 per point: 6 taps used, padded like tap_stride()
-constexpr int INF_WAVE_FLOATS = STG_FLOATS + 8 * INF_TAP_STRIDE * 4;
+constexpr int INF_WAVE_FLOATS = STG_FLOATS + 2 * 8 * INF_TAP_STRIDE * 4;   // staging tile + two sets of tap slots
 constexpr int INF_LDS_FLOATS = INF_WFLOATS + NWAVE * INF_WAVE_FLOATS;
 static_assert(INF_LDS_FLOATS * 4 <= 160 * 1024, "inference image + staging must fit the CU's LDS");
 
@@ -458,73 +463,160 @@ __global__ void __launch_bounds__(NWAVE * 64) deform_infer_kernel(const InferArg
   auto wslab = [&](int k) { return lds + k * SLAB; };
   auto bias = [&](int k) { return lds + INF_SLABS * SLAB + k * 64; };   // b0 | pb1 | sb1 | pb2 | sb2 | ...
   float* stage = lds + INF_WFLOATS + wave * INF_WAVE_FLOATS;
-  float4* taps = reinterpret_cast<float4*>(stage + STG_FLOATS) + (lane >> 3) * INF_TAP_STRIDE;
   const int slot = lane >> 3, j8 = lane & 7, c4 = j8 * 4;   // sampler role: point slot, channel quad
   const int jj = lane & 31, hh = lane >> 5;                 // MFMA role: point column, row half
+  float4* tp0 = reinterpret_cast<float4*>(stage + STG_FLOATS) + slot * INF_TAP_STRIDE;   // two sets of tap slots per point slot
+  float4* tp1 = tp0 + 8 * INF_TAP_STRIDE;
   const int P = a.h.P, ntiles = (P + MT - 1) / MT;
+  if (S3G_INFER_PRIO == 2 && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
+#if S3G_INFER_STAGGER
+  // Waves w and w + 4 share a SIMD.  Started together they stay in lockstep -- both gather, then both queue on the matrix pipe --
+  // and the pipe idles through every gather phase; starting the second four half a tile later lets one wave's heads run under
+  // the other's texel gathers.
+  if (wave >= 4)
+    for (int d = 0; d < S3G_INFER_STAGGER; d++) __builtin_amdgcn_s_sleep(127);
+#endif
+  // texels of one (level, round): spatial planes (x,y) (x,z) (y,z) four corners each; time planes four corners, or -- uniform
+  // time -- the two corners of their row tables
+  constexpr int NTEX = UT ? 18 : 24;
+  struct Tex { float4 v[NTEX]; };
+  // normalised coordinates of the tile's 32 points live in the 4 pad floats of their staging rows
+  auto taps_for = [&](int l, int rr, float4* tp) {
+    const float4 uv = *reinterpret_cast<const float4*>(stage + (8 * rr + slot) * STG_LD + 32);
+    const float u[4] = {uv.x, uv.y, uv.z, uv.w};
+    produce_taps_level(a.h, u, j8, l, tp);
+  };
+  auto issue = [&](Tex& T, int l, const float4* tp) {
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const int W = a.h.d.res[l][PAIR0[i]], H = a.h.d.res[l][PAIR1[i]];
+      const float* pl = a.h.d.planes[l][i];
+      if (S3G_INFER_EXPERIMENT == 2) {
+        const PointTap t = read_tap<false>(tp, 0, i, W, H, c4);
+        const float4 c = make_float4(t.fx, t.gx, t.fy, (float)(t.off & 1u) + (float)(size_t)pl);
+        for (int q = 0; q < ((UT && IS_TIME_PLANE[i]) ? 2 : 4); q++) T.v[n++] = c;
+      } else if (UT && IS_TIME_PLANE[i]) {
+        const PointTap t = read_tap<true>(tp, 0, i, W, H, c4);
+        T.v[n++] = texel4(pl, t.off);
+        T.v[n++] = texel4(pl, t.off + t.dx);
+      } else {
+        const PointTap t = read_tap<false>(tp, 0, i, W, H, c4);
+        T.v[n++] = texel4(pl, t.off);
+        T.v[n++] = texel4(pl, t.off + t.dx);
+        T.v[n++] = texel4(pl, t.off + t.dy);
+        T.v[n++] = texel4(pl, t.off + t.dy + t.dx);
+      }
+    }
+  };
+  auto consume = [&](const Tex& T, int l, int rr, const float4* tp) {
+    float4 prod = make_float4(1.f, 1.f, 1.f, 1.f);
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const int W = a.h.d.res[l][PAIR0[i]], H = a.h.d.res[l][PAIR1[i]];
+      float4 s;
+      if (UT && IS_TIME_PLANE[i]) {
+        const PointTap t = read_tap<true>(tp, 0, i, W, H, c4);
+        s = T.v[n] * t.gx;
+        s = s + T.v[n + 1] * t.fx;
+        n += 2;
+      } else {
+        const PointTap t = read_tap<false>(tp, 0, i, W, H, c4);
+        s = T.v[n] * (t.gx * t.gy);
+        s = s + T.v[n + 1] * (t.fx * t.gy);
+        s = s + T.v[n + 2] * (t.gx * t.fy);
+        s = s + T.v[n + 3] * (t.fx * t.fy);
+        n += 4;
+      }
+      prod = prod * s;
+    }
+    *reinterpret_cast<float4*>(stage + (8 * rr + slot) * STG_LD + c4) = prod;
+  };
   for (int tile = blockIdx.x * NWAVE + wave; tile < ntiles; tile += gridDim.x * NWAVE) {
     const int p0 = tile * MT;
+    const int posm = p0 + jj;
+    const bool livem = posm < P;
+    const size_t pm = livem ? (size_t)(a.h.proc_order ? a.h.proc_order[posm] : (uint32_t)posm) : 0;
+    if (hh == 0) {   // one lane per point: coordinates -> the pad of the point's staging row
+      float u[4];
+      point_coords(a.h, (int)pm, u);
+      *reinterpret_cast<float4*>(stage + jj * STG_LD + 32) = make_float4(u[0], u[1], u[2], u[3]);
+    }
     f32x16 hid[2];
     acc_bias<2>(hid, bias(0), lane);
-    for (int l = 0; l < 4; l++) {
-      for (int rr = 0; rr < 4; rr++) {
-        const int pos = p0 + 8 * rr + slot;
-        const int p = pos < P ? (a.h.proc_order ? (int)a.h.proc_order[pos] : pos) : 0;
-        float u[4];
-        point_coords(a.h, p, u);
-        wave_lds_sync();   // the previous round's taps have been read
-        produce_taps_level(a.h, u, j8, l, taps);
-        wave_lds_sync();
-        float4 prod = make_float4(1.f, 1.f, 1.f, 1.f);
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-          const int W = a.h.d.res[l][PAIR0[i]], H = a.h.d.res[l][PAIR1[i]];
-          const float* pl = a.h.d.planes[l][i];
-          float4 s;
-          if (UT && IS_TIME_PLANE[i]) {
-            const PointTap t = read_tap<true>(taps, 0, i, W, H, c4);
-            s = texel4(pl, t.off) * t.gx;
-            s = s + texel4(pl, t.off + t.dx) * t.fx;
-          } else {
-            const PointTap t = read_tap<false>(taps, 0, i, W, H, c4);
-            s = texel4(pl, t.off) * (t.gx * t.gy);
-            s = s + texel4(pl, t.off + t.dx) * (t.fx * t.gy);
-            s = s + texel4(pl, t.off + t.dy) * (t.gx * t.fy);
-            s = s + texel4(pl, t.off + t.dy + t.dx) * (t.fx * t.fy);
-          }
-          prod = prod * s;
-        }
-        *reinterpret_cast<float4*>(stage + (8 * rr + slot) * STG_LD + c4) = prod;
-      }
-      wave_lds_sync();
+    wave_lds_sync();
+    // 16 steps k = (level k >> 2, round k & 3), two in flight: the texel gathers of step k + 2 are requested before step k's
+    // products are formed, and a level's quarter of the feature_out GEMM runs under the next level's first gathers
+    auto level_gemm = [&](int l) {   // the level's tile is complete: re-read it in the MFMA B-operand layout, K quarter l of feature_out
       f32x16 x[1];
+      wave_lds_sync();
 #pragma unroll
       for (int q = 0; q < 4; q++) {   // channels 8q + 4h .. +3 of point jj: the chunk act_load would have read from HBM
         const float4 v = *reinterpret_cast<const float4*>(stage + jj * STG_LD + 8 * q + 4 * hh);
         x[0][4 * q + 0] = v.x; x[0][4 * q + 1] = v.y; x[0][4 * q + 2] = v.z; x[0][4 * q + 3] = v.w;
       }
-      gemm_reg<2, 1, false>(wslab(l >> 1) + 32 * (l & 1) * 65, 65, x, hid, lane);   // K quarter l of feature_out
+      if (S3G_INFER_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+      gemm_reg<2, 1, false>(wslab(l >> 1) + 32 * (l & 1) * 65, 65, x, hid, lane);
+      if (S3G_INFER_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    };
+    if constexpr (UT) {
+      Tex A, B;
+      taps_for(0, 0, tp0);
+      taps_for(0, 1, tp1);
+      wave_lds_sync();
+      issue(A, 0, tp0);
+      issue(B, 0, tp1);
+      for (int k = 0; k < 16; k += 2) {
+        const int l = k >> 2, rr = k & 3;
+        consume(A, l, rr, tp0);
+        if (k + 2 < 16) {
+          wave_lds_sync();
+          taps_for((k + 2) >> 2, (k + 2) & 3, tp0);
+          wave_lds_sync();
+          issue(A, (k + 2) >> 2, tp0);
+        }
+        consume(B, l, rr + 1, tp1);
+        if (rr == 2) level_gemm(l);   // runs under the gathers of step k + 2 just requested
+        if (k + 3 < 16) {
+          wave_lds_sync();
+          taps_for((k + 3) >> 2, (k + 3) & 3, tp1);
+          wave_lds_sync();
+          issue(B, (k + 3) >> 2, tp1);
+        }
+      }
+    } else {   // per-point time (24 texels per step): one step in flight
+      Tex A;
+      for (int l = 0; l < 4; l++) {
+        for (int rr = 0; rr < 4; rr++) {
+          wave_lds_sync();
+          taps_for(l, rr, tp0);
+          wave_lds_sync();
+          issue(A, l, tp0);
+          consume(A, l, rr, tp0);
+        }
+        level_gemm(l);
+      }
     }
-    const int posm = p0 + jj;
-    const bool livem = posm < P;
-    const size_t pm = livem ? (size_t)(a.h.proc_order ? a.h.proc_order[posm] : (uint32_t)posm) : 0;
     f32x16 act[2], acc[2], o[1];
+    if (S3G_INFER_PRIO == 1) __builtin_amdgcn_s_setprio(1);
     // pos head
     acc_bias<2>(act, bias(1), lane);
-    gemm_reg<2, 2, true>(wslab(2), 65, hid, act, lane);
+    if (S3G_INFER_EXPERIMENT != 1) gemm_reg<2, 2, true>(wslab(2), 65, hid, act, lane);
     relu_inplace<2>(act);
     acc_bias<1>(o, bias(3), lane);
-    gemm_reg<1, 2, false>(wslab(4), 33, act, o, lane);
+    if (S3G_INFER_EXPERIMENT != 1) gemm_reg<1, 2, false>(wslab(4), 33, act, o, lane);
     if (livem && hh == 0) {
       float* row = a.dx + pm * 3;
       row[0] = o[0][0]; row[1] = o[0][1]; row[2] = o[0][2];
     }
     // shs head
     acc_bias<2>(act, bias(2), lane);
-    gemm_reg<2, 2, true>(wslab(3), 65, hid, act, lane);
+    if (S3G_INFER_EXPERIMENT != 1) gemm_reg<2, 2, true>(wslab(3), 65, hid, act, lane);
     relu_inplace<2>(act);
     acc_bias<2>(acc, bias(4), lane);
-    gemm_reg<2, 2, false>(wslab(5), 65, act, acc, lane);
+    if (S3G_INFER_EXPERIMENT != 1) gemm_reg<2, 2, false>(wslab(5), 65, act, acc, lane);
+    if (S3G_INFER_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     if (livem) {
       float* row = a.dshs + pm * 48 + 4 * hh;
 #pragma unroll
@@ -536,6 +628,7 @@ __global__ void __launch_bounds__(NWAVE * 64) deform_infer_kernel(const InferArg
               make_float4(acc[mb][4 * q + 0], acc[mb][4 * q + 1], acc[mb][4 * q + 2], acc[mb][4 * q + 3]);
         }
     }
+    wave_lds_sync();   // the next tile's coordinates go into the pads this tile's taps were derived from
   }
 }
 
