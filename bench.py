@@ -284,16 +284,81 @@ def _alt_step(path, pc, cam, gts, hyper, opt, bg, torch_adam):
     return loss.detach()
 
 
+def camera_object(cam, gts):
+    """A stand-in for the reference's Camera (scene/cameras.py:20-70) carrying what train.py / render() read from it."""
+    import math
+    from types import SimpleNamespace
+    gt_image, gt_depth, gt_feat = gts
+    return SimpleNamespace(image_height=cam["image_height"], image_width=cam["image_width"], FoVx=2.0 * math.atan(cam["tanfovx"]),
+                           FoVy=2.0 * math.atan(cam["tanfovy"]), world_view_transform=cam["viewmatrix"],
+                           full_proj_transform=cam["projmatrix"], camera_center=cam["campos"], time=cam["time"],
+                           original_image=gt_image, depth_map=gt_depth, feat_map=gt_feat.permute(1, 2, 0))
+
+
+def patched_reference_step(gaussians, viewpoint_cam, hyper, opt, background, pipe=None, stage="fine"):
+    """One iteration of the UNMODIFIED train.py (:372-437, :489-522; batch_size 1, below densify_until_iter) on the names
+    `s3gaussian_amd.patch.patch_reference()` rebinds -- what `python -m s3gaussian_amd.patch train.py ...` runs per iteration.
+    /root/reference does not exist on the GPU box, so the iteration body is restated here statement by statement: the calls are the
+    patch's replacements, everything train.py does inline (loss assembly one `loss +=` at a time, psnr, the NaN check and
+    `loss.item()` host syncs, the boolean-mask max_radii2D update) is kept as it is there."""
+    from types import SimpleNamespace
+    from s3gaussian_amd import patch
+    from s3gaussian_amd.pipeline import psnr
+    pipe = pipe or SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
+    args = hyper
+    render_pkg = patch.render(viewpoint_cam, gaussians, pipe, background, stage=stage, return_dx=True,
+                              render_feat=True if ('fine' in stage and args.feat_head) else False)
+    image, viewspace_point_tensor, visibility_filter, radii = (render_pkg["render"], render_pkg["viewspace_points"],
+                                                               render_pkg["visibility_filter"], render_pkg["radii"])
+    depth_pred_tensor = render_pkg["depth"].unsqueeze(0)
+    image_tensor = image.unsqueeze(0)
+    gt_image_tensor = viewpoint_cam.original_image.cuda().unsqueeze(0)
+    gt_depth_tensor = viewpoint_cam.depth_map.cuda().unsqueeze(0).float()
+    radii = radii.unsqueeze(0).max(dim=0).values
+    visibility_filter = visibility_filter.unsqueeze(0).any(dim=0)
+    Ll1 = patch.l1_loss(image_tensor, gt_image_tensor[:, :3, :, :])
+    psnr_ = psnr(image_tensor, gt_image_tensor).mean().double()
+    loss = Ll1
+    if 'fine' in stage and not args.no_dx and opt.lambda_dx != 0:
+        loss += torch.mean(torch.abs(render_pkg['dx'])) * opt.lambda_dx
+    if 'fine' in stage and not args.no_dshs and opt.lambda_dshs != 0:
+        loss += torch.mean(torch.abs(render_pkg['dshs'])) * opt.lambda_dshs
+    if opt.lambda_depth != 0:
+        loss += patch.compute_depth("l2", depth_pred_tensor, gt_depth_tensor) * opt.lambda_depth
+    if stage == "fine" and hyper.time_smoothness_weight != 0:
+        loss += patch.compute_regulation(gaussians, hyper.time_smoothness_weight, hyper.l1_time_planes, hyper.plane_tv_weight)
+    if opt.lambda_dssim != 0:
+        loss += opt.lambda_dssim * (1.0 - patch.ssim(image_tensor, gt_image_tensor))
+    if stage == 'fine' and args.feat_head:
+        feat = render_pkg['feat'].to('cuda')
+        gt_feat = viewpoint_cam.feat_map.permute(2, 0, 1).to('cuda')
+        loss += patch.l2_loss(feat, gt_feat) * opt.lambda_feat
+    loss.backward()
+    if torch.isnan(loss).any():
+        raise RuntimeError("loss is nan")
+    viewspace_point_tensor_grad = torch.zeros_like(viewspace_point_tensor) + viewspace_point_tensor.grad
+    with torch.no_grad():
+        _ = 0.4 * loss.item()                              # train.py:442 (progress bar EMA): a host sync per iteration
+        _ = 0.4 * psnr_
+        gaussians.max_radii2D[visibility_filter] = torch.max(gaussians.max_radii2D[visibility_filter], radii[visibility_filter].float())
+        patch.add_densification_stats(gaussians, viewspace_point_tensor_grad, visibility_filter)
+        gaussians.optimizer.step()
+        gaussians.optimizer.zero_grad(set_to_none=True)
+    return loss.detach()
+
+
 def time_alt_paths(pc, cams, views, targets, tkeys, hyper, opt, bg, steps=4, warmup=1):
     """-> {"zero_diff": {...}, "import_swap": {...}}: ms/step and it/s of the two slower call paths on the same scene."""
     groups = [{"params": g["params"], "lr": g["lr"], "name": g.get("name", "")} for g in pc.optimizer.param_groups]
     torch_adam = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
     out = {}
-    for path in ("import_swap", "zero_diff"):
+    for path in ("patched", "import_swap", "zero_diff"):
         try:
             def one(i):
                 v = views[i % len(views)]
                 gts = targets[v] if v in targets else targets[tkeys[i % len(tkeys)]]
+                if path == "patched":
+                    return patched_reference_step(pc, camera_object(cams[v], gts), hyper, opt, bg)
                 return _alt_step(path, pc, cams[v], gts, hyper, opt, bg, torch_adam)
             for i in range(warmup):
                 one(i)
@@ -303,7 +368,14 @@ def time_alt_paths(pc, cams, views, targets, tkeys, hyper, opt, bg, steps=4, war
                 one(i)
             torch.cuda.synchronize()
             ms = 1000.0 * (time.perf_counter() - t0) / steps
-            out[path] = {"ms_per_step": round(ms, 2), "iters_per_s": round(1000.0 / ms, 2), "steps": steps}
+            n = steps * (4 if path == "patched" else 1)
+            if path == "patched":     # the fast one: a longer sample
+                t0 = time.perf_counter()
+                for i in range(warmup, warmup + n):
+                    one(i)
+                torch.cuda.synchronize()
+                ms = 1000.0 * (time.perf_counter() - t0) / n
+            out[path] = {"ms_per_step": round(ms, 2), "iters_per_s": round(1000.0 / ms, 2), "steps": n}
         except Exception as ex:   # never take the headline down
             out[path] = {"ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"}
     return out

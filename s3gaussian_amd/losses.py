@@ -157,6 +157,79 @@ def photometric_loss(image, gt_image, depth=None, gt_depth=None, feat=None, gt_f
                                   max_depth)
 
 
+class _PixelTerms(torch.autograd.Function):
+    """w_l1 * l1(image, gt) + w_depth * depth_l2(depth, gt_depth) + w_feat * l2(feat, gt_feat) with any subset of the three
+    pairs present: one kernel forward (+ the 64-lane combine), one backward (include/s3g_loss.h::s3g_pixel_losses_*).  The
+    zero-edit route (s3gaussian_amd.patch) calls it once per term, because train.py:395-425 adds them one function call at a
+    time; photometric_loss above is the all-in-one form."""
+
+    @staticmethod
+    def forward(ctx, image, gt_image, depth, gt_depth, feat, gt_feat, w_l1, w_depth, w_feat, max_depth):
+        first = next(t for t in (image, depth, feat) if t is not None)
+        if not first.is_cuda:
+            raise RuntimeError(f"pixel_terms: images must live on the GPU (got {first.device}); no CPU fallback")
+        L = _bind()
+        c = lambda t: None if t is None else t.detach().contiguous().float()
+        img, gt, dep, gdep, ft, gft = c(image), c(gt_image), c(depth), c(gt_depth), c(feat), c(gt_feat)
+        H, W = first.shape[-2], first.shape[-1]
+        for a, b, n, name in ((img, gt, 3 * H * W, "image"), (dep, gdep, H * W, "depth"), (ft, gft, 3 * H * W, "feat")):
+            if (a is None) != (b is None) or (a is not None and (a.numel() != n or b.numel() != n)):
+                raise RuntimeError(f"pixel_terms: {name} and its target must both be given, {n} elements each")
+        dev = first.device
+        sums = torch.zeros(5 * SUM_DOUBLES + 5, dtype=torch.float64, device=dev)
+        totals = sums[5 * SUM_DOUBLES:]
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        p = lambda t: None if t is None else t.data_ptr()
+        wl, wd, wf = (float(w_l1) if img is not None else 0.0, float(w_depth) if dep is not None else 0.0,
+                      float(w_feat) if ft is not None else 0.0)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(L.s3g_pixel_losses_forward(H, W, p(img), p(gt), p(dep), p(gdep), p(ft), p(gft), float(max_depth), p(sums), st))
+            _lib.check(L.s3g_pixel_losses_combine(H, W, p(sums), p(totals), wl, wd, 0.0, wf, p(loss), st))
+        ctx.save_for_backward(*(t for t in (img, gt, dep, gdep, ft, gft) if t is not None), totals)
+        ctx.cfg = (H, W, img is not None, dep is not None, ft is not None, wl, wd, wf, float(max_depth),
+                   None if image is None else image.shape, None if depth is None else depth.shape, None if feat is None else feat.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W, has_i, has_d, has_f, wl, wd, wf, max_depth, ishape, dshape, fshape = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        img = gt = dep = gdep = ft = gft = None
+        k = 0
+        if has_i:
+            img, gt = saved[k], saved[k + 1]
+            k += 2
+        if has_d:
+            dep, gdep = saved[k], saved[k + 1]
+            k += 2
+        if has_f:
+            ft, gft = saved[k], saved[k + 1]
+            k += 2
+        totals = saved[k]
+        L = _bind()
+        g = g.detach().reshape(1).contiguous().float()
+        need = ctx.needs_input_grad
+        g_img = torch.empty_like(img) if (has_i and need[0]) else None
+        g_dep = torch.empty_like(dep) if (has_d and need[2]) else None
+        g_ft = torch.empty_like(ft) if (has_f and need[4]) else None
+        p = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(totals.device):
+            _lib.check(L.s3g_pixel_losses_backward(H, W, p(img), p(gt), p(dep), p(gdep), p(ft), p(gft), max_depth, p(totals), p(g),
+                                                   wl, wd, wf, p(g_img), 0, p(g_dep), p(g_ft), torch.cuda.current_stream().cuda_stream))
+        return (None if g_img is None else g_img.view(ishape), None, None if g_dep is None else g_dep.view(dshape), None,
+                None if g_ft is None else g_ft.view(fshape), None, None, None, None, None)
+
+
+def pixel_terms(image=None, gt_image=None, depth=None, gt_depth=None, feat=None, gt_feat=None, w_l1=0.0, w_depth=0.0,
+                w_feat=0.0, max_depth=80.0):
+    """Any subset of: w_l1 * l1_loss(image, gt_image) [3,H,W]; w_depth * compute_depth("l2", depth, gt_depth) [1,H,W] or [H,W];
+    w_feat * l2_loss(feat, gt_feat) [3,H,W]   (utils/loss_utils.py:21-54)."""
+    if image is None and depth is None and feat is None:
+        raise RuntimeError("pixel_terms: nothing to do")
+    return _PixelTerms.apply(image, gt_image, depth, gt_depth, feat, gt_feat, w_l1, w_depth, w_feat, max_depth)
+
+
 class _PlaneRegDesc(C.Structure):
     """struct s3g_plane_reg_desc (include/s3g_loss.h)."""
     _fields_ = [("plane", C.c_void_p), ("grad", C.c_void_p), ("H", C.c_int), ("W", C.c_int), ("w_smooth", C.c_float),

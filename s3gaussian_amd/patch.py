@@ -1,0 +1,205 @@
+"""Zero-edit fast route: run the reference's own `train.py` / `render.py` UNCHANGED at (nearly) the speed of the fused path.
+
+    python -m s3gaussian_amd.patch train.py -s <scene> --configs arguments/... [the reference's own arguments]
+
+or, inside a launcher / `sitecustomize`:   `import s3gaussian_amd.patch as p; p.patch_reference()`   BEFORE `train.py` is imported
+(it binds `render`, `ssim`, `l1_loss`, ... with `from x import y` at import time).
+
+The drop-in packages (`diff_gaussian_rasterization`, `simple_knn`) alone already replace every CUDA kernel of the reference, but
+its Python then still runs the deformation field, the activations / SH glue, SSIM, the plane regularisers and Adam as hundreds of
+PyTorch launches per iteration (2.9 it/s at BASELINE cfg3).  `patch_reference()` rebinds, without touching a file of the reference:
+
+  scene.deformation.deform_network (+ the name imported into scene.gaussian_model, scene/gaussian_model.py:22,55)
+        -> s3gaussian_amd.deformation.deform_network      same parameter names / shapes: checkpoints interchange
+  gaussian_renderer.render   (gaussian_renderer/__init__.py:23-210)
+        -> render() below = s3gaussian_amd.pipeline.render on the reference's Camera / GaussianModel objects: fused sampler + MLP,
+           one glue kernel each way, RGB + feature image as ONE two-image rasterizer node, same result-dict keys
+  utils.loss_utils.{l1_loss, l2_loss, ssim, compute_depth}   (utils/loss_utils.py:21-96; train.py:395-425 calls them by name)
+        -> one fused kernel pair each (include/s3g_loss.h)
+  GaussianModel.compute_regulation   (scene/gaussian_model.py:710-749)   -> one pass over the 143 MB of planes
+  GaussianModel.training_setup       (scene/gaussian_model.py:170-201)   -> the same call, then `self.optimizer` rebuilt as
+           s3gaussian_amd.optim.Adam over the SAME param_groups (one launch per step, identical state layout, so
+           cat_tensors_to_optimizer / prune_optimizer keep working)
+  GaussianModel.add_densification_stats   (scene/gaussian_model.py:693-695)   -> one pass, no boolean-index host syncs
+
+What train.py does inline (loss assembly one `loss +=` at a time, `loss.item()`, psnr, the max_radii2D update with boolean masks)
+stays as it is; `bench.py` times exactly that iteration body as `config.paths.patched`.  Every replacement is value-checked against
+the formulation it replaces (tests/test_patch_gpu.py) and the call sites it binds to are pinned against the reference's sources
+with `ast` (tests/test_patch_cpu.py).
+"""
+from __future__ import annotations
+
+import math
+import sys
+from typing import Dict
+
+import torch
+
+from . import losses as _losses
+from . import pipeline as _pipeline
+
+
+# ---- replacements (usable directly; patch_reference() only rebinds names to them) --------------------------------------------------
+def _cam_dict(cam) -> Dict:
+    """The fields pipeline.render reads, from a reference Camera (scene/cameras.py:20-70) -- cached on the object."""
+    if isinstance(cam, dict):
+        return cam
+    d = getattr(cam, "_s3g_cam", None)
+    if d is None:
+        d = dict(image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
+                 tanfovy=math.tan(cam.FoVy * 0.5), viewmatrix=cam.world_view_transform.cuda(),
+                 projmatrix=cam.full_proj_transform.cuda(), campos=cam.camera_center.cuda(), time=float(cam.time))
+        try:
+            cam._s3g_cam = d
+        except Exception:
+            pass
+    return d
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, stage="fine",
+           return_decomposition=False, return_dx=False, render_feat=False):
+    """Signature of gaussian_renderer/__init__.py:23; `pc` is the reference's GaussianModel (same attribute names as
+    pipeline.GaussianParams), `viewpoint_camera` its Camera."""
+    if getattr(pipe, "compute_cov3D_python", False):
+        raise NotImplementedError("pipe.compute_cov3D_python: run the reference's own render() for this switch")
+    return _pipeline.render(_cam_dict(viewpoint_camera), pc, pipe, bg_color, scaling_modifier, override_color, stage,
+                            return_decomposition, return_dx, render_feat)
+
+
+def _as_image(t: torch.Tensor, channels: int):
+    """[1,C,H,W] / [C,H,W] (/ [H,W] for one channel) -> [C,H,W], or None when the batch has more than one view."""
+    if t.dim() == 4 and t.shape[0] == 1:
+        t = t[0]
+    if channels == 1 and t.dim() == 2:
+        t = t[None]
+    return t if (t.dim() == 3 and t.shape[0] == channels) else None
+
+
+def l1_loss(network_output, gt):
+    """utils/loss_utils.py:50-51.  One view ([1,3,H,W] or [3,H,W]): fused kernel; anything else: the reference's expression."""
+    a, b = _as_image(network_output, 3), _as_image(gt, 3)
+    if a is None or b is None or not network_output.is_cuda:
+        return torch.abs(network_output - gt).mean()
+    return _losses.pixel_terms(image=a, gt_image=b, w_l1=1.0)
+
+
+def l2_loss(network_output, gt):
+    """utils/loss_utils.py:53-54 (train.py:419-422 calls it on the [3,H,W] feature image)."""
+    a, b = _as_image(network_output, 3), _as_image(gt, 3)
+    if a is None or b is None or not network_output.is_cuda:
+        return ((network_output - gt) ** 2).mean()
+    return _losses.pixel_terms(feat=a, gt_feat=b, w_feat=1.0)
+
+
+def compute_depth(loss_type, pred_depth, gt_depth, max_depth=80):
+    """utils/loss_utils.py:24-45; only the "l2" branch train.py:411 uses is accelerated."""
+    a, b = _as_image(pred_depth.squeeze(0) if pred_depth.dim() == 4 else pred_depth, 1), None
+    if a is not None:
+        b = _as_image(gt_depth.squeeze(0) if gt_depth.dim() == 4 else gt_depth, 1)
+    if loss_type != "l2" or a is None or b is None or not pred_depth.is_cuda:
+        return _REFERENCE["compute_depth"](loss_type, pred_depth, gt_depth, max_depth) if "compute_depth" in _REFERENCE else \
+            _pipeline.compute_depth_l2(pred_depth, gt_depth, float(max_depth))
+    return _losses.pixel_terms(depth=a, gt_depth=b, w_depth=1.0, max_depth=float(max_depth))
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """utils/loss_utils.py:66-96."""
+    if window_size != 11 or not size_average or not img1.is_cuda or (img1.dim() == 4 and img1.shape[0] != 1):
+        return _REFERENCE["ssim"](img1, img2, window_size, size_average) if "ssim" in _REFERENCE else _pipeline.ssim(img1, img2, window_size)
+    return _losses.ssim(img1, img2)
+
+
+def compute_regulation(self, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight):
+    """GaussianModel.compute_regulation, scene/gaussian_model.py:748-749."""
+    return _losses.plane_regulation(self._deformation.deformation_net.grid.grids, time_smoothness_weight, l1_time_planes_weight,
+                                    plane_tv_weight)
+
+
+@torch.no_grad()
+def add_densification_stats(self, viewspace_point_tensor, update_filter):
+    """GaussianModel.add_densification_stats, scene/gaussian_model.py:693-695: `xyz_gradient_accum[f] += ||grad[f,:2]||`,
+    `denom[f] += 1` in one pass (radii = 0 leaves max_radii2D, which train.py:491 updates itself, untouched)."""
+    from .optim import densify_stats
+    if not viewspace_point_tensor.is_cuda:
+        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor[update_filter, :2], dim=-1, keepdim=True)
+        self.denom[update_filter] += 1
+        return
+    zero_radii = torch.zeros(update_filter.shape[0], dtype=torch.int32, device=update_filter.device)
+    densify_stats(self.xyz_gradient_accum, self.denom, self.max_radii2D, viewspace_point_tensor, zero_radii, update_filter)
+
+
+def fused_optimizer_from(optimizer: torch.optim.Optimizer):
+    """The optimizer GaussianModel.training_setup just built (torch.optim.Adam(l, lr=0.0, eps=1e-15), scene/gaussian_model.py:189)
+    rebuilt as the one-launch Adam over the SAME groups (names, lrs and Parameter objects are kept)."""
+    from .optim import Adam
+    groups = [{k: v for k, v in g.items() if k in ("params", "lr", "name", "betas", "eps")} for g in optimizer.param_groups]
+    d = optimizer.defaults
+    return Adam(groups, lr=d.get("lr", 0.0), betas=d.get("betas", (0.9, 0.999)), eps=d.get("eps", 1e-15))
+
+
+_REFERENCE: Dict = {}     # the reference's own callables, kept for the cases a replacement hands back
+_PATCHED = False
+
+
+def patch_reference(verbose: bool = False) -> Dict[str, str]:
+    """Rebinds the names listed in the module docstring inside the ALREADY IMPORTABLE reference packages (`scene`, `utils`,
+    `gaussian_renderer` on sys.path, i.e. the working directory is the reference checkout).  Idempotent.  Returns what was bound."""
+    global _PATCHED
+    import importlib
+    done = {}
+    if _PATCHED:
+        return done
+    from . import deformation as _deformation
+    sd = importlib.import_module("scene.deformation")
+    sd.deform_network = _deformation.deform_network
+    done["scene.deformation.deform_network"] = "s3gaussian_amd.deformation.deform_network"
+    gm = importlib.import_module("scene.gaussian_model")
+    if hasattr(gm, "deform_network"):
+        gm.deform_network = _deformation.deform_network
+        done["scene.gaussian_model.deform_network"] = "s3gaussian_amd.deformation.deform_network"
+    GM = gm.GaussianModel
+    _REFERENCE["training_setup"] = GM.training_setup
+
+    def training_setup(self, training_args):
+        _REFERENCE["training_setup"](self, training_args)
+        if self._xyz.is_cuda:
+            self.optimizer = fused_optimizer_from(self.optimizer)
+
+    GM.training_setup = training_setup
+    GM.compute_regulation = compute_regulation
+    GM.add_densification_stats = add_densification_stats
+    done.update({"GaussianModel.training_setup": "reference + s3gaussian_amd.optim.Adam", "GaussianModel.compute_regulation":
+                 "s3gaussian_amd.losses.plane_regulation", "GaussianModel.add_densification_stats": "s3gaussian_amd.optim.densify_stats"})
+    lu = importlib.import_module("utils.loss_utils")
+    for name, fn in (("l1_loss", l1_loss), ("l2_loss", l2_loss), ("ssim", ssim), ("compute_depth", compute_depth)):
+        if hasattr(lu, name):
+            _REFERENCE[name] = getattr(lu, name)
+            setattr(lu, name, fn)
+            done[f"utils.loss_utils.{name}"] = f"s3gaussian_amd.patch.{name}"
+    gr = importlib.import_module("gaussian_renderer")
+    _REFERENCE["render"] = gr.render
+    gr.render = render
+    done["gaussian_renderer.render"] = "s3gaussian_amd.patch.render"
+    _PATCHED = True
+    if verbose:
+        for k, v in done.items():
+            print(f"[s3gaussian_amd.patch] {k} -> {v}", file=sys.stderr)
+    return done
+
+
+def main(argv=None):
+    """python -m s3gaussian_amd.patch <script.py> [its arguments]: patch, then run the reference script as __main__."""
+    import os
+    import runpy
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv:
+        raise SystemExit("usage: python -m s3gaussian_amd.patch train.py [arguments of the reference's train.py]")
+    script = argv[0]
+    sys.path.insert(0, os.path.dirname(os.path.abspath(script)) or ".")
+    patch_reference(verbose=True)
+    sys.argv = argv
+    runpy.run_path(script, run_name="__main__")
+
+
+if __name__ == "__main__":
+    main()

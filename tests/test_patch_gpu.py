@@ -1,0 +1,98 @@
+"""Zero-edit route (s3gaussian_amd/patch.py), GPU side: every replacement against the formulation it replaces --
+utils/loss_utils.py:21-96, scene/gaussian_model.py:693-695,177-189, gaussian_renderer/__init__.py:23-210 -- values rtol 1e-5,
+gradients rel-L2 1e-5; and one whole iteration body of train.py:372-522 run on the replacements equals pipeline.training_step."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def test_loss_replacements_match_the_reference_expressions(gpu_device):
+    from oracle import hexplane_ref as hr
+    from s3gaussian_amd import patch
+    dev = gpu_device
+    g = torch.Generator().manual_seed(0)
+    H, W = 93, 157
+    img, gt = torch.rand(1, 3, H, W, generator=g), torch.rand(1, 3, H, W, generator=g)
+    dep, gdep = torch.rand(1, 1, H, W, generator=g) * 90, torch.rand(1, 1, H, W, generator=g) * 100 - 5
+    ft, gft = torch.randn(3, H, W, generator=g), torch.randn(3, H, W, generator=g)
+    cases = [("l1_loss", lambda f, a, b: f(a, b), hr.l1_loss, img, gt), ("l2_loss", lambda f, a, b: f(a, b), hr.l2_loss, ft, gft),
+             ("ssim", lambda f, a, b: f(a, b), hr.ssim, img, gt),
+             ("compute_depth", lambda f, a, b: f("l2", a, b), lambda t, a, b: hr.depth_l2(a, b), dep, gdep)]
+    for name, call, ref, a, b in cases:
+        ar = a.clone().requires_grad_(True)
+        vr = call(ref, ar, b) if name != "compute_depth" else ref("l2", ar, b)
+        vr.backward()
+        ag = a.to(dev).requires_grad_(True)
+        vg = call(getattr(patch, name), ag, b.to(dev))
+        (vg * 1.0).backward()
+        np.testing.assert_allclose(vg.item(), vr.item(), rtol=1e-5, err_msg=name)
+        assert rel_l2(ag.grad.cpu().numpy(), ar.grad.numpy()) < 1e-5, name
+    # a batch of two views is handed back to the plain expression
+    two = torch.rand(2, 3, H, W, generator=g).to(dev)
+    assert torch.allclose(patch.l1_loss(two, two * 0.5), (two * 0.5).abs().mean())
+
+
+def test_add_densification_stats_and_fused_optimizer(gpu_device):
+    from s3gaussian_amd import patch
+    from s3gaussian_amd.optim import Adam
+    dev = gpu_device
+    g = torch.Generator().manual_seed(1)
+    P = 3001
+    m = SimpleNamespace(xyz_gradient_accum=torch.rand(P, 1, generator=g).to(dev), denom=torch.randint(0, 5, (P, 1), generator=g).float().to(dev),
+                        max_radii2D=(torch.rand(P, generator=g) * 9).to(dev))
+    grad = torch.randn(P, 3, generator=g).to(dev)
+    filt = (torch.rand(P, generator=g) < 0.3).to(dev)
+    want_a, want_d, radii0 = m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone()
+    want_a[filt] += torch.norm(grad[filt, :2], dim=-1, keepdim=True)
+    want_d[filt] += 1
+    patch.add_densification_stats(m, grad, filt)
+    np.testing.assert_allclose(m.xyz_gradient_accum.cpu().numpy(), want_a.cpu().numpy(), rtol=2e-7)
+    assert torch.equal(m.denom, want_d) and torch.equal(m.max_radii2D, radii0)
+    a, b = torch.nn.Parameter(torch.randn(5, 3, device=dev)), torch.nn.Parameter(torch.randn(7, device=dev))
+    ref = torch.optim.Adam([{"params": [a], "lr": 0.01, "name": "xyz"}, {"params": [b], "lr": 0.02, "name": "opacity"}], lr=0.0, eps=1e-15)
+    ours = patch.fused_optimizer_from(ref)
+    assert isinstance(ours, Adam) and [gr["name"] for gr in ours.param_groups] == ["xyz", "opacity"]
+    assert ours.param_groups[0]["params"][0] is a and ours.param_groups[1]["lr"] == 0.02 and ours.param_groups[0]["eps"] == 1e-15
+
+
+def test_one_train_py_iteration_on_the_replacements_equals_the_fused_step(gpu_device):
+    """bench.py's `patched` path (bench.patched_reference_step = train.py:372-522 for one view on the rebound names) against
+    pipeline.training_step from the same state: same loss, same parameters after the step."""
+    import bench
+    from s3gaussian_amd import patch, synth
+    from s3gaussian_amd.pipeline import GaussianParams, default_hyper, default_opt, training_step
+    dev = gpu_device
+    scn = synth.street_scene(P=15_000, seed=3, width=240, height=160, n_frames=2)
+    hyper, opt = default_hyper(), default_opt()
+    H, W = 160, 240
+    g = torch.Generator().manual_seed(0)
+    gts = (torch.rand(3, H, W, generator=g).to(dev), (torch.rand(1, H, W, generator=g) * 60).to(dev), torch.rand(3, H, W, generator=g).to(dev))
+    cam = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scn["cameras"][1].items()}
+    res = {}
+    for path in ("fused", "patched"):
+        torch.manual_seed(0)
+        pc = GaussianParams(3, hyper)
+        gs = scn["gaussians"]
+        pc.init_from_tensors(gs["xyz"], gs["log_scales"], gs["rotations_raw"], gs["opacity_logit"], gs["shs"], dev)
+        pc._deformation.deformation_net.set_aabb(*scn["aabb"])
+        pc.training_setup(opt)
+        if path == "fused":
+            loss, _ = training_step(pc, cam, *gts, hyper, opt, scn["bg"].to(dev), densify_stats=True)
+        else:
+            loss = bench.patched_reference_step(pc, bench.camera_object(cam, gts), hyper, opt, scn["bg"].to(dev))
+        res[path] = (float(loss), {n: p.detach().clone() for n, p in pc.named_parameters()}, pc.xyz_gradient_accum.clone(),
+                     pc.denom.clone(), pc.max_radii2D.clone())
+    assert abs(res["fused"][0] - res["patched"][0]) <= 1e-5 * abs(res["fused"][0])
+    for n, p in res["fused"][1].items():
+        # the first Adam step moves every element by lr * sign(g): an element whose gradient is a cancellation to round-off may
+        # take the other sign when the loss terms are summed in another order, so a few elements per million may differ by 2 lr
+        close = torch.isclose(p, res["patched"][1][n], rtol=1e-4, atol=1e-6)
+        assert float((~close).float().mean()) < 1e-3, n
+    assert torch.equal(res["fused"][3], res["patched"][3]) and torch.equal(res["fused"][4], res["patched"][4])
+    np.testing.assert_allclose(res["fused"][2].cpu().numpy(), res["patched"][2].cpu().numpy(), rtol=1e-4, atol=1e-9)
