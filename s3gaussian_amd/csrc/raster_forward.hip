@@ -589,21 +589,51 @@ blend_decompose_kernel(int W, int H, int gx, int tiles, const uint2* __restrict_
                        float* __restrict__ out_color_d, float* __restrict__ out_depth_d, float* __restrict__ out_color_s,
                        float* __restrict__ out_depth_s) {
   __shared__ StagedGaussian sg[256];
-  __shared__ uint8_t scls[256];
+  __shared__ uint16_t sub[2][256];      // the batch's entries of each class, in list order
+  __shared__ int wave_cnt[2][4];
   const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
   if (tile >= (uint32_t)tiles) return;
   const int tx = tile % gx, ty = tile / gx;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = tx * TILE_X + (tid & 15), py = ty * TILE_Y + (tid >> 4);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
   const uint2 rg = ranges[tile];
-  int todo = (int)(rg.y - rg.x);
-  bool done[2] = {!inside, !inside};   // [0] static chain, [1] dynamic chain
-  float T[2] = {1.f, 1.f}, Cr[2] = {0.f, 0.f}, Cg[2] = {0.f, 0.f}, Cb[2] = {0.f, 0.f}, D[2] = {0.f, 0.f};
-  for (uint32_t base = rg.x; base < rg.y; base += 256, todo -= 256) {
-    if (__syncthreads_count(done[0] && done[1]) == 256) break;
-    if (base + tid < rg.y) {
+  // one chain per class, each in its own scalar variables and its own loop over the class's sub-list of the batch: a chain
+  // stops at ITS saturation, never pays for the other class's entries, and nothing is indexed by a run-time class (the first
+  // version walked the full list once with T[k], C[k] selected per entry: 0.70 ms against 0.23 ms for the plain blend pass)
+  bool done_s = !inside, done_d = !inside;
+  float Ts = 1.f, Crs = 0.f, Cgs = 0.f, Cbs = 0.f, Ds = 0.f;
+  float Td = 1.f, Crd = 0.f, Cgd = 0.f, Cbd = 0.f, Dd = 0.f;
+  auto chain = [&](const uint16_t* __restrict__ list, int n, bool& done, float& T, float& Cr, float& Cg, float& Cb, float& D) {
+    for (int j = 0; !done && j < n; j++) {
+      const int e = list[j];
+      const float4 A = sg[e].a;
+      const float dx = A.x - pxf, dy = A.y - pyf;
+      const float4 B = sg[e].b;
+      const float q = gaussian_exponent2(dx, dy, A.z, A.w, B.x);
+      if (q > 0.f) continue;
+      const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(q));
+      if (alpha < 1.0f / 255.0f) continue;
+      const float test_T = T * (1.f - alpha);
+      if (test_T < 0.0001f) {
+        done = true;
+        continue;
+      }
+      const float w = alpha * T;
+      const float4 Cc = sg[e].c;
+      Cr = __builtin_fmaf(B.w, w, Cr);
+      Cg = __builtin_fmaf(Cc.x, w, Cg);
+      Cb = __builtin_fmaf(Cc.y, w, Cb);
+      D = __builtin_fmaf(B.z, w, D);
+      T = test_T;
+    }
+  };
+  for (uint32_t base = rg.x; base < rg.y; base += 256) {
+    if (__syncthreads_count(done_s && done_d) == 256) break;   // also protects sg[] / sub[] reuse
+    const bool valid = base + tid < rg.y;
+    int c = 0;
+    if (valid) {
       const uint32_t id = point_list[base + tid];
       const float2 m = means2D[id];
       const float4 co = conic_opacity[id];
@@ -612,34 +642,25 @@ blend_decompose_kernel(int W, int H, int gx, int tiles, const uint2* __restrict_
       s.b = make_float4(-0.5f * LOG2E * co.z, co.w, depths[id], colors[3 * (size_t)id]);
       s.c = make_float4(colors[3 * (size_t)id + 1], colors[3 * (size_t)id + 2], co.x, co.y);
       sg[tid] = s;
-      scls[tid] = cls[id] ? 1 : 0;
+      c = cls[id] ? 1 : 0;
     }
+    // stable partition of the batch by class: ballots inside the wave, a 4-entry prefix across the waves
+    const unsigned long long b1 = __ballot(valid && c == 1), b0 = __ballot(valid && c == 0);
+    if (lane == 0) { wave_cnt[0][wave] = __popcll(b0); wave_cnt[1][wave] = __popcll(b1); }
     __syncthreads();
-    const int cnt = min(256, todo);
-    for (int j = 0; j < cnt && !(done[0] && done[1]); j++) {
-      const int k = scls[j];
-      if (done[k]) continue;
-      const float4 A = sg[j].a;
-      const float dx = A.x - pxf, dy = A.y - pyf;
-      const float4 B = sg[j].b;
-      const float q = gaussian_exponent2(dx, dy, A.z, A.w, B.x);
-      if (q > 0.f) continue;
-      const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(q));
-      if (alpha < 1.0f / 255.0f) continue;
-      const float test_T = T[k] * (1.f - alpha);
-      if (test_T < 0.0001f) {
-        done[k] = true;
-        continue;
-      }
-      const float w = alpha * T[k];
-      const float4 Cc = sg[j].c;
-      Cr[k] = __builtin_fmaf(B.w, w, Cr[k]);
-      Cg[k] = __builtin_fmaf(Cc.x, w, Cg[k]);
-      Cb[k] = __builtin_fmaf(Cc.y, w, Cb[k]);
-      D[k] = __builtin_fmaf(B.z, w, D[k]);
-      T[k] = test_T;
+    int off0 = 0, off1 = 0, n0 = 0, n1 = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      if (w < wave) { off0 += wave_cnt[0][w]; off1 += wave_cnt[1][w]; }
+      n0 += wave_cnt[0][w]; n1 += wave_cnt[1][w];
     }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (valid) sub[c][(c ? off1 + __popcll(b1 & below) : off0 + __popcll(b0 & below))] = (uint16_t)tid;
+    __syncthreads();
+    chain(sub[0], n0, done_s, Ts, Crs, Cgs, Cbs, Ds);
+    chain(sub[1], n1, done_d, Td, Crd, Cgd, Cbd, Dd);
   }
+  const float T[2] = {Ts, Td}, Cr[2] = {Crs, Crd}, Cg[2] = {Cgs, Cgd}, Cb[2] = {Cbs, Cbd}, D[2] = {Ds, Dd};
   if (inside) {
     const size_t pix = (size_t)py * W + px, N = (size_t)H * W;
     // an EMPTY class renders as zeros WITHOUT background, like the reference's P == 0 early-out (rasterize_points.cu:81-116)

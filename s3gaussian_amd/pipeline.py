@@ -280,6 +280,50 @@ def eval_sh(deg, sh, dirs):
     return result
 
 
+class _LazyResult(dict):
+    """render()'s result dict with entries that are only computed when somebody reads them.  The reference returns
+    `visibility_filter_d = radii_d > 0` for the masked subsets (gaussian_renderer/__init__.py:199-203): variable-size results of
+    boolean indexing, i.e. two host synchronisations per evaluation frame for values its callers (utils/video_utils.py:185,193)
+    read into a variable and never use.  Same keys, same values, evaluated on first access."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._lazy = {}
+
+    def set_lazy(self, key, thunk):
+        self._lazy[key] = thunk
+        super().__setitem__(key, None)
+
+    def _force(self, key):
+        thunk = self._lazy.pop(key, None)
+        if thunk is not None:
+            super().__setitem__(key, thunk())
+
+    def __getitem__(self, key):
+        self._force(key)
+        return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        self._force(key)
+        return super().get(key, default)
+
+    def _force_all(self):
+        for key in list(self._lazy):
+            self._force(key)
+
+    def items(self):
+        self._force_all()
+        return super().items()
+
+    def values(self):
+        self._force_all()
+        return super().values()
+
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)
+        super().__setitem__(key, value)
+
+
 def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg_color: torch.Tensor,
            scaling_modifier=1.0, override_color=None, stage="fine", return_decomposition=False, return_dx=False,
            render_feat=False, densify_accum=None):
@@ -383,8 +427,8 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
         rendered_image, radii, depth = rasterizer(means3D=means3D_final, means2D=means2D, shs=shs_final,
                                                   colors_precomp=colors_precomp, opacities=opacity, scales=scales_final,
                                                   rotations=rotations_final, cov3D_precomp=cov3D_precomp)
-    out = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
-           "radii": radii, "depth": depth}
+    out = _LazyResult({"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+                       "radii": radii, "depth": depth})
     if densify_accum is not None:
         out["densify_stats_fused"] = fuse_stats
     if want_feat:
@@ -394,9 +438,11 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
                                                cov3D_precomp=cov3D_precomp)
         out["feat"] = rendered_image2
     if decomposed is not None:
-        vis = radii > 0
-        out.update({"render_d": decomposed["render_d"], "depth_d": decomposed["depth_d"], "visibility_filter_d": vis[dynamic_mask],
-                    "render_s": decomposed["render_s"], "depth_s": decomposed["depth_s"], "visibility_filter_s": vis[~dynamic_mask]})
+        vis = out["visibility_filter"]
+        out.update({"render_d": decomposed["render_d"], "depth_d": decomposed["depth_d"],
+                    "render_s": decomposed["render_s"], "depth_s": decomposed["depth_s"]})
+        out.set_lazy("visibility_filter_d", lambda: vis[dynamic_mask])    # boolean indexing = a host sync each: on demand
+        out.set_lazy("visibility_filter_s", lambda: vis[~dynamic_mask])
     elif return_decomposition and dx is not None:
         max_values = torch.max(torch.abs(dx), dim=1)[0]
         dynamic_mask = max_values > torch.mean(max_values)
