@@ -406,6 +406,11 @@ def main():
     ap.add_argument("--no-alt-paths", action="store_true", help="skip timing the zero_diff / import_swap call paths")
     ap.add_argument("--scale-mult", type=float, default=1.0,
                     help="multiply every Gaussian's scale: larger splats -> more (tile, Gaussian) instances R per view (R-sweep)")
+    ap.add_argument("--sparse-rows", action="store_true",
+                    help="N > 1: exchange the SH / opacity / scale / rotation gradients as compact rows of the union of the ranks' "
+                         "visible sets (dp.SparseRowExchange) instead of dense all-reduces")
+    ap.add_argument("--single-phase-step", action="store_true",
+                    help="N > 1: finish every collective, then one optimizer step (default: dp.finish_and_step, two phases)")
     ap.add_argument("--reorder", action="store_true",
                     help="keep the Gaussians themselves in Morton order (GaussianParams.reorder_spatially() once after the scene is "
                          "built; a real run repeats it after every densification)")
@@ -435,15 +440,39 @@ def main():
         targets[v] = make_targets(pc, cams[v], bg, hyper, seed=1000 + v)
     tkeys = list(targets)
     # large gradients are all-reduced as soon as backward produces them (overlaps the rest of the backward pass)
-    reducer = dp.OverlappedGradAllReducer(pc.optimizer, average=False) if world > 1 else None   # follows densify/prune
+    SPARSE = ("f_dc", "f_rest", "opacity", "scaling", "rotation")   # gradients that are exactly zero for Gaussians no rank sees
+    reducer = sparse = None
+    comm = {"elems": 0, "events": [], "sparse_rows": 0}
     if world > 1:
+        if a.sparse_rows:
+            dense = lambda: [p for g in pc.optimizer.param_groups if g.get("name") not in SPARSE for p in g["params"]]
+            reducer = dp.OverlappedGradAllReducer(dense, average=False)
+            sparse = dp.SparseRowExchange(average=False)
+        else:
+            reducer = dp.OverlappedGradAllReducer(pc.optimizer, average=False)   # follows densify/prune
         pc.optimizer.grad_scale = 1.0 / world   # the SUM all-reduce is averaged inside the Adam kernel
 
     def hook(pc_, pkg):
         if reducer is not None:
-            reducer()
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()            # backward's last kernel is queued: from here on the stream waits for collectives + steps
+            comm["events"].append([ev])
             g_xy, any_vis, rmax = dp.reduce_densification_stats(pkg["viewspace_points"].grad, pkg["visibility_filter"], pkg["radii"])
             dp.add_densification_stats(pc_.xyz_gradient_accum, pc_.denom, pc_.max_radii2D, g_xy, any_vis, rmax)
+            if sparse is not None:
+                rows = [p for g in pc_.optimizer.param_groups if g.get("name") in SPARSE for p in g["params"]]
+                comm["elems"] += sparse(rows, pkg["visibility_filter"])
+                comm["sparse_rows"] += sparse.last_rows
+
+    def optimizer_step():
+        if a.single_phase_step or sparse is not None:
+            comm["elems"] += reducer.finish()
+            pc.optimizer.step()
+        else:
+            comm["elems"] += reducer.finish_and_step(pc.optimizer)
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        comm["events"][-1].append(ev)
 
     visible, instances = [], []
 
@@ -453,7 +482,7 @@ def main():
         # densification bookkeeping (train.py:489-493) is part of every iteration below densify_until_iter: single GPU ->
         # inside the rasterizer's per-Gaussian backward; data parallel -> after the all-reduce of the statistics (hook)
         loss, pkg = training_step(pc, cams[v], gt_img, gt_depth, gt_feat, hyper, opt, bg, stage="fine", grad_hook=hook,
-                                  densify_stats=(world == 1))
+                                  densify_stats=(world == 1), optimizer_step=optimizer_step if world > 1 else None)
         return loss, pkg
 
     for i in range(a.warmup):
@@ -464,6 +493,7 @@ def main():
     for i in range(10):
         L.s3g_profile_read(i, None, None, None)
     L.s3g_profile_enable(1)
+    comm.update(elems=0, events=[], sparse_rows=0)
     vis_masks = []     # summed after the timed region (workload statistics are not part of the step)
     t0 = time.perf_counter()
     for i in range(a.warmup, a.warmup + a.steps):
@@ -615,6 +645,18 @@ def main():
                        "render_deform_infer_kernel_ms": round(infer_kernel_ms, 4) if infer_kernel_ms else None},
             "roofline": roof,
         }
+        if world > 1:
+            # what the all-reduce cost this rank: stream time from "backward queued" to "optimizer step queued" minus the Adam
+            # kernel itself = waiting for collectives + the small statistics reduces.  NO multi-GPU run has been measured in the
+            # build sandbox (one GPU per lease); these fields exist so that the first SCALE run explains itself.
+            tail = [e[0].elapsed_time(e[1]) for e in comm["events"] if len(e) == 2]
+            adam = next((k["ms_per_step"] for k in kernels if k["kernel"] == "s3g::adam_kernel"), 0.0)
+            out["comm"] = {"backend": torch.distributed.get_backend(), "bytes_reduced_per_step_per_rank": round(4.0 * comm["elems"] / max(a.steps, 1)),
+                           "tail_ms_backward_end_to_step_end": round(sum(tail) / max(len(tail), 1), 3), "adam_ms_per_step": adam,
+                           "comm_ms_exposed": round(max(sum(tail) / max(len(tail), 1) - adam, 0.0), 3),
+                           "optimizer_step": "single phase" if (a.single_phase_step or a.sparse_rows) else "two phases (dp.finish_and_step)",
+                           "sparse_row_exchange": bool(a.sparse_rows),
+                           "sparse_rows_per_step": round(comm["sparse_rows"] / max(a.steps, 1)) if a.sparse_rows else None}
         if world == 1 and not a.no_alt_paths:
             out["config"]["paths"] = {"fused": {"ms_per_step": out["ms_per_step"], "iters_per_s": out["value"]}}
             out["config"]["paths"].update(time_alt_paths(pc, cams, views, targets, tkeys, hyper, opt, bg))

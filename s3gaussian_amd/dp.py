@@ -223,6 +223,59 @@ class OverlappedGradAllReducer(GradAllReducer):
 
     __call__ = finish
 
+    @torch.no_grad()
+    def finish_and_step(self, optimizer: torch.optim.Optimizer, late_groups: Sequence[str] = ("grid", "xyz", "deformation")) -> int:
+        """finish() + optimizer.step() in TWO PHASES, so that the optimizer does not sit idle behind the last collectives.
+        The gradients become ready in a fixed order on this path -- SH / opacity / scale / rotation right after the render
+        glue backward, the HexPlane planes (143 MB) and xyz at the very end -- so when backward returns the early collectives
+        are done or nearly done while ~157 MB are still on the wire.  Phase 1 waits only for the collectives of the groups NOT
+        named in `late_groups` (the stream then depends on nothing later: RCCL executes them in issue order) and steps exactly
+        those parameters; phase 2 waits for the rest, reduces what no hook covered, and steps the remaining parameters.  Every
+        parameter is stepped exactly once with its fully reduced gradient: the result equals finish(); optimizer.step()
+        (tests/test_dp_cpu.py).  Group names are the reference's (scene/gaussian_model.py:177-187)."""
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            optimizer.step()
+            return 0
+        world = dist.get_world_size()
+        late_ids = {id(p) for g in optimizer.param_groups if g.get("name") in late_groups for p in g["params"]}
+        early_params = [p for p in self.params if p.grad is not None and id(p) in self._started and id(p) not in late_ids]
+        early_ptrs = {(_flat_view(p.grad).data_ptr() if _flat_view(p.grad) is not None else None) for p in early_params}
+        total, rest_works = 0, []
+        for work, v in self._inflight:
+            if v.data_ptr() in early_ptrs:
+                work.wait()
+                if self.average:
+                    v.mul_(1.0 / world)
+                total += v.numel()
+            else:
+                rest_works.append((work, v))
+        step_subset(optimizer, early_params)                      # runs while the late collectives are still in flight
+        self._inflight = rest_works          # (the early parameters stay in _started: finish() must not reduce them again)
+        stepped = {id(p) for p in early_params}
+        total += self.finish()
+        step_subset(optimizer, [p for p in self.params if id(p) not in stepped])
+        return total
+
+
+@torch.no_grad()
+def step_subset(optimizer: torch.optim.Optimizer, params: Sequence[torch.nn.Parameter]) -> None:
+    """optimizer.step() restricted to `params`: every torch optimizer (and s3gaussian_amd.optim.Adam) skips parameters whose
+    .grad is None, so the other parameters' gradients are hidden for the duration of the call.  Per-parameter state (Adam's step
+    count and moments) only advances for the parameters stepped, so stepping two disjoint subsets equals one full step."""
+    keep = {id(p) for p in params}
+    hidden = []
+    for g in optimizer.param_groups:
+        for p in g["params"]:
+            if id(p) not in keep and p.grad is not None:
+                hidden.append((p, p.grad))
+                p.grad = None
+    try:
+        if any(p.grad is not None for p in params):
+            optimizer.step()
+    finally:
+        for p, gr in hidden:
+            p.grad = gr
+
 
 @torch.no_grad()
 def reduce_densification_stats(viewspace_grad: torch.Tensor, visibility: torch.Tensor, radii: torch.Tensor,

@@ -590,14 +590,15 @@ def training_loss(pc: GaussianParams, pkg: Dict, gt_image, gt_depth, gt_feat, hy
 
 
 def training_step(pc: GaussianParams, cam: Dict, gt_image, gt_depth, gt_feat, hyper, opt, bg, stage="fine",
-                  pipe: Optional[SimpleNamespace] = None, grad_hook=None, densify_stats=False):
+                  pipe: Optional[SimpleNamespace] = None, grad_hook=None, densify_stats=False, optimizer_step=None):
     """One iteration of train.py for one view: render -> loss -> backward -> Adam step.  `grad_hook(pc, pkg)` runs
     between backward and the optimizer step (used by the data-parallel wrapper for the RCCL all-reduce).
     densify_stats=True also does the bookkeeping of train.py:489-493 (max_radii2D, xyz_gradient_accum, denom) for this
     single-view batch: inside the rasterizer's per-Gaussian backward when the RGB + feature pair runs as ONE two-image node
     (the default fine-stage configuration), else -- coarse stage, pipe.fused_pair=False, debug snapshots, P == 0 -- as one fused
     pass over the viewspace gradient afterwards (optim.densify_stats).  Data-parallel runs reduce the statistics first
-    (dp.reduce_densification_stats) and must leave this off."""
+    (dp.reduce_densification_stats) and must leave this off.  `optimizer_step()` replaces `pc.optimizer.step()` (data parallel:
+    dp.OverlappedGradAllReducer.finish_and_step, which steps the early-reduced groups while the last collectives are in flight)."""
     pipe = pipe or SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
     acc = (pc.xyz_gradient_accum, pc.denom, pc.max_radii2D) if densify_stats else None
     pkg = render(cam, pc, pipe, bg, stage=stage, return_dx=True, render_feat=(stage == "fine" and hyper.feat_head),
@@ -612,6 +613,9 @@ def training_step(pc: GaussianParams, cam: Dict, gt_image, gt_depth, gt_feat, hy
         _densify_stats(pc.xyz_gradient_accum, pc.denom, pc.max_radii2D, vg, pkg["radii"])
     if grad_hook is not None:
         grad_hook(pc, pkg)
-    pc.optimizer.step()
+    if optimizer_step is not None:
+        optimizer_step()
+    else:
+        pc.optimizer.step()
     pc.optimizer.zero_grad(set_to_none=True)
     return loss.detach(), pkg

@@ -175,6 +175,67 @@ def test_overlapped_reducer_world_size_2():
     assert results == {0: True, 1: True}
 
 
+def _two_phase_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from s3gaussian_amd import dp
+    dp.init_from_env(backend="gloo")
+    ok = True
+    res = {}
+    for mode in ("single", "two_phase"):
+        torch.manual_seed(0)   # identical replicas
+        named = {"xyz": torch.nn.Parameter(torch.randn(3000, 3)), "f_rest": torch.nn.Parameter(torch.randn(3000, 15, 3)),
+                 "opacity": torch.nn.Parameter(torch.randn(3000, 1)),
+                 "grid": torch.nn.Parameter(torch.randn(1, 32, 8, 16).contiguous(memory_format=torch.channels_last)),
+                 "deformation": torch.nn.Parameter(torch.randn(64, 64)), "unused": torch.nn.Parameter(torch.randn(5))}
+        opt = torch.optim.Adam([{"params": [p], "lr": 0.01 * (i + 1), "name": n} for i, (n, p) in enumerate(named.items())], lr=0.0, eps=1e-15)
+        red = dp.OverlappedGradAllReducer(opt, bucket_mb=0.001, inplace_mb=0.004)
+        for step in range(3):
+            opt.zero_grad(set_to_none=True)
+            k = float(rank + 1 + step)
+            loss = sum((p * k).sum() + 0.5 * (p ** 2).sum() for n, p in named.items() if n != "unused")
+            loss.backward()
+            if mode == "single":
+                n_red = red.finish()
+                opt.step()
+            else:
+                n_red = red.finish_and_step(opt)
+            ok = ok and n_red == sum(p.numel() for n, p in named.items() if n != "unused")   # every gradient reduced exactly once
+            ok = ok and not red._inflight and not red._started
+        red.remove_hooks()
+        res[mode] = {n: p.detach().clone() for n, p in named.items()}
+        ok = ok and all(float(opt.state[p]["step"]) == 3.0 for n, p in named.items() if n != "unused") and len(opt.state[named["unused"]]) == 0
+    ok = ok and all(torch.equal(res["single"][n], res["two_phase"][n]) for n in res["single"])
+    # step_subset alone: two disjoint subsets == one full step
+    torch.manual_seed(1)
+    a, b = torch.nn.Parameter(torch.randn(10)), torch.nn.Parameter(torch.randn(4, 3))
+    a2, b2 = torch.nn.Parameter(a.detach().clone()), torch.nn.Parameter(b.detach().clone())
+    o1 = torch.optim.Adam([{"params": [a]}, {"params": [b]}], lr=0.1)
+    o2 = torch.optim.Adam([{"params": [a2]}, {"params": [b2]}], lr=0.1)
+    for x, y in ((a, b), (a2, b2)):
+        x.grad, y.grad = torch.ones(10) * 0.3, torch.ones(4, 3) * -0.7
+    o1.step()
+    dp.step_subset(o2, [b2])
+    ok = ok and torch.equal(a2.detach(), torch.nn.Parameter(a2.detach()).detach()) and a2.grad is not None and len(o2.state[a2]) == 0
+    dp.step_subset(o2, [a2])
+    ok = ok and torch.equal(a.detach(), a2.detach()) and torch.equal(b.detach(), b2.detach())
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_two_phase_optimizer_step_equals_the_single_phase_world_size_2():
+    """finish_and_step(): early groups stepped while the late collectives are in flight == finish(); optimizer.step()."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_phase_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert results == {0: True, 1: True}
+
+
 def test_single_process_is_a_noop():
     from s3gaussian_amd import dp
     p = torch.nn.Parameter(torch.zeros(4))
