@@ -166,49 +166,60 @@ def _oracle_iteration_factory(P, width, height, seed, point_splat):
     return one_iter
 
 
-def _two_point_fit(P_full, width, height, seed, point_splat, budget_s):
-    """t(P) = a + b * P from two sample sizes at the FULL image: `a` carries everything that scales with the pixels (tile
-    walk / splat image, SSIM's five convolutions, pixel losses, the 143 MB of plane regularisers), `b` everything that scales
-    with the Gaussians (HexPlane gathers, MLP, glue, per-Gaussian raster work, blending work per instance).  The estimate for
-    the full workload is a + b * P_full -- only the P-proportional term is extrapolated."""
-    sizes = (max(2000, P_full // 120), max(6000, P_full // 40))
-    times = []
-    for P in sizes:
-        it = _oracle_iteration_factory(P, width, height, seed, point_splat)
+def _time_iteration(P, width, height, seed, point_splat, repeats=1, warm=True):
+    it = _oracle_iteration_factory(P, width, height, seed, point_splat)
+    if warm:
         it()                                   # warm-up (allocator, OpenMP team, lazy inits)
-        t0 = time.perf_counter()
-        n = 0
-        while n < 1 or (time.perf_counter() - t0 < budget_s / 2 and n < 5):
-            it()
-            n += 1
-        times.append((time.perf_counter() - t0) / n)
-    b = max((times[1] - times[0]) / (sizes[1] - sizes[0]), 0.0)
-    a_ = max(times[0] - b * sizes[0], 0.0)
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        it()
+    return (time.perf_counter() - t0) / repeats
+
+
+def _fit(P_full, width, height, seed, point_splat, sizes):
+    """Least-squares t(P) = a + b * P over `sizes` samples at the FULL image: `a` carries everything that scales with the pixels
+    (tile walk / splat image, SSIM's five convolutions, pixel losses, the 143 MB of plane regularisers), `b` everything that scales
+    with the Gaussians (HexPlane gathers, MLP, glue, per-Gaussian raster work, blending work per instance).  The residuals of the
+    fit at the sampled sizes are reported next to the estimate for P_full."""
+    import numpy as np
+    times = [_time_iteration(P, width, height, seed, point_splat, repeats=2 if P <= 40_000 else 1) for P in sizes]
+    A = np.stack([np.ones(len(sizes)), np.asarray(sizes, np.float64)], 1)
+    (a_, b), *_ = np.linalg.lstsq(A, np.asarray(times, np.float64), rcond=None)
+    a_, b = max(float(a_), 0.0), max(float(b), 0.0)
     est = a_ + b * P_full
     return est, {"sample_P": list(sizes), "sample_s_per_iter": [round(x, 3) for x in times], "pixel_term_s": round(a_, 3),
-                 "per_gaussian_term_us": round(b * 1e6, 3), "estimate_s_per_iter": round(est, 2)}
+                 "per_gaussian_term_us": round(b * 1e6, 3), "estimate_s_per_iter": round(est, 2),
+                 "fit_residual_rel": [round((a_ + b * P - t_) / t_, 4) for P, t_ in zip(sizes, times)]}
 
 
 def cpu_baseline(P_full, width, height, seed=0):
     """Reported baseline, not the target: the same fine-stage iteration on the host cores of this box.
-      kind "port"        : the oracle path (PyTorch hexplane+MLP+glue+losses, C/OpenMP tile rasterizer fwd+bwd x2)
-      kind "point_splat" : BASELINE.json north_star's variant -- the reference-architecture PyTorch hexplane + MLP with the
-                           rasterizer stubbed to a point splat (BASELINE config #1's CPU-runnable plumbing path).
-    Both on a bounded sample (two sizes of P at the full 1066x1600 image, ~10 s each), extrapolated with t = a + b*P."""
+      top level ("port", what = "point_splat"): BASELINE.json north_star's baseline -- the reference-architecture PyTorch
+          hexplane + MLP + glue + losses (oracle/hexplane_ref.py) with the rasterizer stubbed to a nearest-pixel point splat.
+          ONE real iteration at the FULL workload (P_full Gaussians, full image), measured, nothing extrapolated
+          (a warm-up iteration at P/40 first: allocator, thread pools);
+      "tile_rasterizer_port": the oracle path proper (same PyTorch front end, C/OpenMP restatement of the tile rasterizer
+          fwd+bwd x2) sampled at THREE sizes of P up to P_full/4 at the full image, least-squares t = a + b*P with the residuals."""
     cores = os.cpu_count() or 1
-    torch.set_num_threads(min(cores, 64))
-    est, model = _two_point_fit(P_full, width, height, seed, False, 10.0)
-    out = {"value": round(1.0 / est, 5), "unit": "iters/s", "cores": cores, "kind": "port", "model": model,
-           "sample": f"oracle path at P = {model['sample_P']} of {P_full} Gaussians, full {width}x{height} image, "
-                     f"{model['sample_s_per_iter']} s/iter; t(P) = {model['pixel_term_s']} s + {model['per_gaussian_term_us']} us * P "
-                     f"-> {model['estimate_s_per_iter']} s/iter at full size (torch threads {min(cores, 64)}, OpenMP all cores)"}
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    _time_iteration(max(2000, P_full // 40), width, height, seed, True, repeats=1, warm=False)
+    t_full = _time_iteration(P_full, width, height, seed, True, repeats=1, warm=False)
+    out = {"value": round(1.0 / t_full, 5), "unit": "iters/s", "cores": cores, "kind": "port", "what": "point_splat",
+           "sample": f"ONE full iteration of the workload itself ({P_full} Gaussians, {width}x{height}): reference-architecture PyTorch "
+                     f"hexplane+MLP+glue+losses, rasterizer stubbed to a nearest-pixel point splat: {t_full:.2f} s "
+                     f"(torch threads {threads} of {cores} cores); measured, not extrapolated"}
     try:
-        est2, model2 = _two_point_fit(P_full, width, height, seed, True, 8.0)
-        out["point_splat"] = {"value": round(1.0 / est2, 5), "unit": "iters/s", "cores": cores, "kind": "point_splat", "model": model2,
-                              "sample": "reference-architecture PyTorch hexplane+MLP+glue+losses, rasterizer stubbed to a "
-                                        f"nearest-pixel point splat; same two-size fit -> {model2['estimate_s_per_iter']} s/iter"}
+        sizes = (max(2000, P_full // 120), max(6000, P_full // 40), max(20000, P_full // 4))
+        est, model = _fit(P_full, width, height, seed, False, sizes)
+        out["tile_rasterizer_port"] = {
+            "value": round(1.0 / est, 5), "unit": "iters/s", "cores": cores, "kind": "port", "model": model,
+            "sample": f"oracle path (PyTorch front end + C/OpenMP tile rasterizer fwd+bwd x2) at P = {model['sample_P']} of {P_full} "
+                      f"Gaussians, full image: {model['sample_s_per_iter']} s/iter; least squares t(P) = {model['pixel_term_s']} s + "
+                      f"{model['per_gaussian_term_us']} us * P -> {model['estimate_s_per_iter']} s/iter at full size, residuals "
+                      f"{model['fit_residual_rel']}"}
     except Exception as ex:
-        out["point_splat"] = {"value": None, "kind": "point_splat", "sample": f"failed: {type(ex).__name__}: {ex}"}
+        out["tile_rasterizer_port"] = {"value": None, "kind": "port", "sample": f"failed: {type(ex).__name__}: {ex}"}
     return out
 
 

@@ -125,33 +125,11 @@ def test_product_package_never_imports_oracle():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r02_bench_line.json is what `python bench.py` printed on the MI355X: one JSON object with the driver's
-    fields, the roofline of the dominant kernel (hipEvent times measured live; strict algorithmic vs implementation bytes;
-    PMC traffic labelled with its source) and the CPU baseline (two-term fit + the north_star's point-splat variant)."""
+    """profiles/r03_bench_line.json is what `python bench.py` printed on the MI355X at the end of the round; the same validator
+    runs on a LIVE bench.py invocation in tests/test_bench_gpu.py (the contract is tested on the program, not only on a file)."""
     import json
-    line = open(os.path.join(ROOT, "profiles", "r02_bench_line.json")).read().strip().splitlines()[-1]
-    d = json.loads(line)
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, k
-    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    assert d["metric"] == "train_iters_per_sec" and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert isinstance(base, dict)
-    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
-    assert abs(d["value"] - d["n_gpus"] * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
-    c = d["config"]
-    assert c["path"] == "fused" and set(c["paths"]) == {"fused", "import_swap", "zero_diff"}
-    assert c["paths"]["zero_diff"]["iters_per_s"] < c["paths"]["import_swap"]["iters_per_s"] < c["paths"]["fused"]["iters_per_s"]
-    assert c["instances_R_per_view"] > 0 and c["visible_V_per_view"] > 0 and c["mean_tile_list_length"] > 0
-    assert abs(c["psnr_delta_vs_oracle_db"]) <= 0.1
-    r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] is not None
-    assert "NOT collected in this run" in r["traffic_source"]
-    dom = max(r["kernels"], key=lambda k: k["ms_per_step"])
-    assert dom["kernel"] == r["kernel"]
-    for k in r["kernels"]:
-        assert k["algorithmic_bytes_per_launch"] <= k["implementation_bytes_per_launch"]
-    cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"] and "pixel_term_s" in cb["model"]
-    assert cb["point_splat"]["kind"] == "point_splat" and cb["point_splat"]["value"] > 0
+    from tests.util import validate_bench_line
+    path = os.path.join(ROOT, "profiles", "r03_bench_line.json")
+    if not os.path.exists(path):
+        pytest.skip("the round's bench line has not been collected yet (tools/collect_profiles.sh r03)")
+    validate_bench_line(json.loads(open(path).read().strip().splitlines()[-1]), default_workload=True)

@@ -63,3 +63,36 @@ def settings_from(s, device, sh_degree=0, debug=False):
         bg=s["bg"].to(device), scale_modifier=1.0, viewmatrix=cam["viewmatrix"].to(device),
         projmatrix=cam["projmatrix"].to(device), sh_degree=sh_degree, campos=cam["campos"].to(device),
         prefiltered=False, debug=debug)
+
+
+def validate_bench_line(d, default_workload=True):
+    """The driver's bench.py contract (one JSON line) + this repo's additions; used on a LIVE run (tests/test_bench_gpu.py) and on
+    the committed line of the round (tests/test_abi_cpu.py)."""
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "train_iters_per_sec" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert abs(d["value"] - d["n_gpus"] * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
+    c = d["config"]
+    assert ("BASELINE cfg3" in c["workload"]) == default_workload, c["workload"]     # the label is derived from the arguments
+    assert str(c["gaussians"]) in c["workload"]
+    assert c["path"] == "fused" and set(c["paths"]) == {"fused", "patched", "import_swap", "zero_diff"}
+    ips = {k: v["iters_per_s"] for k, v in c["paths"].items()}
+    assert ips["zero_diff"] < ips["import_swap"] < ips["patched"] <= ips["fused"] * 1.02, ips
+    assert c["instances_R_per_view"] > 0 and c["visible_V_per_view"] > 0 and c["mean_tile_list_length"] > 0
+    assert c["render_ms_per_frame"] > 0
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    if r["traffic"] is not None:
+        assert "NOT collected in this run" in r["traffic_source"]
+    dom = max(r["kernels"], key=lambda k: k["ms_per_step"])
+    assert dom["kernel"] == r["kernel"]
+    for k in r["kernels"]:
+        assert k["algorithmic_bytes_per_launch"] <= k["implementation_bytes_per_launch"] and k["avg_launch_ms"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["what"] == "point_splat" and cb["cores"] >= 1 and cb["value"] > 0
+    assert "measured, not extrapolated" in cb["sample"]
+    tr = cb["tile_rasterizer_port"]
+    assert tr["value"] > 0 and len(tr["model"]["sample_P"]) == 3 and len(tr["model"]["fit_residual_rel"]) == 3
