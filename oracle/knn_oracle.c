@@ -1,9 +1,11 @@
 /*
  * oracle/knn_oracle.c -- CPU restatement of simple_knn (distCUDA2).
  *
- * TEST INFRASTRUCTURE ONLY (see raster_oracle.c header).  PARITY UNPINNED BY THE REFERENCE (it has
- * no tests); cross-checked in tests/ against a brute-force O(P^2) 3-NN, which the algorithm equals
- * exactly because the box pruning is conservative (simple_knn.cu:168-181).
+ * TEST INFRASTRUCTURE ONLY (see raster_oracle.c header).  The reference has no tests of its own for this path; this
+ * restatement is PINNED BY THE REFERENCE ITSELF since round 3: oracle/_ref/libref_knn.so is the reference's simple_knn.cu built
+ * for gfx950 (oracle/build_ref.sh, host-pointer shim oracle/ref_knn_shim.cpp), compared on the GPU box up to the 1.2 M points of
+ * cfg3 (tests/test_knn_gpu.py::test_knn_oracle_and_distcuda2_are_pinned_by_the_reference_build); and on the CPU against a
+ * brute-force O(P^2) 3-NN, which the algorithm equals exactly because the box pruning is conservative (simple_knn.cu:168-181).
  *
  * Follows KNN = /root/reference/submodules/simple-knn/simple_knn.cu:
  *   :45-61  prepMorton / coord2Morton (10 bits per axis)

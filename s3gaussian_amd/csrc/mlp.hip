@@ -686,7 +686,7 @@ constexpr int WG_WAVES = 8;  // waves per wgrad workgroup (one persistent workgr
 #define S3G_WGRAD_STREAM 0   // streaming loads for the planes a launch reads once: measured SLOWER (0.955 -> 1.01 ms, r3), kept as an A/B switch
 #endif
 #ifndef S3G_WGRAD_PAIRED
-#define S3G_WGRAD_PAIRED 1   // 0: the nine separate launches of round 2 (A/B builds: tools/build_variant.sh)
+#define S3G_WGRAD_PAIRED 2   // 2: all nine GEMMs in ONE launch; 1: five launches (GEMMs sharing an operand paired); 0: the nine launches of round 2
 #endif
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -1010,6 +1010,239 @@ static int launch_wgrad_multi(const WJob* jobs, int njobs, int P, hipStream_t st
   return S3G_OK;
 }
 
+// ---- ALL weight gradients in one launch --------------------------------------------------------------------------------------
+// One persistent workgroup per CU, one wave per GEMM ("job"), every wave of a workgroup on the SAME tile sequence: each of the ten
+// stash / signal planes and the feature rows leave HBM once per iteration (3288 B per point instead of 4056 B with nine launches),
+// the launch ramps and tails of five launches become one, and jobs of different intensity (the 3-row heads are all loads, the
+// 64 x 64 GEMMs balanced) cover each other.  Only TWO code paths live in the workgroup -- "wide" (G up to 64 columns, runtime
+// strides / ReLU) and "head" (G = [P,3]; one wave does both heads, one after the other: 2 x 32 MFMAs per tile = a wide job's 64) --
+// which is what separates this from the r2 dead end (nine differently unrolled paths per CU: 1.55 -> 1.93 ms).
+struct WJobX {
+  const float* G;   // wide: [P][gstride], gw columns used;  head: [P][3]
+  const float* A;   // [P][astride], 64 columns used
+  float* dW;        // [gw][astride] window
+  float* db;        // [gw] or NULL
+  int gstride, gw, astride;
+  float relu_lo;
+  int kind;         // 0 wide, 1 head (then G2 / A2 / dW2 / db2 = the second head, or NULL)
+  const float* G2;
+  const float* A2;
+  float* dW2;
+  float* db2;
+};
+struct WAllArgs {
+  WJobX job[8];
+  int P;
+};
+
+__device__ __forceinline__ void wgrad_wide_wave(const WJobX& jb, float* __restrict__ red, int P, int lane) {
+  constexpr int STEPS = MT / 2;
+  const int i = lane & 31, k = lane >> 5;
+  const int gcol = min(2 * i, jb.gw - 2);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+  float bsum[2] = {0.f, 0.f};
+  const int nfull = P / MT, stride = gridDim.x;
+  struct Set {
+    float g[STEPS][2];
+    float v[STEPS][2];
+  };
+  auto issue = [&](Set& S, int tile) {  // requires tile < nfull
+    const int p0 = tile * MT;
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      const float2 x = *reinterpret_cast<const float2*>(jb.G + (size_t)(p0 + 2 * s + k) * jb.gstride + gcol);
+      S.g[s][0] = x.x; S.g[s][1] = x.y;
+      const float2 y = *reinterpret_cast<const float2*>(jb.A + (size_t)(p0 + 2 * s + k) * jb.astride + 2 * i);
+      S.v[s][0] = y.x; S.v[s][1] = y.y;
+    }
+  };
+  auto consume = [&](const Set& S) {
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      const float b0 = fmaxf(S.v[s][0], jb.relu_lo), b1 = fmaxf(S.v[s][1], jb.relu_lo);
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        bsum[m] += S.g[s][m];
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(S.g[s][m], b0, acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(S.g[s][m], b1, acc[m][1], 0, 0, 0);
+      }
+    }
+  };
+  {
+    Set A, B;
+    const int t0 = blockIdx.x;
+    const int cnt = t0 < nfull ? (nfull - t0 + stride - 1) / stride : 0;
+    const int last = nfull - 1;
+    if (cnt > 0) {
+      issue(A, t0);
+      for (int it = 0; it < cnt; it += 2) {
+        issue(B, min(t0 + (it + 1) * stride, last));
+        __builtin_amdgcn_sched_barrier(0);
+        consume(A);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 >= cnt) break;
+        issue(A, min(t0 + (it + 2) * stride, last));
+        __builtin_amdgcn_sched_barrier(0);
+        consume(B);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (P % MT != 0 && (nfull % stride) == (int)blockIdx.x) {   // the ragged last tile, masked loads
+    const int p0 = nfull * MT;
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      const int p = p0 + 2 * s + k;
+      float ga[2] = {0.f, 0.f}, ba[2] = {0.f, 0.f};
+      if (p < P) {
+        ga[0] = jb.G[(size_t)p * jb.gstride + gcol]; ga[1] = jb.G[(size_t)p * jb.gstride + gcol + 1];
+        ba[0] = fmaxf(jb.A[(size_t)p * jb.astride + 2 * i], jb.relu_lo);
+        ba[1] = fmaxf(jb.A[(size_t)p * jb.astride + 2 * i + 1], jb.relu_lo);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        bsum[m] += ga[m];
+#pragma unroll
+        for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[m], ba[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+  // this wave is the job's only contributor in the workgroup: stage the block in LDS (plain stores) for a coalesced flush
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) red[(2 * acc_row(r, lane) + m) * 64 + 2 * (lane & 31) + n] = acc[m][n][r];
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
+    if (k == 0) red[32 * 2 * 64 + 2 * i + m] = tot;
+  }
+  wave_lds_sync();
+  for (int e = lane; e < jb.gw * 64; e += 64) atomicAdd(&jb.dW[(size_t)(e >> 6) * jb.astride + (e & 63)], red[e]);
+  if (jb.db != nullptr && lane < jb.gw) atomicAdd(&jb.db[lane], red[32 * 2 * 64 + lane]);
+}
+
+// one 3-row head: dW[3][64] += sum_p G[p][0..2] (x) A[p][0..63]   (G rows are 12 bytes: a tile's 32 x 3 block is one coalesced
+// 8-byte load per lane, the operand of step s is picked out with two ds_bpermute -- as in mlp_wgrad_kernel<3, ...>)
+__device__ __forceinline__ void wgrad_head_wave(const float* __restrict__ G, const float* __restrict__ A, float* __restrict__ dW,
+                                                float* __restrict__ db, float* __restrict__ red, int P, int lane) {
+  constexpr int STEPS = MT / 2;
+  const int i = lane & 31, k = lane >> 5;
+  f32x16 acc[2];
+#pragma unroll
+  for (int n = 0; n < 2; n++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+  float bsum = 0.f;
+  const int nfull = P / MT, stride = gridDim.x;
+  struct Set {
+    float g[2];
+    float v[STEPS][2];
+  };
+  auto issue = [&](Set& S, int tile) {
+    const int p0 = tile * MT;
+    const float2 x = *reinterpret_cast<const float2*>(G + (size_t)p0 * 3 + 2 * (lane < 48 ? lane : lane - 48));
+    S.g[0] = x.x; S.g[1] = x.y;
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      const float2 y = *reinterpret_cast<const float2*>(A + (size_t)(p0 + 2 * s + k) * HID + 2 * i);
+      S.v[s][0] = y.x; S.v[s][1] = y.y;
+    }
+  };
+  auto consume = [&](const Set& S) {
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      const int e = 6 * s + 3 * k + (i < 3 ? i : 0);
+      const float x = __shfl(S.g[0], e >> 1), y = __shfl(S.g[1], e >> 1);
+      const float ga = i < 3 ? ((e & 1) ? y : x) : 0.f;
+      bsum += ga;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, S.v[s][0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, S.v[s][1], acc[1], 0, 0, 0);
+    }
+  };
+  {
+    Set SA, SB;
+    const int t0 = blockIdx.x;
+    const int cnt = t0 < nfull ? (nfull - t0 + stride - 1) / stride : 0;
+    const int last = nfull - 1;
+    if (cnt > 0) {
+      issue(SA, t0);
+      for (int it = 0; it < cnt; it += 2) {
+        issue(SB, min(t0 + (it + 1) * stride, last));
+        __builtin_amdgcn_sched_barrier(0);
+        consume(SA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 >= cnt) break;
+        issue(SA, min(t0 + (it + 2) * stride, last));
+        __builtin_amdgcn_sched_barrier(0);
+        consume(SB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (P % MT != 0 && (nfull % stride) == (int)blockIdx.x) {
+    const int p0 = nfull * MT;
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      const int p = p0 + 2 * s + k;
+      const float ga = (p < P && i < 3) ? G[(size_t)p * 3 + i] : 0.f;
+      float ba[2] = {0.f, 0.f};
+      if (p < P) { ba[0] = A[(size_t)p * HID + 2 * i]; ba[1] = A[(size_t)p * HID + 2 * i + 1]; }
+      bsum += ga;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, ba[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, ba[1], acc[1], 0, 0, 0);
+    }
+  }
+  // rows 0..2 of the 32-row block are registers 0..2 of the k == 0 lanes
+  wave_lds_sync();
+  if (k == 0) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      red[r * 64 + 2 * i] = acc[0][r];
+      red[r * 64 + 2 * i + 1] = acc[1][r];
+    }
+  }
+  const float tot = bsum + __shfl_xor(bsum, 32);
+  if (k == 0 && i < 3) red[3 * 64 + i] = tot;
+  wave_lds_sync();
+  for (int e = lane; e < 3 * 64; e += 64) atomicAdd(&dW[e], red[e]);
+  if (db != nullptr && lane < 3) atomicAdd(&db[lane], red[3 * 64 + lane]);
+  wave_lds_sync();
+}
+
+__global__ void __launch_bounds__(WG_WAVES * 64) mlp_wgrad_all_kernel(const WAllArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red_all[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const WJobX jb = a.job[wave];
+  float* red = red_all + wave * WM_RED;
+  if (jb.kind == 0) {
+    wgrad_wide_wave(jb, red, a.P, lane);
+  } else {
+    wgrad_head_wave(jb.G, jb.A, jb.dW, jb.db, red, a.P, lane);
+    if (jb.G2 != nullptr) wgrad_head_wave(jb.G2, jb.A2, jb.dW2, jb.db2, red, a.P, lane);
+  }
+}
+
+static int launch_wgrad_all(const WJobX* jobs, int njobs, int P, hipStream_t stream) {
+  WAllArgs a;
+  memset(&a, 0, sizeof a);
+  for (int j = 0; j < njobs; j++) a.job[j] = jobs[j];
+  a.P = P;
+  const int ntiles = (P + MT - 1) / MT;
+  const int blocks = min(ntiles, 256);
+  hipLaunchKernelGGL(mlp_wgrad_all_kernel, dim3(blocks), dim3(njobs * 64), (size_t)njobs * WM_RED * sizeof(float), stream, a);
+  S3G_HIP_CHECK(hipGetLastError());
+  return S3G_OK;
+}
+
 template <int GW, int AW, bool RELU_A, int ASTRIDE = AW>
 static int launch_wgrad(const float* G, const float* A, float* dW, float* db, int P, hipStream_t stream) {
   WgradArgs a{G, A, dW, db, P};
@@ -1038,6 +1271,7 @@ static int mlp_set_attrs() {
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_multi_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WM_RED * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_multi_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WM_RED * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WM_RED * 4));
     device_setup_done(done);
   }
   return S3G_OK;
@@ -1093,7 +1327,19 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   // ... and D0 / P1 / S1 share `hidden` (stash plane 0); D1 fills the fourth wave pair of the workgroup
   const WJob d0{workspace + 1 * PS, stash + 0 * PS, gw->D0, gw->db0, HID, NONE}, d1{workspace + 0 * PS, stash + 3 * PS, gw->D1, gw->db1, HID, NONE};
   const WJob p1{workspace + 2 * PS, stash + 0 * PS, gw->P1, gw->pb1, HID, RELU}, s1{workspace + 3 * PS, stash + 0 * PS, gw->S1, gw->sb1, HID, RELU};
-  if (S3G_WGRAD_PAIRED) {
+  if (S3G_WGRAD_PAIRED == 2) {   // everything in ONE launch (mlp_wgrad_all_kernel)
+    auto wide = [](const WJob& j, int gw = HID) { return WJobX{j.G, j.A, j.dW, j.db, gw, gw, j.astride, j.relu_lo, 0, nullptr, nullptr, nullptr, nullptr}; };
+    const WJobX s2{g_dshs, stash + 2 * PS, gw->S2, gw->sb2, 48, 48, HID, NONE, 0, nullptr, nullptr, nullptr, nullptr};
+    WJobX head{g_dx, stash + 1 * PS, gw->P2, gw->pb2, 3, 3, HID, NONE, 1, nullptr, nullptr, nullptr, nullptr};
+    if (g_feat != nullptr) {
+      head.G2 = g_feat; head.A2 = stash + 4 * PS; head.dW2 = gw->D2; head.db2 = gw->db2;
+      const WJobX jobs[8] = {wide(w0a), wide(w0b), wide(d0), wide(p1), wide(s1), wide(d1), s2, head};
+      if (int e = launch_wgrad_all(jobs, 8, P, stream)) return e;
+    } else {
+      const WJobX jobs[6] = {wide(w0a), wide(w0b), wide(p1), wide(s1), s2, head};
+      if (int e = launch_wgrad_all(jobs, 6, P, stream)) return e;
+    }
+  } else if (S3G_WGRAD_PAIRED) {
     { const WJob jobs[2] = {w0a, w0b}; if (int e = (launch_wgrad_multi<false, true>(jobs, 2, P, stream))) return e; }   // ghid shared, feature halves read once
     if (g_feat != nullptr) {  // NULL: the dino head received no gradient; its six parameter gradients are left untouched
       const WJob jobs[4] = {d0, p1, s1, d1};
