@@ -582,7 +582,9 @@ def main():
             # implementation: mask words in, 5 gradient-signal planes out (read back by the weight-gradient launches)
             6: ("s3g::mlp_backward_kernel", lambda n, _: n * (216.0 + 512.0), lambda n, _: n * (40.0 + 216.0 + 5 * 256.0 + 512.0),
                 lambda n: n * MLP_FLOP),
-            7: ("s3g::mlp_wgrad_kernel", lambda n, _: n * 512.0, lambda n, _: n * 4.0 * (2 * 67 + 6 * 128 + 112), lambda n: n * MLP_FLOP),
+            # ONE launch for all nine GEMMs (mlp_wgrad_all_kernel): every stash / signal plane and the feature rows read once:
+            # 5 x 256 (stash) + 5 x 256 (signals) + 512 (features) + 12 + 12 + 192 (head gradients) = 3288 B per point
+            7: ("s3g::mlp_wgrad_all_kernel", lambda n, _: n * 512.0, lambda n, _: n * 3288.0, lambda n: n * MLP_FLOP),
             8: ("s3g::adam_kernel", lambda n, _: n * 28.0, None, None),   # p, g, m, v read; p, m, v written
         }
         traffic_db, traffic_launches, traffic_source = {}, {}, None
@@ -592,7 +594,7 @@ def main():
             try:
                 db = json.load(open(pmc))
                 traffic_db = db.get("hbm_bytes_per_launch", {})
-                traffic_launches = db.get("launches_per_bracket", {"s3g::mlp_wgrad_kernel": 9})
+                traffic_launches = db.get("launches_per_bracket", {})
                 traffic_source = ("profiles/kernel_traffic.json: " + db.get("command", "rocprofv3 --pmc passes") +
                                   " -- NOT collected in this run; hipEvent times are")
             except Exception:

@@ -21,6 +21,12 @@ for k in f w; do c=$(find /tmp/pmc_$k -name "*counter_collection.csv" | head -1)
 cp "$OUT/${TAG}_pmc/kernel_traffic.json" "$ROOT/profiles/kernel_traffic.json" 2>/dev/null
 cd /tmp
 python "$ROOT/bench.py" > "$OUT/${TAG}_bench_line.json" 2> "$OUT/${TAG}_bench_line.err"
+# R sweep (same Gaussians, every scale multiplied: more (tile, Gaussian) instances per view) and P sweep, final tree
+: > "$OUT/${TAG}_sweep.jsonl"
+for extra in "--scale-mult 2.0" "--scale-mult 3.5" "--P 600000" "--P 2500000"; do
+  python "$ROOT/bench.py" --no-cpu-baseline --no-alt-paths $extra >> "$OUT/${TAG}_sweep.jsonl" 2>/dev/null
+done
+S3G_HEX_BACKWARD=walk python "$ROOT/bench.py" --no-cpu-baseline --no-alt-paths --P 2500000 >> "$OUT/${TAG}_sweep.jsonl" 2>/dev/null
 # two ranks on the one GPU of the lease: functional check of the view-parallel path (gloo; RCCL refuses two ranks on one device)
 cd "$ROOT"
 S3G_DIST_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \

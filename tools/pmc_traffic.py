@@ -62,7 +62,7 @@ def main():
         fh.write("kernel,launches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg\n")
         for k, n, f, w in rows:
             fh.write(f"{k},{n},{f:.1f},{w:.1f}\n")
-    launches = {"s3g::mlp_wgrad_kernel": 9}   # launches inside bench.py's hipEvent bracket for that id
+    launches = {}   # every hipEvent bracket of bench.py covers ONE launch since round 3 (the nine weight-gradient launches became one)
     json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 3 --warmup 1 "
                           "--no-cpu-baseline --no-alt-paths (two passes, tools/collect_profiles.sh)",
                "launches_per_bracket": launches,
