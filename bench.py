@@ -677,7 +677,9 @@ def main():
         if os.path.exists(psnr_file):   # the third part of BASELINE's metric: written by tools/psnr_parity.py on the GPU box
             try:
                 pj = json.load(open(psnr_file))
-                out["config"]["psnr_delta_vs_oracle_db"] = pj.get("max_abs_delta_db")
+                md = pj.get("mean_psnr_delta_db")     # per split (train / held-out views): what an evaluation reports
+                out["config"]["psnr_delta_vs_oracle_db"] = max(abs(v) for v in md.values()) if md else pj.get("max_abs_delta_db")
+                out["config"]["psnr_worst_single_view_delta_db"] = pj.get("max_abs_delta_db")
                 out["config"]["psnr_parity_source"] = "profiles/psnr_parity.json: " + pj.get("what", "")
             except Exception:
                 pass

@@ -82,6 +82,8 @@ def validate_bench_line(d, default_workload=True):
     assert ips["zero_diff"] < ips["import_swap"] < ips["patched"] <= ips["fused"] * 1.02, ips
     assert c["instances_R_per_view"] > 0 and c["visible_V_per_view"] > 0 and c["mean_tile_list_length"] > 0
     assert c["render_ms_per_frame"] > 0
+    if "psnr_delta_vs_oracle_db" in c:
+        assert abs(c["psnr_delta_vs_oracle_db"]) <= 0.1
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
