@@ -563,7 +563,7 @@ def main():
         # Strict = SURVEY 8(d): what the math must read and write (inputs, outputs, parameters once); scratch that exists only
         # because of how this implementation is split into kernels (G slab, activation stash, gradient signals) is counted
         # under implementation bytes and never enters `frac`.
-        G_ROWS = float(getattr(L, "s3g_hexplane_backward_scratch_rows", lambda: 24)())   # 128-byte rows of scratch per point
+        G_ROWS = float(L.s3g_hexplane_backward_scratch_rows(int(levels)))   # 128-byte rows of scratch per point (r2: 24, r3: 4)
         models = {
             # two-image pass (RGB+depth and feature image from one geometry): + colors2 per instance, + one image per pixel
             0: ("s3g::blend_forward_kernel", lambda R, N: (56.0 if pair else 44.0) * R + (36.0 if pair else 24.0) * N, None, None),
@@ -574,7 +574,9 @@ def main():
             3: ("s3g::hexplane_backward_point_kernel", lambda n, l: n * (28.0 + 4.0 * FEAT) + plane_bytes,
                 lambda n, l: n * (28.0 + 4.0 * FEAT + G_ROWS * 128.0) + plane_bytes, None),
             # plane gradients written once; reading the scratch back is implementation
-            4: ("s3g::hexplane_scatter_kernel", lambda n, l: plane_bytes, lambda n, l: n * (60.0 + G_ROWS * 128.0) + plane_bytes, None),
+            # (each of the three orientation walks reads the point's rows)
+            4: ("s3g::hexplane_scatter_kernel", lambda n, l: plane_bytes,
+                lambda n, l: n * (60.0 + (3.0 if G_ROWS < 24 else 1.0) * G_ROWS * 128.0) + plane_bytes, None),
             # features in, three heads out; the 5 stashed activations are implementation
             # implementation: + 5 stashed activation planes (for the weight gradients) + 5 ReLU mask words per lane (40 B/point)
             5: ("s3g::mlp_forward_kernel", lambda n, _: n * (512.0 + 216.0), lambda n, _: n * (512.0 + 5 * 256.0 + 40.0 + 216.0),

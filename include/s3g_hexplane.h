@@ -52,6 +52,7 @@ int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, co
  * s3g_hexplane_backward_workspace_bytes(d, P, features != NULL) bytes (sort buffers, per-orientation dL/dxyz partials, the
  * row tables and their gradients when uniform_time; + 3 KB per point of per-plane sample gradients on the features == NULL
  * path), uninitialised. */
+int s3g_hexplane_backward_scratch_rows(int levels);   /* 128-byte rows of scratch per point the features == NULL path writes */
 #define S3G_HEX_SORT_STATE_WORDS 7
 size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P, int have_features);
 int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,

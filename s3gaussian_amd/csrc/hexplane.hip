@@ -27,6 +27,19 @@
 
 namespace s3g {
 
+// G slab contents.  0 (rounds 1-2): dL/d(sample) of all 24 plane-levels, 3 KB per point.  1 (round 3): ONE row per level,
+// T = dL/dfeature * feature = g * prod_j s_j (the per-point pass has it for free at the end of its product rule); the scatter
+// walk re-derives the one sample it is about to scatter -- the four texels (two row-table entries) of the footprint it is
+// accumulating anyway, L1-resident in the sorted order -- and uses dL/ds_i = T / s_i.  512 B per point written instead of
+// 3 KB, 1.5 KB read back instead of 3 KB.  A sample whose magnitude is not safely divisible (|s| <= 1e-18, or not finite) is
+// left out by the walk and scattered EXACTLY (g * prod_{j != i} s_j, direct atomics) by the per-point pass, which has all six
+// samples: both passes evaluate the same predicate on the same bits of s (same taps, same operation order, contraction off).
+#ifndef S3G_HEX_TSLAB
+#define S3G_HEX_TSLAB 1
+#endif
+constexpr float TSLAB_SAFE = 1e-18f;
+__device__ __forceinline__ bool tslab_divisible(float s) { return fabsf(s) > TSLAB_SAFE && fabsf(s) < __builtin_huge_valf(); }
+
 template <bool UT>
 __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) {
   extern __shared__ float4 tapbuf[];   // [32 points][levels][TAP_SLOTS]
@@ -173,27 +186,82 @@ __device__ __forceinline__ void samples_level(const HexArgs& a, const float4* __
     }
   }
 }
+template <typename V> __device__ __forceinline__ float vget(V v, int k);
+template <> __device__ __forceinline__ float vget<f4v>(f4v v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+template <> __device__ __forceinline__ float vget<f2v_>(f2v_ v, int k) { return k == 0 ? v.x : v.y; }
+// one sample of plane i of level l at point coordinates u, channel c: make_tap + the four weighted texels in the order every
+// kernel of this file uses (with uniform time the (axis, t) planes are height-1 row tables: res[l][3] == 1, iy == 0)
+__device__ __forceinline__ float walk_sample(const HexArgs& a, int l, int i, const float* u, int c) {
+  const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
+  const Tap t = make_tap(u[PAIR0[i]], u[PAIR1[i]], W, H);
+  const float* pl = a.d.planes[l][i];
+  float acc = fetch(pl, t.o00, c) * t.w00;
+  acc = acc + fetch(pl, t.o01, c) * t.w01;
+  acc = acc + fetch(pl, t.o10, c) * t.w10;
+  acc = acc + fetch(pl, t.o11, c) * t.w11;
+  return acc;
+}
+// The scatter walk divides T by the sample it re-derives; where it cannot (same predicate on the same bits) the exact gradient
+// g * prod_{j != i} s_j is scattered here with the walk's own corner weights.  Runs for (nearly) zero or non-finite samples only,
+// so it keeps nothing of the hot path's registers: everything is re-derived from the point's coordinates.
 template <typename V>
-__device__ __forceinline__ void finish_level(const HexArgs& a, int l, int c0, const LevelS<V>& S, V g, bool store,
-                                             float* __restrict__ G, size_t gbase, float* du) {
+__device__ __forceinline__ void tslab_exact_scatter(const HexArgs& a, int p, int l, int c0, V g, uint32_t badbits) {
+  float u[4];
+  point_coords(a, p, u);
+#pragma unroll 1
+  for (int i = 0; i < 6; i++) {
+    float* gp = a.gplanes[l][i];
+    if (!((badbits >> i) & 1u) || gp == nullptr) continue;
+    const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
+    const Tap t = make_tap(u[PAIR0[i]], u[PAIR1[i]], W, H);
+#pragma unroll 1
+    for (int k = 0; k < vec_of<V>::N; k++) {
+      const int c = c0 + k;
+      if (tslab_divisible(walk_sample(a, l, i, u, c))) continue;
+      float gk = vget<V>(g, k);
+#pragma unroll 1
+      for (int jj = 0; jj < 6; jj++)
+        if (jj != i) gk *= walk_sample(a, l, jj, u, c);
+      atomicAdd(gp + (size_t)t.o00 * HEXC + c, t.w00 * gk);
+      if (t.o01 >= 0) atomicAdd(gp + (size_t)t.o01 * HEXC + c, t.w01 * gk);
+      if (t.o10 >= 0) atomicAdd(gp + (size_t)t.o10 * HEXC + c, t.w10 * gk);
+      if (t.o11 >= 0) atomicAdd(gp + (size_t)t.o11 * HEXC + c, t.w11 * gk);
+    }
+  }
+}
+template <bool UT, typename V>
+__device__ __forceinline__ void finish_level(const HexArgs& a, int p, int l, int c0, const LevelS<V>& S, V g,
+                                             bool store, float* __restrict__ G, size_t gbase, float* du) {
   // product rule in the order autograd applies it to ((((1*s0)*s1)*s2)*s3)*s4)*s5: pre[i] = prod_{j<i} s_j, suffix by recursion
   V pre[6];
   pre[0] = vsplat<V>(1.f);
 #pragma unroll
   for (int i = 1; i < 6; i++) pre[i] = pre[i - 1] * S.s[i - 1];
   V gs = g;  // dL/d(prefix product through plane i)
+  uint32_t badbits = 0;   // T-slab: planes with a sample the scatter walk cannot divide by
 #pragma unroll
   for (int i = 5; i >= 0; i--) {
     const V gi = gs * pre[i];  // dL/ds_i
     gs = gs * S.s[i];
     if (store) {
-      // point-major G: row (orientation, level, kind) of this point's block, gbase = processing position * 24 rows
-      V* grow = reinterpret_cast<V*>(G + gbase + (size_t)(((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * HEXC + c0));
-      if (G_NONTEMPORAL) __builtin_nontemporal_store(gi, grow);   // written once, read once by the scatter pass much later
-      else *grow = gi;
+      if (!S3G_HEX_TSLAB) {
+        // point-major G: row (orientation, level, kind) of this point's block, gbase = processing position * 24 rows
+        V* grow = reinterpret_cast<V*>(G + gbase + (size_t)(((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * HEXC + c0));
+        if (G_NONTEMPORAL) __builtin_nontemporal_store(gi, grow);   // written once, read once by the scatter pass much later
+        else *grow = gi;
+      } else {
+#pragma unroll
+        for (int k = 0; k < vec_of<V>::N; k++) badbits |= tslab_divisible(vget<V>(S.s[i], k)) ? 0u : (1u << i);
+      }
       if (PAIR0[i] < 3) du[PAIR0[i]] += S.mx[i] * vdot(S.dX[i], gi);
       if (PAIR1[i] < 3) du[PAIR1[i]] += S.my[i] * vdot(S.dY[i], gi);
     }
+  }
+  if (S3G_HEX_TSLAB && store) {   // gs = g * s5 * s4 * ... * s0 = dL/dfeature * feature: the level's ONE row, gbase = position * levels rows
+    V* trow = reinterpret_cast<V*>(G + gbase + (size_t)(l * HEXC + c0));
+    if (G_NONTEMPORAL) __builtin_nontemporal_store(gs, trow);
+    else *trow = gs;
+    if (badbits) tslab_exact_scatter<V>(a, p, l, c0, g, badbits);   // rare: a sample that is (nearly) zero or not finite
   }
 }
 
@@ -210,7 +278,7 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
     const int pi = p0 + slot;
     const bool live = pi < a.P;
     const int p = live ? (a.proc_order ? (int)a.proc_order[pi] : pi) : 0;
-    const size_t gbase = (size_t)pi * (size_t)(6 * L * HEXC);   // point-major layout: 24 rows of this PROCESSING position
+    const size_t gbase = (size_t)pi * (size_t)((S3G_HEX_TSLAB ? 1 : 6) * L * HEXC);   // point-major layout: the rows of this PROCESSING position
     float u[4];
     point_coords(a, p, u);
     wave_lds_sync();
@@ -224,7 +292,7 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
       LevelS<V> S;
       issue_level<UT>(a, taps, l, c0, grow, X);
       samples_level<UT>(a, taps, l, c0, X, S);
-      finish_level(a, l, c0, S, X.g, live, G, gbase, du);
+      finish_level<UT>(a, p, l, c0, S, X.g, live, G, gbase, du);
     }
     // sum over the 32 channels (the lanes of this point), then undo the aabb normalisation
 #pragma unroll
@@ -387,8 +455,16 @@ static inline int segment_length(int P) { return P >= 1000000 ? 256 : 128; }
 constexpr bool FOOT_SHIFT = true;
 typedef float f2v __attribute__((ext_vector_type(2)));
 template <typename T> struct lanes_of;
-template <> struct lanes_of<float> { static constexpr int CPL = 1; };
-template <> struct lanes_of<f2v> { static constexpr int CPL = 2; };
+template <> struct lanes_of<float> {
+  static constexpr int CPL = 1;
+  static __device__ __forceinline__ float first(float v) { return v; }
+  static __device__ __forceinline__ float splat(float v) { return v; }
+};
+template <> struct lanes_of<f2v> {
+  static constexpr int CPL = 2;
+  static __device__ __forceinline__ float first(f2v v) { return v.x; }
+  static __device__ __forceinline__ f2v splat(float v) { return f2v{v, v}; }
+};
 __device__ __forceinline__ float vzero(float) { return 0.f; }
 __device__ __forceinline__ f2v vzero(f2v) { return f2v{0.f, 0.f}; }
 __device__ __forceinline__ float vfma(float g, float w, float acc) { return __builtin_fmaf(g, w, acc); }
@@ -536,7 +612,7 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   if (k0 >= a.P) return;  // whole walkers drop out; the LDS traffic below is private to a walker (wave-ordered)
   const uint32_t* order = order_all + (size_t)o * a.P;
   const uint32_t* comp = comp_all + (size_t)o * a.P;
-  const size_t GP = (size_t)(6 * a.d.levels * HEXC);   // point-major layout: floats per point
+  const size_t GP = (size_t)((S3G_HEX_TSLAB ? 1 : 6) * a.d.levels * HEXC);   // point-major layout: floats per point
   const int i0 = PLA[o], i1 = PLT[o];
   const int ip = (j & 1) ? i1 : i0;                   // the plane of this lane's tap
   const int axw = PAIR0[ip], axh = PAIR1[ip];
@@ -592,9 +668,13 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
           // unconditional (level clamped; rows exist for every plane): a load behind a uniform branch costs two branch
           // instructions and splits the basic block the scheduler could have filled
           const int lv = min(l0 + l, a.d.levels - 1);
-          const float* row = G + (size_t)cpos[qq] * GP + (size_t)(((o * a.d.levels + lv) * 2) * HEXC + c);
-          g[qq][l][0] = load_g<T>(row);
-          g[qq][l][1] = load_g<T>(row + HEXC);
+          if (S3G_HEX_TSLAB) {   // ONE row per level: T = dL/dfeature * feature; both planes of the walk divide it by their sample (step 3)
+            g[qq][l][0] = load_g<T>(G + (size_t)cpos[qq] * GP + (size_t)(lv * HEXC + c));
+          } else {
+            const float* row = G + (size_t)cpos[qq] * GP + (size_t)(((o * a.d.levels + lv) * 2) * HEXC + c);
+            g[qq][l][0] = load_g<T>(row);
+            g[qq][l][1] = load_g<T>(row + HEXC);
+          }
         }
       }
 #pragma unroll
@@ -624,8 +704,29 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
             PackedTap t;
             t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
             t.w00 = lo.z; t.w01 = lo.w; t.w10 = hi.x; t.w11 = hi.y;
-            if (UT && m == 1) foot2_add<true>(ft[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[i1]], c);
-            else foot2_add<false>(ft[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
+            T gm;
+            if (S3G_HEX_TSLAB) {
+              // the sample this footprint produced in the forward, from the texels the walk is accumulating into anyway (an
+              // out-of-range corner has weight exactly 0 and reads the nw texel, like the per-point pass), then dL/ds = T / s
+              static_assert(!S3G_HEX_TSLAB || CPL == 1, "the T-slab walk is written for one channel per lane");
+              const int Wm = a.d.res[l0 + l][PAIR0[m ? i1 : i0]];
+              const float* pl = a.d.planes[l0 + l][m ? i1 : i0] + (size_t)t.key * HEXC + c;
+              const float v00 = pl[0], v01 = pl[(t.flags & 1) ? HEXC : 0];
+              float sv = v00 * t.w00;
+              sv = sv + v01 * t.w01;
+              if (!(UT && m == 1)) {
+                const float v10 = pl[(t.flags & 2) ? (size_t)Wm * HEXC : 0];
+                const float v11 = pl[((t.flags & 3) == 3) ? (size_t)Wm * HEXC + HEXC : 0];
+                sv = sv + v10 * t.w10;
+                sv = sv + v11 * t.w11;
+              }
+              const float tv = lanes_of<T>::first(g[qq][l][0]);
+              gm = lanes_of<T>::splat(tslab_divisible(sv) ? tv * __builtin_amdgcn_rcpf(sv) : 0.f);
+            } else {
+              gm = g[qq][l][m];
+            }
+            if (UT && m == 1) foot2_add<true>(ft[l][m], t, gm, gp, a.d.res[l0 + l][PAIR0[i1]], c);
+            else foot2_add<false>(ft[l][m], t, gm, gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
           }
         }
       }
@@ -679,17 +780,6 @@ __device__ __forceinline__ WalkTap walk_tap_read(const float* src) {
   t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
   t.wx0 = lo.z; t.wx1 = lo.w; t.wy0 = hi.x; t.wy1 = hi.y;
   return t;
-}
-// one sample of plane i of level l at point coordinates u, channel c (exact path of the division-safety fallback)
-__device__ __forceinline__ float walk_sample(const HexArgs& a, int l, int i, const float* u, int c) {
-  const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
-  const Tap t = make_tap(u[PAIR0[i]], u[PAIR1[i]], W, H);
-  const float* pl = a.d.planes[l][i];
-  float acc = fetch(pl, t.o00, c) * t.w00;
-  acc = acc + fetch(pl, t.o01, c) * t.w01;
-  acc = acc + fetch(pl, t.o10, c) * t.w10;
-  acc = acc + fetch(pl, t.o11, c) * t.w11;
-  return acc;
 }
 __global__ void __launch_bounds__(256, WALK_WG_PER_CU)
 hexplane_backward_walk_kernel(const HexArgs a, const float* __restrict__ feat, const uint32_t* __restrict__ order_all,
@@ -977,7 +1067,7 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
 static void carve_backward(Carver& c, const s3g_hexplane_desc* d, int P, bool walk, float** G, float** tables, SortWork* w,
                            float** dup, uint16_t** badmask) {
   const size_t n = (size_t)P;
-  float* g = walk ? nullptr : c.take<float>((size_t)d->levels * 6 * n * HEXC);   // legacy path: per-plane gradient slab
+  float* g = walk ? nullptr : c.take<float>((size_t)d->levels * (S3G_HEX_TSLAB ? 1 : 6) * n * HEXC);   // slab path: T rows (r3) / per-plane gradient rows
   float* tb = d->uniform_time ? c.take<float>(2 * time_table_floats(d)) : nullptr;
   SortWork s;
   s.table = c.take<uint32_t>((size_t)N_ORDERS * SORT_NB * SORT_BINS);
@@ -994,6 +1084,9 @@ static void carve_backward(Carver& c, const s3g_hexplane_desc* d, int P, bool wa
   if (dup) *dup = du;
   if (badmask) *badmask = bm;
 }
+
+// 128-byte rows of scratch the default (slab) backward writes per point and level set: bench.py prices the implementation bytes
+extern "C" int s3g_hexplane_backward_scratch_rows(int levels) { return (S3G_HEX_TSLAB ? 1 : 6) * levels; }
 
 extern "C" size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P, int have_features) {
   if (!d || d->levels < 1 || d->levels > S3G_HEX_MAX_LEVELS || P < 0) return 0;
