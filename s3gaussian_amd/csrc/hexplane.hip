@@ -512,6 +512,7 @@ template <typename T>
 struct Foot2T {
   int key0, key1, fl0, fl1, mru;
   T a0[4], a1[4];
+  float v0[S3G_HEX_TSLAB ? 4 : 1], v1[S3G_HEX_TSLAB ? 4 : 1];   // T-slab: the footprints' own texel VALUES (loaded when a footprint is installed)
 };
 using Foot2 = Foot2T<float>;
 template <typename T>
@@ -578,6 +579,85 @@ __device__ __forceinline__ void foot2_add(Foot2T<T>& F, const PackedTap& t, T g,
     F.a1[2] = vfma(g1, t.w10, F.a1[2]); F.a1[3] = vfma(g1, t.w11, F.a1[3]);
   }
   F.mru = h1 ? 1 : 0;
+}
+
+// T-slab form of foot2_add: `tv` is the point's T = dL/dfeature * feature for this level; the sample the footprint produced in the
+// forward is re-derived from the footprint's texel VALUES -- kept in the cache entry, so a HIT (three calls in four) costs no load
+// at all and a miss loads the four (two) texels of the footprint it installs -- and dL/ds = T / s is what gets accumulated.
+// An out-of-range corner has weight exactly 0 and takes the nw texel's value, like the per-point pass; a sample that is not safely
+// divisible contributes nothing here (the per-point pass scattered it exactly: same predicate, same bits).
+// key0 / key1 hold (texel index << 2 | corner flags) here -- the flags are a function of the index -- which frees fl0 / fl1.
+// Measured alternatives (cfg3, scatter ms): texels fetched where they are used 2.21; all four points of the group requested up
+// front 1.49 (one level per walk; two levels spill: 7.3); one point ahead in two alternating register sets 2.03 (spills) / 1.60
+// (one level per walk); THIS 1.35, of which 0.33 are the misses' exposed L1 round trips (1.04 with the loads compiled out).
+template <bool ROW = false>
+__device__ __forceinline__ void foot2_add_t(Foot2T<float>& F, const PackedTap& t, float tv, float* __restrict__ gp,
+                                            const float* __restrict__ pl /* plane values + channel */, int W, int c) {
+  const int tkf = (t.key << 2) | (t.flags & 3);
+  bool h0 = tkf == F.key0, h1 = tkf == F.key1;
+  if (!(h0 || h1)) {  // miss (uniform inside the walker's lanes)
+    const float* px = pl + (size_t)t.key * HEXC;
+    const float n0 = px[0], n1 = px[(t.flags & 1) ? HEXC : 0];
+    float n2 = 0.f, n3 = 0.f;
+    if (!ROW) {
+      n2 = px[(t.flags & 2) ? (size_t)W * HEXC : 0];
+      n3 = px[((t.flags & 3) == 3) ? (size_t)W * HEXC + HEXC : 0];
+    }
+    const bool m1 = F.mru != 0;                       // most recent entry
+    const int mkf = m1 ? F.key1 : F.key0;
+    const int mkey = mkf >> 2, mfl = mkf & 3;          // (-1 stays -1)
+    const bool down = FOOT_SHIFT && !ROW && mkf >= 0 && t.key == mkey + W;
+    const bool right = FOOT_SHIFT && mkf >= 0 && t.key == mkey + 1 && (mfl & 1);
+    const bool shift = down || right;
+    const bool w1 = shift ? m1 : !m1;                 // entry that is flushed (partly) and rewritten
+    const int KF = w1 ? F.key1 : F.key0;
+    const int K = KF >> 2, FL = KF & 3;
+    const float A0 = w1 ? F.a1[0] : F.a0[0], A1 = w1 ? F.a1[1] : F.a0[1];
+    const float A2 = ROW ? 0.f : (w1 ? F.a1[2] : F.a0[2]), A3 = ROW ? 0.f : (w1 ? F.a1[3] : F.a0[3]);
+    if (KF >= 0) {
+      const uint32_t k = ((uint32_t)K * HEXC + (uint32_t)c) * 4u;
+      const uint32_t dy = (uint32_t)W * (HEXC * 4u);
+      char* base = reinterpret_cast<char*>(gp);
+      vatomic(base, k, A0);                                                    // nw leaves in every case
+      if ((FL & 1) && !right) vatomic(base, k + HEXC * 4u, A1);               // ne stays when shifting right
+      if (!ROW && (FL & 2) && !down) vatomic(base, k + dy, A2);               // sw stays when shifting down
+      if (!ROW && (FL & 3) == 3 && !shift) vatomic(base, k + dy + HEXC * 4u, A3);
+    }
+    const float m0 = down ? A2 : (right ? A1 : 0.f), mm1 = down ? A3 : 0.f, m2 = right ? A3 : 0.f;
+    F.a1[0] = w1 ? m0 : F.a1[0];   F.a0[0] = w1 ? F.a0[0] : m0;
+    F.a1[1] = w1 ? mm1 : F.a1[1];  F.a0[1] = w1 ? F.a0[1] : mm1;
+    F.v1[0] = w1 ? n0 : F.v1[0];   F.v0[0] = w1 ? F.v0[0] : n0;
+    F.v1[1] = w1 ? n1 : F.v1[1];   F.v0[1] = w1 ? F.v0[1] : n1;
+    if (!ROW) {
+      F.a1[2] = w1 ? m2 : F.a1[2];   F.a0[2] = w1 ? F.a0[2] : m2;
+      F.a1[3] = w1 ? 0.f : F.a1[3];  F.a0[3] = w1 ? F.a0[3] : 0.f;
+      F.v1[2] = w1 ? n2 : F.v1[2];   F.v0[2] = w1 ? F.v0[2] : n2;
+      F.v1[3] = w1 ? n3 : F.v1[3];   F.v0[3] = w1 ? F.v0[3] : n3;
+    }
+    F.key1 = w1 ? tkf : F.key1;  F.key0 = w1 ? F.key0 : tkf;
+    h1 = w1;
+    h0 = !w1;
+  }
+  float sv = (h1 ? F.v1[0] : F.v0[0]) * t.w00;
+  sv = sv + (h1 ? F.v1[1] : F.v0[1]) * t.w01;
+  if (!ROW) {
+    sv = sv + (h1 ? F.v1[2] : F.v0[2]) * t.w10;
+    sv = sv + (h1 ? F.v1[3] : F.v0[3]) * t.w11;
+  }
+  const float g = tslab_divisible(sv) ? tv * __builtin_amdgcn_rcpf(sv) : 0.f;
+  const float g0 = h0 ? g : 0.f, g1 = h1 ? g : 0.f;
+  F.a0[0] = vfma(g0, t.w00, F.a0[0]); F.a0[1] = vfma(g0, t.w01, F.a0[1]);
+  F.a1[0] = vfma(g1, t.w00, F.a1[0]); F.a1[1] = vfma(g1, t.w01, F.a1[1]);
+  if (!ROW) {
+    F.a0[2] = vfma(g0, t.w10, F.a0[2]); F.a0[3] = vfma(g0, t.w11, F.a0[3]);
+    F.a1[2] = vfma(g1, t.w10, F.a1[2]); F.a1[3] = vfma(g1, t.w11, F.a1[3]);
+  }
+  F.mru = h1 ? 1 : 0;
+}
+// end of a walk: back to the (key, flags) form foot2_flush_all expects
+__device__ __forceinline__ void foot2_unpack_t(Foot2T<float>& F) {
+  F.fl0 = F.key0 & 3; F.fl1 = F.key1 & 3;
+  F.key0 >>= 2; F.key1 >>= 2;
 }
 
 // A WALKER = 32 / CPL lanes (each owning CPL adjacent channels) walks seg_len consecutive points of the sorted order.  The
@@ -704,29 +784,16 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
             PackedTap t;
             t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
             t.w00 = lo.z; t.w01 = lo.w; t.w10 = hi.x; t.w11 = hi.y;
-            T gm;
-            if (S3G_HEX_TSLAB) {
-              // the sample this footprint produced in the forward, from the texels the walk is accumulating into anyway (an
-              // out-of-range corner has weight exactly 0 and reads the nw texel, like the per-point pass), then dL/ds = T / s
-              static_assert(!S3G_HEX_TSLAB || CPL == 1, "the T-slab walk is written for one channel per lane");
+            if constexpr (S3G_HEX_TSLAB != 0) {
+              static_assert(S3G_HEX_TSLAB == 0 || CPL == 1, "the T-slab walk is written for one channel per lane");
+              const float* pl = a.d.planes[l0 + l][m ? i1 : i0] + c;
               const int Wm = a.d.res[l0 + l][PAIR0[m ? i1 : i0]];
-              const float* pl = a.d.planes[l0 + l][m ? i1 : i0] + (size_t)t.key * HEXC + c;
-              const float v00 = pl[0], v01 = pl[(t.flags & 1) ? HEXC : 0];
-              float sv = v00 * t.w00;
-              sv = sv + v01 * t.w01;
-              if (!(UT && m == 1)) {
-                const float v10 = pl[(t.flags & 2) ? (size_t)Wm * HEXC : 0];
-                const float v11 = pl[((t.flags & 3) == 3) ? (size_t)Wm * HEXC + HEXC : 0];
-                sv = sv + v10 * t.w10;
-                sv = sv + v11 * t.w11;
-              }
-              const float tv = lanes_of<T>::first(g[qq][l][0]);
-              gm = lanes_of<T>::splat(tslab_divisible(sv) ? tv * __builtin_amdgcn_rcpf(sv) : 0.f);
+              if (UT && m == 1) foot2_add_t<true>(ft[l][m], t, lanes_of<T>::first(g[qq][l][0]), gp, pl, Wm, c);
+              else foot2_add_t<false>(ft[l][m], t, lanes_of<T>::first(g[qq][l][0]), gp, pl, Wm, c);
             } else {
-              gm = g[qq][l][m];
+              if (UT && m == 1) foot2_add<true>(ft[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[i1]], c);
+              else foot2_add<false>(ft[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
             }
-            if (UT && m == 1) foot2_add<true>(ft[l][m], t, gm, gp, a.d.res[l0 + l][PAIR0[i1]], c);
-            else foot2_add<false>(ft[l][m], t, gm, gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
           }
         }
       }
@@ -739,6 +806,7 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
         float* gp = a.gplanes[l0 + l][m ? i1 : i0];
         if (gp == nullptr) continue;
         const int W = a.d.res[l0 + l][PAIR0[m ? i1 : i0]];
+        if constexpr (S3G_HEX_TSLAB != 0 && CPL == 1) foot2_unpack_t(ft[l][m]);
         if (UT && m == 1) foot2_flush_all<true>(ft[l][m], gp, W, c);
         else foot2_flush_all<false>(ft[l][m], gp, W, c);
       }
