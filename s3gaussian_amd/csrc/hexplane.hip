@@ -589,7 +589,10 @@ __device__ __forceinline__ void foot2_add(Foot2T<T>& F, const PackedTap& t, T g,
 // key0 / key1 hold (texel index << 2 | corner flags) here -- the flags are a function of the index -- which frees fl0 / fl1.
 // Measured alternatives (cfg3, scatter ms): texels fetched where they are used 2.21; all four points of the group requested up
 // front 1.49 (one level per walk; two levels spill: 7.3); one point ahead in two alternating register sets 2.03 (spills) / 1.60
-// (one level per walk); THIS 1.35, of which 0.33 are the misses' exposed L1 round trips (1.04 with the loads compiled out).
+// (one level per walk); THIS 1.35, of which 0.33 are the misses' exposed round trips (1.04 with the loads compiled out: the planes
+// do not fit the L2, a new footprint row comes from the Infinity Cache).  Against those 0.33 ms: the tap lanes touching the
+// footprint's four lines a group ahead 1.72 (four more live registers spill); lookup and accumulation as two phases per point so
+// that a point's misses overlap 1.54 (the flags / re-read taps cost more than the overlap gains).
 template <bool ROW = false>
 __device__ __forceinline__ void foot2_add_t(Foot2T<float>& F, const PackedTap& t, float tv, float* __restrict__ gp,
                                             const float* __restrict__ pl /* plane values + channel */, int W, int c) {
