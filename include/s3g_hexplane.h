@@ -50,7 +50,7 @@ int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, co
 /* dL_dfeatures [P, levels*32] -> dL_dxyz [P,3] (written) and dL_dplanes[l][i] (same layout as planes; ACCUMULATED,
  * the caller zero-fills them; a NULL entry skips that plane).  `workspace`: device scratch of
  * s3g_hexplane_backward_workspace_bytes(d, P, features != NULL) bytes (sort buffers, per-orientation dL/dxyz partials, the
- * row tables and their gradients when uniform_time; + 3 KB per point of per-plane sample gradients on the features == NULL
+ * row tables and their gradients when uniform_time; + 128 B per point and level (one row T = dL/dfeature * feature; rounds 1-2: 3 KB per point) on the features == NULL
  * path), uninitialised. */
 int s3g_hexplane_backward_scratch_rows(int levels);   /* 128-byte rows of scratch per point the features == NULL path writes */
 #define S3G_HEX_SORT_STATE_WORDS 7
@@ -60,8 +60,9 @@ int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, c
                           const float* features /* [P, levels*32]: the OUTPUT of the matching s3g_hexplane_forward (same
                           planes, xyz, time).  With it dL/d(sample_i) = dL/dfeature * feature / sample_i needs only the one
                           sample each scatter walk re-derives from its local texels, and the workspace is 30 bytes per point;
-                          NULL selects the older two-pass algorithm, which stores dL/d(sample) for all 24 plane-levels
-                          (3 KB per point). */,
+                          NULL selects the two-pass algorithm (the default, faster): a per-point pass stores ONE row per level,
+                          T = dL/dfeature * feature, and finishes dL/dxyz; the scatter walks divide T by the sample they re-derive
+                          (128 B per point and level of scratch; rounds 1-2 stored dL/d(sample) for all 24 plane-levels). */,
                           float* dL_dxyz, float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6],
                           void* workspace,
                           unsigned int* sort_state /* [S3G_HEX_SORT_STATE_WORDS * P] device or NULL: the three spatial orders

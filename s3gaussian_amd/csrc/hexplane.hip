@@ -12,8 +12,9 @@
 //
 // Backward without an atomic storm.  A direct scatter is 96 line-coalesced float atomics per point; MI355X retires
 // ~10 G such line-ops/s whatever the contention (tools/ubench/atomic_lines.hip), i.e. 11.5 ms at 1.2 M points.  So:
-//   pass A  (blocked order) re-gathers the taps, applies the product rule, writes dL/ds for all 24 plane-levels to the
-//                           scratch G[P][24][32] (point-major: 3 KB per point, streamed -- HBM is 288 GB) and finishes dL/dxyz;
+//   pass A  (blocked order) re-gathers the taps, applies the product rule, finishes dL/dxyz and writes to the scratch G ONE row
+//                           per level, T = dL/dfeature * feature (point-major, 512 B per point, streamed; rounds 1-2 wrote
+//                           dL/ds for all 24 plane-levels = 3 KB per point: see S3G_HEX_TSLAB below);
 //   sort    four 2-level counting sorts of the point indices -- by (major, minor) finest-level texel cell, one per plane
 //           orientation, and the blocked processing order -- with LDS histograms (no global atomics, no library sort); the
 //           orders only steer the walks, so the caller may keep them for several iterations (sort_state / sort_reuse);

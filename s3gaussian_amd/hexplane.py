@@ -23,10 +23,11 @@ from . import _lib
 MAX_LEVELS, CHANNELS = 8, 32
 SORT_REFRESH = 8   # backward passes between two re-sorts of the points (see _HexPlaneSample.backward)
 SORT_STATE_WORDS = 7   # S3G_HEX_SORT_STATE_WORDS (include/s3g_hexplane.h): 3 orders + 3 ranks + the blocked processing order
-# Backward algorithm (include/s3g_hexplane.h): "slab" = per-point pass writes dL/d(sample) of all 24 plane-levels (3 KB per
-# point), three sorted scatter walks read them back -- the faster one today (2.96 ms at 1.2 M points); "walk" = no slab: each
-# scatter walk forms dL/d(sample) = dL/dfeature * feature / sample from the forward's output and the texels it is about to
-# touch anyway (30 B of scratch per point instead of 3 KB, ~1/4 of the memory traffic, 3.36 ms).
+# Backward algorithm (include/s3g_hexplane.h): "slab" (default) = the per-point pass finishes dL/dxyz and writes ONE row per point
+# and level, T = dL/dfeature * feature (512 B per point since round 3; rounds 1-2 wrote dL/d(sample) of all 24 plane-levels, 3 KB);
+# three sorted scatter walks read it back and divide by the sample they re-derive from the footprint they are accumulating
+# (2.37 ms at 1.2 M points).  "walk" = no slab and no per-point pass at all: each scatter walk forms dL/d(sample) =
+# dL/dfeature * feature / sample from the forward's output and also derives its share of dL/dxyz (30 B of scratch per point; 3.36 ms).
 BACKWARD_MODE = os.environ.get("S3G_HEX_BACKWARD", "slab")
 
 
