@@ -38,6 +38,7 @@ namespace s3g {
 #ifndef S3G_HEX_TSLAB
 #define S3G_HEX_TSLAB 1
 #endif
+#define S3G_POINT_PREFETCH 1
 constexpr float TSLAB_SAFE = 1e-18f;
 __device__ __forceinline__ bool tslab_divisible(float s) { return fabsf(s) > TSLAB_SAFE && fabsf(s) < __builtin_huge_valf(); }
 
@@ -287,6 +288,29 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
     wave_lds_sync();
     const float* grow = a.gfeat + (size_t)p * F + c0;
     float du[3] = {0.f, 0.f, 0.f};
+    if constexpr (S3G_HEX_TSLAB != 0 && S3G_POINT_PREFETCH != 0 && LV == 4) {
+      // T-slab: with the 24 G rows gone the kernel has registers to spare (188 of 256): the NEXT level's texels are requested
+      // before this level's arithmetic, in two alternating register sets (fully unrolled: no set crosses a back-edge)
+      LevelIn<V> X0, X1;
+      issue_level<UT>(a, taps, 0, c0, grow, X0);
+#pragma unroll
+      for (int l = 0; l < 4; l += 2) {
+        issue_level<UT>(a, taps, l + 1, c0, grow, X1);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          LevelS<V> S;
+          samples_level<UT>(a, taps, l, c0, X0, S);
+          finish_level<UT>(a, p, l, c0, S, X0.g, live, G, gbase, du);
+        }
+        if (l + 2 < 4) issue_level<UT>(a, taps, l + 2, c0, grow, X0);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          LevelS<V> S;
+          samples_level<UT>(a, taps, l + 1, c0, X1, S);
+          finish_level<UT>(a, p, l + 1, c0, S, X1.g, live, G, gbase, du);
+        }
+      }
+    } else {
 #pragma unroll LV > 0 ? LV : 1
     for (int l = 0; l < L; l++) {
       LevelIn<V> X;
@@ -294,6 +318,7 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
       issue_level<UT>(a, taps, l, c0, grow, X);
       samples_level<UT>(a, taps, l, c0, X, S);
       finish_level<UT>(a, p, l, c0, S, X.g, live, G, gbase, du);
+    }
     }
     // sum over the 32 channels (the lanes of this point), then undo the aabb normalisation
 #pragma unroll
