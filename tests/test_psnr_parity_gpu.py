@@ -28,7 +28,9 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-P, W, H, K = 100_000, 480, 320, 200    # > 65 536 points: every MLP wave loops over more than one tile; V < P
+# > 65 536 points: every MLP wave loops over more than one tile; V < P.  The oracle side costs ~2.2 s per iteration on the GPU box's
+# host cores: the routine suite runs 120 iterations; S3G_PSNR_ITERS=200 reproduces the committed profiles/psnr_parity.json
+P, W, H, K = 100_000, 480, 320, int(os.environ.get("S3G_PSNR_ITERS", "120"))
 
 
 def _psnr(a, b):
@@ -152,13 +154,14 @@ def test_training_on_the_gpu_path_reaches_the_psnr_of_the_oracle_path(gpu_device
     rec = dict(what=f"{K} fine-stage iterations, {P} Gaussians, {H}x{W}, {len(train_ids)} train + {len(test_ids)} held-out views, "
                     "same init / view order / targets: fused GPU path vs oracle path (CPU, reference algorithm, torch Adam)",
                max_abs_delta_db=worst, mean_psnr_delta_db=mean_delta, views=rows,
-               rel_loss_gap_at={str(i): float(gaps[i]) for i in (0, 1, 2, 5, 10, 20, 50, 100, 150, K - 1) if i < K},
+               rel_loss_gap_at={str(i): float(gaps[i]) for i in sorted({0, 1, 2, 5, 10, 20, 50, 100, 150, K - 1}) if i < K},
                max_rel_loss_gap_first20=float(max(gaps[:20])), loss_first10_mean=first, loss_last10_mean_gpu=float(np.mean(losses_gpu[-10:])),
                loss_last10_mean_oracle=float(np.mean(losses_orc[-10:])),
                max_rel_loss_gap=float(max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(losses_gpu, losses_orc))))
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "psnr_parity.json"), "w"), indent=1)
+        name = "psnr_parity.json" if K >= 200 else f"psnr_parity_{K}it.json"
+        json.dump(rec, open(os.path.join(ROOT, "gpurun_out", name), "w"), indent=1)
     except OSError:
         pass
     assert rec["loss_last10_mean_gpu"] < 0.9 * first, rec          # it actually trained
