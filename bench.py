@@ -643,6 +643,16 @@ def main():
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                          "implementation_bytes_per_launch": dom["implementation_bytes_per_launch"],
                          "traffic_source": traffic_source, "kernels": kernels})
+        # the HexPlane backward is ONE operation split into two kernels by this implementation (per-point pass + scatter walks):
+        # their combined figures, for information next to the per-kernel entries (the top-level fields stay per kernel)
+        pair = [k for k in kernels if k["kernel"] in ("s3g::hexplane_backward_point_kernel", "s3g::hexplane_scatter_kernel")]
+        if roof is not None and len(pair) == 2:
+            ms = sum(k["avg_launch_ms"] for k in pair)
+            nb = sum(k["algorithmic_bytes_per_launch"] for k in pair)
+            tr = [k.get("traffic") for k in pair]
+            roof["hexplane_backward_pair"] = {"ms": round(ms, 4), "algorithmic_bytes": nb, "hbm_GBps": round(nb / (ms * 1e-3) / 1e9, 1),
+                                              "frac": round(nb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                              "traffic": sum(tr) if all(t is not None for t in tr) else None}
         fwd = next((k for k in kernels if k["kernel"] == "s3g::blend_forward_kernel"), None)
         out = {
             "metric": "train_iters_per_sec", "value": round(world * a.steps / dt, 3), "unit": "iters/s", "n_gpus": world,
