@@ -540,6 +540,22 @@ def main():
         _ms = C.c_double()
         _n = L.s3g_profile_read(9, C.byref(_ms), None, None)
         infer_kernel_ms = (_ms.value / _n) if _n else None   # s3g::deform_infer_kernel (HexPlane (+) MLP heads), per frame
+        # the same frames with the inference kernel's GEMM layers on the bf16 matrix pipe (exactly split operands: fp32 accuracy,
+        # include/s3g_mlp.h::s3g_deform_infer_split) -- reported beside the default, which stays the exact fp32 chain
+        import s3gaussian_amd.deformation as _deformation
+        _arith = _deformation.INFER_ARITHMETIC
+        _deformation.INFER_ARITHMETIC = "bf16x3"
+        try:
+            for i in range(3):
+                render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(n_frames):
+                render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
+            torch.cuda.synchronize()
+            render_split_ms = 1000.0 * (time.perf_counter() - t1) / n_frames
+        finally:
+            _deformation.INFER_ARITHMETIC = _arith
 
     if rank == 0:
         # ---- roofline leg: every hot kernel timed in-library with hipEvents on the launch stream (include/s3g_raster.h),
@@ -667,7 +683,8 @@ def main():
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
                        "blend_forward_avg_ms": fwd["avg_launch_ms"] if fwd else None,
                        "render_ms_per_frame": round(render_ms, 3),
-                       "render_deform_infer_kernel_ms": round(infer_kernel_ms, 4) if infer_kernel_ms else None},
+                       "render_deform_infer_kernel_ms": round(infer_kernel_ms, 4) if infer_kernel_ms else None,
+                       "render_ms_per_frame_bf16x3": round(render_split_ms, 3)},
             "roofline": roof,
         }
         if world > 1:

@@ -63,6 +63,12 @@ int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* feature
 size_t s3g_deform_infer_workspace_bytes(const s3g_hexplane_desc* d);
 int s3g_deform_infer(const s3g_hexplane_desc* d, const s3g_mlp_params* w, int P, const float* xyz, const float* time,
                      const unsigned int* proc_order, float* dx, float* dshs, void* workspace, void* stream);
+/* The same call with the three GEMM layers on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16 x the fp32 MFMA rate): every fp32
+ * operand -- weights and activations -- is the EXACT sum of three bf16 pieces and a product is accumulated (in fp32) as the six
+ * piece products of weight >= 2^-16; what is dropped is <= 2^-23 of each product, i.e. fp32 accuracy (measured against fp64 beside
+ * the exact path: tests/test_infer_gpu.py), but not bit-identical to s3g_deform_infer.  The sampler half is the same code. */
+int s3g_deform_infer_split(const s3g_hexplane_desc* d, const s3g_mlp_params* w, int P, const float* xyz, const float* time,
+                           const unsigned int* proc_order, float* dx, float* dshs, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -419,6 +419,141 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_backward_kernel(const MlpBwdAr
 #undef WSLAB
 #undef BIAS
 
+// ---- fp32 GEMMs on the bf16 matrix pipe: three-way operand split ------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 runs at the vector-fma rate (64 cycles per 4096 FLOP and SIMD); v_mfma_f32_32x32x16_bf16 does 32768
+// FLOP in 32 cycles on the real matrix pipe, beside the VALU instead of in its place.  Every fp32 operand is written as the EXACT
+// sum of three bf16 numbers (round to nearest, subtract, repeat: 8 + 8 + 8 significand bits), and a product a*b is accumulated
+// as the six piece products whose weight is >= 2^-16 of it:
+//     a*b ~= a0*b0 + (a0*b1 + a1*b0) + (a0*b2 + a1*b1 + a2*b0)          dropped: a1*b2 + a2*b1 + a2*b2 <= 2^-23 |a*b|
+// Each piece product is exact in fp32 (8 x 8 bits) and the matrix pipe accumulates in fp32, so a dot product carries the error
+// of an fp32 fma chain (rounding 2^-24 per step) plus <= 2^-23 per product: fp32 accuracy, 6 x 32 instead of 8 x 64 cycles per
+// K = 16.  Used by the inference kernel only (deform_infer_kernel<UT, true>); the training kernels are the exact chains above.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t bf16_pair(float lo, float hi) {   // one v_cvt_pk_bf16_f32 (round to nearest even)
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+// (a, b) -> word t of the three pieces; a == lo(p0) + lo(p1) + lo(p2) exactly (the residuals are exact fp32 differences)
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = bf16_pair(a, b);
+  const float ra = a - bf16_lo(p0), rb = b - bf16_hi(p0);
+  p1 = bf16_pair(ra, rb);
+  p2 = bf16_pair(ra - bf16_lo(p1), rb - bf16_hi(p1));
+}
+struct Split8 { u32x4 p[3]; };   // eight values = one lane's share of an MFMA operand (K = 16: k = 8 * (lane >> 5) + e), three pieces
+__device__ __forceinline__ Split8 split8(const float (&v)[8]) {
+  Split8 s;
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    uint32_t p0, p1, p2;
+    split_pair(v[2 * t], v[2 * t + 1], p0, p1, p2);
+    s.p[0][t] = p0; s.p[1][t] = p1; s.p[2][t] = p2;
+  }
+  return s;
+}
+// acc += A * B for one K = 16 step, A and B given as pieces; smallest terms first
+__device__ __forceinline__ f32x16 mfma_split(f32x16 acc, const Split8& a, const Split8& b) {
+#define S3G_PIECE(i, j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.p[i]), __builtin_bit_cast(bf16x8, b.p[j]), acc, 0, 0, 0)
+  S3G_PIECE(2, 0); S3G_PIECE(1, 1); S3G_PIECE(0, 2); S3G_PIECE(1, 0); S3G_PIECE(0, 1); S3G_PIECE(0, 0);
+#undef S3G_PIECE
+  return acc;
+}
+// The accumulator registers of a layer as the B operand of the next, exactly as in gemm_reg: at K step (mbi, s) lane l supplies
+// its own registers in[mbi][8s .. 8s+7] = features 32*mbi + 16*s + 4*(l>>5) + {0,1,2,3, 8,9,10,11} of point l & 31, and the A
+// operand holds the weights of those same features in the same element order (split_feature below is that order).
+template <int MBI> struct ActSplit { Split8 b[MBI][2]; };
+template <int MBI, bool RELU>
+__device__ __forceinline__ void act_split(ActSplit<MBI>& S, const f32x16 (&in)[MBI]) {
+#pragma unroll
+  for (int mbi = 0; mbi < MBI; mbi++)
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = RELU ? fmaxf(in[mbi][8 * s + e], 0.f) : in[mbi][8 * s + e];
+      S.b[mbi][s] = split8(v);
+    }
+}
+__host__ __device__ constexpr int split_feature(int ks, int h, int e) { return 16 * ks + 4 * h + (e & 3) + 8 * (e >> 2); }   // ks = 2 * mbi + s
+
+// The split weight image of the inference network (32-bit words; a word = two bf16).  A FRAGMENT is the A operand of one
+// (32-row block mbo, K step ks): 64 lanes x 16 bytes per piece, stored piece after piece in lane order -- one conflict-free
+// ds_read_b128 per piece and lane.  Rows a layer does not have are not stored: the lanes of those rows read some stored row
+// instead, and the accumulator rows they produce are never written out (S2 rows 48..63, P2 rows 3..31).
+// P1 stays fp32 (split on the fly by the lanes that use it: 44 VALU instructions per fragment) -- all five layers pre-split
+// would need 119 KB beside the 48 KB of staging tiles.
+namespace spw {
+constexpr int FRAG = 256;                            // words per piece of a full fragment
+constexpr int W0 = 0;                                // [mbo 2][ks 8][piece 3][FRAG]
+constexpr int S1 = W0 + 2 * 8 * 3 * FRAG;            // [mbo 2][ks 4][piece 3][FRAG]
+constexpr int S2A = S1 + 2 * 4 * 3 * FRAG;           // [ks 4][piece 3][FRAG]        rows 0..31
+constexpr int S2B = S2A + 4 * 3 * FRAG;              // [ks 4][piece 3][FRAG / 2]    rows 32..47: slot = 16 * h + (row & 15)
+constexpr int P2 = S2B + 4 * 3 * (FRAG / 2);         // [ks 4][piece 3][h 2][row 3][4 words]
+constexpr int P1LD = 68;                             // fp32 [row 64][64 inputs + 4]: 16 lanes' 16-byte chunks fall in 16 distinct bank groups
+constexpr int P1 = P2 + 4 * 3 * 2 * 3 * 4;
+constexpr int BIAS = P1 + 64 * P1LD;                 // b0 64 | pb1 64 | sb1 64 | sb2 64 (48 used) | pb2 32 (3 used)
+constexpr int B_B0 = 0, B_PB1 = 64, B_SB1 = 128, B_SB2 = 192, B_PB2 = 256, NBIAS = 288;
+constexpr int WORDS = (BIAS + NBIAS + 255) / 256 * 256;   // whole 1 KiB DMA rows
+static_assert(P2 % 4 == 0 && P1 % 4 == 0 && BIAS % 4 == 0, "16-byte aligned regions");
+}  // namespace spw
+
+__device__ __forceinline__ uint32_t split_word(const float* __restrict__ W, int rows, int ld, int row, int f0, int f1, int piece) {
+  uint32_t p[3];
+  const float a = row < rows ? W[(size_t)row * ld + f0] : 0.f, b = row < rows ? W[(size_t)row * ld + f1] : 0.f;
+  split_pair(a, b, p[0], p[1], p[2]);
+  return piece == 0 ? p[0] : (piece == 1 ? p[1] : p[2]);
+}
+__global__ void __launch_bounds__(256) mlp_pack_split_kernel(const s3g_mlp_params w, uint32_t* __restrict__ img) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= spw::WORDS) return;
+  uint32_t out = 0;
+  if (x < spw::S2B) {   // full fragments: W0 | S1 | S2 rows 0..31
+    const float* W; int KS, ld, rows, y;
+    if (x < spw::S1) { W = w.W0; KS = 8; ld = FEAT; rows = 64; y = x - spw::W0; }
+    else if (x < spw::S2A) { W = w.S1; KS = 4; ld = HID; rows = 64; y = x - spw::S1; }
+    else { W = w.S2; KS = 4; ld = HID; rows = 48; y = x - spw::S2A; }
+    const int t = y & 3, lane = (y >> 2) & 63, piece = (y >> 8) % 3, fr = (y >> 8) / 3, ks = fr % KS, mbo = fr / KS;
+    out = split_word(W, rows, ld, 32 * mbo + (lane & 31), split_feature(ks, lane >> 5, 2 * t), split_feature(ks, lane >> 5, 2 * t + 1), piece);
+  } else if (x < spw::P2) {   // S2 rows 32..47
+    const int y = x - spw::S2B, t = y & 3, slot = (y >> 2) & 31, piece = (y >> 7) % 3, ks = (y >> 7) / 3;
+    out = split_word(w.S2, 48, HID, 32 + (slot & 15), split_feature(ks, slot >> 4, 2 * t), split_feature(ks, slot >> 4, 2 * t + 1), piece);
+  } else if (x < spw::P1) {   // P2: three rows
+    const int y = x - spw::P2, t = y & 3, q = y >> 2, row = q % 3, h = (q / 3) & 1, piece = (q / 6) % 3, ks = q / 18;
+    out = split_word(w.P2, 3, HID, row, split_feature(ks, h, 2 * t), split_feature(ks, h, 2 * t + 1), piece);
+  } else if (x < spw::BIAS) {   // P1 as it is, rows padded
+    const int y = x - spw::P1, row = y / spw::P1LD, f = y % spw::P1LD;
+    out = f < HID ? __float_as_uint(w.P1[row * HID + f]) : 0u;
+  } else if (x < spw::BIAS + spw::NBIAS) {
+    const int y = x - spw::BIAS;
+    const float v = y < 64 ? w.b0[y] : y < 128 ? w.pb1[y - 64] : y < 192 ? w.sb1[y - 128] : y < 256 ? (y - 192 < 48 ? w.sb2[y - 192] : 0.f)
+                                                                                                  : (y - 256 < 3 ? w.pb2[y - 256] : 0.f);
+    out = __float_as_uint(v);
+  }
+  img[x] = out;
+}
+// acc[mbo] += (rows 32*mbo .. +31 of the layer) x B for the K steps ks0 .. ks0 + 2*MBI - 1, fragments at frag + ((mbo*KS + ks)*3 + piece)*FRAG
+template <int MBO, int MBI>
+__device__ __forceinline__ void gemm_split(const uint32_t* frag, int KS, int ks0, const ActSplit<MBI>& B, f32x16 (&acc)[MBO], int lane) {
+#pragma unroll
+  for (int mbi = 0; mbi < MBI; mbi++)
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      Split8 a[MBO];
+#pragma unroll
+      for (int mbo = 0; mbo < MBO; mbo++)
+#pragma unroll
+        for (int pc = 0; pc < 3; pc++)
+          a[mbo].p[pc] = *reinterpret_cast<const u32x4*>(frag + ((mbo * KS + ks0 + 2 * mbi + s) * 3 + pc) * spw::FRAG + lane * 4);
+#pragma unroll
+      for (int mbo = 0; mbo < MBO; mbo++) acc[mbo] = mfma_split(acc[mbo], a[mbo], B.b[mbi][s]);
+    }
+}
+
 // ---- inference: HexPlane sampler (+) MLP heads in ONE kernel (render(): gaussian_renderer/__init__.py:82-97) --------
 // Under no_grad nothing is stashed and the feature (dino) head is not needed, so the weight image shrinks to the first six slabs
 // (W0 | W0 | P1 | S1 | P2 | S2 = 104 KB) and 46 KB of LDS are left: each wave gets a 32-point x 32-channel staging tile and one
@@ -447,26 +582,44 @@ constexpr int INF_TAP_STRIDE = TAP_SLOTS + 1;    // float4 per point: 6 taps use
 constexpr int INF_WAVE_FLOATS = STG_FLOATS + 2 * 8 * INF_TAP_STRIDE * 4;   // staging tile + two sets of tap slots
 constexpr int INF_LDS_FLOATS = INF_WFLOATS + NWAVE * INF_WAVE_FLOATS;
 static_assert(INF_LDS_FLOATS * 4 <= 160 * 1024, "inference image + staging must fit the CU's LDS");
+// SPLIT (three-way bf16 operands, above): image spw::WORDS, and 6 instead of 9 tap slots per point (the 8 points of a round still
+// read 8 disjoint bank groups: 24 words apart)
+constexpr int INF_TAP_STRIDE_SPLIT = 6;
+constexpr int INF_WAVE_FLOATS_SPLIT = STG_FLOATS + 2 * 8 * INF_TAP_STRIDE_SPLIT * 4;
+constexpr int INF_LDS_FLOATS_SPLIT = spw::WORDS + NWAVE * INF_WAVE_FLOATS_SPLIT;
+static_assert(INF_LDS_FLOATS_SPLIT * 4 <= 160 * 1024, "split inference image + staging must fit the CU's LDS");
 
-template <bool UT>
+template <bool UT, bool SPLIT>
 __global__ void __launch_bounds__(NWAVE * 64) deform_infer_kernel(const InferArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = wave; c < INF_SLABS * SLAB / 256; c += NWAVE)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.packed + c * 256 + lane * 4),
-                                     (__attribute__((address_space(3))) void*)(lds + c * 256), 16, 0, 0);
-  if (wave < 2)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.packed + NSLAB * SLAB + wave * 256 + lane * 4),
-                                     (__attribute__((address_space(3))) void*)(lds + INF_SLABS * SLAB + wave * 256), 16, 0, 0);
+  constexpr int WIMG = SPLIT ? spw::WORDS : INF_WFLOATS, TAPS = SPLIT ? INF_TAP_STRIDE_SPLIT : INF_TAP_STRIDE;
+  constexpr int WAVE_FLOATS = SPLIT ? INF_WAVE_FLOATS_SPLIT : INF_WAVE_FLOATS;
+  if constexpr (SPLIT) {
+    for (int c = wave; c < spw::WORDS / 256; c += NWAVE)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.packed + c * 256 + lane * 4),
+                                       (__attribute__((address_space(3))) void*)(lds + c * 256), 16, 0, 0);
+  } else {
+    for (int c = wave; c < INF_SLABS * SLAB / 256; c += NWAVE)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.packed + c * 256 + lane * 4),
+                                       (__attribute__((address_space(3))) void*)(lds + c * 256), 16, 0, 0);
+    if (wave < 2)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.packed + NSLAB * SLAB + wave * 256 + lane * 4),
+                                       (__attribute__((address_space(3))) void*)(lds + INF_SLABS * SLAB + wave * 256), 16, 0, 0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   auto wslab = [&](int k) { return lds + k * SLAB; };
-  auto bias = [&](int k) { return lds + INF_SLABS * SLAB + k * 64; };   // b0 | pb1 | sb1 | pb2 | sb2 | ...
-  float* stage = lds + INF_WFLOATS + wave * INF_WAVE_FLOATS;
+  auto bias = [&](int k) {   // k: b0 | pb1 | sb1 | pb2 | sb2
+    if constexpr (SPLIT) return lds + spw::BIAS + (k == 0 ? spw::B_B0 : k == 1 ? spw::B_PB1 : k == 2 ? spw::B_SB1 : k == 3 ? spw::B_PB2 : spw::B_SB2);
+    else return lds + INF_SLABS * SLAB + k * 64;
+  };
+  const uint32_t* wsplit = reinterpret_cast<const uint32_t*>(lds);   // SPLIT: the spw image
+  float* stage = lds + WIMG + wave * WAVE_FLOATS;
   const int slot = lane >> 3, j8 = lane & 7, c4 = j8 * 4;   // sampler role: point slot, channel quad
   const int jj = lane & 31, hh = lane >> 5;                 // MFMA role: point column, row half
-  float4* tp0 = reinterpret_cast<float4*>(stage + STG_FLOATS) + slot * INF_TAP_STRIDE;   // two sets of tap slots per point slot
-  float4* tp1 = tp0 + 8 * INF_TAP_STRIDE;
+  float4* tp0 = reinterpret_cast<float4*>(stage + STG_FLOATS) + slot * TAPS;   // two sets of tap slots per point slot
+  float4* tp1 = tp0 + 8 * TAPS;
   const int P = a.h.P, ntiles = (P + MT - 1) / MT;
   if (S3G_INFER_PRIO == 2 && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
 #if S3G_INFER_STAGGER
@@ -531,6 +684,13 @@ __global__ void __launch_bounds__(NWAVE * 64) deform_infer_kernel(const InferArg
       }
       prod = prod * s;
     }
+    // SPLIT: wait states between the packed-fp32 multiplies that produce `prod` and the ds_write_b128 that stores it.  With the
+    // other wave of the SIMD issuing v_mfma_f32_32x32x16_bf16, hipcc's own spacing (ROCm 7.2: one SALU instruction) was measured
+    // NOT to be enough: about one step in 10^3, on the younger wave of the SIMD (waves 4..7), stored stale values for the LAST
+    // quarter of the wave (lanes 48..63 = two points: errors of 1e-1 in two adjacent rows, different rows every launch).  It never
+    // happens with one wave per SIMD, nor beside the fp32 MFMAs of the exact kernel; waiting for the texel loads, for the LDS queue
+    // or for the wave's own MFMAs does not help; 16 wait states here do (profiles/r03_split_hazard.jsonl).
+    if (SPLIT) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(prod.x), "+v"(prod.y), "+v"(prod.z), "+v"(prod.w));
     *reinterpret_cast<float4*>(stage + (8 * rr + slot) * STG_LD + c4) = prod;
   };
   for (int tile = blockIdx.x * NWAVE + wave; tile < ntiles; tile += gridDim.x * NWAVE) {
@@ -557,7 +717,15 @@ __global__ void __launch_bounds__(NWAVE * 64) deform_infer_kernel(const InferArg
         x[0][4 * q + 0] = v.x; x[0][4 * q + 1] = v.y; x[0][4 * q + 2] = v.z; x[0][4 * q + 3] = v.w;
       }
       if (S3G_INFER_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-      gemm_reg<2, 1, false>(wslab(l >> 1) + 32 * (l & 1) * 65, 65, x, hid, lane);
+      if constexpr (SPLIT) {
+        ActSplit<1> xs;
+        act_split<1, false>(xs, x);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // fragment addresses are derived here, not carried (and spilled) across the sampler steps
+        gemm_split<2, 1>(wsplit + spw::W0, 8, 2 * l, xs, hid, ln);
+      } else {
+        gemm_reg<2, 1, false>(wslab(l >> 1) + 32 * (l & 1) * 65, 65, x, hid, lane);
+      }
       if (S3G_INFER_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     };
     if constexpr (UT) {
@@ -600,6 +768,55 @@ __global__ void __launch_bounds__(NWAVE * 64) deform_infer_kernel(const InferArg
     }
     f32x16 act[2], acc[2], o[1];
     if (S3G_INFER_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    if constexpr (SPLIT) {
+      ActSplit<2> hs, as;
+      act_split<2, true>(hs, hid);   // relu(hidden): the input of both heads
+      int ln = lane;
+      asm volatile("" : "+v"(ln));   // (as in level_gemm: the heads' LDS addresses are not loop invariants kept in registers)
+      const int jj = ln & 31, hh = ln >> 5;
+      // pos head.  P1 is fp32 in LDS: a lane's eight weights of a fragment are two swizzled 16-byte chunks of its row
+      acc_bias<2>(act, bias(1), ln);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+        for (int mbo = 0; mbo < 2; mbo++) {
+          const float* wr = lds + spw::P1 + (32 * mbo + jj) * spw::P1LD + 4 * hh + 16 * ks;   // inputs 16 ks + 4 h + {0..3, 8..11}
+          const float4 lo = *reinterpret_cast<const float4*>(wr);
+          const float4 hi = *reinterpret_cast<const float4*>(wr + 8);
+          const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          act[mbo] = mfma_split(act[mbo], split8(v), hs.b[ks >> 1][ks & 1]);
+        }
+      relu_inplace<2>(act);
+      act_split<2, false>(as, act);
+      acc_bias<1>(o, bias(3), ln);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {   // P2: rows 0..2 are stored; the other lanes read row 0 (their accumulator rows are never written out)
+        Split8 w;
+#pragma unroll
+        for (int pc = 0; pc < 3; pc++)
+          w.p[pc] = *reinterpret_cast<const u32x4*>(wsplit + spw::P2 + ((((ks * 3 + pc) * 2 + hh) * 3 + (jj < 3 ? jj : 0)) << 2));
+        o[0] = mfma_split(o[0], w, as.b[ks >> 1][ks & 1]);
+      }
+      if (livem && hh == 0) {
+        float* row = a.dx + pm * 3;
+        row[0] = o[0][0]; row[1] = o[0][1]; row[2] = o[0][2];
+      }
+      // shs head
+      acc_bias<2>(act, bias(2), ln);
+      gemm_split<2, 2>(wsplit + spw::S1, 4, 0, hs, act, ln);
+      relu_inplace<2>(act);
+      act_split<2, false>(as, act);
+      acc_bias<2>(acc, bias(4), ln);
+      gemm_split<1, 2>(wsplit + spw::S2A, 4, 0, as, *reinterpret_cast<f32x16(*)[1]>(&acc[0]), ln);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {   // rows 32..47: lanes of rows 48..63 read rows 32..47 again (never written out)
+        Split8 w;
+#pragma unroll
+        for (int pc = 0; pc < 3; pc++)
+          w.p[pc] = *reinterpret_cast<const u32x4*>(wsplit + spw::S2B + (ks * 3 + pc) * (spw::FRAG / 2) + ((16 * hh + (jj & 15)) << 2));
+        acc[1] = mfma_split(acc[1], w, as.b[ks >> 1][ks & 1]);
+      }
+    } else {
     // pos head
     acc_bias<2>(act, bias(1), lane);
     if (S3G_INFER_EXPERIMENT != 1) gemm_reg<2, 2, true>(wslab(2), 65, hid, act, lane);
@@ -616,6 +833,7 @@ __global__ void __launch_bounds__(NWAVE * 64) deform_infer_kernel(const InferArg
     relu_inplace<2>(act);
     acc_bias<2>(acc, bias(4), lane);
     if (S3G_INFER_EXPERIMENT != 1) gemm_reg<2, 2, false>(wslab(5), 65, act, acc, lane);
+    }
     if (S3G_INFER_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     if (livem) {
       float* row = a.dshs + pm * 48 + 4 * hh;
@@ -1373,8 +1591,8 @@ extern "C" size_t s3g_deform_infer_workspace_bytes(const s3g_hexplane_desc* d) {
   return ((size_t)PACK_FLOATS + (d->uniform_time ? time_table_floats(d) : 0)) * sizeof(float);
 }
 
-extern "C" int s3g_deform_infer(const s3g_hexplane_desc* d, const s3g_mlp_params* w, int P, const float* xyz, const float* time,
-                                const unsigned int* proc_order, float* dx, float* dshs, void* workspace, void* stream_) {
+static int deform_infer_impl(const s3g_hexplane_desc* d, const s3g_mlp_params* w, int P, const float* xyz, const float* time,
+                             const unsigned int* proc_order, float* dx, float* dshs, void* workspace, void* stream_, bool split) {
   if (int e = check_desc(d)) return e;
   if (d->levels != 4) {
     set_error("s3g_deform_infer: the fused path is built for 4 levels x 32 channels = feature_out's 128 inputs");
@@ -1388,8 +1606,10 @@ extern "C" int s3g_deform_infer(const s3g_hexplane_desc* d, const s3g_mlp_params
   hipStream_t stream = (hipStream_t)stream_;
   static std::atomic<uint64_t> done{0};
   if (device_needs_setup(done)) {
-    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)deform_infer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, INF_LDS_FLOATS * 4));
-    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)deform_infer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, INF_LDS_FLOATS * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)deform_infer_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, INF_LDS_FLOATS * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)deform_infer_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, INF_LDS_FLOATS * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)deform_infer_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, INF_LDS_FLOATS_SPLIT * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)deform_infer_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, INF_LDS_FLOATS_SPLIT * 4));
     device_setup_done(done);
   }
   float* packed = (float*)workspace;
@@ -1399,13 +1619,30 @@ extern "C" int s3g_deform_infer(const s3g_hexplane_desc* d, const s3g_mlp_params
   a.packed = packed; a.dx = dx; a.dshs = dshs;
   TimeRows rows;
   if (d->uniform_time) use_time_rows(a.h, rows, packed + PACK_FLOATS, nullptr, stream);
-  hipLaunchKernelGGL(mlp_pack_kernel, dim3(NSLAB + 1), dim3(256), 0, stream, *w, packed);
+  static_assert(spw::WORDS <= PACK_FLOATS, "both weight images fit the front of the workspace");
+  if (split) hipLaunchKernelGGL(mlp_pack_split_kernel, dim3(spw::WORDS / 256), dim3(256), 0, stream, *w, reinterpret_cast<uint32_t*>(packed));
+  else hipLaunchKernelGGL(mlp_pack_kernel, dim3(NSLAB + 1), dim3(256), 0, stream, *w, packed);
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
+  const dim3 grid(blocks), wg(NWAVE * 64);
   profile_begin(S3G_PROFILE_DEFORM_INFER, stream);
-  if (d->uniform_time) hipLaunchKernelGGL(deform_infer_kernel<true>, dim3(blocks), dim3(NWAVE * 64), INF_LDS_FLOATS * 4, stream, a);
-  else hipLaunchKernelGGL(deform_infer_kernel<false>, dim3(blocks), dim3(NWAVE * 64), INF_LDS_FLOATS * 4, stream, a);
+  if (split) {
+    if (d->uniform_time) hipLaunchKernelGGL((deform_infer_kernel<true, true>), grid, wg, INF_LDS_FLOATS_SPLIT * 4, stream, a);
+    else hipLaunchKernelGGL((deform_infer_kernel<false, true>), grid, wg, INF_LDS_FLOATS_SPLIT * 4, stream, a);
+  } else {
+    if (d->uniform_time) hipLaunchKernelGGL((deform_infer_kernel<true, false>), grid, wg, INF_LDS_FLOATS * 4, stream, a);
+    else hipLaunchKernelGGL((deform_infer_kernel<false, false>), grid, wg, INF_LDS_FLOATS * 4, stream, a);
+  }
   profile_end(S3G_PROFILE_DEFORM_INFER, stream, (double)P, 4.0);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
+}
+
+extern "C" int s3g_deform_infer(const s3g_hexplane_desc* d, const s3g_mlp_params* w, int P, const float* xyz, const float* time,
+                                const unsigned int* proc_order, float* dx, float* dshs, void* workspace, void* stream) {
+  return deform_infer_impl(d, w, P, xyz, time, proc_order, dx, dshs, workspace, stream, false);
+}
+extern "C" int s3g_deform_infer_split(const s3g_hexplane_desc* d, const s3g_mlp_params* w, int P, const float* xyz, const float* time,
+                                      const unsigned int* proc_order, float* dx, float* dshs, void* workspace, void* stream) {
+  return deform_infer_impl(d, w, P, xyz, time, proc_order, dx, dshs, workspace, stream, true);
 }

@@ -22,6 +22,9 @@ from .mlp import deform_infer, deform_mlp
 
 # S3G_FUSED_INFERENCE=0: inference renders go through the two separate kernels (sampler, then MLP) like training does
 FUSED_INFERENCE = os.environ.get("S3G_FUSED_INFERENCE", "1") != "0"
+# Arithmetic of the fused inference kernel's GEMM layers: "f32" = exact fp32 fma chains (v_mfma_f32_32x32x2_f32, bit-identical to the
+# training kernels), "bf16x3" = the bf16 matrix pipe on exactly split operands (include/s3g_mlp.h::s3g_deform_infer_split)
+INFER_ARITHMETIC = os.environ.get("S3G_INFER_ARITHMETIC", "f32")
 
 
 def poc_fre(input_data, poc_buf):
@@ -136,7 +139,7 @@ class Deformation(nn.Module):
                 and len(self.grid.resolutions) == 4):
             # inference render without the feature image: sampler (+) heads in one kernel, no [P,128] round trip
             dx, dshs = deform_infer(self.grid, xyz[:, :3], time[:, :1], self.feature_out, self.pos_deform, self.shs_deform,
-                                    self.dino_head, uniform_time)
+                                    self.dino_head, uniform_time, arithmetic=INFER_ARITHMETIC)
             return dx, dshs.reshape([xyz.shape[0], 16, 3]), None
         reg = None
         if reg_weights is not None:   # plane regulariser evaluated on the sampler's autograd node (hexplane_sample)

@@ -37,6 +37,8 @@ def _bind():
         L.s3g_deform_infer_workspace_bytes.argtypes = [C.POINTER(_HexDesc)]
         L.s3g_deform_infer.restype = C.c_int
         L.s3g_deform_infer.argtypes = [C.POINTER(_HexDesc), C.POINTER(_Params), C.c_int, vp, vp, vp, vp, vp, vp, vp]
+        L.s3g_deform_infer_split.restype = C.c_int
+        L.s3g_deform_infer_split.argtypes = L.s3g_deform_infer.argtypes
         _bound = True
     return L
 
@@ -112,10 +114,14 @@ def _head_params(feature_out, pos_deform, shs_deform, dino_head):
 
 
 @torch.no_grad()
-def deform_infer(grid, xyz, time, feature_out, pos_deform, shs_deform, dino_head, uniform_time=None):
+def deform_infer(grid, xyz, time, feature_out, pos_deform, shs_deform, dino_head, uniform_time=None, arithmetic="f32"):
     """Inference only: HexPlane sampler (+) feature_out + position / SH heads in ONE kernel (include/s3g_mlp.h::s3g_deform_infer).
     xyz [P,3], time [P,1] -> (dx [P,3], dshs [P,48]); bit-identical to `deform_mlp(grid(xyz, time), ..., need_feat=False)[:2]`
-    without ever materialising the [P,128] features.  `grid` is the HexPlaneField (4 levels x 32 channels)."""
+    without ever materialising the [P,128] features.  `grid` is the HexPlaneField (4 levels x 32 channels).
+    arithmetic="bf16x3": the three GEMM layers on the bf16 matrix pipe with every fp32 operand split exactly into three bf16 pieces
+    (s3g_deform_infer_split: fp32 accuracy, not bit-identical; the sampler half is unchanged)."""
+    if arithmetic not in ("f32", "bf16x3"):
+        raise ValueError(f"deform_infer: arithmetic must be 'f32' or 'bf16x3', got {arithmetic!r}")
     from .hexplane import _make_desc
     if not xyz.is_cuda:
         raise RuntimeError(f"deform_infer: xyz must live on the GPU (got {xyz.device}); no CPU fallback")
@@ -136,9 +142,9 @@ def deform_infer(grid, xyz, time, feature_out, pos_deform, shs_deform, dino_head
     ws = torch.empty(max(L.s3g_deform_infer_workspace_bytes(C.byref(d)), 4) // 4, dtype=torch.float32, device=dev)
     w = _pack([p.detach() for p in _head_params(feature_out, pos_deform, shs_deform, dino_head)])
     with torch.cuda.device(dev):
-        _lib.check(L.s3g_deform_infer(C.byref(d), C.byref(w), P, xyz_c.data_ptr(), t_c.data_ptr(),
-                                      order.data_ptr() if order is not None else None, dx.data_ptr(), dshs.data_ptr(),
-                                      ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        fn = L.s3g_deform_infer_split if arithmetic == "bf16x3" else L.s3g_deform_infer
+        _lib.check(fn(C.byref(d), C.byref(w), P, xyz_c.data_ptr(), t_c.data_ptr(), order.data_ptr() if order is not None else None,
+                      dx.data_ptr(), dshs.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
     return dx, dshs
 
 

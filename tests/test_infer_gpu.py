@@ -52,6 +52,61 @@ def test_fused_inference_is_bit_identical_to_the_two_kernels(gpu_device, P, tmod
             assert torch.equal(dx0, dx2) and torch.equal(dshs0, dshs2)
 
 
+def _heads_fp64(d, feats):
+    """The reference's Linear stacks (scene/deformation.py:53-76, 126-160) in fp64 on the fp32 features the sampler produced."""
+    f = feats.double()
+    lin = lambda m, x: x @ m.weight.double().t() + m.bias.double()
+    hidden = lin(d.feature_out[0], f)
+    h = torch.relu(hidden)
+    dx = lin(d.pos_deform[3], torch.relu(lin(d.pos_deform[1], h)))
+    dshs = lin(d.shs_deform[3], torch.relu(lin(d.shs_deform[1], h)))
+    return dx, dshs
+
+
+@pytest.mark.parametrize("tmode", ["uniform", "per_point"])
+@pytest.mark.parametrize("P", [1, 33, 5000, 70_001, 1_200_000])
+def test_split_bf16_inference_has_fp32_accuracy(gpu_device, P, tmode):
+    """s3g_deform_infer_split: the GEMM layers on the bf16 matrix pipe with every operand split exactly into three bf16 pieces.  Its
+    distance from the fp64 evaluation of the same layers must be that of the exact fp32 kernel (rounding noise of an fp32 chain),
+    not that of a bf16 network (1e-2): both distances are measured here on the same inputs and recorded."""
+    import json
+    import os
+    from s3gaussian_amd import synth
+    from s3gaussian_amd.mlp import deform_infer
+    dev = gpu_device
+    sc = synth.street_scene(P=max(P, 64), seed=3, n_frames=2)
+    d = _net(dev, sc["aabb"], seed=P % 5)
+    with torch.no_grad():   # heads with outputs of order 1 (the default init of the last layers is tiny)
+        for m in (d.pos_deform[3], d.shs_deform[3]):
+            m.weight.mul_(30.0)
+    g = torch.Generator().manual_seed(P + 1)
+    xyz = sc["gaussians"]["xyz"][:P].to(dev).contiguous()
+    time = (torch.rand(P, 1, generator=g).to(dev) * 1.2 - 0.1) if tmode == "per_point" else torch.full((P, 1), 0.63, device=dev)
+    ut = tmode == "uniform"
+    with torch.no_grad():
+        feats = d.grid(xyz, time, uniform_time=ut)
+        dx64, dshs64 = _heads_fp64(d, feats)
+        args = (d.grid, xyz, time, d.feature_out, d.pos_deform, d.shs_deform, d.dino_head)
+        dx_e, dshs_e = deform_infer(*args, uniform_time=ut)
+        dx_s, dshs_s = deform_infer(*args, uniform_time=ut, arithmetic="bf16x3")
+        again = [deform_infer(*args, uniform_time=ut, arithmetic="bf16x3") for _ in range(3)]
+    out_s = torch.cat([dx_s, dshs_s], 1)
+    bad_rows = sorted({int(r) for dx2, dshs2 in again for r in (torch.cat([dx2, dshs2], 1) != out_s).any(1).nonzero().flatten()[:64]})
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm().clamp_min(1e-300))
+    mx = lambda a, b: float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-300))
+    st = dict(what="deform_infer arithmetic", P=P, tmode=tmode, rows_that_differ_between_runs=bad_rows[:32],
+              exact=dict(dx_rel_l2=rel(dx_e, dx64), dshs_rel_l2=rel(dshs_e, dshs64), dx_max=mx(dx_e, dx64), dshs_max=mx(dshs_e, dshs64)),
+              bf16x3=dict(dx_rel_l2=rel(dx_s, dx64), dshs_rel_l2=rel(dshs_s, dshs64), dx_max=mx(dx_s, dx64), dshs_max=mx(dshs_s, dshs64)))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/infer_arithmetic_stats.jsonl", "a") as fh:
+        fh.write(json.dumps(st) + "\n")
+    assert not bad_rows, st          # deterministic: four runs, bit-identical
+    for k in ("dx_rel_l2", "dshs_rel_l2"):
+        assert st["bf16x3"][k] <= max(3.0 * st["exact"][k], 3e-7), st
+    for k in ("dx_max", "dshs_max"):     # max error over the array, relative to its largest entry
+        assert st["bf16x3"][k] <= max(4.0 * st["exact"][k], 1e-6), st
+
+
 def test_render_uses_the_fused_inference_path_and_is_unchanged(gpu_device, monkeypatch):
     from types import SimpleNamespace
     import s3gaussian_amd.deformation as dm
@@ -85,3 +140,35 @@ def test_render_uses_the_fused_inference_path_and_is_unchanged(gpu_device, monke
     with torch.no_grad():
         render(cam, pc, pipe, scn["bg"].to(dev), stage="fine", render_feat=True)
     assert len(calls) == 1
+
+
+def test_render_with_split_arithmetic_is_the_same_picture(gpu_device, monkeypatch):
+    """pipeline.render() with deformation.INFER_ARITHMETIC = "bf16x3": the deformation differs from the exact kernel's by fp32
+    rounding noise, so the picture may differ only where a splat sits on a discrete threshold (radius rounding, alpha < 1/255)."""
+    from types import SimpleNamespace
+    import s3gaussian_amd.deformation as dm
+    from s3gaussian_amd import synth
+    from s3gaussian_amd.pipeline import GaussianParams, default_hyper, render
+    dev = gpu_device
+    scn = synth.street_scene(P=60_000, seed=4, width=320, height=208, n_frames=2)
+    torch.manual_seed(1)
+    pc = GaussianParams(3, default_hyper())
+    gs = scn["gaussians"]
+    pc.init_from_tensors(gs["xyz"], gs["log_scales"], gs["rotations_raw"], gs["opacity_logit"], gs["shs"], dev)
+    pc._deformation.deformation_net.set_aabb(*scn["aabb"])
+    with torch.no_grad():
+        for p in pc._deformation.deformation_net.pos_deform.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+        for p in pc._deformation.deformation_net.shs_deform.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    cam = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scn["cameras"][1].items()}
+    pipe = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
+    with torch.no_grad():
+        a = render(cam, pc, pipe, scn["bg"].to(dev), stage="fine", return_dx=True)
+        monkeypatch.setattr(dm, "INFER_ARITHMETIC", "bf16x3")
+        b = render(cam, pc, pipe, scn["bg"].to(dev), stage="fine", return_dx=True)
+    assert not torch.equal(a["dx"], b["dx"])                                  # the other kernel really ran
+    assert float((a["dx"] - b["dx"]).abs().max()) <= 2e-6 * float(a["dx"].abs().max()) + 1e-7
+    diff = (a["render"] - b["render"]).abs()
+    assert float(diff.mean()) < 1e-5 and float((diff > 1e-3).float().mean()) < 1e-4, (float(diff.mean()), float(diff.max()))
+    assert float((a["radii"] != b["radii"]).float().mean()) < 1e-4

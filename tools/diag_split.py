@@ -1,0 +1,51 @@
+"""Run-to-run determinism and timing of the split-bf16 fused inference kernel (one JSON line; S3G_LIB_PATH selects a variant build)."""
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from s3gaussian_amd import _lib, synth  # noqa: E402
+from s3gaussian_amd.deformation import deform_network  # noqa: E402
+from s3gaussian_amd.mlp import deform_infer, deform_mlp  # noqa: E402
+from s3gaussian_amd.pipeline import default_hyper  # noqa: E402
+
+dev = torch.device("cuda:0")
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 70_001
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+sc = synth.street_scene(P=P, n_frames=2, seed=3)
+torch.manual_seed(0)
+net = deform_network(default_hyper())
+net.deformation_net.set_aabb(*sc["aabb"])
+d = net.to(dev).deformation_net
+with torch.no_grad():
+    for p in d.grid.grids.parameters():
+        p.add_(0.2 * torch.randn_like(p))
+xyz = sc["gaussians"]["xyz"].to(dev)
+t = torch.full((P, 1), 0.63, device=dev)
+args = (d.grid, xyz, t, d.feature_out, d.pos_deform, d.shs_deform, d.dino_head)
+L = _lib.lib()
+L.s3g_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+with torch.no_grad():
+    ex = torch.cat(deform_infer(*args, uniform_time=True), 1)
+    two = torch.cat(deform_mlp(d.grid(xyz, t, uniform_time=True), d.feature_out, d.pos_deform, d.shs_deform, d.dino_head, need_feat=False)[:2], 1)
+    ex_runs = [torch.cat(deform_infer(*args, uniform_time=True), 1) for _ in range(reps)]
+    exact_ok = bool(all(torch.equal(r, two) for r in ex_runs + [ex]))
+    runs = [torch.cat(deform_infer(*args, uniform_time=True, arithmetic="bf16x3"), 1) for _ in range(reps)]
+    torch.cuda.synchronize()
+    bad = [(r != runs[0]).any(1).nonzero().flatten().tolist() for r in runs[1:]]
+    rows = sorted({x for b in bad for x in b})
+    L.s3g_profile_read(9, None, None, None)
+    L.s3g_profile_enable(1)
+    for _ in range(10):
+        deform_infer(*args, uniform_time=True, arithmetic="bf16x3")
+    torch.cuda.synchronize()
+    L.s3g_profile_enable(0)
+    ms = C.c_double()
+    n = L.s3g_profile_read(9, C.byref(ms), None, None)
+err = float((runs[0] - ex).abs().max() / ex.abs().max())
+print(json.dumps(dict(lib=os.path.basename(_lib.LIB_PATH), P=P, reps=reps, exact_fused_equals_two_kernels=exact_ok, bad_rows=len(rows), per_run=[len(b) for b in bad],
+                      sample=rows[:12], row_mod8=sorted({r % 8 for r in rows}), wave=sorted({(r // 32) % 8 for r in rows}),
+                      max_diff_vs_exact_rel=err, ms=ms.value / max(n, 1))))

@@ -29,6 +29,19 @@ with torch.no_grad():
     torch.cuda.synchronize()
     for i in (2, 5, 9):
         L.s3g_profile_read(i, None, None, None)
+    for arith in ("bf16x3",):     # the GEMM layers on the bf16 matrix pipe (s3g_deform_infer_split), bracket 9 as well
+        for _ in range(3):
+            deform_infer(d.grid, xyz, t, d.feature_out, d.pos_deform, d.shs_deform, d.dino_head, uniform_time=True, arithmetic=arith)
+        torch.cuda.synchronize()
+        L.s3g_profile_read(9, None, None, None)
+        L.s3g_profile_enable(1)
+        for _ in range(10):
+            deform_infer(d.grid, xyz, t, d.feature_out, d.pos_deform, d.shs_deform, d.dino_head, uniform_time=True, arithmetic=arith)
+        torch.cuda.synchronize()
+        L.s3g_profile_enable(0)
+        ms = C.c_double()
+        n = L.s3g_profile_read(9, C.byref(ms), None, None)
+        print(f"deform_infer (fused, {arith}): {ms.value / max(n, 1):.4f} ms avg over {n}")
     L.s3g_profile_enable(1)
     for _ in range(10):
         deform_infer(d.grid, xyz, t, d.feature_out, d.pos_deform, d.shs_deform, d.dino_head, uniform_time=True)
