@@ -702,6 +702,22 @@ def main():
         if world == 1 and not a.no_alt_paths:
             out["config"]["paths"] = {"fused": {"ms_per_step": out["ms_per_step"], "iters_per_s": out["value"]}}
             out["config"]["paths"].update(time_alt_paths(pc, cams, views, targets, tkeys, hyper, opt, bg))
+            try:   # the fused step again with the MLP kernels' per-point GEMM chains on the bf16 matrix pipe (opt-in, fp32 accuracy)
+                from s3gaussian_amd import mlp as _mlp
+                _mlp.set_mlp_arithmetic("bf16x3")
+                for i in range(3):
+                    step(i % len(views))
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for i in range(a.steps):
+                    step(i % len(views))
+                torch.cuda.synchronize()
+                ms2 = 1000.0 * (time.perf_counter() - t2) / a.steps
+                out["config"]["paths"]["fused_mlp_bf16x3"] = {"ms_per_step": round(ms2, 3), "iters_per_s": round(1000.0 / ms2, 2), "steps": a.steps}
+            except Exception as ex:   # never take the headline down
+                out["config"]["paths"]["fused_mlp_bf16x3"] = {"ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"}
+            finally:
+                _mlp.set_mlp_arithmetic("f32")
         psnr_file = os.path.join(ROOT, "profiles", "psnr_parity.json")
         if os.path.exists(psnr_file):   # the third part of BASELINE's metric: written by tools/psnr_parity.py on the GPU box
             try:

@@ -53,6 +53,16 @@ int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* feature
                             const float* g_dshs, const float* g_feat, float* g_features, const s3g_mlp_params* gw,
                             float* workspace, void* stream);
 
+/* Arithmetic of the per-point GEMM chains of the two calls above (process-wide setting, default S3G_MLP_F32):
+ *   S3G_MLP_F32     v_mfma_f32_32x32x2_f32, exact fp32 fma chains.
+ *   S3G_MLP_BF16X3  v_mfma_f32_32x32x16_bf16 (the bf16 matrix pipe, 16 x the rate) with every fp32 operand -- weights, activations,
+ *                   gradients -- split EXACTLY into three bf16 pieces and six piece products accumulated in fp32 per product: what
+ *                   is dropped is <= 2^-23 of each product (fp32 accuracy; not bit-identical to S3G_MLP_F32).
+ * The weight-gradient GEMMs (K = points) are the exact fp32 chain in both modes.  Returns S3G_ERR_INVALID_ARG for another mode. */
+enum { S3G_MLP_F32 = 0, S3G_MLP_BF16X3 = 1 };
+int s3g_deform_mlp_set_arithmetic(int mode);
+int s3g_deform_mlp_get_arithmetic(void);
+
 /* Inference only (no autograd): HexPlane sampler (+) feature_out + position / SH heads in ONE kernel -- what
  * deform_network.forward_dynamic computes under torch.no_grad() for a render that does not draw the feature image
  * (/root/reference/scene/deformation.py:108-166 with the default switches, called from gaussian_renderer/__init__.py:82-97).

@@ -180,245 +180,6 @@ __device__ __forceinline__ void masked_bits(f32x16 (&dst)[MB], const f32x16 (&ac
     }
 }
 
-// ---- weight slabs: the LDS image is built once per call in global memory and DMA-copied by every workgroup ---------
-// Slab k is the [in][out+1] image of one layer (feature_out is cut in two K halves), padded to SLAB floats = 17 KiB =
-// 17 global_load_lds_dwordx4 wave-instructions (1 KiB each).
-constexpr int SLAB = 17 * 256;  // floats
-constexpr int NSLAB = 9;        // W0[:, :64] | W0[:, 64:] | P1 | S1 | P2 | S2 | D0 | D1 | D2
-constexpr int PACK_FLOATS = NSLAB * SLAB + 8 * 64;  // + the 8 bias vectors zero padded to 64
-
-__global__ void __launch_bounds__(256) mlp_pack_kernel(const s3g_mlp_params w, float* __restrict__ packed) {
-  const int k = blockIdx.x, tid = threadIdx.x;
-  float* dst = packed + (size_t)k * SLAB;
-  if (k == NSLAB) {  // biases
-    float* bl = packed + (size_t)NSLAB * SLAB;
-    const float* src[8] = {w.b0, w.pb1, w.sb1, w.pb2, w.sb2, w.db0, w.db1, w.db2};
-    const int n[8] = {64, 64, 64, 3, 48, 64, 64, 3};
-    for (int e = tid; e < 8 * 64; e += 256) bl[e] = (e & 63) < n[e >> 6] ? src[e >> 6][e & 63] : 0.f;
-    return;
-  }
-  const float* W = k <= 1 ? w.W0 : k == 2 ? w.P1 : k == 3 ? w.S1 : k == 4 ? w.P2 : k == 5 ? w.S2 : k == 6 ? w.D0 : k == 7 ? w.D1 : w.D2;
-  const int out = (k == 4 || k == 8) ? 3 : (k == 5 ? 48 : 64), outpad = (k == 4 || k == 8) ? 32 : 64;
-  const int in = k <= 1 ? FEAT : HID, in0 = k == 1 ? 64 : 0, ld = outpad + 1;
-  for (int e = tid; e < SLAB; e += 256) dst[e] = 0.f;
-  __syncthreads();
-  for (int e = tid; e < outpad * 64; e += 256) {
-    const int o = e / 64, i = e % 64;
-    dst[i * ld + o] = o < out ? W[(size_t)o * in + in0 + i] : 0.f;
-  }
-}
-
-constexpr int NWAVE = 8;  // waves per workgroup; one persistent workgroup per CU (the weights fill its LDS)
-constexpr int MLP_LDS_FLOATS = PACK_FLOATS;
-
-// Whole packed image (9 slabs + biases, 155 KB) global -> LDS through the DMA path, once per workgroup.
-__device__ __forceinline__ void load_weights(float* lds, const float* __restrict__ packed, int wave, int lane) {
-  static_assert(PACK_FLOATS % 256 == 0, "image is a whole number of 1 KiB DMA rows");
-  for (int c = wave; c < PACK_FLOATS / 256; c += NWAVE)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(packed + c * 256 + lane * 4),
-                                     (__attribute__((address_space(3))) void*)(lds + c * 256), 16, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-}
-#define WSLAB(k) (lds + (k) * SLAB)
-#define BIAS(k) (lds + NSLAB * SLAB + (k) * 64)  // b0 | pb1 | sb1 | pb2 | sb2 | db0 | db1 | db2
-
-struct MlpFwdArgs {
-  int P;
-  const float* x;
-  const float* packed;
-  float *dx, *dshs, *feat, *stash;
-  uint32_t* maskbits;  // [tiles][5][64] ReLU mask words (NULL when no backward follows)
-};
-
-__global__ void __launch_bounds__(NWAVE * 64) mlp_forward_kernel(const MlpFwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  load_weights(lds, a.packed, wave, lane);
-  const int ntiles = (a.P + MT - 1) / MT;
-  const size_t PS = (size_t)a.P * HID;  // one stash plane
-  // the 128 input features of the NEXT tile are requested before this tile's MFMAs are issued (raw loads, clamped row: lanes
-  // past the end of the array re-read the last point, whose outputs are never stored)
-  struct XIn { float4 v[16]; };   // chunk c = columns 8c + 4h .. +3 of the lane's point
-  const int jj = lane & 31, hh = lane >> 5;
-  auto issue = [&](XIn& X, int tile) {
-    const float* row = a.x + (size_t)min(tile * MT + jj, a.P - 1) * FEAT + 4 * hh;
-#pragma unroll
-    for (int c = 0; c < 16; c++) X.v[c] = *reinterpret_cast<const float4*>(row + 8 * c);
-  };
-  auto unpack = [&](f32x16 (&x)[2], const XIn& X, int half) {
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const float4 v = X.v[8 * half + c];
-      x[c >> 2][4 * (c & 3) + 0] = v.x; x[c >> 2][4 * (c & 3) + 1] = v.y;
-      x[c >> 2][4 * (c & 3) + 2] = v.z; x[c >> 2][4 * (c & 3) + 3] = v.w;
-    }
-  };
-  const int stride = gridDim.x * NWAVE, t0 = blockIdx.x * NWAVE + wave;
-  XIn cur, nxt;
-  if (t0 < ntiles) issue(cur, t0);
-  for (int tile = t0; tile < ntiles; tile += stride) {
-    issue(nxt, min(tile + stride, ntiles - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    const int p0 = tile * MT, npts = min(MT, a.P - p0);
-    f32x16 hid[2], act[2], acc[2], o[1];
-    {  // hidden = W0 x + b0, K = 128 in two halves
-      f32x16 x[2];
-      acc_bias<2>(hid, BIAS(0), lane);
-      unpack(x, cur, 0);
-      gemm_reg<2, 2, false>(WSLAB(0), 65, x, hid, lane);
-      unpack(x, cur, 1);
-      gemm_reg<2, 2, false>(WSLAB(1), 65, x, hid, lane);
-    }
-    uint32_t* mw = a.maskbits ? a.maskbits + (size_t)tile * 5 * 64 + lane : nullptr;
-    if (a.stash) act_store<HID, 2, false>(hid, a.stash + 0 * PS, 0, p0, npts, lane);
-    if (mw) mw[0 * 64] = pack_positive<2>(hid);
-    // pos head: dx = P2 relu(P1 relu(hidden) + pb1) + pb2
-    acc_bias<2>(act, BIAS(1), lane);
-    gemm_reg<2, 2, true>(WSLAB(2), 65, hid, act, lane);
-    relu_inplace<2>(act);
-    if (a.stash) act_store<HID, 2, false>(act, a.stash + 1 * PS, 0, p0, npts, lane);
-    if (mw) mw[1 * 64] = pack_positive<2>(act);
-    acc_bias<1>(o, BIAS(3), lane);
-    gemm_reg<1, 2, false>(WSLAB(4), 33, act, o, lane);
-    act_store3(o, a.dx, p0, npts, lane);
-    // shs head: dshs = S2 relu(S1 relu(hidden) + sb1) + sb2
-    acc_bias<2>(act, BIAS(2), lane);
-    gemm_reg<2, 2, true>(WSLAB(3), 65, hid, act, lane);
-    relu_inplace<2>(act);
-    if (a.stash) act_store<HID, 2, false>(act, a.stash + 2 * PS, 0, p0, npts, lane);
-    if (mw) mw[2 * 64] = pack_positive<2>(act);
-    acc_bias<2>(acc, BIAS(4), lane);
-    gemm_reg<2, 2, false>(WSLAB(5), 65, act, acc, lane);
-    act_store<48, 2, false, 48>(acc, a.dshs, 0, p0, npts, lane);
-    if (a.feat != nullptr) {  // inference renders that do not draw the feature image skip the head (31 % of the MFMAs)
-    // dino head: feat = D2 relu(D1 relu(D0 hidden + db0) + db1) + db2   (input is the raw hidden, deformation.py:126)
-    acc_bias<2>(act, BIAS(5), lane);
-    gemm_reg<2, 2, false>(WSLAB(6), 65, hid, act, lane);
-    relu_inplace<2>(act);
-    if (a.stash) act_store<HID, 2, false>(act, a.stash + 3 * PS, 0, p0, npts, lane);
-    if (mw) mw[3 * 64] = pack_positive<2>(act);
-    acc_bias<2>(acc, BIAS(6), lane);
-    gemm_reg<2, 2, false>(WSLAB(7), 65, act, acc, lane);
-    relu_inplace<2>(acc);
-    if (a.stash) act_store<HID, 2, false>(acc, a.stash + 4 * PS, 0, p0, npts, lane);
-    if (mw) mw[4 * 64] = pack_positive<2>(acc);
-    acc_bias<1>(o, BIAS(7), lane);
-    gemm_reg<1, 2, false>(WSLAB(8), 33, acc, o, lane);
-    act_store3(o, a.feat, p0, npts, lane);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    cur = nxt;   // copies at the very end: the prefetch has had the whole tile to land
-  }
-}
-
-struct MlpBwdArgs {
-  int P;
-  const float* packed;
-  const uint32_t* maskbits;  // [tiles][5][64] from the forward: hidden | pos1 | shs1 | dino1 | dino2
-  const float *g_dx, *g_dshs, *g_feat;
-  float *g_x, *ws;
-};
-
-// Everything the backward chain of one tile reads from memory: the three upstream gradients of the lane's point and the five
-// ReLU mask words -- 45 registers, requested for the NEXT tile before the current tile's ~600 MFMAs are issued.
-struct BwdIn {
-  float gd[3], gf[3];
-  float4 gs[6];       // g_dshs columns 8q + 4h .. +3 (q = 0..3) and 32 + 8q + 4h .. +3 (q = 0, 1): the 48 live columns
-  uint32_t bits[5];
-};
-
-// Per-point backward chain, same register-resident scheme with the transposed weight reads.
-__global__ void __launch_bounds__(NWAVE * 64) mlp_backward_kernel(const MlpBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  load_weights(lds, a.packed, wave, lane);
-  const int ntiles = (a.P + MT - 1) / MT;
-  const size_t PS = (size_t)a.P * HID;
-  const int j = lane & 31, h = lane >> 5;
-  const bool dino = a.g_feat != nullptr;
-  // Raw, select-free loads with clamped addresses (lanes past the end of the array re-read the last point: their columns are
-  // never stored): a bounds select on a loaded value would be scheduled where the load was issued and stall there.
-  auto issue = [&](BwdIn& I, int tile) {
-    const size_t p = (size_t)min(tile * MT + j, a.P - 1);
-    const uint32_t* mw = a.maskbits + (size_t)tile * 5 * 64 + lane;
-#pragma unroll
-    for (int k = 0; k < 5; k++) I.bits[k] = mw[k * 64];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      I.gd[k] = a.g_dx[p * 3 + k];
-      I.gf[k] = dino ? a.g_feat[p * 3 + k] : 0.f;
-    }
-    const float* row = a.g_dshs + p * 48 + 4 * h;
-#pragma unroll
-    for (int c = 0; c < 6; c++) I.gs[c] = *reinterpret_cast<const float4*>(row + 8 * c);
-  };
-  auto head3 = [&](f32x16 (&g3)[1], const float (&v)[3]) {  // features 0..2 live in registers 0..2 of the h = 0 lanes
-    acc_zero<1>(g3);
-#pragma unroll
-    for (int k = 0; k < 3; k++) g3[0][k] = h == 0 ? v[k] : 0.f;
-  };
-  const int stride = gridDim.x * NWAVE, t0 = blockIdx.x * NWAVE + wave;
-  BwdIn cur, nxt;
-  if (t0 < ntiles) issue(cur, t0);
-  for (int tile = t0; tile < ntiles; tile += stride) {
-    issue(nxt, min(tile + stride, ntiles - 1));   // unconditional (clamped): see mlp_wgrad_kernel
-    __builtin_amdgcn_sched_barrier(0);
-    const int p0 = tile * MT, npts = min(MT, a.P - p0);
-    f32x16 ghid[2], g[2], acc[2], g3[1];
-    acc_zero<2>(ghid);
-    // ---- dino head (skipped when the feature image has no gradient: g_feat == NULL) ----
-    if (dino) {
-      head3(g3, cur.gf);
-      acc_zero<2>(acc);
-      gemm_reg_t<2, 1, 3>(WSLAB(8), 33, g3, acc, lane);           // D2^T g_feat (3 live K steps)
-      masked_bits<2, false>(g, acc, cur.bits[4]);                  // gradient wrt dino2 pre-activation
-      act_store<HID, 2, false>(g, a.ws + 0 * PS, 0, p0, npts, lane);
-      acc_zero<2>(acc);
-      gemm_reg_t<2, 2>(WSLAB(7), 65, g, acc, lane);               // D1^T
-      masked_bits<2, false>(g, acc, cur.bits[3]);
-      act_store<HID, 2, false>(g, a.ws + 1 * PS, 0, p0, npts, lane);
-      gemm_reg_t<2, 2>(WSLAB(6), 65, g, ghid, lane);              // ghid = D0^T (dino input is the raw hidden: no mask)
-    }
-    // ---- pos head ----
-    head3(g3, cur.gd);
-    acc_zero<2>(acc);
-    gemm_reg_t<2, 1, 3>(WSLAB(4), 33, g3, acc, lane);             // P2^T g_dx
-    masked_bits<2, false>(g, acc, cur.bits[1]);
-    act_store<HID, 2, false>(g, a.ws + 2 * PS, 0, p0, npts, lane);
-    acc_zero<2>(acc);
-    gemm_reg_t<2, 2>(WSLAB(2), 65, g, acc, lane);                 // P1^T
-    // ---- shs head ----
-    {
-      f32x16 gs[2], t[2];
-#pragma unroll
-      for (int c = 0; c < 8; c++) {  // chunk c = columns 8c + 4h .. +3; chunks 6, 7 (columns >= 48) do not exist
-        const float4 v = c < 6 ? cur.gs[c < 6 ? c : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
-        gs[c >> 2][4 * (c & 3) + 0] = v.x; gs[c >> 2][4 * (c & 3) + 1] = v.y;
-        gs[c >> 2][4 * (c & 3) + 2] = v.z; gs[c >> 2][4 * (c & 3) + 3] = v.w;
-      }
-      acc_zero<2>(t);
-      gemm_reg_t<2, 2>(WSLAB(5), 65, gs, t, lane);                // S2^T g_dshs (rows 48..63 of the image are zero)
-      masked_bits<2, false>(g, t, cur.bits[2]);
-    }
-    act_store<HID, 2, false>(g, a.ws + 3 * PS, 0, p0, npts, lane);
-    gemm_reg_t<2, 2>(WSLAB(3), 65, g, acc, lane);                 // + S1^T  (same relu(hidden) mask as P1^T)
-    masked_bits<2, true>(ghid, acc, cur.bits[0]);
-    act_store<HID, 2, false>(ghid, a.ws + 4 * PS, 0, p0, npts, lane);
-    // ---- feature_out: g_x[:, half] = W0[:, half]^T ghid ----
-    acc_zero<2>(acc);
-    gemm_reg_t<2, 2>(WSLAB(0), 65, ghid, acc, lane);
-    act_store<FEAT, 2, false>(acc, a.g_x, 0, p0, npts, lane);
-    acc_zero<2>(acc);
-    gemm_reg_t<2, 2>(WSLAB(1), 65, ghid, acc, lane);
-    act_store<FEAT, 2, false>(acc, a.g_x, 64, p0, npts, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    cur = nxt;
-  }
-}
-#undef WSLAB
-#undef BIAS
-
 // ---- fp32 GEMMs on the bf16 matrix pipe: three-way operand split ------------------------------------------------------------------
 // v_mfma_f32_32x32x2_f32 runs at the vector-fma rate (64 cycles per 4096 FLOP and SIMD); v_mfma_f32_32x32x16_bf16 does 32768
 // FLOP in 32 cycles on the real matrix pipe, beside the VALU instead of in its place.  Every fp32 operand is written as the EXACT
@@ -480,6 +241,303 @@ __device__ __forceinline__ void act_split(ActSplit<MBI>& S, const f32x16 (&in)[M
     }
 }
 __host__ __device__ constexpr int split_feature(int ks, int h, int e) { return 16 * ks + 4 * h + (e & 3) + 8 * (e >> 2); }   // ks = 2 * mbi + s
+
+// gemm_reg / gemm_reg_t with both operands split on the fly: the A operand is read from the SAME fp32 [in][out+1] LDS image (eight
+// ds_read_b32 per fragment instead of one per fp32 MFMA: the same LDS traffic) and split by the lane that uses it.
+template <int MBO, int MBI, bool RELU_IN, int RSTEPS = 16>
+__device__ __forceinline__ void gemm_reg_split(const float* wl, int ld, const f32x16 (&in)[MBI], f32x16 (&acc)[MBO], int lane) {
+  const float* base = wl + 4 * (lane >> 5) * ld + (lane & 31);
+#pragma unroll
+  for (int mbi = 0; mbi < MBI; mbi++)
+#pragma unroll
+    for (int s = 0; s < (RSTEPS + 7) / 8; s++) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = RELU_IN ? fmaxf(in[mbi][8 * s + e], 0.f) : in[mbi][8 * s + e];
+      const Split8 b = split8(v);
+#pragma unroll
+      for (int mbo = 0; mbo < MBO; mbo++) {
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) w[e] = base[(32 * mbi + rrow(8 * s + e)) * ld + 32 * mbo];
+        acc[mbo] = mfma_split(acc[mbo], split8(w), b);
+      }
+    }
+}
+template <int MBO, int MBI, int RSTEPS = 16>
+__device__ __forceinline__ void gemm_reg_t_split(const float* wl, int ld, const f32x16 (&g)[MBI], f32x16 (&acc)[MBO], int lane) {
+  const float* base = wl + (lane & 31) * ld + 4 * (lane >> 5);
+#pragma unroll
+  for (int mbi = 0; mbi < MBI; mbi++)
+#pragma unroll
+    for (int s = 0; s < (RSTEPS + 7) / 8; s++) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = g[mbi][8 * s + e];
+      const Split8 b = split8(v);
+#pragma unroll
+      for (int mbo = 0; mbo < MBO; mbo++) {
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) w[e] = base[32 * mbo * ld + 32 * mbi + rrow(8 * s + e)];
+        acc[mbo] = mfma_split(acc[mbo], split8(w), b);
+      }
+    }
+}
+// arithmetic selected at compile time by the kernels' SPLIT parameter
+template <bool SPLIT, int MBO, int MBI, bool RELU_IN, int RSTEPS = 16>
+__device__ __forceinline__ void gemm_fw(const float* wl, int ld, const f32x16 (&in)[MBI], f32x16 (&acc)[MBO], int lane) {
+  if constexpr (SPLIT) gemm_reg_split<MBO, MBI, RELU_IN, RSTEPS>(wl, ld, in, acc, lane);
+  else gemm_reg<MBO, MBI, RELU_IN, RSTEPS>(wl, ld, in, acc, lane);
+}
+template <bool SPLIT, int MBO, int MBI, int RSTEPS = 16>
+__device__ __forceinline__ void gemm_bw(const float* wl, int ld, const f32x16 (&g)[MBI], f32x16 (&acc)[MBO], int lane) {
+  if constexpr (SPLIT) gemm_reg_t_split<MBO, MBI, RSTEPS>(wl, ld, g, acc, lane);
+  else gemm_reg_t<MBO, MBI, RSTEPS>(wl, ld, g, acc, lane);
+}
+
+// ---- weight slabs: the LDS image is built once per call in global memory and DMA-copied by every workgroup ---------
+// Slab k is the [in][out+1] image of one layer (feature_out is cut in two K halves), padded to SLAB floats = 17 KiB =
+// 17 global_load_lds_dwordx4 wave-instructions (1 KiB each).
+constexpr int SLAB = 17 * 256;  // floats
+constexpr int NSLAB = 9;        // W0[:, :64] | W0[:, 64:] | P1 | S1 | P2 | S2 | D0 | D1 | D2
+constexpr int PACK_FLOATS = NSLAB * SLAB + 8 * 64;  // + the 8 bias vectors zero padded to 64
+
+__global__ void __launch_bounds__(256) mlp_pack_kernel(const s3g_mlp_params w, float* __restrict__ packed) {
+  const int k = blockIdx.x, tid = threadIdx.x;
+  float* dst = packed + (size_t)k * SLAB;
+  if (k == NSLAB) {  // biases
+    float* bl = packed + (size_t)NSLAB * SLAB;
+    const float* src[8] = {w.b0, w.pb1, w.sb1, w.pb2, w.sb2, w.db0, w.db1, w.db2};
+    const int n[8] = {64, 64, 64, 3, 48, 64, 64, 3};
+    for (int e = tid; e < 8 * 64; e += 256) bl[e] = (e & 63) < n[e >> 6] ? src[e >> 6][e & 63] : 0.f;
+    return;
+  }
+  const float* W = k <= 1 ? w.W0 : k == 2 ? w.P1 : k == 3 ? w.S1 : k == 4 ? w.P2 : k == 5 ? w.S2 : k == 6 ? w.D0 : k == 7 ? w.D1 : w.D2;
+  const int out = (k == 4 || k == 8) ? 3 : (k == 5 ? 48 : 64), outpad = (k == 4 || k == 8) ? 32 : 64;
+  const int in = k <= 1 ? FEAT : HID, in0 = k == 1 ? 64 : 0, ld = outpad + 1;
+  for (int e = tid; e < SLAB; e += 256) dst[e] = 0.f;
+  __syncthreads();
+  for (int e = tid; e < outpad * 64; e += 256) {
+    const int o = e / 64, i = e % 64;
+    dst[i * ld + o] = o < out ? W[(size_t)o * in + in0 + i] : 0.f;
+  }
+}
+
+constexpr int NWAVE = 8;  // waves per workgroup; one persistent workgroup per CU (the weights fill its LDS)
+constexpr int MLP_LDS_FLOATS = PACK_FLOATS;
+
+// Whole packed image (9 slabs + biases, 155 KB) global -> LDS through the DMA path, once per workgroup.
+__device__ __forceinline__ void load_weights(float* lds, const float* __restrict__ packed, int wave, int lane) {
+  static_assert(PACK_FLOATS % 256 == 0, "image is a whole number of 1 KiB DMA rows");
+  for (int c = wave; c < PACK_FLOATS / 256; c += NWAVE)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(packed + c * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(lds + c * 256), 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+#define WSLAB(k) (lds + (k) * SLAB)
+#define BIAS(k) (lds + NSLAB * SLAB + (k) * 64)  // b0 | pb1 | sb1 | pb2 | sb2 | db0 | db1 | db2
+
+struct MlpFwdArgs {
+  int P;
+  const float* x;
+  const float* packed;
+  float *dx, *dshs, *feat, *stash;
+  uint32_t* maskbits;  // [tiles][5][64] ReLU mask words (NULL when no backward follows)
+};
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(NWAVE * 64) mlp_forward_kernel(const MlpFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_weights(lds, a.packed, wave, lane);
+  const int ntiles = (a.P + MT - 1) / MT;
+  const size_t PS = (size_t)a.P * HID;  // one stash plane
+  // the 128 input features of the NEXT tile are requested before this tile's MFMAs are issued (raw loads, clamped row: lanes
+  // past the end of the array re-read the last point, whose outputs are never stored)
+  struct XIn { float4 v[16]; };   // chunk c = columns 8c + 4h .. +3 of the lane's point
+  const int jj = lane & 31, hh = lane >> 5;
+  auto issue = [&](XIn& X, int tile) {
+    const float* row = a.x + (size_t)min(tile * MT + jj, a.P - 1) * FEAT + 4 * hh;
+#pragma unroll
+    for (int c = 0; c < 16; c++) X.v[c] = *reinterpret_cast<const float4*>(row + 8 * c);
+  };
+  auto unpack = [&](f32x16 (&x)[2], const XIn& X, int half) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const float4 v = X.v[8 * half + c];
+      x[c >> 2][4 * (c & 3) + 0] = v.x; x[c >> 2][4 * (c & 3) + 1] = v.y;
+      x[c >> 2][4 * (c & 3) + 2] = v.z; x[c >> 2][4 * (c & 3) + 3] = v.w;
+    }
+  };
+  const int stride = gridDim.x * NWAVE, t0 = blockIdx.x * NWAVE + wave;
+  XIn cur, nxt;
+  if (t0 < ntiles) issue(cur, t0);
+  for (int tile = t0; tile < ntiles; tile += stride) {
+    issue(nxt, min(tile + stride, ntiles - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    const int p0 = tile * MT, npts = min(MT, a.P - p0);
+    f32x16 hid[2], act[2], acc[2], o[1];
+    int ln = lane;   // SPLIT: per-tile copy, so that the seven per-lane output pointers are not carried (and spilled) across the loop
+    if constexpr (SPLIT) asm volatile("" : "+v"(ln));
+    {  // hidden = W0 x + b0, K = 128 in two halves
+      f32x16 x[2];
+      acc_bias<2>(hid, BIAS(0), ln);
+      unpack(x, cur, 0);
+      gemm_fw<SPLIT, 2, 2, false>(WSLAB(0), 65, x, hid, ln);
+      unpack(x, cur, 1);
+      gemm_fw<SPLIT, 2, 2, false>(WSLAB(1), 65, x, hid, ln);
+    }
+    uint32_t* mw = a.maskbits ? a.maskbits + (size_t)tile * 5 * 64 + ln : nullptr;
+    if (a.stash) act_store<HID, 2, false>(hid, a.stash + 0 * PS, 0, p0, npts, ln);
+    if (mw) mw[0 * 64] = pack_positive<2>(hid);
+    // pos head: dx = P2 relu(P1 relu(hidden) + pb1) + pb2
+    acc_bias<2>(act, BIAS(1), ln);
+    gemm_fw<SPLIT, 2, 2, true>(WSLAB(2), 65, hid, act, ln);
+    relu_inplace<2>(act);
+    if (a.stash) act_store<HID, 2, false>(act, a.stash + 1 * PS, 0, p0, npts, ln);
+    if (mw) mw[1 * 64] = pack_positive<2>(act);
+    acc_bias<1>(o, BIAS(3), ln);
+    gemm_fw<SPLIT, 1, 2, false>(WSLAB(4), 33, act, o, ln);
+    act_store3(o, a.dx, p0, npts, ln);
+    // shs head: dshs = S2 relu(S1 relu(hidden) + sb1) + sb2
+    acc_bias<2>(act, BIAS(2), ln);
+    gemm_fw<SPLIT, 2, 2, true>(WSLAB(3), 65, hid, act, ln);
+    relu_inplace<2>(act);
+    if (a.stash) act_store<HID, 2, false>(act, a.stash + 2 * PS, 0, p0, npts, ln);
+    if (mw) mw[2 * 64] = pack_positive<2>(act);
+    acc_bias<2>(acc, BIAS(4), ln);
+    gemm_fw<SPLIT, 2, 2, false>(WSLAB(5), 65, act, acc, ln);
+    act_store<48, 2, false, 48>(acc, a.dshs, 0, p0, npts, ln);
+    if (a.feat != nullptr) {  // inference renders that do not draw the feature image skip the head (31 % of the MFMAs)
+    // dino head: feat = D2 relu(D1 relu(D0 hidden + db0) + db1) + db2   (input is the raw hidden, deformation.py:126)
+    acc_bias<2>(act, BIAS(5), ln);
+    gemm_fw<SPLIT, 2, 2, false>(WSLAB(6), 65, hid, act, ln);
+    relu_inplace<2>(act);
+    if (a.stash) act_store<HID, 2, false>(act, a.stash + 3 * PS, 0, p0, npts, ln);
+    if (mw) mw[3 * 64] = pack_positive<2>(act);
+    acc_bias<2>(acc, BIAS(6), ln);
+    gemm_fw<SPLIT, 2, 2, false>(WSLAB(7), 65, act, acc, ln);
+    relu_inplace<2>(acc);
+    if (a.stash) act_store<HID, 2, false>(acc, a.stash + 4 * PS, 0, p0, npts, ln);
+    if (mw) mw[4 * 64] = pack_positive<2>(acc);
+    acc_bias<1>(o, BIAS(7), ln);
+    gemm_fw<SPLIT, 1, 2, false>(WSLAB(8), 33, acc, o, ln);
+    act_store3(o, a.feat, p0, npts, ln);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;   // copies at the very end: the prefetch has had the whole tile to land
+  }
+}
+
+struct MlpBwdArgs {
+  int P;
+  const float* packed;
+  const uint32_t* maskbits;  // [tiles][5][64] from the forward: hidden | pos1 | shs1 | dino1 | dino2
+  const float *g_dx, *g_dshs, *g_feat;
+  float *g_x, *ws;
+};
+
+// Everything the backward chain of one tile reads from memory: the three upstream gradients of the lane's point and the five
+// ReLU mask words -- 45 registers, requested for the NEXT tile before the current tile's ~600 MFMAs are issued.
+struct BwdIn {
+  float gd[3], gf[3];
+  float4 gs[6];       // g_dshs columns 8q + 4h .. +3 (q = 0..3) and 32 + 8q + 4h .. +3 (q = 0, 1): the 48 live columns
+  uint32_t bits[5];
+};
+
+// Per-point backward chain, same register-resident scheme with the transposed weight reads.
+template <bool SPLIT>
+__global__ void __launch_bounds__(NWAVE * 64) mlp_backward_kernel(const MlpBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_weights(lds, a.packed, wave, lane);
+  const int ntiles = (a.P + MT - 1) / MT;
+  const size_t PS = (size_t)a.P * HID;
+  const int j = lane & 31, h = lane >> 5;
+  const bool dino = a.g_feat != nullptr;
+  // Raw, select-free loads with clamped addresses (lanes past the end of the array re-read the last point: their columns are
+  // never stored): a bounds select on a loaded value would be scheduled where the load was issued and stall there.
+  auto issue = [&](BwdIn& I, int tile) {
+    const size_t p = (size_t)min(tile * MT + j, a.P - 1);
+    const uint32_t* mw = a.maskbits + (size_t)tile * 5 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 5; k++) I.bits[k] = mw[k * 64];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      I.gd[k] = a.g_dx[p * 3 + k];
+      I.gf[k] = dino ? a.g_feat[p * 3 + k] : 0.f;
+    }
+    const float* row = a.g_dshs + p * 48 + 4 * h;
+#pragma unroll
+    for (int c = 0; c < 6; c++) I.gs[c] = *reinterpret_cast<const float4*>(row + 8 * c);
+  };
+  auto head3 = [&](f32x16 (&g3)[1], const float (&v)[3]) {  // features 0..2 live in registers 0..2 of the h = 0 lanes
+    acc_zero<1>(g3);
+#pragma unroll
+    for (int k = 0; k < 3; k++) g3[0][k] = h == 0 ? v[k] : 0.f;
+  };
+  const int stride = gridDim.x * NWAVE, t0 = blockIdx.x * NWAVE + wave;
+  BwdIn cur, nxt;
+  if (t0 < ntiles) issue(cur, t0);
+  for (int tile = t0; tile < ntiles; tile += stride) {
+    issue(nxt, min(tile + stride, ntiles - 1));   // unconditional (clamped): see mlp_wgrad_kernel
+    __builtin_amdgcn_sched_barrier(0);
+    const int p0 = tile * MT, npts = min(MT, a.P - p0);
+    f32x16 ghid[2], g[2], acc[2], g3[1];
+    acc_zero<2>(ghid);
+    // ---- dino head (skipped when the feature image has no gradient: g_feat == NULL) ----
+    if (dino) {
+      head3(g3, cur.gf);
+      acc_zero<2>(acc);
+      gemm_bw<SPLIT, 2, 1, 3>(WSLAB(8), 33, g3, acc, lane);           // D2^T g_feat (3 live K steps)
+      masked_bits<2, false>(g, acc, cur.bits[4]);                  // gradient wrt dino2 pre-activation
+      act_store<HID, 2, false>(g, a.ws + 0 * PS, 0, p0, npts, lane);
+      acc_zero<2>(acc);
+      gemm_bw<SPLIT, 2, 2>(WSLAB(7), 65, g, acc, lane);               // D1^T
+      masked_bits<2, false>(g, acc, cur.bits[3]);
+      act_store<HID, 2, false>(g, a.ws + 1 * PS, 0, p0, npts, lane);
+      gemm_bw<SPLIT, 2, 2>(WSLAB(6), 65, g, ghid, lane);              // ghid = D0^T (dino input is the raw hidden: no mask)
+    }
+    // ---- pos head ----
+    head3(g3, cur.gd);
+    acc_zero<2>(acc);
+    gemm_bw<SPLIT, 2, 1, 3>(WSLAB(4), 33, g3, acc, lane);             // P2^T g_dx
+    masked_bits<2, false>(g, acc, cur.bits[1]);
+    act_store<HID, 2, false>(g, a.ws + 2 * PS, 0, p0, npts, lane);
+    acc_zero<2>(acc);
+    gemm_bw<SPLIT, 2, 2>(WSLAB(2), 65, g, acc, lane);                 // P1^T
+    // ---- shs head ----
+    {
+      f32x16 gs[2], t[2];
+#pragma unroll
+      for (int c = 0; c < 8; c++) {  // chunk c = columns 8c + 4h .. +3; chunks 6, 7 (columns >= 48) do not exist
+        const float4 v = c < 6 ? cur.gs[c < 6 ? c : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        gs[c >> 2][4 * (c & 3) + 0] = v.x; gs[c >> 2][4 * (c & 3) + 1] = v.y;
+        gs[c >> 2][4 * (c & 3) + 2] = v.z; gs[c >> 2][4 * (c & 3) + 3] = v.w;
+      }
+      acc_zero<2>(t);
+      gemm_bw<SPLIT, 2, 2>(WSLAB(5), 65, gs, t, lane);                // S2^T g_dshs (rows 48..63 of the image are zero)
+      masked_bits<2, false>(g, t, cur.bits[2]);
+    }
+    act_store<HID, 2, false>(g, a.ws + 3 * PS, 0, p0, npts, lane);
+    gemm_bw<SPLIT, 2, 2>(WSLAB(3), 65, g, acc, lane);                 // + S1^T  (same relu(hidden) mask as P1^T)
+    masked_bits<2, true>(ghid, acc, cur.bits[0]);
+    act_store<HID, 2, false>(ghid, a.ws + 4 * PS, 0, p0, npts, lane);
+    // ---- feature_out: g_x[:, half] = W0[:, half]^T ghid ----
+    acc_zero<2>(acc);
+    gemm_bw<SPLIT, 2, 2>(WSLAB(0), 65, ghid, acc, lane);
+    act_store<FEAT, 2, false>(acc, a.g_x, 0, p0, npts, lane);
+    acc_zero<2>(acc);
+    gemm_bw<SPLIT, 2, 2>(WSLAB(1), 65, ghid, acc, lane);
+    act_store<FEAT, 2, false>(acc, a.g_x, 64, p0, npts, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+  }
+}
+#undef WSLAB
+#undef BIAS
 
 // The split weight image of the inference network (32-bit words; a word = two bf16).  A FRAGMENT is the A operand of one
 // (32-row block mbo, K step ks): 64 lanes x 16 bytes per piece, stored piece after piece in lane order -- one conflict-free
@@ -1482,11 +1540,26 @@ extern "C" size_t s3g_deform_mlp_stash_bytes(int P) {
 }
 extern "C" size_t s3g_deform_mlp_pack_bytes(void) { return (size_t)PACK_FLOATS * sizeof(float); }
 
+// arithmetic of the per-point GEMM chains of s3g_deform_mlp_forward / _backward (process-wide; the weight-gradient GEMMs, whose K
+// dimension is the points, are always the exact fp32 chain)
+static std::atomic<int> g_mlp_arithmetic{S3G_MLP_F32};
+extern "C" int s3g_deform_mlp_set_arithmetic(int mode) {
+  if (mode != S3G_MLP_F32 && mode != S3G_MLP_BF16X3) {
+    set_error("s3g_deform_mlp_set_arithmetic: mode must be S3G_MLP_F32 or S3G_MLP_BF16X3");
+    return S3G_ERR_INVALID_ARG;
+  }
+  g_mlp_arithmetic.store(mode, std::memory_order_relaxed);
+  return S3G_OK;
+}
+extern "C" int s3g_deform_mlp_get_arithmetic(void) { return g_mlp_arithmetic.load(std::memory_order_relaxed); }
+
 static int mlp_set_attrs() {
   static std::atomic<uint64_t> done{0};
   if (device_needs_setup(done)) {
-    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
-    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_backward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_multi_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WM_RED * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_multi_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WM_RED * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WM_RED * 4));
@@ -1512,7 +1585,10 @@ extern "C" int s3g_deform_mlp_forward(const s3g_mlp_params* w, int P, const floa
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
   profile_begin(S3G_PROFILE_MLP_FORWARD, stream);
-  hipLaunchKernelGGL(mlp_forward_kernel, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, a);
+  if (g_mlp_arithmetic.load(std::memory_order_relaxed) == S3G_MLP_BF16X3)
+    hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, a);
+  else
+    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, a);
   profile_end(S3G_PROFILE_MLP_FORWARD, stream, (double)P, 0.0);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
@@ -1534,7 +1610,10 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
   profile_begin(S3G_PROFILE_MLP_BACKWARD, stream);
-  hipLaunchKernelGGL(mlp_backward_kernel, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, b);
+  if (g_mlp_arithmetic.load(std::memory_order_relaxed) == S3G_MLP_BF16X3)
+    hipLaunchKernelGGL(mlp_backward_kernel<true>, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, b);
+  else
+    hipLaunchKernelGGL(mlp_backward_kernel<false>, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, b);
   profile_end(S3G_PROFILE_MLP_BACKWARD, stream, (double)P, 0.0);
   S3G_HIP_CHECK(hipGetLastError());
   profile_begin(S3G_PROFILE_MLP_WGRAD, stream);

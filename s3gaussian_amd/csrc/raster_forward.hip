@@ -692,7 +692,7 @@ static inline uint32_t round_up8(uint32_t v) { return (v + 7u) & ~7u; }
 using namespace s3g;
 
 extern "C" const char* s3g_last_error(void) { return g_err; }
-extern "C" int s3g_abi_version(void) { return 8; }
+extern "C" int s3g_abi_version(void) { return 9; }
 
 static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2, float* out_color2,
                                s3g_resize_fn geometry_buffer, void* geometry_user, s3g_resize_fn binning_buffer,

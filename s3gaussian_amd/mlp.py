@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -39,8 +40,31 @@ def _bind():
         L.s3g_deform_infer.argtypes = [C.POINTER(_HexDesc), C.POINTER(_Params), C.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.s3g_deform_infer_split.restype = C.c_int
         L.s3g_deform_infer_split.argtypes = L.s3g_deform_infer.argtypes
+        L.s3g_deform_mlp_set_arithmetic.restype = C.c_int
+        L.s3g_deform_mlp_set_arithmetic.argtypes = [C.c_int]
+        L.s3g_deform_mlp_get_arithmetic.restype = C.c_int
         _bound = True
+        env = os.environ.get("S3G_MLP_ARITHMETIC")
+        if env:
+            set_mlp_arithmetic(env)
     return L
+
+
+_ARITHMETIC = {"f32": 0, "bf16x3": 1}     # S3G_MLP_F32, S3G_MLP_BF16X3 (include/s3g_mlp.h)
+
+
+def set_mlp_arithmetic(mode: str) -> None:
+    """Arithmetic of the per-point GEMM chains of deform_mlp's forward and backward kernels (process-wide; environment:
+    S3G_MLP_ARITHMETIC): "f32" = exact fp32 fma chains (default), "bf16x3" = the bf16 matrix pipe on operands split exactly into three
+    bf16 pieces (fp32 accuracy, not bit-identical).  The weight-gradient GEMMs are the exact chain in both modes."""
+    if mode not in _ARITHMETIC:
+        raise ValueError(f"set_mlp_arithmetic: mode must be one of {sorted(_ARITHMETIC)}, got {mode!r}")
+    _lib.check(_bind().s3g_deform_mlp_set_arithmetic(_ARITHMETIC[mode]))
+
+
+def get_mlp_arithmetic() -> str:
+    v = _bind().s3g_deform_mlp_get_arithmetic()
+    return next(k for k, x in _ARITHMETIC.items() if x == v)
 
 
 def _pack(tensors) -> _Params:

@@ -42,10 +42,22 @@ def _min_abs_preactivation(d, x):
     return worst
 
 
+@pytest.fixture
+def arithmetic(request):
+    """Sets the process-wide arithmetic of the per-point GEMM chains (include/s3g_mlp.h) for one test and restores the default."""
+    from s3gaussian_amd import mlp
+    mlp.set_mlp_arithmetic(request.param)
+    yield request.param
+    mlp.set_mlp_arithmetic("f32")
+
+
+# "bf16x3": the bf16 matrix pipe on operands split exactly into three bf16 pieces -- held to the SAME tolerances as the exact chain
+@pytest.mark.parametrize("arithmetic", ["f32", "bf16x3"], indirect=True)
 @pytest.mark.parametrize("P", [1, 31, 32, 33, 127, 128, 129, 5000])
-def test_fused_mlp_matches_linear_stack(gpu_device, P):
-    from s3gaussian_amd.mlp import deform_mlp
+def test_fused_mlp_matches_linear_stack(gpu_device, P, arithmetic):
+    from s3gaussian_amd.mlp import deform_mlp, get_mlp_arithmetic
     import copy
+    assert get_mlp_arithmetic() == arithmetic
     d64 = _modules(P).double()
     dg = copy.deepcopy(d64).float().to(gpu_device)
     g = torch.Generator().manual_seed(P + 1)
@@ -147,3 +159,52 @@ def test_unused_feature_head_gets_no_gradient(gpu_device):
             assert g0[k] is None and g1[k] is not None and float(g1[k].abs().max()) == 0.0, k
         elif g1[k] is not None:   # weight gradients are flushed with float atomics: equal to summation-order round-off
             assert g0[k] is not None and rel_l2(g0[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-6, k
+
+
+def test_split_arithmetic_at_baseline_size(gpu_device):
+    """1.2 M points (every wave loops over several tiles; two waves per SIMD on every CU): the bf16x3 kernels against the exact ones
+    on the same inputs.  Forward: fp32 rounding noise apart.  Backward: the ReLU masks come from each forward's own activations,
+    so a point whose pre-activation is within rounding of zero may take the other branch -- rows are compared, and only a
+    vanishing fraction may differ.  Three launches of each: per-point results bit-identical."""
+    import json
+    import os
+    from s3gaussian_amd import mlp as M
+    dev = gpu_device
+    P = 1_200_000
+    d = _modules(11).float().to(dev)
+    with torch.no_grad():
+        for m in (d.pos_deform[3], d.shs_deform[3], d.dino_head[4]):
+            m.weight.mul_(30.0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(P, 128, device=dev, generator=g) * 0.5
+    w = [torch.randn(P, n, device=dev, generator=g) for n in (3, 48, 3)]
+    mods = (d.feature_out, d.pos_deform, d.shs_deform, d.dino_head)
+
+    def run():
+        xg = x.clone().requires_grad_(True)
+        for p in d.parameters():
+            p.grad = None
+        outs = M.deform_mlp(xg, *mods)
+        sum((o * wi).sum() for o, wi in zip(outs, w)).backward()
+        return [o.detach() for o in outs] + [xg.grad, d.feature_out[0].weight.grad.clone(), d.shs_deform[1].weight.grad.clone()]
+
+    try:
+        exact = run()
+        M.set_mlp_arithmetic("bf16x3")
+        split = [run() for _ in range(3)]
+    finally:
+        M.set_mlp_arithmetic("f32")
+    for r in split[1:]:
+        for a, b in zip(r[:4], split[0][:4]):
+            assert torch.equal(a, b)                       # deterministic (the weight gradients are atomic sums: not compared bitwise)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    st = dict(what="mlp arithmetic bf16x3 vs f32", P=P, dx=rel(split[0][0], exact[0]), dshs=rel(split[0][1], exact[1]), feat=rel(split[0][2], exact[2]),
+              g_features=rel(split[0][3], exact[3]), gW0=rel(split[0][4], exact[4]), gS1=rel(split[0][5], exact[5]))
+    row = (split[0][3] - exact[3]).norm(dim=1) / exact[3].norm(dim=1).clamp_min(1e-20)
+    st["g_features_rows_off_by_1e-3"] = float((row > 1e-3).float().mean())
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/mlp_arithmetic_stats.jsonl", "a") as fh:
+        fh.write(json.dumps(st) + "\n")
+    assert max(st["dx"], st["dshs"], st["feat"]) < 1e-6, st
+    assert st["g_features_rows_off_by_1e-3"] < 2e-3, st
+    assert max(st["gW0"], st["gS1"]) < 5e-3, st
