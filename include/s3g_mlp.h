@@ -57,7 +57,9 @@ int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* feature
  *   S3G_MLP_F32     v_mfma_f32_32x32x2_f32, exact fp32 fma chains.
  *   S3G_MLP_BF16X3  v_mfma_f32_32x32x16_bf16 (the bf16 matrix pipe, 16 x the rate) with every fp32 operand -- weights, activations,
  *                   gradients -- split EXACTLY into three bf16 pieces and six piece products accumulated in fp32 per product: what
- *                   is dropped is <= 2^-23 of each product (fp32 accuracy; not bit-identical to S3G_MLP_F32).
+ *                   is dropped is <= 2^-23 of each product (fp32 accuracy; not bit-identical to S3G_MLP_F32).  The split is
+ *                   exact for 2^-110 <= |x| < 3.39e38 (smaller numbers keep an absolute error below 2^-133; larger ones
+ *                   become infinite like any bf16 conversion): tests/test_split_arith_cpu.py.
  * The weight-gradient GEMMs (K = points) are the exact fp32 chain in both modes.  Returns S3G_ERR_INVALID_ARG for another mode. */
 enum { S3G_MLP_F32 = 0, S3G_MLP_BF16X3 = 1 };
 int s3g_deform_mlp_set_arithmetic(int mode);

@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# S3G_LIB_PATH: load another build of the SAME ABI instead (kernel A/B experiments on the GPU box: tools/build_variant.sh);
+# S3G_LIB_PATH: load another build of the SAME ABI instead (kernel A/B experiments on the GPU box: tools/mkvariants.py);
 # the default, and the only path the tests and bench.py use, is the in-tree library.
 LIB_PATH = os.environ.get("S3G_LIB_PATH") or os.path.join(_HERE, "lib", "libs3g.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
