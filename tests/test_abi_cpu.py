@@ -133,3 +133,24 @@ def test_committed_bench_line_follows_the_contract():
     if not os.path.exists(path):
         pytest.skip("the round's bench line has not been collected yet (tools/collect_profiles.sh r03)")
     validate_bench_line(json.loads(open(path).read().strip().splitlines()[-1]), default_workload=True)
+
+
+def test_mlp_arithmetic_switch_round_trips_without_a_gpu():
+    """include/s3g_mlp.h::s3g_deform_mlp_set_arithmetic is a host-side, process-wide setting: default exact fp32, the two documented
+    modes accepted, anything else refused with S3G_ERR_INVALID_ARG and the setting left alone."""
+    import pytest
+    from s3gaussian_amd import _lib, mlp
+    L = _lib.lib()
+    L.s3g_last_error.restype = __import__("ctypes").c_char_p
+    assert mlp.get_mlp_arithmetic() == "f32" and L.s3g_deform_mlp_get_arithmetic() == 0
+    try:
+        mlp.set_mlp_arithmetic("bf16x3")
+        assert mlp.get_mlp_arithmetic() == "bf16x3" and L.s3g_deform_mlp_get_arithmetic() == 1
+        assert L.s3g_deform_mlp_set_arithmetic(7) != 0 and b"arithmetic" in L.s3g_last_error()
+        assert mlp.get_mlp_arithmetic() == "bf16x3"
+        with pytest.raises(ValueError):
+            mlp.set_mlp_arithmetic("bf16")
+    finally:
+        mlp.set_mlp_arithmetic("f32")
+    with pytest.raises(ValueError):          # the inference kernel's switch is validated before anything touches a device
+        mlp.deform_infer(None, None, None, None, None, None, None, arithmetic="fp16")
