@@ -747,7 +747,9 @@ __global__ void __launch_bounds__(NWAVE * 64) deform_infer_kernel(const InferArg
     // NOT to be enough: about one step in 10^3, on the younger wave of the SIMD (waves 4..7), stored stale values for the LAST
     // quarter of the wave (lanes 48..63 = two points: errors of 1e-1 in two adjacent rows, different rows every launch).  It never
     // happens with one wave per SIMD, nor beside the fp32 MFMAs of the exact kernel; waiting for the texel loads, for the LDS queue
-    // or for the wave's own MFMAs does not help; 16 wait states here do (profiles/r03_split_hazard.jsonl).
+    // or for the wave's own MFMAs does not help; 16 wait states here do (profiles/r03_split_hazard.jsonl).  (The
+    // per-component operands also make hipcc form the last products with plain v_mul_f32: the stored registers are no longer
+    // written by a packed instruction at all.  The tap slots are stored from v_mov copies, the coordinates by lanes 0..31 only.)
     if (SPLIT) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(prod.x), "+v"(prod.y), "+v"(prod.z), "+v"(prod.w));
     *reinterpret_cast<float4*>(stage + (8 * rr + slot) * STG_LD + c4) = prod;
   };
