@@ -82,8 +82,10 @@ def validate_bench_line(d, default_workload=True):
     ips = {k: v["iters_per_s"] for k, v in c["paths"].items() if k != "fused_mlp_bf16x3"}
     if "fused_mlp_bf16x3" in c["paths"]:     # the opt-in arithmetic of the MLP kernels: timed, never the headline
         assert c["paths"]["fused_mlp_bf16x3"].get("ms_per_step"), c["paths"]["fused_mlp_bf16x3"]
-    if "render_ms_per_frame_bf16x3" in c:
-        assert 0 < c["render_ms_per_frame_bf16x3"] <= 1.05 * c["render_ms_per_frame"]
+    if "render_ms_per_frame_bf16x3" in c:     # faster only where the deformation kernel matters: no ordering asserted on small scenes
+        assert c["render_ms_per_frame_bf16x3"] > 0
+        if default_workload:
+            assert c["render_ms_per_frame_bf16x3"] <= 1.05 * c["render_ms_per_frame"]
     assert ips["zero_diff"] < ips["import_swap"] < ips["patched"] <= ips["fused"] * 1.02, ips
     assert c["instances_R_per_view"] > 0 and c["visible_V_per_view"] > 0 and c["mean_tile_list_length"] > 0
     assert c["render_ms_per_frame"] > 0
