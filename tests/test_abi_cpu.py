@@ -133,6 +133,15 @@ def test_committed_bench_line_follows_the_contract():
     if not os.path.exists(path):
         pytest.skip("the round's bench line has not been collected yet (tools/collect_profiles.sh r03)")
     validate_bench_line(json.loads(open(path).read().strip().splitlines()[-1]), default_workload=True)
+    # the line of the final tree (both arithmetics timed) goes through the same checker; an unknown path key does not
+    split = os.path.join(ROOT, "profiles", "r03_bench_line_split.json")
+    if os.path.exists(split):
+        d = json.loads(open(split).read().strip().splitlines()[-1])
+        validate_bench_line(d, default_workload=True)
+        assert "fused_mlp_bf16x3" in d["config"]["paths"] and d["config"]["render_ms_per_frame_bf16x3"] < d["config"]["render_ms_per_frame"]
+        d["config"]["paths"]["something_else"] = {"ms_per_step": 1.0, "iters_per_s": 1000.0}
+        with pytest.raises(AssertionError):
+            validate_bench_line(d, default_workload=True)
 
 
 def test_mlp_arithmetic_switch_round_trips_without_a_gpu():
