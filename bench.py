@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32), the dtype the MLP computes in
+VALU_CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md: peak engine clock; 256 CUs x 4 SIMDs, a wave64 VALU instruction occupies a SIMD for 4 cycles
 
 
 def build_scene(P, width, height, n_frames, device, seed=0, scale_mult=1.0):
@@ -206,9 +207,9 @@ def cpu_baseline(P_full, width, height, seed=0):
     _time_iteration(max(2000, P_full // 40), width, height, seed, True, repeats=1, warm=False)
     t_full = _time_iteration(P_full, width, height, seed, True, repeats=1, warm=False)
     out = {"value": round(1.0 / t_full, 5), "unit": "iters/s", "cores": cores, "kind": "port", "what": "point_splat",
-           "sample": f"ONE full iteration of the workload itself ({P_full} Gaussians, {width}x{height}): reference-architecture PyTorch "
-                     f"hexplane+MLP+glue+losses, rasterizer stubbed to a nearest-pixel point splat: {t_full:.2f} s "
-                     f"(torch threads {threads} of {cores} cores); measured, not extrapolated"}
+           "sample": f"measured, not extrapolated: ONE full iteration of the workload itself ({P_full} Gaussians, {width}x{height}) in "
+                     f"{t_full:.2f} s -- reference-architecture PyTorch hexplane+MLP+glue+losses, rasterizer stubbed to a nearest-pixel "
+                     f"point splat (torch threads {threads} of {cores} cores)"}
     try:
         sizes = (max(2000, P_full // 120), max(6000, P_full // 40), max(20000, P_full // 4))
         est, model = _fit(P_full, width, height, seed, False, sizes)
@@ -392,11 +393,12 @@ def time_alt_paths(pc, cams, views, targets, tkeys, hyper, opt, bg, steps=4, war
     return out
 
 
-def workload_label(a):
+def workload_label(a, world=None):
     """Name of the workload, derived from the arguments: a BASELINE.json config name only when the run IS that config."""
+    world = a.gpus if world is None else world
     std = (a.width, a.height, a.frames, a.scale_mult) == (1600, 1066, 50, 1.0)
     if std and a.P == 1_200_000:
-        return "BASELINE cfg3 (configs[2])" if a.gpus == 1 else f"BASELINE cfg4 (configs[3]: cfg3 view-parallel over {a.gpus} ranks)"
+        return "BASELINE cfg3 (configs[2])" if world == 1 else f"BASELINE cfg4 (configs[3]: cfg3 view-parallel over {world} ranks)"
     if std and a.P == 600_000:
         return "BASELINE cfg2 (configs[1])"
     if std and a.P == 2_500_000:
@@ -404,7 +406,7 @@ def workload_label(a):
     return f"synthetic street scene, NOT a BASELINE config (scale_mult {a.scale_mult})"
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -425,19 +427,87 @@ def main():
     ap.add_argument("--reorder", action="store_true",
                     help="keep the Gaussians themselves in Morton order (GaussianParams.reorder_spatially() once after the scene is "
                          "built; a real run repeats it after every densification)")
-    a = ap.parse_args()
+    ap.add_argument("--sync-raster", action="store_true",
+                    help="rasterizer forward with the reference's one host wait per call (default: host-asynchronous, raster_C.ASYNC)")
+    return ap.parse_args(argv)
 
-    from s3gaussian_amd import _lib, dp
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (one process per GPU,
+    `torch.distributed.run --standalone`-style rendezvous on 127.0.0.1 and a FREE port) and return the launcher's exit code.
+    Refuses when the node has fewer than N GPUs, unless S3G_DIST_BACKEND=gloo asks for the functional oversubscribed run
+    (RCCL rejects two ranks on one device)."""
+    import subprocess
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < a.gpus and os.environ.get("S3G_DIST_BACKEND") != "gloo":
+        print(f"bench.py: --gpus {a.gpus} but this node has {n_dev} GPU(s); refusing to print a mislabelled line "
+              "(S3G_DIST_BACKEND=gloo runs the ranks on the GPUs there are, functional only)", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this image's driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def timed_loop(step, indices, world, device, after_step=None):
+    """Enqueue step(i) for i in indices.  -> (wall seconds from the barrier before to the barrier after -- MAX over ranks is taken by
+    the caller --, host seconds spent enqueuing, per-step stream milliseconds from one hipEvent pair per step).  Nothing in the
+    loop waits for the device (the rasterizer forward is host-asynchronous by default); the events are read afterwards."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(indices) + 1)]
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs[0].record()
+    for k, i in enumerate(indices):
+        out = step(i)
+        evs[k + 1].record()
+        if after_step is not None:
+            after_step(out)
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    per_step = [evs[k].elapsed_time(evs[k + 1]) for k in range(len(indices))]
+    return dt, t_enq, per_step
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    a = parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's N > 1 invocation goes through torch.distributed.run and sets WORLD_SIZE; a plain `bench.py --gpus N`
+        # must not print a 1-GPU line under an N-GPU label: launch the ranks here
+        raise SystemExit(launch_ranks(a, argv))
+
+    from s3gaussian_amd import _lib, dp, raster_C
     from s3gaussian_amd.pipeline import training_step
     rank, world, local = dp.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: the label would not match the run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # one rank per GPU; the modulo only matters for functional tests that oversubscribe one GPU (S3G_DIST_BACKEND=gloo)
     device = torch.device("cuda", local % torch.cuda.device_count() if world > 1 else 0)
     torch.cuda.set_device(device)
+    if a.sync_raster:
+        raster_C.set_async(False)
     import ctypes as C
     L = _lib.lib()
     L.s3g_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+
+    def clear_profile_slots():
+        for i in range(10):
+            L.s3g_profile_read(i, None, None, None)
 
     pc, cams, hyper, opt, bg = build_scene(a.P, a.width, a.height, a.frames, device, scale_mult=a.scale_mult)
     if a.reorder:
@@ -468,6 +538,7 @@ def main():
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()            # backward's last kernel is queued: from here on the stream waits for collectives + steps
             comm["events"].append([ev])
+            dp.reduce_skip_flag(device)     # a rank whose asynchronous forward overflowed makes EVERY replica drop this step
             g_xy, any_vis, rmax = dp.reduce_densification_stats(pkg["viewspace_points"].grad, pkg["visibility_filter"], pkg["radii"])
             dp.add_densification_stats(pc_.xyz_gradient_accum, pc_.denom, pc_.max_radii2D, g_xy, any_vis, rmax)
             if sparse is not None:
@@ -485,8 +556,6 @@ def main():
         ev.record()
         comm["events"][-1].append(ev)
 
-    visible, instances = [], []
-
     def step(i):
         v = views[i]
         gt_img, gt_depth, gt_feat = targets[v] if v in targets else targets[tkeys[i % len(tkeys)]]
@@ -496,69 +565,86 @@ def main():
                                   densify_stats=(world == 1), optimizer_step=optimizer_step if world > 1 else None)
         return loss, pkg
 
+    # ---- 1. the headline: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, with the
+    #         in-library kernel brackets OFF (they are hipEventCreate + hipEventRecord pairs inside the timed region otherwise) ----
+    L.s3g_profile_enable(0)
     for i in range(a.warmup):
         step(i)
-    if world > 1:
-        torch.distributed.barrier()
     torch.cuda.synchronize()
-    for i in range(10):
-        L.s3g_profile_read(i, None, None, None)
-    L.s3g_profile_enable(1)
+    raster_C.async_reset_statistics(device)
     comm.update(elems=0, events=[], sparse_rows=0)
     vis_masks = []     # summed after the timed region (workload statistics are not part of the step)
-    t0 = time.perf_counter()
-    for i in range(a.warmup, a.warmup + a.steps):
-        loss, pkg = step(i)
-        vis_masks.append(pkg["visibility_filter"])
-    torch.cuda.synchronize()
+    headline_idx = list(range(a.warmup, a.warmup + a.steps))
+    dt, t_enq, per_step = timed_loop(step, headline_idx, world, device, after_step=lambda out: vis_masks.append(out[1]["visibility_filter"]))
+    astat = raster_C.async_status(device, block=True)
+    if astat["overflows"]:
+        # a step whose forward overflowed its speculative arena did no work: the capacity has grown by now, time the loop again
+        vis_masks.clear()
+        comm.update(elems=0, events=[], sparse_rows=0)
+        raster_C.async_reset_statistics(device)
+        dt, t_enq, per_step = timed_loop(step, headline_idx, world, device, after_step=lambda out: vis_masks.append(out[1]["visibility_filter"]))
+        astat2 = raster_C.async_status(device, block=True)
+        astat2["overflows_in_discarded_first_attempt"] = len(astat["overflows"])
+        astat = astat2
+        if astat["overflows"]:
+            raise SystemExit("bench.py: the asynchronous rasterizer overflowed its arena twice in the timed region; run with --sync-raster")
     if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    L.s3g_profile_enable(0)
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, t_enq], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, t_enq = float(t[0].item()), float(t[1].item())
+    comm_timed = {"elems": comm["elems"], "events": list(comm["events"]), "sparse_rows": comm["sparse_rows"]}
 
-    # render ms/frame (the second half of BASELINE's metric): one render(stage="fine") under no_grad, SURVEY.md 3.5
+    # ---- 2. roofline leg: the SAME steps again with the nine hot kernels bracketed by hipEvent pairs inside libs3g.so -------
+    clear_profile_slots()
+    L.s3g_profile_enable(1)
+    _, _, per_step_instrumented = timed_loop(step, headline_idx, world, device)
+    L.s3g_profile_enable(0)
+    prof = {}
+    for i in range(9):
+        ms, x, y = C.c_double(), C.c_double(), C.c_double()
+        n = L.s3g_profile_read(i, C.byref(ms), C.byref(x), C.byref(y))
+        prof[i] = (n, ms.value / n, x.value / n, y.value / n) if n else (0, 0.0, 0.0, 0.0)
+
+    # ---- 3. render ms/frame (the second half of BASELINE's metric): one render(stage="fine") under no_grad, SURVEY.md 3.5 ----
     from types import SimpleNamespace
     from s3gaussian_amd.pipeline import render as render_fn
     pipe = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
-    with torch.no_grad():
+    n_frames = 20
+
+    def render_loop():
         for i in range(3):
             render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
         torch.cuda.synchronize()
-        L.s3g_profile_read(9, None, None, None)
-        L.s3g_profile_enable(1)
         t1 = time.perf_counter()
-        n_frames = 20
         for i in range(n_frames):
             render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
         torch.cuda.synchronize()
-        render_ms = 1000.0 * (time.perf_counter() - t1) / n_frames
+        return 1000.0 * (time.perf_counter() - t1) / n_frames
+
+    with torch.no_grad():
+        render_ms = render_loop()
+        clear_profile_slots()
+        L.s3g_profile_enable(1)          # a separate, instrumented pass for the inference kernel's own time
+        for i in range(8):
+            render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
+        torch.cuda.synchronize()
         L.s3g_profile_enable(0)
         _ms = C.c_double()
         _n = L.s3g_profile_read(9, C.byref(_ms), None, None)
         infer_kernel_ms = (_ms.value / _n) if _n else None   # s3g::deform_infer_kernel (HexPlane (+) MLP heads), per frame
+        clear_profile_slots()
         # the same frames with the inference kernel's GEMM layers on the bf16 matrix pipe (exactly split operands: fp32 accuracy,
         # include/s3g_mlp.h::s3g_deform_infer_split) -- reported beside the default, which stays the exact fp32 chain
         import s3gaussian_amd.deformation as _deformation
         _arith = _deformation.INFER_ARITHMETIC
         _deformation.INFER_ARITHMETIC = "bf16x3"
         try:
-            for i in range(3):
-                render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(n_frames):
-                render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
-            torch.cuda.synchronize()
-            render_split_ms = 1000.0 * (time.perf_counter() - t1) / n_frames
+            render_split_ms = render_loop()
         finally:
             _deformation.INFER_ARITHMETIC = _arith
 
     if rank == 0:
-        # ---- roofline leg: every hot kernel timed in-library with hipEvents on the launch stream (include/s3g_raster.h),
+        # ---- roofline: every hot kernel timed in-library with hipEvents on the launch stream (include/s3g_raster.h),
         # priced against its ALGORITHMIC bytes / flops (DESIGN.md section 7 states each model) -----------------------------
         V = float(sum(int(m.sum()) for m in vis_masks)) / max(a.steps, 1)    # mean visible Gaussians per step (both raster calls share them)
         P = float(a.P)
@@ -569,22 +655,22 @@ def main():
         FEAT = 32.0 * levels
         MLP_FLOP = 2.0 * (128 * 64 + 4 * 64 * 64 + 2 * 64 * 3 + 64 * 48)   # per point and direction: 56064
         pair = bool(hyper.feat_head)   # pipeline.render blends both images of an iteration in one pass each way
+        N_pix = float(a.width * a.height)
+        # instances per view: the asynchronous forward does not know R when it records its bracket (it reports -1); the true
+        # counts arrive through the status ring (raster_C.async_status) -- synchronous forward: the bracket carries them
+        R_mean = astat["mean_instances"] if (astat.get("drained") and astat.get("mean_instances")) else max(prof[0][2], 0.0)
 
-        def read(i):
-            ms, x, y = C.c_double(), C.c_double(), C.c_double()
-            n = L.s3g_profile_read(i, C.byref(ms), C.byref(x), C.byref(y))
-            return (n, ms.value / n, x.value / n, y.value / n) if n else (0, 0.0, 0.0, 0.0)
-
-        # id -> (kernel, STRICT algorithmic bytes(R or P, pixels), implementation bytes incl. scratch, flops).
+        # id -> (kernel, STRICT algorithmic bytes, implementation bytes incl. scratch, flops) as functions of the bracket's (x, y).
         # Strict = SURVEY 8(d): what the math must read and write (inputs, outputs, parameters once); scratch that exists only
         # because of how this implementation is split into kernels (G slab, activation stash, gradient signals) is counted
         # under implementation bytes and never enters `frac`.
         G_ROWS = float(L.s3g_hexplane_backward_scratch_rows(int(levels)))   # 128-byte rows of scratch per point (r2: 24, r3: 4)
+        RB = lambda R_, N_: (56.0 if pair else 44.0) * R_mean + (36.0 if pair else 24.0) * N_
         models = {
             # two-image pass (RGB+depth and feature image from one geometry): + colors2 per instance, + one image per pixel
-            0: ("s3g::blend_forward_kernel", lambda R, N: (56.0 if pair else 44.0) * R + (36.0 if pair else 24.0) * N, None, None),
-            1: ("s3g::blend_backward_kernel", lambda R, N: (56.0 if pair else 44.0) * R + (36.0 if pair else 24.0) * N + 40.0 * V,
-                lambda R, N: (56.0 if pair else 44.0) * R + (36.0 if pair else 24.0) * N + (56.0 if pair else 40.0) * R, None),
+            0: ("s3g::blend_forward_kernel", RB, None, None),
+            1: ("s3g::blend_backward_kernel", lambda R_, N_: RB(R_, N_) + 40.0 * V,
+                lambda R_, N_: RB(R_, N_) + (56.0 if pair else 40.0) * R_mean, None),
             2: ("s3g::hexplane_forward_kernel", lambda n, l: n * (16.0 + 4.0 * FEAT) + plane_bytes, None, None),
             # xyz,t 16 B + dL/dfeatures 4F B read, dL/dxyz 12 B written, planes read once; the scratch rows are implementation
             3: ("s3g::hexplane_backward_point_kernel", lambda n, l: n * (28.0 + 4.0 * FEAT) + plane_bytes,
@@ -605,7 +691,7 @@ def main():
             7: ("s3g::mlp_wgrad_all_kernel", lambda n, _: n * 512.0, lambda n, _: n * 3288.0, lambda n: n * MLP_FLOP),
             8: ("s3g::adam_kernel", lambda n, _: n * 28.0, None, None),   # p, g, m, v read; p, m, v written
         }
-        traffic_db, traffic_launches, traffic_source = {}, {}, None
+        traffic_db, traffic_launches, traffic_source, valu_db = {}, {}, None, {}
         default_workload = (a.P, a.width, a.height, a.frames, a.scale_mult) == (1_200_000, 1600, 1066, 50, 1.0)
         pmc = os.path.join(ROOT, "profiles", "kernel_traffic.json")
         if os.path.exists(pmc) and default_workload:   # the PMC passes were collected on the default workload only
@@ -613,18 +699,18 @@ def main():
                 db = json.load(open(pmc))
                 traffic_db = db.get("hbm_bytes_per_launch", {})
                 traffic_launches = db.get("launches_per_bracket", {})
-                traffic_source = ("profiles/kernel_traffic.json: " + db.get("command", "rocprofv3 --pmc passes") +
-                                  " -- NOT collected in this run; hipEvent times are")
+                valu_db = db.get("valu_wave_instructions_per_launch", {})   # SQ_INSTS_VALU pass of the same command
+                traffic_source = ("NOT collected in this run (the hipEvent times are): profiles/kernel_traffic.json: " +
+                                  db.get("command", "rocprofv3 --pmc passes"))
             except Exception:
                 traffic_db = {}
         kernels = []
-        R_mean = 0.0
         for i, (name, fbytes, fimpl, fflops) in models.items():
-            n, avg_ms, x, y = read(i)
+            n, avg_ms, x, y = prof[i]
             if not n:
                 continue
-            if i == 0:
-                R_mean = x
+            if i in (0, 1):
+                y = N_pix
             nbytes = fbytes(x, y)
             t = avg_ms * 1e-3
             gbs = nbytes / t / 1e9
@@ -639,10 +725,22 @@ def main():
                             "mfma_frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4)})
                 if tf / PEAK_MFMA_F32_TFLOPS > frac:   # the roof this kernel sits closer to
                     bound, frac = "mfma", tf / PEAK_MFMA_F32_TFLOPS
-            ent["bound"] = bound
+            base = name.split(" ")[0]
+            if i in (0, 1):
+                # the blend passes are VALU / v_exp-bound in dense tiles (~80 FLOP/B >> the 25 FLOP/B machine
+                # balance).  VALU roof: a wave64 instruction holds its 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs at
+                # VALU_CLOCK_GHZ.  Instruction counts are PMC data (SQ_INSTS_VALU), like `traffic` not collected in this run.
+                ent["bound"] = "valu"
+                if base in valu_db:
+                    busy_ms = valu_db[base] * 4.0 / (1024.0 * VALU_CLOCK_GHZ * 1e9) * 1e3
+                    ent.update({"valu_wave_instructions_per_launch": valu_db[base], "valu_issue_ms": round(busy_ms, 4),
+                                "valu_frac": round(busy_ms / avg_ms, 4)})
+                    bound, frac = "valu", busy_ms / avg_ms
+                else:
+                    ent["valu_frac"] = None   # no SQ_INSTS_VALU pass for this workload: the HBM figure below is NOT this kernel's roof
+            ent["bound"] = bound if i not in (0, 1) else "valu"
             ent["frac"] = round(frac, 4)
             ent["ms_per_step"] = round(avg_ms * n / a.steps, 4)
-            base = name.split(" ")[0]
             if base in traffic_db:   # PMC bytes per launch (the wgrad bracket may cover several launches)
                 ent["traffic"] = traffic_db[base] * (traffic_launches.get(base, 1) if i == 7 else 1)
             kernels.append(ent)
@@ -658,28 +756,41 @@ def main():
             roof.update({"avg_launch_ms": dom["avg_launch_ms"], "launches_per_step": dom["launches_per_step"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                          "implementation_bytes_per_launch": dom["implementation_bytes_per_launch"],
-                         "traffic_source": traffic_source, "kernels": kernels})
+                         "traffic_source": traffic_source, "kernels": kernels,
+                         "bracketed_kernels_ms_per_step": round(sum(k["ms_per_step"] for k in kernels), 4),
+                         "timed_in": "a separate instrumented loop over the same steps (the headline loop runs with the brackets off)"})
         # the HexPlane backward is ONE operation split into two kernels by this implementation (per-point pass + scatter walks):
         # their combined figures, for information next to the per-kernel entries (the top-level fields stay per kernel)
-        pair = [k for k in kernels if k["kernel"] in ("s3g::hexplane_backward_point_kernel", "s3g::hexplane_scatter_kernel")]
-        if roof is not None and len(pair) == 2:
-            ms = sum(k["avg_launch_ms"] for k in pair)
-            nb = sum(k["algorithmic_bytes_per_launch"] for k in pair)
-            tr = [k.get("traffic") for k in pair]
+        hb = [k for k in kernels if k["kernel"] in ("s3g::hexplane_backward_point_kernel", "s3g::hexplane_scatter_kernel")]
+        if roof is not None and len(hb) == 2:
+            ms = sum(k["avg_launch_ms"] for k in hb)
+            nb = sum(k["algorithmic_bytes_per_launch"] for k in hb)
+            tr = [k.get("traffic") for k in hb]
             roof["hexplane_backward_pair"] = {"ms": round(ms, 4), "algorithmic_bytes": nb, "hbm_GBps": round(nb / (ms * 1e-3) / 1e9, 1),
                                               "frac": round(nb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                               "traffic": sum(tr) if all(t is not None for t in tr) else None}
         fwd = next((k for k in kernels if k["kernel"] == "s3g::blend_forward_kernel"), None)
+        srt = sorted(per_step)
         out = {
             "metric": "train_iters_per_sec", "value": round(world * a.steps / dt, 3), "unit": "iters/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_label(a) + f": {a.P} Gaussians, {a.height}x{a.width}, 3 cams x {a.frames} frames, fine stage "
+            # one hipEvent pair per step on the launch stream (rank 0): stream time between step boundaries; next to the host's
+            # own time to ENQUEUE a step -- the step is GPU-bound while the second stays below the first
+            "step_ms_min": round(srt[0], 3), "step_ms_median": round(srt[len(srt) // 2], 3), "step_ms_max": round(srt[-1], 3),
+            "gpu_ms_per_step": round(sum(per_step) / len(per_step), 3),
+            "host_enqueue_ms_per_step": round(1000.0 * t_enq / a.steps, 3),
+            "instrumented_loop_ms_per_step": round(sum(per_step_instrumented) / len(per_step_instrumented), 3),
+            "config": {"workload": workload_label(a, world) + f": {a.P} Gaussians, {a.height}x{a.width}, 3 cams x {a.frames} frames, fine stage "
                                    "(hexplane+deformation ON), RGB+depth render + feature render, L1+DSSIM+depthL2+featL2+regs, Adam",
                        "path": "fused", "gaussians": a.P, "image": [a.height, a.width], "views_per_step_per_rank": 1,
                        "scale_mult": a.scale_mult, "gaussians_in_morton_order": bool(a.reorder), "instances_R_per_view": round(R_mean), "visible_V_per_view": round(V),
                        "mean_tile_list_length": round(R_mean / (((a.width + 15) // 16) * ((a.height + 15) // 16)), 1),
                        "densify_bookkeeping_in_step": True,
+                       "rasterizer_forward": ("host-asynchronous (speculative arena capacity, s3g_raster_forward_async)" if astat.get("enabled")
+                                              else "synchronous (one host wait per forward, like the reference)"),
+                       "raster_async": {k: astat.get(k) for k in ("enabled", "calls", "drained", "overflows", "overflows_in_discarded_first_attempt")
+                                        if k in astat},
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
                        "blend_forward_avg_ms": fwd["avg_launch_ms"] if fwd else None,
                        "render_ms_per_frame": round(render_ms, 3),
@@ -691,28 +802,37 @@ def main():
             # what the all-reduce cost this rank: stream time from "backward queued" to "optimizer step queued" minus the Adam
             # kernel itself = waiting for collectives + the small statistics reduces.  NO multi-GPU run has been measured in the
             # build sandbox (one GPU per lease); these fields exist so that the first SCALE run explains itself.
-            tail = [e[0].elapsed_time(e[1]) for e in comm["events"] if len(e) == 2]
+            tail = [e[0].elapsed_time(e[1]) for e in comm_timed["events"] if len(e) == 2]
             adam = next((k["ms_per_step"] for k in kernels if k["kernel"] == "s3g::adam_kernel"), 0.0)
-            out["comm"] = {"backend": torch.distributed.get_backend(), "bytes_reduced_per_step_per_rank": round(4.0 * comm["elems"] / max(a.steps, 1)),
+            backend = torch.distributed.get_backend()
+            try:
+                lib_version = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+            except Exception:
+                lib_version = None
+            dev_ids = [None] * world
+            torch.distributed.all_gather_object(dev_ids, f"{os.uname().nodename}:cuda:{device.index}")
+            out["comm"] = {"backend": backend, "world_size": torch.distributed.get_world_size(), "rccl_version": lib_version,
+                           "devices": dev_ids, "distinct_devices": len(set(dev_ids)),
+                           "bytes_reduced_per_step_per_rank": round(4.0 * comm_timed["elems"] / max(a.steps, 1)),
                            "tail_ms_backward_end_to_step_end": round(sum(tail) / max(len(tail), 1), 3), "adam_ms_per_step": adam,
                            "comm_ms_exposed": round(max(sum(tail) / max(len(tail), 1) - adam, 0.0), 3),
                            "optimizer_step": "single phase" if (a.single_phase_step or a.sparse_rows) else "two phases (dp.finish_and_step)",
                            "sparse_row_exchange": bool(a.sparse_rows),
-                           "sparse_rows_per_step": round(comm["sparse_rows"] / max(a.steps, 1)) if a.sparse_rows else None}
+                           "sparse_rows_per_step": round(comm_timed["sparse_rows"] / max(a.steps, 1)) if a.sparse_rows else None,
+                           "scaling_curve_measured_by_the_builder": False}
         if world == 1 and not a.no_alt_paths:
             out["config"]["paths"] = {"fused": {"ms_per_step": out["ms_per_step"], "iters_per_s": out["value"]}}
             out["config"]["paths"].update(time_alt_paths(pc, cams, views, targets, tkeys, hyper, opt, bg))
+            out["config"]["paths_note"] = ("`patched` / `import_swap` / `zero_diff` are restatements of train.py's iteration body inside "
+                                           "bench.py (the reference tree does not exist on the GPU box); the reference's own render() / "
+                                           "train.py have not been executed against the drop-ins on a GPU")
             try:   # the fused step again with the MLP kernels' per-point GEMM chains on the bf16 matrix pipe (opt-in, fp32 accuracy)
                 from s3gaussian_amd import mlp as _mlp
                 _mlp.set_mlp_arithmetic("bf16x3")
                 for i in range(3):
                     step(i % len(views))
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
-                for i in range(a.steps):
-                    step(i % len(views))
-                torch.cuda.synchronize()
-                ms2 = 1000.0 * (time.perf_counter() - t2) / a.steps
+                dt2, _, _ = timed_loop(step, [i % len(views) for i in range(a.steps)], 1, device)
+                ms2 = 1000.0 * dt2 / a.steps
                 out["config"]["paths"]["fused_mlp_bf16x3"] = {"ms_per_step": round(ms2, 3), "iters_per_s": round(1000.0 / ms2, 2), "steps": a.steps}
             except Exception as ex:   # never take the headline down
                 out["config"]["paths"]["fused_mlp_bf16x3"] = {"ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"}
@@ -723,7 +843,9 @@ def main():
             try:
                 pj = json.load(open(psnr_file))
                 md = pj.get("mean_psnr_delta_db")     # per split (train / held-out views): what an evaluation reports
-                out["config"]["psnr_delta_vs_oracle_db"] = max(abs(v) for v in md.values()) if md else pj.get("max_abs_delta_db")
+                # rounds 1-2 reported the worst single view under "psnr_delta_vs_oracle_db"; since round 3 the 0.1 dB bar is on the
+                # split MEANS (two fp32 trainings diverge chaotically per view): both are printed under names that say which
+                out["config"]["psnr_mean_delta_vs_oracle_db"] = max(abs(v) for v in md.values()) if md else None
                 out["config"]["psnr_worst_single_view_delta_db"] = pj.get("max_abs_delta_db")
                 out["config"]["psnr_parity_source"] = "profiles/psnr_parity.json: " + pj.get("what", "")
             except Exception:
@@ -736,6 +858,7 @@ def main():
                                        "sample": f"failed: {type(ex).__name__}: {ex}"}
         print(json.dumps(out))
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

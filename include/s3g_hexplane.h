@@ -36,7 +36,8 @@ typedef struct s3g_hexplane_desc {
                                               * render() always calls the field (gaussian_renderer/__init__.py:58:
                                               * one camera timestamp repeated P times).  The three time planes of a level
                                               * are then pre-interpolated along t into 1-D row tables once per call and
-                                              * sampled with 2 taps instead of 4. */
+                                              * sampled with 2 taps instead of 4.  Only time[0] is read then: the
+                                              * `time` arrays below may hold a single element. */
 } s3g_hexplane_desc;
 
 /* features [P, levels*32].  xyz [P,3], time [P] (device fp32).  proc_order: optional (may be NULL) permutation of

@@ -35,6 +35,15 @@ typedef struct s3g_adam_tensor {
  * 1 - beta in double before rounding to fp32 (1 - fp32(0.999) differs from fp32(0.001) by 1.3e-5 relative). */
 int s3g_adam_step(int n, const s3g_adam_tensor* tensors /* host array */, double beta1, double beta2, void* stream);
 
+/* The same step behind a device-side guard: if *skip_flag (device uint32, read by the kernel when it runs) is non-zero the
+ * launch changes nothing.  Pairs with s3g_raster_forward_async (s3g_raster.h): a forward whose instance count exceeded its
+ * speculative arena renders nothing and back-propagates zeros; with its `status_device` word as skip_flag the optimizer step
+ * of that iteration is dropped as well, so the model is exactly what it was before the iteration and the view can be rendered
+ * again once the host has noticed -- without the host ever waiting for the device inside an iteration.  skip_flag == NULL:
+ * identical to s3g_adam_step. */
+int s3g_adam_step_guarded(int n, const s3g_adam_tensor* tensors /* host array */, double beta1, double beta2,
+                          const unsigned int* skip_flag /* device */, void* stream);
+
 /* Densification bookkeeping of one iteration in one pass over [P] (train.py:489-493 +
  * scene/gaussian_model.py:693-695; the reference: ~8 indexing / norm / max launches):
  *     where visible[i]:  xyz_gradient_accum[i] += sqrt(gx^2 + gy^2);  denom[i] += 1;

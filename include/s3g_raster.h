@@ -105,6 +105,43 @@ int s3g_raster_forward2(const s3g_raster_inputs* in, const float* colors2,
                         float* out_color, float* out_depth, float* out_color2, int* radii,
                         int* num_rendered, void* stream /* hipStream_t */);
 
+/* Host-asynchronous forward ("remove the host sync").  s3g_raster_forward / _forward2 wait for the
+ * device once per call, exactly where the reference does (rasterizer_impl.cu:281-282), because the instance count R sizes the
+ * binning arena.  Here the caller sizes the arenas BEFORE the call for a speculative capacity -- as many (tile, Gaussian)
+ * instances and rect slots as it is prepared to hold, e.g. twice the largest count it has seen -- and the call only enqueues
+ * kernels: the host can run any number of iterations ahead of the GPU.
+ *   arenas            device, at least s3g_raster_arena_bytes(...) bytes each, 128-byte aligned, caller-owned;
+ *   sort_lds_keys     estimate of the longest per-tile list (sizes the LDS buffer of the short-list sort launch; lists that
+ *                     exceed it are sorted in global memory; 0 = 4096);
+ *   long_lists        != 0: also launch the long-list sort pass (lists of more than 4096 instances);
+ *   status_device     optional device word, written by EVERY call: bit 0 = the counts exceeded the capacity (instances >
+ *                     capacity_instances, slots > capacity_slots, or a list > 4096 with long_lists == 0), bit 1 = a Gaussian was
+ *                     culled although in->prefiltered was set.  On overflow the call renders the background only, every list is
+ *                     empty, the matching backward returns zero gradients and skips the densification bookkeeping -- a
+ *                     well-defined no-op that s3g_adam_step_guarded (s3g_optim.h) can be told to honour, never an
+ *                     out-of-bounds write;
+ *   status_host       optional PINNED host array of 8 words, filled by a copy enqueued behind the counting kernels:
+ *                     [0] instances binned (0 on overflow) [1] longest list [2] error bits [3] slots [4] overflow
+ *                     [5] true instance count [6] true slot count.  Valid once `stream` has passed this call (record an event
+ *                     after it and poll); a caller that sees [4] != 0 raises its capacity and renders that view again.
+ * The matching backward is the ordinary one with R = capacity_instances (the arena layout depends on it), workspace sized for
+ * that R.  colors2 / out_color2: both NULL (one image) or both given (the two-image pass of s3g_raster_forward2). */
+typedef struct s3g_raster_async {
+  uint32_t capacity_instances;
+  uint32_t capacity_slots;      /* >= capacity_instances (slots = rect areas before the exact cull) */
+  uint32_t sort_lds_keys;
+  int long_lists;
+  void* geometry_arena;
+  void* binning_arena;
+  void* image_arena;
+  uint32_t* status_device;
+  uint32_t* status_host;
+} s3g_raster_async;
+int s3g_raster_arena_bytes(int P, int width, int height, uint32_t capacity_instances, uint32_t capacity_slots,
+                           size_t* geometry_bytes, size_t* binning_bytes, size_t* image_bytes);
+int s3g_raster_forward_async(const s3g_raster_inputs* in, const float* colors2, const s3g_raster_async* async_,
+                             float* out_color, float* out_depth, float* out_color2, int* radii, void* stream);
+
 /* Backward.  `R` is the num_rendered returned by the matching forward; radii / arenas are the ones it filled.
  * `workspace`: device scratch of s3g_raster_backward_workspace_bytes(P, R) bytes (per-instance gradient records;
  * contents need no initialisation and are dead after the call).
@@ -188,7 +225,7 @@ int s3g_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 /* Optional in-library timing of the hot kernels with hipEvent pairs recorded on the launch stream (bench.py's roofline
  * leg).  s3g_profile_read sums and clears the recorded launches of one id (synchronising on their events) and returns
  * how many there were; the two totals are per-id work counts:
- *   blend kernels: (sorted instances R, pixels)   hexplane kernels: (points P, levels)   MLP kernels: (points P, 0)
+ *   blend kernels: (sorted instances R -- -1 per launch of the asynchronous forward, which does not know it --, pixels)   hexplane kernels: (points P, levels)   MLP kernels: (points P, 0)
  *   Adam: (parameters updated, 0).
  * MLP_WGRAD brackets the nine weight-gradient launches of one backward call. */
 enum {

@@ -12,10 +12,12 @@ constexpr bool ADAM_NONTEMPORAL = true;   // streaming loads / stores: 0.605 -> 
 struct AdamArgs {
   s3g_adam_tensor t[S3G_ADAM_MAX_TENSORS];
   float beta1, beta2, w1, w2;  // w_k = 1 - beta_k rounded from DOUBLE, like torch's python-side `1 - beta`
+  const uint32_t* skip;        // optional device word: != 0 -> the whole step is a no-op (s3g_adam_step_guarded)
 };
 
 // grid = (blocks per tensor, tensors): a tensor is swept by its own row of workgroups with 16-byte accesses
 __global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
+  if (a.skip != nullptr && *a.skip != 0u) return;   // uniform: one scalar load
   const s3g_adam_tensor& t = a.t[blockIdx.y];
   const float b2 = a.beta2, w1 = a.w1, w2 = a.w2;
   const float step_size = t.step_size, isb = t.inv_sqrt_bc2, eps = t.eps, gs = t.grad_scale;
@@ -84,7 +86,17 @@ extern "C" int s3g_densify_stats(int P, const float* grad_xy, int grad_stride, c
   return S3G_OK;
 }
 
+static int adam_step_impl(int n, const s3g_adam_tensor* tensors, double beta1, double beta2, const uint32_t* skip, void* stream_);
+
 extern "C" int s3g_adam_step(int n, const s3g_adam_tensor* tensors, double beta1, double beta2, void* stream_) {
+  return adam_step_impl(n, tensors, beta1, beta2, nullptr, stream_);
+}
+extern "C" int s3g_adam_step_guarded(int n, const s3g_adam_tensor* tensors, double beta1, double beta2,
+                                     const uint32_t* skip_flag, void* stream_) {
+  return adam_step_impl(n, tensors, beta1, beta2, skip_flag, stream_);
+}
+
+static int adam_step_impl(int n, const s3g_adam_tensor* tensors, double beta1, double beta2, const uint32_t* skip, void* stream_) {
   if (n < 0 || n > S3G_ADAM_MAX_TENSORS || (n > 0 && !tensors)) {
     set_error("s3g_adam_step: bad argument (at most %d tensors per call)", S3G_ADAM_MAX_TENSORS);
     return S3G_ERR_INVALID_ARG;
@@ -104,6 +116,7 @@ extern "C" int s3g_adam_step(int n, const s3g_adam_tensor* tensors, double beta1
     total += t.numel;
   }
   a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.w1 = (float)(1.0 - beta1); a.w2 = (float)(1.0 - beta2);
+  a.skip = skip;
   const size_t want = (largest / 4 + 255) / 256;
   const int bx = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
   profile_begin(S3G_PROFILE_ADAM, (hipStream_t)stream_);

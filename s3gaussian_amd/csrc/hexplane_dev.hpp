@@ -77,7 +77,7 @@ __device__ __forceinline__ void point_coords(const HexArgs& a, int p, float* u) 
 #pragma unroll
   for (int k = 0; k < 3; k++)
     u[k] = (a.xyz[3 * (size_t)p + k] - a.d.aabb_max[k]) * (2.0f / (a.d.aabb_min[k] - a.d.aabb_max[k])) - 1.0f;
-  u[3] = a.time[p];
+  u[3] = a.d.uniform_time ? a.time[0] : a.time[p];   // uniform time: `time` may hold a single element (s3g_hexplane.h)
 }
 
 // coordinate pairs in itertools.combinations(range(4), 2) order

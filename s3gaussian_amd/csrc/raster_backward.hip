@@ -274,6 +274,7 @@ struct GeomBwdArgs {
   const uint32_t* tile_hi;        // absolute end of the written records of each tile
   const float* records;           // [R][NREC]
   const float4* conic_opacity;
+  const uint32_t* ctrl;           // forward's control words: ctrl[4] != 0 = asynchronous forward overflowed, nothing was binned
   // outputs (every element of every output is written, zeros for culled Gaussians)
   float* dL_dmean2D;        // [P,3]
   float* dL_dconic;         // [P,4]  optional (may be NULL)
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(256) geometry_backward_kernel(const GeomBwdArg
   const bool live = gid < a.P;
   const int idx = live ? gid : a.P - 1;  // keep every lane alive for the wave-cooperative gather below
   const size_t i3 = 3 * (size_t)idx;
-  const bool vis = live && a.radii[idx] > 0;
+  const bool vis = live && a.radii[idx] > 0 && a.ctrl[4] == 0u;   // overflowed asynchronous forward: zero gradients, no bookkeeping
 
   // ---- gather the per-instance records of this Gaussian (one per tile of its rect) ----
   float acc[NR];
@@ -618,7 +619,7 @@ static int raster_backward_impl(const char* who, const s3g_raster_inputs* in, co
   ga.tan_fovx = in->tan_fovx; ga.tan_fovy = in->tan_fovy;
   ga.W = W; ga.H = H; ga.gx = gx;
   ga.rect = g.rect; ga.gauss_off = g.gauss_off; ga.slot_pos = b.slot_pos; ga.tile_hi = im.tile_hi;
-  ga.records = records; ga.conic_opacity = g.conic_opacity;
+  ga.records = records; ga.conic_opacity = g.conic_opacity; ga.ctrl = im.ctrl;
   ga.dL_dmean2D = dL_dmean2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolor = dL_dcolor;
   ga.dL_dcolor2 = dL_dcolor2; ga.dL_ddepth = dL_ddepth;
   ga.dL_dmean3D = dL_dmean3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dsh = dL_dsh; ga.dL_dscale = dL_dscale; ga.dL_drot = dL_drot;

@@ -224,6 +224,7 @@ struct BinArgs {
   const float2* means2D;
   const float4* conic_opacity;
   const uint32_t* tile_mask;       // from preprocess_kernel (rects of <= BIG_RECT tiles)
+  const uint32_t* ctrl;            // bin_write only: ctrl[4] != 0 = the speculative arena capacity was exceeded, write nothing
 };
 
 template <bool WRITE>
@@ -231,6 +232,7 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [tiles] histogram / cursors, then 8 words of scratch
   uint32_t* cell = lds;
   uint32_t* wsum = lds + a.tile_n;  // [4] wave totals + [1] carry
+  if (WRITE && a.ctrl[4] != 0u) return;  // host-asynchronous forward: the instances do not fit the arena (see scan_tiles_kernel)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t* trow = a.table + (size_t)blockIdx.x * a.tiles;
   for (int i = tid; i < a.tile_n; i += BIN_THREADS) cell[i] = WRITE ? a.ranges[a.tile_lo + i].x + trow[a.tile_lo + i] : 0u;
@@ -357,9 +359,16 @@ __device__ __forceinline__ uint32_t block_inclusive_scan_1024(uint32_t v, uint32
   return incl;
 }
 
+// Host-asynchronous forward (s3g_raster_forward_async): the binning arena was sized BEFORE this kernel knew R.  cap_R != 0
+// turns the capacity check on: if R > cap_R, S > cap_S or the longest list > cap_tile, ctrl[4] = 1, every range is emptied and
+// R / S read as 0, so that every later kernel of the forward AND of the backward finds nothing to do (bin_write and the
+// per-Gaussian backward also look at ctrl[4] themselves); the true counts stay in ctrl[5..6] for the host, which reads them
+// late, without stalling.  *status (optional device word, written on every call): bit 0 = overflow, bit 1 = a Gaussian was
+// culled although `prefiltered` was set.
 __global__ void __launch_bounds__(1024) scan_tiles_kernel(int tiles, const uint32_t* __restrict__ tile_count,
                                                           uint2* __restrict__ ranges, uint32_t* __restrict__ ctrl,
-                                                          int nb, uint32_t* __restrict__ chunk_total) {
+                                                          int nb, uint32_t* __restrict__ chunk_total, uint32_t cap_R,
+                                                          uint32_t cap_S, uint32_t cap_tile, uint32_t* __restrict__ status) {
   __shared__ uint32_t buf[2][1024];
   __shared__ uint32_t wmax[16];
   const int tid = threadIdx.x;
@@ -384,12 +393,26 @@ __global__ void __launch_bounds__(1024) scan_tiles_kernel(int tiles, const uint3
   for (int off = 32; off >= 1; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off));
   if ((tid & 63) == 0) wmax[tid >> 6] = vmax;
   __syncthreads();
+  uint32_t m = 0;
+  for (int w = 0; w < 16; w++) m = max(m, wmax[w]);
+  const bool overflow = cap_R != 0u && (carry > cap_R || total > cap_S || m > cap_tile);   // `total` = S (last scan above)
+  if (overflow)
+    for (int i = tid; i < tiles; i += 1024) ranges[i] = make_uint2(0u, 0u);
   if (tid == 0) {
-    uint32_t m = 0;
-    for (int w = 0; w < 16; w++) m = max(m, wmax[w]);
-    ctrl[0] = carry;
+    ctrl[0] = overflow ? 0u : carry;
     ctrl[1] = m;
+    if (overflow) ctrl[3] = 0u;
+    ctrl[4] = overflow ? 1u : 0u;
+    ctrl[5] = carry;
+    ctrl[6] = total;
+    if (status) *status = (overflow ? 1u : 0u) | ((ctrl[2] & 1u) ? 2u : 0u);
   }
+}
+
+// slot_pos[0 .. S) = 0xffffffff ("tile culled") with S read on the device (the asynchronous forward does not know it).
+__global__ void __launch_bounds__(256) fill_slots_kernel(uint32_t* __restrict__ slot_pos, const uint32_t* __restrict__ ctrl) {
+  const uint32_t S = ctrl[3];
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < S; i += gridDim.x * 256u) slot_pos[i] = 0xffffffffu;
 }
 
 // =========================================================================================================
@@ -692,19 +715,27 @@ static inline uint32_t round_up8(uint32_t v) { return (v + 7u) & ~7u; }
 using namespace s3g;
 
 extern "C" const char* s3g_last_error(void) { return g_err; }
-extern "C" int s3g_abi_version(void) { return 9; }
+extern "C" int s3g_abi_version(void) { return 10; }
 
+// as != NULL: the host-asynchronous variant (s3g_raster_forward_async) -- arenas are the caller's, sized for a speculative
+// capacity, and nothing below waits for the device.
 static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2, float* out_color2,
                                s3g_resize_fn geometry_buffer, void* geometry_user, s3g_resize_fn binning_buffer,
                                void* binning_user, s3g_resize_fn image_buffer, void* image_user, float* out_color,
-                               float* out_depth, int* radii, int* num_rendered, void* stream_) {
+                               float* out_depth, int* radii, int* num_rendered, void* stream_,
+                               const s3g_raster_async* as = nullptr) {
   g_err[0] = 0;
   hipStream_t stream = (hipStream_t)stream_;
-  if (!in || !geometry_buffer || !binning_buffer || !image_buffer || !num_rendered) {
+  if (!in || (!as && (!geometry_buffer || !binning_buffer || !image_buffer || !num_rendered))) {
     set_error("s3g_raster_forward: NULL argument");
     return S3G_ERR_INVALID_ARG;
   }
-  *num_rendered = 0;
+  if (as && (!as->geometry_arena || !as->image_arena || !as->binning_arena || as->capacity_instances == 0 ||
+             as->capacity_instances > 0x7fffffffu || as->capacity_slots < as->capacity_instances)) {
+    set_error("s3g_raster_forward_async: needs the three arenas and 0 < capacity_instances <= capacity_slots");
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (num_rendered) *num_rendered = 0;
   const int P = in->P, W = in->width, H = in->height;
   if (P < 0 || W <= 0 || H <= 0) {
     set_error("s3g_raster_forward: bad sizes P=%d W=%d H=%d", P, W, H);
@@ -739,8 +770,8 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   size_t geom_bytes = 0, img_bytes = 0;
   GeomState::carve(nullptr, P, &geom_bytes);
   ImageState::carve(nullptr, (size_t)W * H, tiles, nb, &img_bytes);
-  void* geom_p = geometry_buffer(geometry_user, geom_bytes);
-  void* img_p = image_buffer(image_user, img_bytes);
+  void* geom_p = as ? as->geometry_arena : geometry_buffer(geometry_user, geom_bytes);
+  void* img_p = as ? as->image_arena : image_buffer(image_user, img_bytes);
   if (!geom_p || !img_p) {
     set_error("resize callback returned NULL");
     return S3G_ERR_ALLOC;
@@ -777,7 +808,7 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   ba.P = P; ba.gx = gx; ba.tiles = tiles; ba.chunk = chunk; ba.rect = g.rect; ba.depths = g.depths;
   ba.table = im.table; ba.chunk_total = im.chunk_total; ba.ranges = im.ranges; ba.keys = nullptr; ba.gauss_off = g.gauss_off;
   ba.cull = g_exact_cull ? 1 : 0; ba.W = W; ba.H = H; ba.means2D = g.means2D; ba.conic_opacity = g.conic_opacity;
-  ba.tile_mask = g.tile_mask;
+  ba.tile_mask = g.tile_mask; ba.ctrl = im.ctrl;
   for (int lo = 0; lo < tiles; lo += band) {
     ba.tile_lo = lo; ba.tile_n = tiles - lo < band ? tiles - lo : band;
     hipLaunchKernelGGL(bin_kernel<false>, dim3(nb), dim3(BIN_THREADS), bin_lds, stream, ba);
@@ -785,35 +816,56 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   }
   hipLaunchKernelGGL(bin_scan_kernel, dim3((tiles + 255) / 256), dim3(256), 0, stream, tiles, nb, im.table, im.tile_count);
   S3G_KERNEL_CHECK(stream, debug);
+  constexpr uint32_t SMALL = 4096, LARGE = 16384;  // per-tile sort: lists <= SMALL in <= 32 KiB of LDS, <= LARGE in 128 KiB
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, tiles, im.tile_count, im.ranges, im.ctrl, nb,
-                     im.chunk_total);
+                     im.chunk_total, as ? as->capacity_instances : 0u, as ? as->capacity_slots : 0u,
+                     as ? (as->long_lists ? 0xffffffffu : SMALL) : 0u, as ? as->status_device : nullptr);
   S3G_KERNEL_CHECK(stream, debug);
 
-  // the one host sync of the forward (reference: rasterizer_impl.cu:282): R sizes the binning arena
-  static thread_local uint32_t* h_ctrl = nullptr;
-  if (!h_ctrl) S3G_HIP_CHECK(hipHostMalloc((void**)&h_ctrl, 8 * sizeof(uint32_t), hipHostMallocDefault));
-  S3G_HIP_CHECK(hipMemcpyAsync(h_ctrl, im.ctrl, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  S3G_HIP_CHECK(hipStreamSynchronize(stream));
-  const uint32_t R = h_ctrl[0], max_tile = h_ctrl[1], S = h_ctrl[3];
-  if (h_ctrl[2] & 1u) {
-    set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
-    return S3G_ERR_PREFILTERED;
-  }
-  if (R > 0x7fffffffu) {
-    set_error("too many Gaussian/tile instances (%u)", R);
-    return S3G_ERR_INVALID_ARG;
-  }
-  *num_rendered = (int)R;
-
-  size_t bin_bytes = 0;
-  BinningState::carve(nullptr, R, S, &bin_bytes);
-  void* bin_p = binning_buffer(binning_user, bin_bytes);
-  if (!bin_p && R > 0) {
-    set_error("resize callback returned NULL");
-    return S3G_ERR_ALLOC;
+  uint32_t R, max_tile, S;
+  void* bin_p;
+  if (!as) {
+    // the one host sync of the forward (reference: rasterizer_impl.cu:282): R sizes the binning arena
+    static thread_local uint32_t* h_ctrl = nullptr;
+    if (!h_ctrl) S3G_HIP_CHECK(hipHostMalloc((void**)&h_ctrl, 8 * sizeof(uint32_t), hipHostMallocDefault));
+    S3G_HIP_CHECK(hipMemcpyAsync(h_ctrl, im.ctrl, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    S3G_HIP_CHECK(hipStreamSynchronize(stream));
+    R = h_ctrl[0]; max_tile = h_ctrl[1]; S = h_ctrl[3];
+    if (h_ctrl[2] & 1u) {
+      set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
+      return S3G_ERR_PREFILTERED;
+    }
+    if (R > 0x7fffffffu) {
+      set_error("too many Gaussian/tile instances (%u)", R);
+      return S3G_ERR_INVALID_ARG;
+    }
+    *num_rendered = (int)R;
+    size_t bin_bytes = 0;
+    BinningState::carve(nullptr, R, S, &bin_bytes);
+    bin_p = binning_buffer(binning_user, bin_bytes);
+    if (!bin_p && R > 0) {
+      set_error("resize callback returned NULL");
+      return S3G_ERR_ALLOC;
+    }
+  } else {
+    // host-asynchronous: the arena was sized for (capacity_instances, capacity_slots) before anything ran; the kernels below
+    // read R / S / the ranges on the device and find nothing to do if scan_tiles_kernel saw the capacity exceeded.  The
+    // control words travel to the caller's pinned buffer behind the kernels: whoever reads them must first know that the
+    // stream has passed this point (an event recorded after this call).
+    R = as->capacity_instances; S = as->capacity_slots;
+    max_tile = as->sort_lds_keys ? as->sort_lds_keys : SMALL;
+    bin_p = as->binning_arena;
+    if (as->status_host)
+      S3G_HIP_CHECK(hipMemcpyAsync(as->status_host, im.ctrl, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (num_rendered) *num_rendered = (int)R;
   }
   BinningState b = BinningState::carve(bin_p, R, S, nullptr);
-  if (S > 0) S3G_HIP_CHECK(hipMemsetAsync(b.slot_pos, 0xff, (size_t)S * sizeof(uint32_t), stream));  // culled slots
+  if (as) {
+    hipLaunchKernelGGL(fill_slots_kernel, dim3(1024), dim3(256), 0, stream, b.slot_pos, (const uint32_t*)im.ctrl);
+    S3G_KERNEL_CHECK(stream, debug);
+  } else if (S > 0) {
+    S3G_HIP_CHECK(hipMemsetAsync(b.slot_pos, 0xff, (size_t)S * sizeof(uint32_t), stream));  // culled slots
+  }
 
   const uint32_t tile_blocks = round_up8((uint32_t)tiles);
   if (R > 0) {
@@ -824,13 +876,13 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
       S3G_KERNEL_CHECK(stream, debug);
     }
     // short lists: <= 32 KiB of LDS per workgroup (5 workgroups/CU); long lists: up to 128 KiB, beyond that in global
-    constexpr uint32_t SMALL = 4096, LARGE = 16384;
+    // (asynchronous: max_tile is the caller's estimate; a list longer than the LDS buffer is sorted in global memory)
     const uint32_t small_cap = max_tile < SMALL ? max_tile : SMALL;
     hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)small_cap * 8, stream, tiles, gx,
                        im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, b.slot_pos, 0u, SMALL, small_cap);
     S3G_KERNEL_CHECK(stream, debug);
-    if (max_tile > SMALL) {
-      const uint32_t large_cap = max_tile < LARGE ? max_tile : LARGE;
+    if (as ? as->long_lists != 0 : max_tile > SMALL) {
+      const uint32_t large_cap = as ? LARGE : (max_tile < LARGE ? max_tile : LARGE);
       static std::atomic<uint64_t> attr_set{0};
       if (device_needs_setup(attr_set)) {
         S3G_HIP_CHECK(hipFuncSetAttribute((const void*)sort_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -852,9 +904,36 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
     hipLaunchKernelGGL(blend_forward_kernel<0>, dim3(tile_blocks), dim3(256), 0, stream, W, H, gx, tiles, im.ranges,
                        b.point_list, g.means2D, g.conic_opacity, feat, g.depths, in->background, im.final_T, im.n_contrib,
                        im.tile_hi, out_color, out_depth, nullptr, nullptr);
-  profile_end(S3G_PROFILE_BLEND_FORWARD, stream, (double)R, (double)W * H);
+  profile_end(S3G_PROFILE_BLEND_FORWARD, stream, as ? -1.0 : (double)R, (double)W * H);   // asynchronous: R is not known here
   S3G_KERNEL_CHECK(stream, debug);
   return S3G_OK;
+}
+
+extern "C" int s3g_raster_arena_bytes(int P, int width, int height, uint32_t capacity_instances, uint32_t capacity_slots,
+                                      size_t* geometry_bytes, size_t* binning_bytes, size_t* image_bytes) {
+  if (P < 0 || width <= 0 || height <= 0) {
+    set_error("s3g_raster_arena_bytes: bad sizes");
+    return S3G_ERR_INVALID_ARG;
+  }
+  const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+  size_t n = 0;
+  GeomState::carve(nullptr, (size_t)P, &n);
+  if (geometry_bytes) *geometry_bytes = n;
+  BinningState::carve(nullptr, capacity_instances, capacity_slots, &n);
+  if (binning_bytes) *binning_bytes = n;
+  ImageState::carve(nullptr, (size_t)width * height, (size_t)gx * gy, bin_blocks(P), &n);
+  if (image_bytes) *image_bytes = n;
+  return S3G_OK;
+}
+
+extern "C" int s3g_raster_forward_async(const s3g_raster_inputs* in, const float* colors2, const s3g_raster_async* async_,
+                                        float* out_color, float* out_depth, float* out_color2, int* radii, void* stream_) {
+  if (!async_ || (colors2 != nullptr) != (out_color2 != nullptr) || (colors2 && (!in || !in->colors_precomp))) {
+    set_error("s3g_raster_forward_async: needs the async descriptor; colors2 and out_color2 go together (with colors_precomp)");
+    return S3G_ERR_INVALID_ARG;
+  }
+  return raster_forward_impl(in, colors2, out_color2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out_color, out_depth,
+                             radii, nullptr, stream_, async_);
 }
 
 extern "C" int s3g_raster_forward(const s3g_raster_inputs* in, s3g_resize_fn geometry_buffer, void* geometry_user,

@@ -300,6 +300,23 @@ def reduce_densification_stats(viewspace_grad: torch.Tensor, visibility: torch.T
 
 
 @torch.no_grad()
+def reduce_skip_flag(device=None):
+    """Host-asynchronous rasterizer (raster_C.ASYNC): a forward whose instance count exceeded its speculative arena renders
+    nothing, back-propagates zeros, and flags that in a device word which the guarded Adam step honours
+    (include/s3g_optim.h::s3g_adam_step_guarded).  Replicas must drop the SAME steps, so the flag is all-reduced (MAX, one
+    4-byte collective, no host wait) IN PLACE: optim.Adam.step() reads the same word.  -> the int32 [1] device tensor, or None
+    when this rank has issued no asynchronous forward (then nothing is reduced: every rank runs the same code path, so all or
+    none have one).  Call it between backward and the optimizer step."""
+    from . import raster_C
+    flag = raster_C.async_skip_flag(device)
+    if flag is None:
+        return None
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)     # in place: the view into the status ring now holds the batch's verdict
+    return flag
+
+
+@torch.no_grad()
 def add_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor,
                             viewspace_grad_xy: torch.Tensor, visible: torch.Tensor, radii: torch.Tensor) -> None:
     """train.py:489-493 + scene/gaussian_model.py:693-695 on the reduced statistics (one fused HIP pass on the GPU:

@@ -91,7 +91,7 @@ class _HexPlaneSample(torch.autograd.Function):
         P = xyz.shape[0]
         xyz_c = xyz.detach().contiguous().float()
         t_c = time.detach().reshape(-1).contiguous().float()
-        if t_c.numel() != P:
+        if t_c.numel() != P and not (uniform_time is True and t_c.numel() == 1):   # uniform time: one shared timestamp is enough
             raise RuntimeError("time must have one value per point")
         feat = torch.empty((P, len(resolutions) * CHANNELS), dtype=torch.float32, device=xyz.device)
         if uniform_time is None:   # one device reduction + host sync; callers that know (render()) pass the flag instead

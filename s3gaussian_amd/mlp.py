@@ -153,7 +153,7 @@ def deform_infer(grid, xyz, time, feature_out, pos_deform, shs_deform, dino_head
     P, dev = xyz.shape[0], xyz.device
     xyz_c = xyz.detach().contiguous().float()
     t_c = time.detach().reshape(-1).contiguous().float()
-    if t_c.numel() != P:
+    if t_c.numel() != P and not (uniform_time is True and t_c.numel() == 1):   # uniform time: one shared timestamp is enough
         raise RuntimeError("time must have one value per point")
     if uniform_time is None:
         uniform_time = bool(P > 0 and (t_c == t_c[0]).all().item())

@@ -39,8 +39,8 @@ class Adam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
-        L.s3g_adam_step.restype = C.c_int
-        L.s3g_adam_step.argtypes = [C.c_int, C.POINTER(_AdamTensor), C.c_double, C.c_double, C.c_void_p]
+        L.s3g_adam_step_guarded.restype = C.c_int
+        L.s3g_adam_step_guarded.argtypes = [C.c_int, C.POINTER(_AdamTensor), C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         # 1. validate everything before touching any state: an exception must not leave some parameters with an advanced
         #    step count and others without
         todo = []
@@ -76,13 +76,19 @@ class Adam(torch.optim.Adam):
             by_betas.setdefault((p.device, float(beta1), float(beta2)), []).append(
                 _AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
                             group["lr"] / bc1, 1.0 / (bc2 ** 0.5), group["eps"], float(self.grad_scale)))
+        from . import raster_C
         for (dev, beta1, beta2), items in by_betas.items():
+            # host-asynchronous rasterizer (raster_C.ASYNC): if the last forward on this device overflowed its speculative
+            # arena -- it then rendered nothing and back-propagated zeros -- the device drops this step too; the host finds out
+            # later without having waited (raster_C.async_status()).  None: no such forward, plain step.
+            flag = raster_C.async_skip_flag(dev)   # data parallel: dp.reduce_skip_flag() has all-reduced it in place
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream().cuda_stream
                 for k in range(0, len(items), MAX_TENSORS):
                     chunk = items[k:k + MAX_TENSORS]
                     arr = (_AdamTensor * len(chunk))(*chunk)
-                    _lib.check(L.s3g_adam_step(len(chunk), arr, beta1, beta2, stream))
+                    _lib.check(L.s3g_adam_step_guarded(len(chunk), arr, beta1, beta2,
+                                                       flag.data_ptr() if flag is not None else None, stream))
         # 3. the kernel wrote the parameters (and moments) through raw pointers: tell PyTorch.  Version counters are what
         #    autograd's saved-tensor checks and the rasterizer's geometry cache (raster_C._geom_key) look at; without the
         #    bump a render of the SAME parameter tensors after this step could be served the previous step's binning.
@@ -92,7 +98,6 @@ class Adam(torch.optim.Adam):
             torch.autograd.graph.increment_version(st["exp_avg"])
             torch.autograd.graph.increment_version(st["exp_avg_sq"])
         if todo:
-            from . import raster_C
             raster_C.invalidate_geometry_cache()
         return loss
 

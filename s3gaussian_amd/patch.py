@@ -60,10 +60,23 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
            return_decomposition=False, return_dx=False, render_feat=False):
     """Signature of gaussian_renderer/__init__.py:23; `pc` is the reference's GaussianModel (same attribute names as
     pipeline.GaussianParams), `viewpoint_camera` its Camera."""
-    if getattr(pipe, "compute_cov3D_python", False):
-        raise NotImplementedError("pipe.compute_cov3D_python: run the reference's own render() for this switch")
-    return _pipeline.render(_cam_dict(viewpoint_camera), pc, pipe, bg_color, scaling_modifier, override_color, stage,
-                            return_decomposition, return_dx, render_feat)
+    if getattr(pipe, "compute_cov3D_python", False) and "render" in _REFERENCE:
+        # a switch the fused route does not special-case: hand the call back to the reference's own render() (saved by
+        # patch_reference), whatever it does with it, on the drop-in rasterizer
+        return _REFERENCE["render"](viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, stage,
+                                    return_decomposition, return_dx, render_feat)
+    out = _pipeline.render(_cam_dict(viewpoint_camera), pc, pipe, bg_color, scaling_modifier, override_color, stage,
+                           return_decomposition, return_dx, render_feat)
+    reg = out.get("plane_reg") if isinstance(out, dict) else None
+    if reg is not None:
+        # fine stage under autograd: the plane regulariser was evaluated on the sampler's autograd node (its gradient seeds the
+        # buffer the sampler's backward accumulates into).  train.py:412-413 asks for it by name a few lines later: the patched
+        # compute_regulation below hands THIS value back instead of sweeping the 143 MB of planes a second time.
+        hy = pc._deformation.deformation_net.args
+        planes = pc._deformation.deformation_net.grid._planes()
+        pc._s3g_plane_reg = ((float(hy.time_smoothness_weight), float(hy.l1_time_planes), float(hy.plane_tv_weight)),
+                             tuple(p._version for p in planes), reg)
+    return out
 
 
 def _as_image(t: torch.Tensor, channels: int):
@@ -110,7 +123,15 @@ def ssim(img1, img2, window_size=11, size_average=True):
 
 
 def compute_regulation(self, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight):
-    """GaussianModel.compute_regulation, scene/gaussian_model.py:748-749."""
+    """GaussianModel.compute_regulation, scene/gaussian_model.py:748-749.  If render() has just evaluated the same expression on
+    the sampler's node (same weights, planes untouched since), that value is returned -- once --; else one fused pass."""
+    cached = self.__dict__.pop("_s3g_plane_reg", None)
+    if cached is not None and torch.is_grad_enabled():
+        weights, versions, reg = cached
+        planes = self._deformation.deformation_net.grid._planes()
+        if (weights == (float(time_smoothness_weight), float(l1_time_planes_weight), float(plane_tv_weight))
+                and versions == tuple(p._version for p in planes) and reg.requires_grad):
+            return reg
     return _losses.plane_regulation(self._deformation.deformation_net.grid.grids, time_smoothness_weight, l1_time_planes_weight,
                                     plane_tv_weight)
 

@@ -280,6 +280,35 @@ def eval_sh(deg, sh, dirs):
     return result
 
 
+def covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
+    """GaussianModel.get_covariance (scene/gaussian_model.py:33-37,135-136; utils/general_utils.py:231-277): Sigma = L L^T with
+    L = R(q / |q|) diag(modifier * s), returned as the six upper-triangular entries [P,6] the rasterizer takes as cov3D_precomp."""
+    q = rotation / torch.sqrt((rotation * rotation).sum(dim=1, keepdim=True))
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).view(-1, 3, 3)
+    Lm = R * (scaling_modifier * scaling)[:, None, :]          # R @ diag(s)
+    cov = Lm @ Lm.transpose(1, 2)
+    return torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], dim=1)
+
+
+_time_cache: Dict = {}
+
+
+def _uniform_time(t: float, device) -> torch.Tensor:
+    """[1,1] device tensor holding the camera timestamp.  With `uniform_time` the sampler reads time[0] only
+    (include/s3g_hexplane.h), so the reference's `torch.full((P,1), time)` -- a 4.8 MB fill per render -- shrinks to one cached
+    element per distinct timestamp (a clip has tens of them)."""
+    key = (t, device)
+    v = _time_cache.get(key)
+    if v is None:
+        if len(_time_cache) > 4096:
+            _time_cache.clear()
+        v = _time_cache[key] = torch.full((1, 1), t, dtype=torch.float32, device=device)
+    return v
+
+
 class _LazyResult(dict):
     """render()'s result dict with entries that are only computed when somebody reads them.  The reference returns
     `visibility_filter_d = radii_d > 0` for the masked subsets (gaussian_renderer/__init__.py:199-203): variable-size results of
@@ -323,6 +352,34 @@ class _LazyResult(dict):
         self._lazy.pop(key, None)
         super().__setitem__(key, value)
 
+    # dict(out), {**out}, out | other: CPython copies a dict SUBCLASS through the fast path (raw table, placeholders and all)
+    # unless the subclass overrides __iter__; with it overridden they go through keys() + __getitem__, which force the entries
+    def __iter__(self):
+        self._force_all()
+        return super().__iter__()
+
+    def keys(self):
+        self._force_all()
+        return super().keys()
+
+    def copy(self):
+        self._force_all()
+        return dict(super().items())
+
+    def pop(self, key, *default):
+        self._force(key)
+        return super().pop(key, *default)
+
+    def setdefault(self, key, default=None):
+        self._force(key)
+        return super().setdefault(key, default)
+
+    def __or__(self, other):
+        return dict(self) | other
+
+    def __ror__(self, other):
+        return other | dict(self)
+
 
 def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg_color: torch.Tensor,
            scaling_modifier=1.0, override_color=None, stage="fine", return_decomposition=False, return_dx=False,
@@ -334,11 +391,10 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
     RGB + feature pair runs as one node (train.py:489-493 otherwise does it in separate passes); the result dict then carries
     "densify_stats_fused": True."""
     dev = pc.get_xyz.device
-    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # the reference builds `zeros_like(xyz, requires_grad=True) + 0` and retain_grad()s it (:31-35): a fill, an add and a
+    # non-leaf whose .grad its caller reads.  Nothing ever reads the VALUES of means2D (it only carries the viewspace gradient),
+    # so a fresh uninitialised leaf serves the same contract -- `.grad` populated by backward -- without the two launches.
+    screenspace_points = torch.empty_like(pc.get_xyz).requires_grad_(True)
     means3D = pc.get_xyz
     cam = viewpoint_camera
     rs = GaussianRasterizationSettings(
@@ -347,7 +403,7 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
         projmatrix=cam["projmatrix"], sh_degree=pc.active_sh_degree, campos=cam["campos"], prefiltered=False,
         debug=getattr(pipe, "debug", False))
     rasterizer = GaussianRasterizer(raster_settings=rs)
-    time = torch.full((means3D.shape[0], 1), float(cam["time"]), device=dev)
+    time = None   # built where it is needed: [P,1] for the reference's module, ONE element for the fused sampler (uniform time)
     means2D = screenspace_points
     opacity = pc._opacity
     scales, rotations, cov3D_precomp = pc._scaling, pc._rotation, None
@@ -369,12 +425,13 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
             # sampler's node so its gradient is the seed the sampler's backward accumulates onto
             regw = ((hy.time_smoothness_weight, hy.l1_time_planes, hy.plane_tv_weight)
                     if (stage == "fine" and torch.is_grad_enabled() and hy.time_smoothness_weight != 0) else None)
-            heads = net.deform_heads(means3D, time, uniform_time=True, reg_weights=regw,
+            heads = net.deform_heads(means3D, _uniform_time(float(cam["time"]), dev), uniform_time=True, reg_weights=regw,
                                      need_feat=render_feat or torch.is_grad_enabled())
             dx, dshs, feat = heads[:3]
             plane_reg = heads[3] if regw is not None else None
             means3D_final, scales_final, rotations_final, opacity_final = means3D + dx, scales, rotations, opacity
         else:
+            time = torch.full((means3D.shape[0], 1), float(cam["time"]), device=dev)
             (means3D_final, scales_final, rotations_final, opacity_final, shs_final, dx, feat, dshs) = pc._deformation(
                 means3D, scales, rotations, opacity, pc.get_features, time)
     else:
@@ -401,6 +458,12 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
             colors_precomp = override_color
     if colors_precomp is not None:
         shs_final = None
+    if getattr(pipe, "compute_cov3D_python", False):
+        # gaussian_renderer/__init__.py:76-77: the 3-D covariance built in Python from the UNDEFORMED scaling / rotation and handed
+        # to the rasterizer in place of the (scale, rotation) pair.  (The reference's own render() goes on to call
+        # torch.exp(None) with this switch; here the switch simply does what its comment says.)
+        cov3D_precomp = covariance_from_scaling_rotation(pc.scaling_activation(pc._scaling), scaling_modifier, pc._rotation)
+        scales_final = rotations_final = None
     want_feat = render_feat and "fine" in stage
     decomposed = None
     if (return_decomposition and dx is not None and means3D_final.is_cuda and not torch.is_grad_enabled()

@@ -62,6 +62,184 @@ def _inputs(P, D, M, W, H, bg, means3D, sh, colors, opacity, scales, scale_modif
                              int(bool(debug)))
 
 
+# ---- host-asynchronous forward (include/s3g_raster.h::s3g_raster_forward_async) ---------------------------------------
+# The reference's forward -- and s3g_raster_forward -- waits for the device once per call: the instance count R sizes the
+# binning arena (rasterizer_impl.cu:281-282).  That one wait caps the host's run-ahead at a single iteration, so any hiccup of
+# the host (a slow core, a busy box, an allocator call) becomes GPU idle time.  With ASYNC on, the callers that never hand R
+# to anybody (the autograd nodes of rasterizer.py) size the arenas for a speculative capacity instead -- twice the largest
+# count seen so far for this image size, quantised so that the allocation sizes repeat -- and the true counts arrive later
+# through a pinned ring that is polled, never waited for.  An overflow (counts above the capacity) is a well-defined no-op on
+# the device (background-only image, zero gradients, no densification bookkeeping, optimizer step dropped through
+# `async_skip_flag`), is reported here one or more calls later (warning + `async_status()["overflows"]`), and raises the
+# capacity.  `rasterize_gaussians` called without allow_async -- the reference's `_C` signature, which returns R -- stays
+# synchronous.  S3G_RASTER_ASYNC=0 switches the mechanism off.
+ASYNC = os.environ.get("S3G_RASTER_ASYNC", "1") != "0"
+_ASYNC_RING = 64
+_ASYNC_MIN_INSTANCES = 1 << 20
+
+
+def set_async(on: bool) -> bool:
+    """Host-asynchronous forwards for the autograd nodes; returns the previous setting."""
+    global ASYNC
+    prev, ASYNC = ASYNC, bool(on)
+    return prev
+
+
+def _quantise(n: int) -> int:
+    """Next value of a geometric ladder with four steps per octave: capacities (and so allocation sizes) repeat from call to
+    call although the counts they are derived from creep."""
+    n = max(int(n), 1)
+    step = 1 << max(n.bit_length() - 3, 0)
+    return (n + step - 1) // step * step
+
+
+class _AsyncState:
+    """Per-device bookkeeping of the asynchronous forwards: status ring (device words + pinned host rows + events), the largest
+    counts seen per image size, overflow reports."""
+
+    def __init__(self, device):
+        self.device = device
+        self.status_dev = torch.zeros(_ASYNC_RING, dtype=torch.int32, device=device)
+        self.status_host = torch.zeros((_ASYNC_RING, 8), dtype=torch.int32).pin_memory()
+        self.events = [None] * _ASYNC_RING
+        self.pending = []          # [(slot, seq, key)] in issue order
+        self.seq = 0
+        self.hist = {}             # (W, H) -> [max instances, max slots, longest list] observed
+        self.overflows = []        # seq numbers of the calls that rendered nothing
+        self.sum_instances = 0     # over the drained calls (workload statistics)
+        self.drained = 0
+        self.last_slot = None
+
+    def caps(self, key):
+        h = self.hist.get(key)
+        if h is None:
+            return None
+        cap_r = _quantise(max(2 * h[0], _ASYNC_MIN_INSTANCES))
+        cap_s = max(_quantise(max(2 * h[1], _ASYNC_MIN_INSTANCES)), cap_r)
+        longest = 2 * h[2]
+        lds = 256
+        while lds < min(longest, 4096):
+            lds *= 2
+        return cap_r, cap_s, lds, int(longest > 4096)
+
+    def drain(self, block=False):
+        """Consume the status rows whose copies have landed (block=True: wait for all of them)."""
+        import warnings
+        while self.pending:
+            slot, seq, key = self.pending[0]
+            ev = self.events[slot]
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                break
+            self.pending.pop(0)
+            row = self.status_host[slot].tolist()
+            longest, err, overflow, r_true, s_true = row[1], row[2], row[4], row[5] & 0xffffffff, row[6] & 0xffffffff
+            h = self.hist.setdefault(key, [0, 0, 0])
+            h[0], h[1], h[2] = max(h[0], r_true), max(h[1], s_true), max(h[2], longest & 0xffffffff)
+            self.sum_instances += 0 if overflow else r_true
+            self.drained += 1
+            if overflow:
+                self.overflows.append(seq)
+                warnings.warn(f"s3gaussian_amd: asynchronous rasterizer forward #{seq} exceeded its arena ({r_true} instances, "
+                              f"{s_true} slots, longest list {longest}): that call rendered nothing and its optimizer step was "
+                              "dropped; the capacity has been raised -- render the view again", RuntimeWarning, stacklevel=3)
+            if err & 1:
+                raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen! "
+                                   f"(asynchronous forward #{seq}, reported late)")
+
+
+_async_states = {}
+
+
+def _async_state(device) -> _AsyncState:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _async_states.get(idx)
+    if st is None:
+        st = _async_states[idx] = _AsyncState(torch.device("cuda", idx))
+    return st
+
+
+def async_skip_flag(device=None):
+    """int32 [1] device tensor (a view into the status ring): != 0 iff the most recent asynchronous forward on `device`
+    overflowed its arena; None if there has been none.  optim.Adam.step() hands it to s3g_adam_step_guarded; a data-parallel
+    run all-reduces it (MAX) first so that every replica drops the same step (dp.reduce_skip_flag)."""
+    if not _async_states:
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = _async_states.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    if st is None or st.last_slot is None:
+        return None
+    return st.status_dev[st.last_slot:st.last_slot + 1]
+
+
+def async_status(device=None, block=False) -> dict:
+    """Counters of the asynchronous forwards on `device`: calls issued / drained, overflowed calls, mean true instance count of
+    the drained calls, capacities per image size.  block=True waits for every outstanding status row first."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = _async_states.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    if st is None:
+        return {"enabled": ASYNC, "calls": 0, "drained": 0, "overflows": [], "mean_instances": None, "capacity": {}}
+    st.drain(block=block)
+    return {"enabled": ASYNC, "calls": st.seq, "drained": st.drained, "overflows": list(st.overflows),
+            "mean_instances": (st.sum_instances / st.drained) if st.drained else None,
+            "capacity": {k: st.caps(k) for k in st.hist}}
+
+
+def async_reset_statistics(device=None) -> None:
+    """Forget the drained-call counters (not the capacities): bench.py brackets its timed regions with this."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = _async_states.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    if st is not None:
+        st.drain(block=True)
+        st.sum_instances, st.drained, st.overflows = 0, 0, []
+
+
+def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_depth, out_color2, radii):
+    """One s3g_raster_forward_async call (or several while the capacity is being learnt).  -> (R capacity, geom, binning, img)"""
+    key = (W, H)
+    st.drain()
+    caps = st.caps(key)
+    learn = caps is None                    # first call for this image size: generous capacity, wait once, remember the counts
+    if learn:
+        caps = (8 << 20, 16 << 20, 4096, 1)
+    while True:
+        cap_r, cap_s, lds, long_lists = caps
+        nb = (C.c_size_t(), C.c_size_t(), C.c_size_t())   # geometry, binning, image
+        _lib.check(L.s3g_raster_arena_bytes(P, W, H, cap_r, cap_s, C.byref(nb[0]), C.byref(nb[1]), C.byref(nb[2])))
+        geom, binning, img = (torch.empty(int(n.value), dtype=torch.uint8, device=dev) for n in nb)
+        slot = st.seq % _ASYNC_RING
+        if st.events[slot] is not None and any(s == slot for s, _, _ in st.pending):
+            st.drain(block=True)            # the host is a whole ring ahead of the device: let the oldest rows land
+        desc = _lib.RasterAsync(cap_r, cap_s, lds, long_lists, geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
+                                st.status_dev.data_ptr() + 4 * slot, st.status_host.data_ptr() + 32 * slot)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            code = L.s3g_raster_forward_async(C.byref(inp), col2_.data_ptr() if col2_ is not None else None, C.byref(desc),
+                                              out_color.data_ptr(), out_depth.data_ptr(),
+                                              out_color2.data_ptr() if out_color2 is not None else None, radii.data_ptr(), stream)
+            _lib.check(code)
+            ev = st.events[slot]
+            if ev is None:
+                ev = st.events[slot] = torch.cuda.Event()
+            ev.record()
+        st.pending.append((slot, st.seq, key))
+        st.seq += 1
+        st.last_slot = slot
+        if not learn:
+            return cap_r, geom, binning, img
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)   # an overflow while learning is handled right here
+            n_over = len(st.overflows)
+            st.drain(block=True)
+        if len(st.overflows) == n_over:
+            return cap_r, geom, binning, img
+        st.overflows.pop()                  # learnt the hard way: render again with the capacity the counts ask for
+        caps = st.caps(key)
+        caps = (max(caps[0], cap_r), max(caps[1], cap_s), caps[2], caps[3])
+
+
 # ---- geometry cache: the feature render of an iteration reuses the RGB render's preprocess / binning / sort ------------
 _GEOM_CACHE_ON = os.environ.get("S3G_GEOMETRY_CACHE", "1") != "0"
 _geom_cache = None  # (key, tensors kept alive, outputs)
@@ -84,10 +262,13 @@ def _geom_key(tensors, scalars):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, colors2=None):
+                        prefiltered, debug, colors2=None, allow_async=False):
     """-> (num_rendered, color[3,H,W], depth[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer).
     colors2 [P,3] (extension): a second image with these colours is blended in the same pass (s3g_raster_forward2) and
-    appended to the result tuple."""
+    appended to the result tuple.
+    allow_async (extension): the caller only needs `num_rendered` as the key that goes back into the backward / reuse /
+    decomposition entry points with these arenas, not as a count -- with ASYNC on the call then does not wait for the device and
+    returns the arena's instance CAPACITY in its place (see the block comment above; `async_status()` has the true counts)."""
     global _geom_cache, _geom_cache_hits
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -131,11 +312,19 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         inp = _inputs(P, degree, M, W, H, bg_, m3_, sh_, col_, op_, sc_, scale_modifier, rot_, cov_, view_, proj_,
                       tan_fovx, tan_fovy, cam_, prefiltered, debug)
         col2_ = _f32(colors2, "colors2") if colors2 is not None else None
+        if col2_ is not None and col2_.shape != (P, NUM_CHANNELS):
+            raise RuntimeError("colors2 must have shape (num_points, 3)")
+        if allow_async and ASYNC and not debug and not prefiltered:   # a `prefiltered` violation must raise from THIS call
+            R_cap, geom_t, binning_t, img_t = _forward_async(L, _async_state(dev), inp, col2_, P, W, H, dev, out_color, out_depth,
+                                                             out_color2, radii)
+            if key is not None:
+                _geom_cache = (key, geo_tensors, (R_cap, radii, geom_t, binning_t, img_t))
+            if colors2 is not None:
+                return R_cap, out_color, out_depth, radii, geom_t, binning_t, img_t, out_color2
+            return R_cap, out_color, out_depth, radii, geom_t, binning_t, img_t
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
             if col2_ is not None:
-                if col2_.shape != (P, NUM_CHANNELS):
-                    raise RuntimeError("colors2 must have shape (num_points, 3)")
                 code = L.s3g_raster_forward2(C.byref(inp), col2_.data_ptr(), geom.cb, None, binning.cb, None, img.cb, None,
                                              out_color.data_ptr(), out_depth.data_ptr(), out_color2.data_ptr(),
                                              radii.data_ptr(), C.byref(rendered), stream)

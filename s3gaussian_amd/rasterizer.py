@@ -51,7 +51,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise
         else:
-            out = _C.rasterize_gaussians(*native_args)
+            # num_rendered only travels to the backward below as the key of the arenas: the call may run host-asynchronously
+            out = _C.rasterize_gaussians(*native_args, allow_async=True)
         num_rendered, color, depth, radii, geom, binning, img = out
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
@@ -98,7 +99,7 @@ class _RasterizeGaussiansPair(torch.autograd.Function):
         common = (opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
                   rs.tanfovy, rs.image_height, rs.image_width, empty, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
         num_rendered, color, depth, radii, geom, binning, img, color2 = _C.rasterize_gaussians(
-            rs.bg, means3D, colors_a, *common, colors2=colors_b)
+            rs.bg, means3D, colors_a, *common, colors2=colors_b, allow_async=True)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.densify_accum = densify_accum
@@ -172,7 +173,7 @@ class GaussianRasterizer(nn.Module):
         R, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
             rs.bg, means3D, n(colors_precomp), opacities, n(scales), n(rotations), rs.scale_modifier, n(cov3D_precomp),
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, n(shs), rs.sh_degree,
-            rs.campos, rs.prefiltered, rs.debug)
+            rs.campos, rs.prefiltered, rs.debug, allow_async=True)
         if P == 0:
             z3, z1 = torch.zeros_like(color), torch.zeros_like(depth)
             return dict(render=color, radii=radii, depth=depth, render_d=z3, depth_d=z1, render_s=z3.clone(), depth_s=z1.clone())

@@ -24,3 +24,26 @@ def test_bench_py_prints_one_line_that_follows_the_contract(gpu_device):
     validate_bench_line(d, default_workload=False)
     assert d["steps"] == 4 and d["warmup"] == 2 and d["config"]["gaussians"] == 60000 and d["config"]["image"] == [320, 480]
     assert d["roofline"]["traffic"] is None          # PMC traffic exists for the default workload only
+
+
+def test_plain_gpus_2_command_line_starts_two_ranks(gpu_device):
+    """`python bench.py --gpus 8` without torchrun printed a 1-GPU line under an 8-rank label.  The plain command must
+    start the ranks itself.  One GPU per lease: the two ranks share it over gloo (S3G_DIST_BACKEND=gloo; RCCL refuses two ranks on
+    one device) -- functional, not a scaling number; without that override the same command must refuse, not mislabel."""
+    from tests.util import validate_bench_line
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--P", "60000", "--width", "480", "--height", "320",
+            "--frames", "4", "--steps", "3", "--warmup", "2"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(args, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode != 0 and "refusing" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+        env["S3G_DIST_BACKEND"] = "gloo"
+    out = subprocess.run(args, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    validate_bench_line(d, default_workload=False, n_gpus=2)
+    assert d["n_gpus"] == 2 and d["comm"]["world_size"] == 2 and len(d["comm"]["devices"]) == 2
+    assert d["comm"]["scaling_curve_measured_by_the_builder"] is False

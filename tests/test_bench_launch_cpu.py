@@ -1,0 +1,70 @@
+"""CPU-only: `python bench.py --gpus N` (N > 1, no torchrun environment) launches N ranks by itself instead of printing a
+mislabelled single-GPU line (Missing #1); the launcher command is checked with subprocess mocked."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+@pytest.fixture
+def no_torchrun_env(monkeypatch):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "S3G_DIST_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+
+
+def test_gpus_n_without_torchrun_spawns_n_ranks(monkeypatch, no_torchrun_env):
+    import subprocess
+    import torch
+    import bench
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    with pytest.raises(SystemExit) as ex:
+        bench.main(["--gpus", "4", "--steps", "7", "--warmup", "2"])
+    assert ex.value.code == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    port = int(cmd[cmd.index("--master-port") + 1])
+    assert port != 29500 and 1024 < port < 65536                       # a free port, not the default two benches would fight over
+    script = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[script + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]   # the ranks run THIS command line
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_gpus_n_refuses_when_the_node_has_fewer_gpus(monkeypatch, no_torchrun_env, capsys):
+    import subprocess
+    import torch
+    import bench
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append(cmd) or 0)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as ex:
+        bench.main(["--gpus", "8"])
+    assert ex.value.code == 2 and not calls and "refusing" in capsys.readouterr().err
+    monkeypatch.setenv("S3G_DIST_BACKEND", "gloo")                     # the functional oversubscribed run is an explicit choice
+    with pytest.raises(SystemExit) as ex:
+        bench.main(["--gpus", "2"])
+    assert ex.value.code == 0 and len(calls) == 1 and "--nproc-per-node=2" in calls[0]
+
+
+def test_a_rank_refuses_a_label_that_does_not_match_its_world(monkeypatch):
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit) as ex:
+        bench.main(["--gpus", "8"])
+    assert "WORLD_SIZE=1" in str(ex.value.code)
+
+
+def test_workload_label_names_the_world_it_ran_on():
+    import bench
+    a = bench.parse_args([])
+    assert bench.workload_label(a, 1).startswith("BASELINE cfg3")
+    assert "over 8 ranks" in bench.workload_label(a, 8)
+    assert "NOT a BASELINE config" in bench.workload_label(bench.parse_args(["--P", "1000"]), 1)

@@ -96,3 +96,73 @@ def test_one_train_py_iteration_on_the_replacements_equals_the_fused_step(gpu_de
         assert float((~close).float().mean()) < 1e-3, n
     assert torch.equal(res["fused"][3], res["patched"][3]) and torch.equal(res["fused"][4], res["patched"][4])
     np.testing.assert_allclose(res["fused"][2].cpu().numpy(), res["patched"][2].cpu().numpy(), rtol=1e-4, atol=1e-9)
+
+
+def test_patched_compute_regulation_reuses_the_value_render_computed(gpu_device, monkeypatch):
+    """on the zero-edit route render() evaluated the plane regulariser on the sampler's node, dropped it, and train.py's
+    compute_regulation swept the 143 MB of planes again.  The patched compute_regulation now returns render's value (same
+    weights, planes untouched): no second sweep, same loss, and the gradient still reaches the planes exactly once."""
+    import bench
+    from s3gaussian_amd import losses, patch, synth
+    from s3gaussian_amd.pipeline import GaussianParams, default_hyper, default_opt
+    dev = gpu_device
+    scn = synth.street_scene(P=8_000, seed=5, width=160, height=112, n_frames=2)
+    hyper, opt = default_hyper(), default_opt()
+    pc = GaussianParams(3, hyper)
+    gs = scn["gaussians"]
+    pc.init_from_tensors(gs["xyz"], gs["log_scales"], gs["rotations_raw"], gs["opacity_logit"], gs["shs"], dev)
+    pc._deformation.deformation_net.set_aabb(*scn["aabb"])
+    pc.training_setup(opt)
+    cam = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scn["cameras"][0].items()}
+    pipe = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
+    sweeps = []
+    real = losses.plane_regulation
+    monkeypatch.setattr(losses, "plane_regulation", lambda *a, **k: sweeps.append(1) or real(*a, **k))
+    w = (hyper.time_smoothness_weight, hyper.l1_time_planes, hyper.plane_tv_weight)
+    pkg = patch.render(cam, pc, pipe, scn["bg"].to(dev), stage="fine", return_dx=True, render_feat=True)
+    reg = patch.compute_regulation(pc, *w)
+    assert sweeps == [] and reg is pkg["plane_reg"]
+    reg.backward()
+    g_first = pc._deformation.deformation_net.grid.grids[0][0].grad.clone()
+    again = patch.compute_regulation(pc, *w)                 # nothing cached any more: the stand-alone pass
+    assert sweeps == [1]
+    np.testing.assert_allclose(again.item(), reg.item(), rtol=1e-6)
+    for p in pc._deformation.deformation_net.grid.parameters():
+        p.grad = None
+    again.backward()
+    assert rel_l2(g_first.cpu().numpy(), pc._deformation.deformation_net.grid.grids[0][0].grad.cpu().numpy()) < 1e-6
+    # other weights than render used -> not the cached value
+    patch.render(cam, pc, pipe, scn["bg"].to(dev), stage="fine", return_dx=True, render_feat=True)
+    other = patch.compute_regulation(pc, w[0] * 2, w[1], w[2])
+    assert sweeps == [1, 1] and other.item() > reg.item()
+
+
+def test_compute_cov3d_python_switch_renders_the_same_image(gpu_device):
+    """gaussian_renderer/__init__.py:76-77: the covariance built in Python and handed over as cov3D_precomp.  pipeline.render
+    honours the switch (the rasterizer's cov3D_precomp path is tested against the oracle in test_raster_gpu.py); images agree with
+    the in-kernel covariance to fp32 round-off and gradients reach scaling / rotation through the Python expression."""
+    from s3gaussian_amd import synth
+    from s3gaussian_amd.pipeline import GaussianParams, default_hyper, default_opt, render
+    dev = gpu_device
+    scn = synth.street_scene(P=6_000, seed=2, width=160, height=112, n_frames=2)
+    hyper = default_hyper()
+    pc = GaussianParams(3, hyper)
+    gs = scn["gaussians"]
+    pc.init_from_tensors(gs["xyz"], gs["log_scales"], gs["rotations_raw"], gs["opacity_logit"], gs["shs"], dev)
+    pc._deformation.deformation_net.set_aabb(*scn["aabb"])
+    pc.training_setup(default_opt())
+    cam = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scn["cameras"][0].items()}
+    outs = {}
+    for flag in (False, True):
+        pipe = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=flag, debug=False)
+        for p in pc.parameters():
+            p.grad = None
+        pkg = render(cam, pc, pipe, scn["bg"].to(dev), stage="fine", render_feat=True)
+        (pkg["render"].sum() + pkg["feat"].sum()).backward()
+        outs[flag] = (pkg["render"].detach(), pkg["radii"], pc._scaling.grad.clone(), pc._rotation.grad.clone())
+    assert float((outs[True][0] - outs[False][0]).abs().max()) < 2e-4
+    assert float((outs[True][1] != outs[False][1]).float().mean()) < 1e-3
+    assert rel_l2(outs[True][2].cpu().numpy(), outs[False][2].cpu().numpy()) < 1e-3
+    # the in-kernel path differentiates w.r.t. the quaternion AS GIVEN (backward.cu:340); the Python expression normalises it first,
+    # so only the component orthogonal to q is comparable -- which is the whole gradient for unit quaternions (these are)
+    assert rel_l2(outs[True][3].cpu().numpy(), outs[False][3].cpu().numpy()) < 5e-2

@@ -65,43 +65,70 @@ def settings_from(s, device, sh_degree=0, debug=False):
         prefiltered=False, debug=debug)
 
 
-def validate_bench_line(d, default_workload=True):
-    """The driver's bench.py contract (one JSON line) + this repo's additions; used on a LIVE run (tests/test_bench_gpu.py) and on
-    the committed line of the round (tests/test_abi_cpu.py)."""
+def validate_bench_line(d, default_workload=True, n_gpus=1, round3_accounting=False):
+    """The driver's bench.py contract (one JSON line) + this repo's additions; used on a LIVE run (tests/test_bench_gpu.py), on
+    the committed lines of the rounds and on the driver's own records BENCH_rNN.json (tests/test_abi_cpu.py).  The driver keeps a
+    trimmed copy of the line (`parsed`: no `config.paths`, no `roofline.kernels`), so those parts are checked where present.
+    Nothing here asserts an ORDER between measured throughputs of fast paths: round 3's validator required patched <= 1.02 x
+    fused, and the driver's own box violated it (its first timed loop carried 2 ms of GPU idle the later loops did not)."""
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["metric"] == "train_iters_per_sec" and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert d["n_gpus"] == n_gpus and d["scaling"] == "weak" and d["data"] == "synthetic" and d["dtype"] == "f32"
     assert abs(d["value"] - d["n_gpus"] * 1000.0 / d["ms_per_step"]) < 0.02 * d["value"]
+    if "step_ms_median" in d:     # round 4: one hipEvent pair per step + the host's enqueue time
+        assert 0 < d["step_ms_min"] <= d["step_ms_median"] <= d["step_ms_max"]
+        assert d["host_enqueue_ms_per_step"] > 0 and d["gpu_ms_per_step"] > 0
+        assert d["gpu_ms_per_step"] <= 1.05 * d["ms_per_step"] + 0.05    # stream time between step boundaries cannot exceed the wall
     c = d["config"]
-    assert ("BASELINE cfg3" in c["workload"]) == default_workload, c["workload"]     # the label is derived from the arguments
+    if n_gpus == 1:
+        assert ("BASELINE cfg3" in c["workload"]) == default_workload, c["workload"]     # the label is derived from the arguments
+    else:
+        assert (f"over {n_gpus} ranks" in c["workload"]) == default_workload, c["workload"]
     assert str(c["gaussians"]) in c["workload"]
-    assert c["path"] == "fused" and {"fused", "patched", "import_swap", "zero_diff"} <= set(c["paths"]) <= {
-        "fused", "patched", "import_swap", "zero_diff", "fused_mlp_bf16x3"}
-    ips = {k: v["iters_per_s"] for k, v in c["paths"].items() if k != "fused_mlp_bf16x3"}
-    if "fused_mlp_bf16x3" in c["paths"]:     # the opt-in arithmetic of the MLP kernels: timed, never the headline
-        assert c["paths"]["fused_mlp_bf16x3"].get("ms_per_step"), c["paths"]["fused_mlp_bf16x3"]
+    assert c["path"] == "fused"
+    if "paths" in c:
+        assert {"fused", "patched", "import_swap", "zero_diff"} <= set(c["paths"]) <= {
+            "fused", "patched", "import_swap", "zero_diff", "fused_mlp_bf16x3"}
+        ips = {k: v["iters_per_s"] for k, v in c["paths"].items() if k != "fused_mlp_bf16x3"}
+        if "fused_mlp_bf16x3" in c["paths"]:     # the opt-in arithmetic of the MLP kernels: timed, never the headline
+            assert c["paths"]["fused_mlp_bf16x3"].get("ms_per_step"), c["paths"]["fused_mlp_bf16x3"]
+        # the slow routes are slow by an order of magnitude (plain PyTorch deformation field / 24 grid_samples): that much is structural
+        assert ips["zero_diff"] < ips["import_swap"] < min(ips["patched"], ips["fused"]), ips
     if "render_ms_per_frame_bf16x3" in c:     # faster only where the deformation kernel matters: no ordering asserted on small scenes
         assert c["render_ms_per_frame_bf16x3"] > 0
-        if default_workload:
-            assert c["render_ms_per_frame_bf16x3"] <= 1.05 * c["render_ms_per_frame"]
-    assert ips["zero_diff"] < ips["import_swap"] < ips["patched"] <= ips["fused"] * 1.02, ips
     assert c["instances_R_per_view"] > 0 and c["visible_V_per_view"] > 0 and c["mean_tile_list_length"] > 0
     assert c["render_ms_per_frame"] > 0
-    if "psnr_delta_vs_oracle_db" in c:
-        assert abs(c["psnr_delta_vs_oracle_db"]) <= 0.1
+    for key in ("psnr_delta_vs_oracle_db", "psnr_mean_delta_vs_oracle_db"):
+        if c.get(key) is not None:
+            assert abs(c[key]) <= 0.1
+    if "raster_async" in c:
+        assert c["raster_async"]["overflows"] == []      # a step that overflowed its arena did no work: never inside the timed loop
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     if r["traffic"] is not None:
-        assert "NOT collected in this run" in r["traffic_source"]
-    dom = max(r["kernels"], key=lambda k: k["ms_per_step"])
-    assert dom["kernel"] == r["kernel"]
-    for k in r["kernels"]:
-        assert k["algorithmic_bytes_per_launch"] <= k["implementation_bytes_per_launch"] and k["avg_launch_ms"] > 0
+        # (the driver's record keeps the first 128 characters of every string)
+        assert "NOT collected in this run" in r["traffic_source"] or r["traffic_source"].startswith("profiles/kernel_traffic.json")
+    if "kernels" in r:
+        dom = max(r["kernels"], key=lambda k: k["ms_per_step"])
+        assert dom["kernel"] == r["kernel"]
+        for k in r["kernels"]:
+            assert k["algorithmic_bytes_per_launch"] <= k["implementation_bytes_per_launch"] and k["avg_launch_ms"] > 0
+            if k["kernel"].startswith("s3g::blend_") and not round3_accounting:   # (round 3's lines carry the two bugs below)
+                assert k["bound"] == "valu"                    # SURVEY 8(d): VALU / v_exp-bound, never priced as an HBM kernel
+                assert abs(k["launches_per_step"] - 1.0) < 1e-6, k   # ONE two-image launch per step (round 3 mixed the render loop in)
+    if n_gpus > 1:
+        cm = d["comm"]
+        assert cm["world_size"] == n_gpus and len(cm["devices"]) == n_gpus and cm["backend"] in ("nccl", "gloo")
+        return
+    assert "cpu_baseline" in d
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["what"] == "point_splat" and cb["cores"] >= 1 and cb["value"] > 0
-    assert "measured, not extrapolated" in cb["sample"]
-    tr = cb["tile_rasterizer_port"]
-    assert tr["value"] > 0 and len(tr["model"]["sample_P"]) == 3 and len(tr["model"]["fit_residual_rel"]) == 3
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    if "what" in cb:          # round 3 on: the top-level baseline is the north_star's point-splat stub, one real full-size iteration
+        assert cb["what"] == "point_splat"
+        assert "measured, not extrapolated" in cb["sample"] or cb["sample"].startswith("ONE full iteration of the workload itself")
+    if "tile_rasterizer_port" in cb:
+        tr = cb["tile_rasterizer_port"]
+        assert tr["value"] > 0 and len(tr["model"]["sample_P"]) == 3 and len(tr["model"]["fit_residual_rel"]) == 3
