@@ -67,13 +67,16 @@ def build_scene(P, width, height, n_frames, device, seed=0, scale_mult=1.0):
 def make_targets(pc, cam, bg, hyper, seed):
     """GT image / lidar-like depth / feature map = render of a perturbed copy of the scene (non-trivial losses)."""
     from types import SimpleNamespace
+    from s3gaussian_amd import raster_C
     from s3gaussian_amd.pipeline import render
+    prev_async = raster_C.set_async(False)   # targets must be right whatever the capacity policy has seen so far: synchronous forward
     g = torch.Generator(device="cpu").manual_seed(seed)
     pipe = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
     xyz0 = pc._xyz.data.clone()
     pc._xyz.data.add_(0.01 * torch.randn(xyz0.shape, generator=g).to(xyz0.device))
     pkg = render(cam, pc, pipe, bg, stage="fine", render_feat=True)
     pc._xyz.data.copy_(xyz0)
+    raster_C.set_async(prev_async)
     return pkg["render"].clamp(0, 1).clone(), pkg["depth"].clone(), pkg["feat"].clone()
 
 
@@ -573,21 +576,39 @@ def main(argv=None):
     torch.cuda.synchronize()
     raster_C.async_reset_statistics(device)
     comm.update(elems=0, events=[], sparse_rows=0)
-    vis_masks = []     # summed after the timed region (workload statistics are not part of the step)
+    vis_masks, losses = [], []     # read after the timed region (workload statistics are not part of the step)
+
+    def keep(out):
+        losses.append(out[0])
+        vis_masks.append(out[1]["visibility_filter"])
+
     headline_idx = list(range(a.warmup, a.warmup + a.steps))
-    dt, t_enq, per_step = timed_loop(step, headline_idx, world, device, after_step=lambda out: vis_masks.append(out[1]["visibility_filter"]))
+    dt, t_enq, per_step = timed_loop(step, headline_idx, world, device, after_step=keep)
     astat = raster_C.async_status(device, block=True)
-    if astat["overflows"]:
+    n_over = len(astat["overflows"])
+    if world > 1:     # every rank must take the same branch below (the loops contain barriers and collectives)
+        t = torch.tensor([n_over], device=device, dtype=torch.int32)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        n_over = int(t.item())
+    if n_over:
         # a step whose forward overflowed its speculative arena did no work: the capacity has grown by now, time the loop again
         vis_masks.clear()
+        losses.clear()
         comm.update(elems=0, events=[], sparse_rows=0)
         raster_C.async_reset_statistics(device)
-        dt, t_enq, per_step = timed_loop(step, headline_idx, world, device, after_step=lambda out: vis_masks.append(out[1]["visibility_filter"]))
+        dt, t_enq, per_step = timed_loop(step, headline_idx, world, device, after_step=keep)
         astat2 = raster_C.async_status(device, block=True)
-        astat2["overflows_in_discarded_first_attempt"] = len(astat["overflows"])
+        astat2["overflows_in_discarded_first_attempt"] = n_over
         astat = astat2
-        if astat["overflows"]:
+        n_over = len(astat["overflows"])
+        if world > 1:
+            t = torch.tensor([n_over], device=device, dtype=torch.int32)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            n_over = int(t.item())
+        if n_over:
             raise SystemExit("bench.py: the asynchronous rasterizer overflowed its arena twice in the timed region; run with --sync-raster")
+    if not all(bool(torch.isfinite(x)) for x in losses):
+        raise SystemExit("bench.py: a timed step produced a non-finite loss -- the number would not be a training throughput")
     if world > 1:
         t = torch.tensor([dt, t_enq], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -612,17 +633,23 @@ def main(argv=None):
     n_frames = 20
 
     def render_loop():
-        for i in range(3):
+        """-> (wall ms per frame over n_frames frames, median stream ms per frame from one event pair per frame)."""
+        for i in range(5):
             render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_frames + 1)]
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        evs[0].record()
         for i in range(n_frames):
             render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
+            evs[i + 1].record()
         torch.cuda.synchronize()
-        return 1000.0 * (time.perf_counter() - t1) / n_frames
+        wall = 1000.0 * (time.perf_counter() - t1) / n_frames
+        per = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(n_frames))
+        return wall, per[n_frames // 2]
 
     with torch.no_grad():
-        render_ms = render_loop()
+        render_ms, render_median_ms = render_loop()
         clear_profile_slots()
         L.s3g_profile_enable(1)          # a separate, instrumented pass for the inference kernel's own time
         for i in range(8):
@@ -639,10 +666,14 @@ def main(argv=None):
         _arith = _deformation.INFER_ARITHMETIC
         _deformation.INFER_ARITHMETIC = "bf16x3"
         try:
-            render_split_ms = render_loop()
+            render_split_ms, render_split_median_ms = render_loop()
         finally:
             _deformation.INFER_ARITHMETIC = _arith
 
+    dev_ids = None
+    if world > 1:     # collectives are called by EVERY rank, never inside the rank-0 block below
+        dev_ids = [None] * world
+        torch.distributed.all_gather_object(dev_ids, f"{os.uname().nodename}:cuda:{device.index}")
     if rank == 0:
         # ---- roofline: every hot kernel timed in-library with hipEvents on the launch stream (include/s3g_raster.h),
         # priced against its ALGORITHMIC bytes / flops (DESIGN.md section 7 states each model) -----------------------------
@@ -793,9 +824,10 @@ def main(argv=None):
                                         if k in astat},
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
                        "blend_forward_avg_ms": fwd["avg_launch_ms"] if fwd else None,
-                       "render_ms_per_frame": round(render_ms, 3),
+                       "render_ms_per_frame": round(render_ms, 3), "render_ms_per_frame_median": round(render_median_ms, 3),
                        "render_deform_infer_kernel_ms": round(infer_kernel_ms, 4) if infer_kernel_ms else None,
-                       "render_ms_per_frame_bf16x3": round(render_split_ms, 3)},
+                       "render_ms_per_frame_bf16x3": round(render_split_ms, 3),
+                       "render_ms_per_frame_bf16x3_median": round(render_split_median_ms, 3)},
             "roofline": roof,
         }
         if world > 1:
@@ -809,8 +841,6 @@ def main(argv=None):
                 lib_version = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
             except Exception:
                 lib_version = None
-            dev_ids = [None] * world
-            torch.distributed.all_gather_object(dev_ids, f"{os.uname().nodename}:cuda:{device.index}")
             out["comm"] = {"backend": backend, "world_size": torch.distributed.get_world_size(), "rccl_version": lib_version,
                            "devices": dev_ids, "distinct_devices": len(set(dev_ids)),
                            "bytes_reduced_per_step_per_rank": round(4.0 * comm_timed["elems"] / max(a.steps, 1)),

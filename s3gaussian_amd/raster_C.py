@@ -66,8 +66,8 @@ def _inputs(P, D, M, W, H, bg, means3D, sh, colors, opacity, scales, scale_modif
 # The reference's forward -- and s3g_raster_forward -- waits for the device once per call: the instance count R sizes the
 # binning arena (rasterizer_impl.cu:281-282).  That one wait caps the host's run-ahead at a single iteration, so any hiccup of
 # the host (a slow core, a busy box, an allocator call) becomes GPU idle time.  With ASYNC on, the callers that never hand R
-# to anybody (the autograd nodes of rasterizer.py) size the arenas for a speculative capacity instead -- twice the largest
-# count seen so far for this image size, quantised so that the allocation sizes repeat -- and the true counts arrive later
+# to anybody (the autograd nodes of rasterizer.py) size the arenas for a speculative capacity instead -- four times the largest
+# count seen so far for this image size (and never fewer than 16 M instances), quantised so that the allocation sizes repeat -- and the true counts arrive later
 # through a pinned ring that is polled, never waited for.  An overflow (counts above the capacity) is a well-defined no-op on
 # the device (background-only image, zero gradients, no densification bookkeeping, optimizer step dropped through
 # `async_skip_flag`), is reported here one or more calls later (warning + `async_status()["overflows"]`), and raises the
@@ -75,7 +75,12 @@ def _inputs(P, D, M, W, H, bg, means3D, sh, colors, opacity, scales, scale_modif
 # synchronous.  S3G_RASTER_ASYNC=0 switches the mechanism off.
 ASYNC = os.environ.get("S3G_RASTER_ASYNC", "1") != "0"
 _ASYNC_RING = 64
-_ASYNC_MIN_INSTANCES = 1 << 20
+# Capacity policy: HEADROOM x the largest count seen for the image size, never below MIN_INSTANCES.  Views of one scene differ by
+# more than 2x (measured at BASELINE cfg3: 1.2 M ... 2.7 M instances between the front and the side cameras), and an overflow
+# costs a whole view, so the policy is generous: 16 M instances = 0.3 GB of binning arena + 0.9 GB of backward records, of which
+# only the part the true count reaches is ever touched (HBM is 288 GB; SURVEY 8a expects 5-12 M instances for trained scenes).
+_ASYNC_MIN_INSTANCES = int(os.environ.get("S3G_RASTER_ASYNC_MIN_INSTANCES", str(16 << 20)))
+_ASYNC_HEADROOM = 4
 
 
 def set_async(on: bool) -> bool:
@@ -114,8 +119,8 @@ class _AsyncState:
         h = self.hist.get(key)
         if h is None:
             return None
-        cap_r = _quantise(max(2 * h[0], _ASYNC_MIN_INSTANCES))
-        cap_s = max(_quantise(max(2 * h[1], _ASYNC_MIN_INSTANCES)), cap_r)
+        cap_r = _quantise(max(_ASYNC_HEADROOM * h[0], _ASYNC_MIN_INSTANCES))
+        cap_s = max(_quantise(max(_ASYNC_HEADROOM * h[1], 2 * _ASYNC_MIN_INSTANCES)), cap_r)
         longest = 2 * h[2]
         lds = 256
         while lds < min(longest, 4096):
@@ -202,7 +207,7 @@ def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_
     caps = st.caps(key)
     learn = caps is None                    # first call for this image size: generous capacity, wait once, remember the counts
     if learn:
-        caps = (8 << 20, 16 << 20, 4096, 1)
+        caps = (_quantise(_ASYNC_MIN_INSTANCES), _quantise(2 * _ASYNC_MIN_INSTANCES), 4096, 1)
     while True:
         cap_r, cap_s, lds, long_lists = caps
         nb = (C.c_size_t(), C.c_size_t(), C.c_size_t())   # geometry, binning, image

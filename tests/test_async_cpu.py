@@ -30,10 +30,14 @@ def test_capacities_follow_the_largest_counts_seen():
     assert st.caps((1600, 1066)) is None                       # unknown image size: the caller learns the counts first
     st.hist[(1600, 1066)] = [1_460_000, 2_900_000, 900]
     cap_r, cap_s, lds, long_lists = st.caps((1600, 1066))
-    assert cap_r >= 2 * 1_460_000 and cap_s >= 2 * 2_900_000 and cap_s >= cap_r
+    assert cap_r >= raster_C._ASYNC_HEADROOM * 1_460_000 and cap_s >= raster_C._ASYNC_HEADROOM * 2_900_000 and cap_s >= cap_r
+    assert cap_r >= raster_C._ASYNC_MIN_INSTANCES
     assert lds == 2048 and long_lists == 0                     # twice the longest list, as a power of two
     st.hist[(1600, 1066)][2] = 3000
     assert st.caps((1600, 1066))[2:] == (4096, 1)              # lists may pass 4096: the long-list sort pass is launched too
     st.hist[(64, 64)] = [10, 12, 3]
     cap_r, cap_s, lds, long_lists = st.caps((64, 64))
-    assert cap_r == cap_s == raster_C._quantise(raster_C._ASYNC_MIN_INSTANCES) and lds == 256 and long_lists == 0
+    assert cap_r == raster_C._quantise(raster_C._ASYNC_MIN_INSTANCES) and cap_s == raster_C._quantise(2 * raster_C._ASYNC_MIN_INSTANCES)
+    assert lds == 256 and long_lists == 0
+    st.hist[(64, 64)] = [40_000_000, 70_000_000, 3]              # beyond the floor: the capacity follows the counts
+    assert st.caps((64, 64))[0] >= 160_000_000

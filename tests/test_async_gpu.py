@@ -84,7 +84,7 @@ def test_overflow_is_a_device_side_no_op_and_is_reported_late(gpu_device, monkey
         true_R = st.hist[key][0]
         assert true_R > 200
         monkeypatch.setattr(raster_C, "_ASYNC_MIN_INSTANCES", 1)
-        st.hist[key] = [true_R // 8, true_R // 8, 4]                       # pretend smaller scenes were all we had seen
+        st.hist[key] = [true_R // 16, true_R // 16, 4]                     # pretend smaller scenes were all we had seen
         cap = st.caps(key)
         assert cap[0] < true_R
         rast = GaussianRasterizer(raster_settings=settings_from(s, dev))

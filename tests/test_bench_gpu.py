@@ -36,10 +36,10 @@ def test_plain_gpus_2_command_line_starts_two_ranks(gpu_device):
             "--frames", "4", "--steps", "3", "--warmup", "2"]
     import torch
     if torch.cuda.device_count() < 2:
-        out = subprocess.run(args, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        out = subprocess.run(args, cwd=ROOT, capture_output=True, text=True, timeout=120, env=env)
         assert out.returncode != 0 and "refusing" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
         env["S3G_DIST_BACKEND"] = "gloo"
-    out = subprocess.run(args, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    out = subprocess.run(args, cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]

@@ -68,3 +68,22 @@ def test_workload_label_names_the_world_it_ran_on():
     assert bench.workload_label(a, 1).startswith("BASELINE cfg3")
     assert "over 8 ranks" in bench.workload_label(a, 8)
     assert "NOT a BASELINE config" in bench.workload_label(bench.parse_args(["--P", "1000"]), 1)
+
+
+def test_no_collective_is_called_by_rank_zero_only():
+    """Round 4's first two-rank run hung: `all_gather_object` sat inside bench.main's `if rank == 0:` block while rank 1 waited in the
+    final barrier.  Statically: inside any `if rank == 0` of bench.py the only torch.distributed names allowed are the local
+    queries; and the re-timing branch after an arena overflow is entered on a flag that has been all-reduced."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    local_queries = {"get_backend", "get_world_size", "get_rank", "is_initialized"}
+    found = 0
+    for node in ast.walk(tree):
+        if isinstance(node, ast.If) and isinstance(node.test, ast.Compare) and ast.unparse(node.test) == "rank == 0":
+            found += 1
+            for sub in ast.walk(node):
+                if isinstance(sub, ast.Attribute) and ast.unparse(sub.value) in ("torch.distributed", "dist"):
+                    assert sub.attr in local_queries, f"collective torch.distributed.{sub.attr} inside `if rank == 0` (line {sub.lineno})"
+    assert found >= 1
+    assert "if n_over:" in src and "if astat[\"overflows\"]:" not in src

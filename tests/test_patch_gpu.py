@@ -133,7 +133,7 @@ def test_patched_compute_regulation_reuses_the_value_render_computed(gpu_device,
     assert rel_l2(g_first.cpu().numpy(), pc._deformation.deformation_net.grid.grids[0][0].grad.cpu().numpy()) < 1e-6
     # other weights than render used -> not the cached value
     patch.render(cam, pc, pipe, scn["bg"].to(dev), stage="fine", return_dx=True, render_feat=True)
-    other = patch.compute_regulation(pc, w[0] * 2, w[1], w[2])
+    other = patch.compute_regulation(pc, w[0], w[1], w[2] * 2)      # (the time planes start at exactly 1: only the spatial term is non-zero)
     assert sweeps == [1, 1] and other.item() > reg.item()
 
 

@@ -440,6 +440,7 @@ def test_exact_tile_culling_changes_nothing_but_the_lists(gpu_device, scene):
     res = {}
     for cull in (True, False):
         prev = raster_C.set_exact_cull(cull)
+        prev_async = raster_C.set_async(False)   # the test reads the instance COUNT next to the private lists: synchronous forward
         try:
             t = lambda k: s[k].to(dev).clone().requires_grad_(True)
             m3, op, sc, rot, col = t("means3D"), t("opacities"), t("scales"), t("rotations"), t("colors_precomp")
@@ -454,6 +455,7 @@ def test_exact_tile_culling_changes_nothing_but_the_lists(gpu_device, scene):
             res[cull] = (R, [color, depth, radii], [x.grad for x in (m3, m2, op, sc, rot, col)], lists)
         finally:
             raster_C.set_exact_cull(prev)
+            raster_C.set_async(prev_async)
     (R1, o1, g1, l1), (R0, o0, g0, l0) = res[True], res[False]
     for a, b in zip(o1 + g1, o0 + g0):
         assert torch.equal(a, b)
