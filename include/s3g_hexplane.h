@@ -54,7 +54,9 @@ int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, co
  * row tables and their gradients when uniform_time; + 128 B per point and level (one row T = dL/dfeature * feature; rounds 1-2: 3 KB per point) on the features == NULL
  * path), uninitialised. */
 int s3g_hexplane_backward_scratch_rows(int levels);   /* 128-byte rows of scratch per point the features == NULL path writes */
-#define S3G_HEX_SORT_STATE_WORDS 7
+/* 32-bit words per point of `sort_state` below: 2 x (walk orders) + 1.  Round 4: one walk order per orientation AND level,
+ * 6 * levels + 1 words (25 at the reference's four levels); rounds 1-3 kept three orders (7 words). */
+int s3g_hexplane_sort_state_words(int levels);
 size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P, int have_features);
 int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
                           const float* dL_dfeatures,
@@ -66,13 +68,14 @@ int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, c
                           (128 B per point and level of scratch; rounds 1-2 stored dL/d(sample) for all 24 plane-levels). */,
                           float* dL_dxyz, float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6],
                           void* workspace,
-                          unsigned int* sort_state /* [S3G_HEX_SORT_STATE_WORDS * P] device or NULL: the three spatial orders
-                          of the points [0,3P), for each of them the position of its k-th point in the processing order
-                          [3P,6P) (where that point's dL/d(sample) rows are), and the 3-D blocked processing order itself
-                          [6P,7P).  They only steer HOW the work is walked (texel reuse, run-length
-                          combining), never the result, so a caller may keep them across iterations while the points move
-                          slowly: sort_reuse != 0 = `sort_state` holds the orders of an earlier call with the same P and the
-                          sorts are skipped; sort_reuse == 0 = they are recomputed and left there.  sort_state[6P..7P) is the
+                          unsigned int* sort_state /* [s3g_hexplane_sort_state_words(levels) * P] device or NULL.  With
+                          NW = 3 * levels walk orders -- order oi = orientation * levels + level sorts the points by that
+                          level's own (major, minor) texel cells --: the orders [0, NW*P), for each of them the position of its
+                          k-th point in the processing order [NW*P, 2*NW*P) (where that point's T rows are), and the 3-D
+                          blocked processing order itself [2*NW*P, (2*NW+1)*P).  They only steer HOW the work is walked (texel
+                          reuse, run-length combining), never the result, so a caller may keep them across iterations while the
+                          points move slowly: sort_reuse != 0 = `sort_state` holds the orders of an earlier call with the same P and the
+                          sorts are skipped; sort_reuse == 0 = they are recomputed and left there.  The last P words are the
                           blocked order, usable as proc_order of later forwards. */,
                           int sort_reuse, void* stream);
 

@@ -38,6 +38,12 @@ namespace s3g {
 #ifndef S3G_HEX_TSLAB
 #define S3G_HEX_TSLAB 1
 #endif
+// Walk orders of the scatter.  0 (rounds 1-3): three orders, the finest level's (major, minor) cells per orientation; every level
+// of an orientation is walked in that order, two levels per walk.  1 (round 4): one order per orientation AND level -- each
+// (orientation, level) walk is monotone in its own cells (see sort_cell below).
+#ifndef S3G_HEX_PER_LEVEL
+#define S3G_HEX_PER_LEVEL 1
+#endif
 #define S3G_POINT_PREFETCH 1
 constexpr float TSLAB_SAFE = 1e-18f;
 __device__ __forceinline__ bool tslab_divisible(float s) { return fabsf(s) > TSLAB_SAFE && fabsf(s) < __builtin_huge_valf(); }
@@ -339,12 +345,17 @@ __device__ constexpr int MIN_[3] = {1, 2, 0};
 __device__ constexpr int PLA[3] = {0, 3, 1};  // (x,y) (y,z) (x,z)
 __device__ constexpr int PLT[3] = {2, 4, 5};  // (x,t) (y,t) (z,t)
 
-// Sort cell of a point along `axis` = its texel column at the FINEST level, computed exactly like make_tap does, so
-// all points of one cell share their four finest-level corner texels (a coarser cell grid would cut cells with texel
-// boundaries -- align_corners grids of different levels do not nest -- and break the register run-length combining).
-__device__ __forceinline__ int sort_cell(const HexArgs& a, int p, int axis) {
+// Sort cell of a point along `axis` = its texel column at level `level`, computed exactly like make_tap does, so all points of
+// one cell share their four corner texels at that level.
+// Round 4: ONE ORDER PER (orientation, LEVEL).  Rounds 1-3 walked every level in the finest level's cell order: align_corners
+// grids of different levels do not nest, a coarse footprint is then re-entered once per fine row that crosses it (eight times at
+// level 0) and alternates at every cut -- which is what the two-entry footprint cache was for.  Counted on the bench's own point
+// cloud with the cache modelled statement by statement (tools/sim/flush_orders.py): 5.9 M line-atomics per backward in the finest
+// order against 2.4 M when every (orientation, level) is walked in ITS OWN cells' order (floor: 1.03 M distinct footprints x 2-4
+// corners); measured before that: 7.9 M, i.e. ~0.8 ms of a 1.43 ms kernel at the 10 G line-ops/s the chip retires.
+__device__ __forceinline__ int sort_cell(const HexArgs& a, int p, int axis, int level) {
   const float u = (a.xyz[3 * (size_t)p + axis] - a.d.aabb_max[axis]) * (2.0f / (a.d.aabb_min[axis] - a.d.aabb_max[axis])) - 1.0f;
-  const int W = a.d.res[a.d.levels - 1][axis];
+  const int W = a.d.res[level][axis];
   float ix = ((u + 1.f) / 2.f) * (float)(W - 1);
   ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
   int cidx = (int)floorf(ix);
@@ -352,33 +363,42 @@ __device__ __forceinline__ int sort_cell(const HexArgs& a, int p, int axis) {
   return min(SORT_BINS - 1, max(0, cidx));
 }
 
-// Order 3 is the PROCESSING order of the per-point passes (forward, backward pass A): a two-level 3-D blocking -- major key
-// = the 8 x 8 x 8 grid of blocks of the volume, minor key = the 8 x 8 x 8 sub-blocks of a block -- so that consecutive
+// The LAST order is the PROCESSING order of the per-point passes (forward, backward pass A): a two-level 3-D blocking -- major
+// key = the 8 x 8 x 8 grid of blocks of the volume, minor key = the 8 x 8 x 8 sub-blocks of a block -- so that consecutive
 // points are close in x, y AND z and all three spatial planes' texels stay in the L2 of the XCD that works on the block.
 // (In an (x, y) order every tap of the (y, z) plane missed: 2.5 GB of 128-byte fetches per pass at 1.2 M points.)
-constexpr int N_ORDERS = 4;
+// Order ids: oi = orientation * levels + level for the 3 * levels walk orders, oi = 3 * levels for the processing order.
+static inline int n_walk_orders(int levels) { return S3G_HEX_PER_LEVEL ? 3 * levels : 3; }
+static inline int n_orders(int levels) { return n_walk_orders(levels) + 1; }
 __device__ __forceinline__ int block_key(const HexArgs& a, int p, int shift) {
   int key = 0;
 #pragma unroll
   for (int axis = 0; axis < 3; axis++) {
     const int Wc = min(a.d.res[a.d.levels - 1][axis], SORT_BINS);
-    const int c = sort_cell(a, p, axis);
+    const int c = sort_cell(a, p, axis, a.d.levels - 1);
     key = key * 8 + (min(63, (c * 64) / Wc) >> shift & 7);
   }
   return key;
 }
-__device__ __forceinline__ int major_key(const HexArgs& a, int p, int o) { return o < 3 ? sort_cell(a, p, MAJ[o]) : block_key(a, p, 3); }
-__device__ __forceinline__ int minor_key(const HexArgs& a, int p, int o) { return o < 3 ? sort_cell(a, p, MIN_[o]) : block_key(a, p, 0); }
+__device__ __forceinline__ int order_key(const HexArgs& a, int p, int oi, bool major) {
+  const int nw = S3G_HEX_PER_LEVEL ? 3 * a.d.levels : 3;
+  if (oi >= nw) return block_key(a, p, major ? 3 : 0);
+  const int o = S3G_HEX_PER_LEVEL ? oi / a.d.levels : oi, level = S3G_HEX_PER_LEVEL ? oi % a.d.levels : a.d.levels - 1;
+  return sort_cell(a, p, major ? MAJ[o] : MIN_[o], level);
+}
+__device__ __forceinline__ int major_key(const HexArgs& a, int p, int oi) { return order_key(a, p, oi, true); }
+__device__ __forceinline__ int minor_key(const HexArgs& a, int p, int oi) { return order_key(a, p, oi, false); }
 
 struct SortWork {
-  uint32_t* table;      // [4][SORT_NB][SORT_BINS]
-  uint32_t* seg_start;  // [4][SORT_BINS + 1]
-  uint32_t* tmp;        // [4][P]  indices grouped by major key
-  uint32_t* order;      // [3][P]  final orders of the three orientation walks
-  uint32_t* comp;       // [3][P]  comp[o][k] = position of point order[o][k] in the processing order (where its G rows are)
-  uint32_t* proc;       // [P]     order 3: processing order of the per-point passes
+  uint32_t* table;      // [NO][SORT_NB][SORT_BINS]      NO = n_orders(levels), NW = n_walk_orders(levels) = NO - 1
+  uint32_t* seg_start;  // [NO][SORT_BINS + 1]
+  uint32_t* tmp;        // [NO][P]  indices grouped by major key
+  uint32_t* order;      // [NW][P]  final orders of the walks: oi = orientation * levels + level
+  uint32_t* comp;       // [NW][P]  comp[oi][k] = position of point order[oi][k] in the processing order (where its T rows are)
+  uint32_t* proc;       // [P]      the last order: processing order of the per-point passes
+  int nw;               // NW
 };
-__device__ __forceinline__ uint32_t* order_of(const SortWork& w, int o, int P) { return o < 3 ? w.order + (size_t)o * P : w.proc; }
+__device__ __forceinline__ uint32_t* order_of(const SortWork& w, int o, int P) { return o < w.nw ? w.order + (size_t)o * P : w.proc; }
 
 template <bool WRITE>
 __global__ void __launch_bounds__(256) hexsort_major_kernel(const HexArgs a, const SortWork w, int chunk) {
@@ -693,9 +713,12 @@ __device__ __forceinline__ void foot2_unpack_t(Foot2T<float>& F) {
 // kernel used to be VALU-bound on make_tap, which every lane repeated for each (level, plane) tap of a point; now the walker's
 // lanes compute the taps of FOUR points at once (lane = point q x tap j), park them in LDS, and every lane reads them back
 // with broadcast loads while it accumulates its channels.
-constexpr int SCATTER_LG = 2;          // levels handled per walk of a segment
+constexpr int SCATTER_LG = S3G_HEX_PER_LEVEL ? 1 : 2;          // levels handled per walk of a segment (per-level orders: one)
 constexpr int SCATTER_CPL = 1;         // channels per lane (2 = v_pk_fma accumulation, but twice the flush atomics: 2.07 vs 1.14 ms -- the walk is bound by atomic line-ops)
-constexpr int SCATTER_WG_PER_CU = SCATTER_CPL == 2 ? 3 : 4;   // waves per SIMD the register budget is set for (5 = 96 VGPRs: the shift path spills, 1.57 vs 1.00 ms)
+#ifndef S3G_HEX_SCATTER_WAVES
+#define S3G_HEX_SCATTER_WAVES 4
+#endif
+constexpr int SCATTER_WG_PER_CU = SCATTER_CPL == 2 ? 3 : S3G_HEX_SCATTER_WAVES;   // waves per SIMD the register budget is set for (two levels per walk: 5 = 96 VGPRs, the shift path spills, 1.57 vs 1.00 ms)
 constexpr int TAPF = 8;  // floats per packed tap in LDS (6 used; 32-byte slots keep the 16-byte reads aligned)
 template <typename T> __device__ __forceinline__ T load_g(const float* p);
 template <> __device__ __forceinline__ float load_g<float>(const float* p) { return G_NONTEMPORAL_LOAD ? __builtin_nontemporal_load(p) : *p; }
@@ -711,7 +734,10 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   constexpr int NTAP = 2 * LG;        // taps per point and walk
   static_assert(LANES >= 4 * NTAP, "tap phase: one lane per (point of the group of four, tap)");
   __shared__ __attribute__((aligned(16))) float tapbuf[WALKERS][2][4][NTAP][TAPF];  // [walker][double buffer][point][tap]
-  const int o = blockIdx.y;
+  // per-level orders: blockIdx.y = orientation * levels + level and the walk handles that one level in ITS order
+  const int oi = blockIdx.y;
+  const int o = S3G_HEX_PER_LEVEL ? oi / a.d.levels : oi;
+  const int lbeg = S3G_HEX_PER_LEVEL ? oi % a.d.levels : 0, lend = S3G_HEX_PER_LEVEL ? lbeg + 1 : a.d.levels;
   const int ln = threadIdx.x & (LANES - 1), hw = threadIdx.x / LANES;
   const int c = ln * CPL;             // first channel of this lane
   const int q = (ln / NTAP) & 3, j = ln % NTAP;  // tap-phase role: point q of the group of four, tap j = (level j >> 1, kind j & 1)
@@ -719,13 +745,13 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   const int seg = blockIdx.x * WALKERS + hw;
   const int k0 = seg * a.seg_len, k1 = min(a.P, k0 + a.seg_len);
   if (k0 >= a.P) return;  // whole walkers drop out; the LDS traffic below is private to a walker (wave-ordered)
-  const uint32_t* order = order_all + (size_t)o * a.P;
-  const uint32_t* comp = comp_all + (size_t)o * a.P;
+  const uint32_t* order = order_all + (size_t)oi * a.P;
+  const uint32_t* comp = comp_all + (size_t)oi * a.P;
   const size_t GP = (size_t)((S3G_HEX_TSLAB ? 1 : 6) * a.d.levels * HEXC);   // point-major layout: floats per point
   const int i0 = PLA[o], i1 = PLT[o];
   const int ip = (j & 1) ? i1 : i0;                   // the plane of this lane's tap
   const int axw = PAIR0[ip], axh = PAIR1[ip];
-  for (int l0 = 0; l0 < a.d.levels; l0 += LG) {
+  for (int l0 = lbeg; l0 < lend; l0 += LG) {
     Foot2T<T> ft[LG][2];
 #pragma unroll
     for (int l = 0; l < LG; l++)
@@ -881,7 +907,8 @@ __device__ __forceinline__ WalkTap walk_tap_read(const float* src) {
 __global__ void __launch_bounds__(256, WALK_WG_PER_CU)
 hexplane_backward_walk_kernel(const HexArgs a, const float* __restrict__ feat, const uint32_t* __restrict__ order_all,
                               float* __restrict__ dup /* [3][P][2] partial dL/du per orientation */,
-                              uint16_t* __restrict__ badmask /* [3][P], zero-filled: bit 2*level + kind */) {
+                              uint16_t* __restrict__ badmask /* [3][P], zero-filled: bit 2*level + kind */,
+                              int order_stride, int order_offset /* order of orientation o = order_all[o * stride + offset] */) {
   constexpr int LG = WALK_LG;
   __shared__ __attribute__((aligned(16))) float tapbuf[8][2][4][8][TAPF];  // [half-wave][double buffer][point][tap]
   // g / f rows of a group of four points, DMA-copied global -> LDS one group ahead (no registers held across the wait):
@@ -894,7 +921,7 @@ hexplane_backward_walk_kernel(const HexArgs a, const float* __restrict__ feat, c
   const int seg = blockIdx.x * 8 + hw;
   const int k0 = seg * a.seg_len, k1 = min(a.P, k0 + a.seg_len);
   if (k0 >= a.P) return;  // whole half-waves drop out; LDS traffic and shuffles below stay inside a half-wave
-  const uint32_t* order = order_all + (size_t)o * a.P;
+  const uint32_t* order = order_all + (size_t)(o * order_stride + order_offset) * a.P;
   const int F = a.d.levels * HEXC;
   const int i0 = PLA[o], i1 = PLT[o];
   const int ip = (j & 1) ? i1 : i0;                   // the plane of this lane's tap
@@ -1167,11 +1194,13 @@ static void carve_backward(Carver& c, const s3g_hexplane_desc* d, int P, bool wa
   float* g = walk ? nullptr : c.take<float>((size_t)d->levels * (S3G_HEX_TSLAB ? 1 : 6) * n * HEXC);   // slab path: T rows (r3) / per-plane gradient rows
   float* tb = d->uniform_time ? c.take<float>(2 * time_table_floats(d)) : nullptr;
   SortWork s;
-  s.table = c.take<uint32_t>((size_t)N_ORDERS * SORT_NB * SORT_BINS);
-  s.seg_start = c.take<uint32_t>((size_t)N_ORDERS * (SORT_BINS + 1));
-  s.tmp = c.take<uint32_t>(N_ORDERS * n);
-  s.order = c.take<uint32_t>(3 * n);
-  s.comp = c.take<uint32_t>(3 * n);
+  const size_t NO = (size_t)n_orders(d->levels), NW = (size_t)n_walk_orders(d->levels);
+  s.nw = (int)NW;
+  s.table = c.take<uint32_t>(NO * SORT_NB * SORT_BINS);
+  s.seg_start = c.take<uint32_t>(NO * (SORT_BINS + 1));
+  s.tmp = c.take<uint32_t>(NO * n);
+  s.order = c.take<uint32_t>(NW * n);
+  s.comp = c.take<uint32_t>(NW * n);
   s.proc = c.take<uint32_t>(n);
   float* du = walk ? c.take<float>(6 * n) : nullptr;
   uint16_t* bm = walk ? c.take<uint16_t>(3 * n) : nullptr;
@@ -1184,6 +1213,10 @@ static void carve_backward(Carver& c, const s3g_hexplane_desc* d, int P, bool wa
 
 // 128-byte rows of scratch the default (slab) backward writes per point and level set: bench.py prices the implementation bytes
 extern "C" int s3g_hexplane_backward_scratch_rows(int levels) { return (S3G_HEX_TSLAB ? 1 : 6) * levels; }
+
+// 32-bit words per point of the caller-kept `sort_state`: the walk orders, their compositions with the processing order, and the
+// processing order itself (round 4: one walk order per orientation AND level, 6 * levels + 1; rounds 1-3: 7)
+extern "C" int s3g_hexplane_sort_state_words(int levels) { return 2 * n_walk_orders(levels) + 1; }
 
 extern "C" size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P, int have_features) {
   if (!d || d->levels < 1 || d->levels > S3G_HEX_MAX_LEVELS || P < 0) return 0;
@@ -1215,22 +1248,23 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
   uint16_t* badmask;
   SortWork w;
   carve_backward(c, d, P, walk, &G, &tables, &w, &dup, &badmask);
-  if (sort_state) {  // caller-owned, persistent
+  const int NO = n_orders(d->levels), NW = n_walk_orders(d->levels);
+  if (sort_state) {  // caller-owned, persistent: s3g_hexplane_sort_state_words(levels) * P words
     w.order = sort_state;
-    w.comp = sort_state + (size_t)3 * P;
-    w.proc = sort_state + (size_t)6 * P;
+    w.comp = sort_state + (size_t)NW * P;
+    w.proc = sort_state + (size_t)2 * NW * P;
   }
 
   // 1. three spatial orders (2-level LDS counting sorts); the legacy path also needs their inverse permutations
   if (!sort_reuse) {
     const int chunk = (((P + SORT_NB - 1) / SORT_NB + 255) / 256) * 256;
-    hipLaunchKernelGGL(hexsort_major_kernel<false>, dim3(SORT_NB, N_ORDERS), dim3(256), 0, stream, a, w, chunk);
-    hipLaunchKernelGGL(hexsort_scan_kernel, dim3(N_ORDERS), dim3(512), 0, stream, w, P);
-    hipLaunchKernelGGL(hexsort_major_kernel<true>, dim3(SORT_NB, N_ORDERS), dim3(256), 0, stream, a, w, chunk);
-    hipLaunchKernelGGL(hexsort_minor_kernel, dim3(SORT_BINS, N_ORDERS), dim3(256), 0, stream, a, w);
-    // comp[o][k]; the inverse of the processing order goes through w.tmp (free after the sorts)
+    hipLaunchKernelGGL(hexsort_major_kernel<false>, dim3(SORT_NB, NO), dim3(256), 0, stream, a, w, chunk);
+    hipLaunchKernelGGL(hexsort_scan_kernel, dim3(NO), dim3(512), 0, stream, w, P);
+    hipLaunchKernelGGL(hexsort_major_kernel<true>, dim3(SORT_NB, NO), dim3(256), 0, stream, a, w, chunk);
+    hipLaunchKernelGGL(hexsort_minor_kernel, dim3(SORT_BINS, NO), dim3(256), 0, stream, a, w);
+    // comp[oi][k]; the inverse of the processing order goes through w.tmp (free after the sorts)
     hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 1), dim3(256), 0, stream, P, w.proc, w.tmp);
-    hipLaunchKernelGGL(hexsort_compose_kernel, dim3((P + 255) / 256, 3), dim3(256), 0, stream, P, w.order, w.tmp, w.comp);
+    hipLaunchKernelGGL(hexsort_compose_kernel, dim3((P + 255) / 256, NW), dim3(256), 0, stream, P, w.order, w.tmp, w.comp);
     S3G_HIP_CHECK(hipGetLastError());
   }
   //    (the sorts above used the real resolutions; from here on the time planes are height-1 row tables if uniform_time)
@@ -1248,7 +1282,7 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     S3G_HIP_CHECK(hipMemsetAsync(badmask, 0, (size_t)3 * P * sizeof(uint16_t), stream));
     profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
     hipLaunchKernelGGL(hexplane_backward_walk_kernel, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, features, w.order, dup,
-                       badmask);
+                       badmask, S3G_HEX_PER_LEVEL ? d->levels : 1, S3G_HEX_PER_LEVEL ? d->levels - 1 : 0);
     profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
     hipLaunchKernelGGL(hexplane_backward_fixup_kernel, dim3(min((P + 7) / 8, 2048), 3), dim3(256), 0, stream, a, badmask, dup);
     hipLaunchKernelGGL(hexplane_dxyz_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a, dup);
@@ -1268,9 +1302,9 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     using ScatterT = std::conditional<SCATTER_CPL == 2, f2v, float>::type;
     constexpr int walkers = 256 / (HEXC / SCATTER_CPL);
     if (d->uniform_time)
-      hipLaunchKernelGGL((hexplane_scatter_kernel<true, ScatterT>), dim3((nseg + walkers - 1) / walkers, 3), dim3(256), 0, stream, a, G, w.order, w.comp);
+      hipLaunchKernelGGL((hexplane_scatter_kernel<true, ScatterT>), dim3((nseg + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, G, w.order, w.comp);
     else
-      hipLaunchKernelGGL((hexplane_scatter_kernel<false, ScatterT>), dim3((nseg + walkers - 1) / walkers, 3), dim3(256), 0, stream, a, G, w.order, w.comp);
+      hipLaunchKernelGGL((hexplane_scatter_kernel<false, ScatterT>), dim3((nseg + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, G, w.order, w.comp);
     profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
   }
   if (d->uniform_time) {

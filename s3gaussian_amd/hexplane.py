@@ -22,7 +22,16 @@ from . import _lib
 
 MAX_LEVELS, CHANNELS = 8, 32
 SORT_REFRESH = 8   # backward passes between two re-sorts of the points (see _HexPlaneSample.backward)
-SORT_STATE_WORDS = 7   # S3G_HEX_SORT_STATE_WORDS (include/s3g_hexplane.h): 3 orders + 3 ranks + the blocked processing order
+SORT_REFRESH = int(os.environ.get("S3G_HEX_SORT_REFRESH", SORT_REFRESH))
+
+
+def sort_state_words(levels: int) -> int:
+    """32-bit words per point of the persistent `sort_state` (include/s3g_hexplane.h::s3g_hexplane_sort_state_words): one walk
+    order per orientation and level, their compositions with the processing order, and the processing order (25 at 4 levels)."""
+    L = _bind()
+    return int(L.s3g_hexplane_sort_state_words(int(levels)))
+
+
 # Backward algorithm (include/s3g_hexplane.h): "slab" (default) = the per-point pass finishes dL/dxyz and writes ONE row per point
 # and level, T = dL/dfeature * feature (512 B per point since round 3; rounds 1-2 wrote dL/d(sample) of all 24 plane-levels, 3 KB);
 # three sorted scatter walks read it back and divide by the sample they re-derive from the footprint they are accumulating
@@ -54,6 +63,8 @@ def _bind():
         L.s3g_hexplane_backward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, vp, C.POINTER(_PlanePtrs), vp, vp, C.c_int, vp]
         L.s3g_hexplane_backward_workspace_bytes.restype = C.c_size_t
         L.s3g_hexplane_backward_workspace_bytes.argtypes = [C.POINTER(_HexDesc), C.c_int, C.c_int]
+        L.s3g_hexplane_sort_state_words.restype = C.c_int
+        L.s3g_hexplane_sort_state_words.argtypes = [C.c_int]
         _bound = True
     return L
 
@@ -153,13 +164,14 @@ class _HexPlaneSample(torch.autograd.Function):
         legacy = BACKWARD_MODE != "walk"
         work = torch.empty(L.s3g_hexplane_backward_workspace_bytes(C.byref(d), P, 0 if legacy else 1), dtype=torch.uint8,
                            device=xyz_c.device)
-        # the three spatial orders live in the field's cache and are refreshed every SORT_REFRESH backward passes (or when
+        # the spatial walk orders live in the field's cache and are refreshed every SORT_REFRESH backward passes (or when
         # P changes): they steer the walk, not the result, and the points move slowly between iterations
         state, reuse = None, 0
         if cache is not None:
             state = cache.get("sort_state")
-            if state is None or state.numel() != SORT_STATE_WORDS * P or state.device != xyz_c.device:
-                state = torch.empty(SORT_STATE_WORDS * P, dtype=torch.int32, device=xyz_c.device)
+            words = sort_state_words(len(resolutions))
+            if state is None or state.numel() != words * P or state.device != xyz_c.device:
+                state = torch.empty(words * P, dtype=torch.int32, device=xyz_c.device)
                 cache["sort_state"], cache["sort_age"] = state, 0
             else:
                 cache["sort_age"] = cache.get("sort_age", 0) + 1
@@ -174,7 +186,7 @@ class _HexPlaneSample(torch.autograd.Function):
                                                state.data_ptr() if state is not None else None, reuse,
                                                torch.cuda.current_stream().cuda_stream))
         if cache is not None:
-            cache["order"] = state[6 * P:7 * P]  # 3-D blocked processing order for the forwards
+            cache["order"] = state[(words - 1) * P:words * P]  # 3-D blocked processing order for the forwards
         return (gxyz if ctx.needs_input_grad[0] else None, None, None, *gplanes)
 
 

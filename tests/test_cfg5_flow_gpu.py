@@ -6,7 +6,7 @@ stage-2 warm start from `prior_checkpoint`).
 The densify / prune DECISIONS are the reference's control plane and stay with it; the helpers below only replay the optimizer
 surgery those decisions perform (`cat_tensors_to_optimizer` / `_prune_optimizer` semantics: single-parameter groups edited,
 `exp_avg` / `exp_avg_sq` extended with zeros or boolean-masked, multi-parameter groups -- the deformation network -- skipped),
-because every per-point buffer of the accelerated path has to survive it: the HexPlane `sort_state` (7 words per point), the MLP
+because every per-point buffer of the accelerated path has to survive it: the HexPlane `sort_state` (25 words per point), the MLP
 stash and mask words, the rasterizer's geometry cache and arenas, the fused Adam's tensor list, the densification accumulators.
 Also: training_step(densify_stats=True) under pipe.debug=True and with P == 0 after a prune."""
 import io
@@ -117,7 +117,9 @@ def test_densify_prune_cycle_between_training_steps(gpu_device):
 
     steps(30, 0)
     P0 = pc._xyz.shape[0]
-    assert grid._order_cache["sort_state"].numel() == 7 * P0
+    from s3gaussian_amd.hexplane import sort_state_words
+    W_ = sort_state_words(4)          # 6 * levels + 1 words per point since round 4 (one walk order per orientation and level)
+    assert W_ == 25 and grid._order_cache["sort_state"].numel() == W_ * P0
     assert float(pc.denom.max()) > 0 and float(pc.xyz_gradient_accum.max()) > 0          # bookkeeping ran inside the backward
     # --- densify (clone the 20 % with the largest mean viewspace gradient), then prune (drop the 10 % least opaque) ------------
     score = (pc.xyz_gradient_accum / pc.denom.clamp_min(1)).squeeze(1)
@@ -140,7 +142,7 @@ def test_densify_prune_cycle_between_training_steps(gpu_device):
     hits = raster_C._geom_cache_hits
     steps(1, 30)
     assert raster_C._geom_cache_hits == hits                                              # new tensors: geometry cache missed
-    assert grid._order_cache["sort_state"].numel() == 7 * P1 and grid._order_cache["sort_age"] == 0   # re-sorted at the new size
+    assert grid._order_cache["sort_state"].numel() == W_ * P1 and grid._order_cache["sort_age"] == 0   # re-sorted at the new size
     assert pc.xyz_gradient_accum.shape == (P1, 1) and pc.max_radii2D.shape == (P1,)
     assert float(pc.optimizer.state[pc._xyz]["step"]) == step_before + 1
     steps(29, 31)

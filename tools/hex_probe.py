@@ -47,11 +47,18 @@ from s3gaussian_amd import _lib  # noqa: E402
 L = _lib.lib()
 L.s3g_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
 L.s3g_profile_enable(1)
-for it in range(6):
+tot = []
+for it in range(10):      # SORT_REFRESH = 8: one of these re-sorts the walk orders, the others reuse them
     for p in f.parameters():
         p.grad = None
-    (f(xyz, t, uniform_time=True) * w).sum().backward()
-torch.cuda.synchronize()
+    out = f(xyz, t, uniform_time=True)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e[0].record()
+    (out * w).sum().backward()
+    e[1].record()
+    torch.cuda.synchronize()
+    tot.append(e[0].elapsed_time(e[1]))
+print("backward(+loss) per iteration, ms: " + " ".join(f"{x:.3f}" for x in tot) + f"   (max - median = the re-sort: {max(tot) - sorted(tot)[len(tot) // 2]:.3f} ms)")
 for i, name in ((2, "hexplane_forward"), (3, "hexplane_backward_point"), (4, "hexplane_scatter")):
     ms = C.c_double()
     n = L.s3g_profile_read(i, C.byref(ms), None, None)
