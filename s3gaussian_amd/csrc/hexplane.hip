@@ -703,6 +703,72 @@ __device__ __forceinline__ void foot2_add_t(Foot2T<float>& F, const PackedTap& t
   }
   F.mru = h1 ? 1 : 0;
 }
+// Single-entry form for the per-level walk orders (S3G_HEX_PER_LEVEL): a walk that is monotone in its OWN level's cells never
+// alternates between footprints, so the second entry buys nothing (tools/sim/flush_orders.py: 2.42 M line-atomics with one entry,
+// 2.42 M with two) and costs nine registers and a select per accumulator and call.  Same miss path (evict / shift down / shift
+// right relative to the one entry), same arithmetic, same division-safety predicate as foot2_add_t.
+struct Foot1 {
+  int key;          // (texel index << 2 | corner flags), -1 = empty
+  float a[4], v[4]; // partial sums and texel values of the footprint's corners (nw, ne, sw, se)
+};
+__device__ __forceinline__ void foot1_init(Foot1& F) {
+  F.key = -1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) F.a[k] = 0.f;
+}
+template <bool ROW = false>
+__device__ __forceinline__ void foot1_add_t(Foot1& F, const PackedTap& t, float tv, float* __restrict__ gp,
+                                            const float* __restrict__ pl /* plane values + channel */, int W, int c) {
+  const int tkf = (t.key << 2) | (t.flags & 3);
+  if (tkf != F.key) {  // miss (uniform inside the walker's lanes)
+    const float* px = pl + (size_t)t.key * HEXC;
+    const float n0 = px[0], n1 = px[(t.flags & 1) ? HEXC : 0];
+    float n2 = 0.f, n3 = 0.f;
+    if (!ROW) {
+      n2 = px[(t.flags & 2) ? (size_t)W * HEXC : 0];
+      n3 = px[((t.flags & 3) == 3) ? (size_t)W * HEXC + HEXC : 0];
+    }
+    const int KF = F.key, K = KF >> 2, FL = KF & 3;
+    const bool down = FOOT_SHIFT && !ROW && KF >= 0 && t.key == K + W;
+    const bool right = FOOT_SHIFT && KF >= 0 && t.key == K + 1 && (FL & 1);
+    const bool shift = down || right;
+    const float A0 = F.a[0], A1 = F.a[1], A2 = ROW ? 0.f : F.a[2], A3 = ROW ? 0.f : F.a[3];
+    if (KF >= 0) {
+      const uint32_t k = ((uint32_t)K * HEXC + (uint32_t)c) * 4u;
+      const uint32_t dy = (uint32_t)W * (HEXC * 4u);
+      char* base = reinterpret_cast<char*>(gp);
+      vatomic(base, k, A0);                                                    // nw leaves in every case
+      if ((FL & 1) && !right) vatomic(base, k + HEXC * 4u, A1);               // ne stays when shifting right
+      if (!ROW && (FL & 2) && !down) vatomic(base, k + dy, A2);               // sw stays when shifting down
+      if (!ROW && (FL & 3) == 3 && !shift) vatomic(base, k + dy + HEXC * 4u, A3);
+    }
+    F.a[0] = down ? A2 : (right ? A1 : 0.f);
+    F.a[1] = down ? A3 : 0.f;
+    F.v[0] = n0; F.v[1] = n1;
+    if (!ROW) {
+      F.a[2] = right ? A3 : 0.f;
+      F.a[3] = 0.f;
+      F.v[2] = n2; F.v[3] = n3;
+    }
+    F.key = tkf;
+  }
+  float sv = F.v[0] * t.w00;
+  sv = sv + F.v[1] * t.w01;
+  if (!ROW) {
+    sv = sv + F.v[2] * t.w10;
+    sv = sv + F.v[3] * t.w11;
+  }
+  const float g = tslab_divisible(sv) ? tv * __builtin_amdgcn_rcpf(sv) : 0.f;
+  F.a[0] = vfma(g, t.w00, F.a[0]); F.a[1] = vfma(g, t.w01, F.a[1]);
+  if (!ROW) {
+    F.a[2] = vfma(g, t.w10, F.a[2]); F.a[3] = vfma(g, t.w11, F.a[3]);
+  }
+}
+template <bool ROW = false>
+__device__ __forceinline__ void foot1_flush_all(const Foot1& F, float* __restrict__ gp, int W, int c) {
+  if (F.key < 0) return;
+  foot_flush(FootT<float>{F.key >> 2, ROW ? (F.key & 1) : (F.key & 3), F.a[0], F.a[1], ROW ? 0.f : F.a[2], ROW ? 0.f : F.a[3]}, gp, W, c);
+}
 // end of a walk: back to the (key, flags) form foot2_flush_all expects
 __device__ __forceinline__ void foot2_unpack_t(Foot2T<float>& F) {
   F.fl0 = F.key0 & 3; F.fl1 = F.key1 & 3;
@@ -714,9 +780,13 @@ __device__ __forceinline__ void foot2_unpack_t(Foot2T<float>& F) {
 // lanes compute the taps of FOUR points at once (lane = point q x tap j), park them in LDS, and every lane reads them back
 // with broadcast loads while it accumulates its channels.
 constexpr int SCATTER_LG = S3G_HEX_PER_LEVEL ? 1 : 2;          // levels handled per walk of a segment (per-level orders: one)
+#ifndef S3G_HEX_FOOT_ENTRIES
+#define S3G_HEX_FOOT_ENTRIES (S3G_HEX_PER_LEVEL ? 1 : 2)
+#endif
 constexpr int SCATTER_CPL = 1;         // channels per lane (2 = v_pk_fma accumulation, but twice the flush atomics: 2.07 vs 1.14 ms -- the walk is bound by atomic line-ops)
+constexpr bool SCATTER_ONE_ENTRY = S3G_HEX_FOOT_ENTRIES == 1 && S3G_HEX_TSLAB != 0 && SCATTER_CPL == 1;
 #ifndef S3G_HEX_SCATTER_WAVES
-#define S3G_HEX_SCATTER_WAVES 4
+#define S3G_HEX_SCATTER_WAVES 6
 #endif
 constexpr int SCATTER_WG_PER_CU = SCATTER_CPL == 2 ? 3 : S3G_HEX_SCATTER_WAVES;   // waves per SIMD the register budget is set for (two levels per walk: 5 = 96 VGPRs, the shift path spills, 1.57 vs 1.00 ms)
 constexpr int TAPF = 8;  // floats per packed tap in LDS (6 used; 32-byte slots keep the 16-byte reads aligned)
@@ -752,11 +822,19 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   const int ip = (j & 1) ? i1 : i0;                   // the plane of this lane's tap
   const int axw = PAIR0[ip], axh = PAIR1[ip];
   for (int l0 = lbeg; l0 < lend; l0 += LG) {
-    Foot2T<T> ft[LG][2];
+    Foot2T<T> ft[SCATTER_ONE_ENTRY ? 1 : LG][SCATTER_ONE_ENTRY ? 1 : 2];
+    Foot1 f1[SCATTER_ONE_ENTRY ? LG : 1][2];
+    if constexpr (SCATTER_ONE_ENTRY) {
 #pragma unroll
-    for (int l = 0; l < LG; l++)
+      for (int l = 0; l < LG; l++)
 #pragma unroll
-      for (int m = 0; m < 2; m++) foot2_init(ft[l][m]);
+        for (int m = 0; m < 2; m++) foot1_init(f1[l][m]);
+    } else {
+#pragma unroll
+      for (int l = 0; l < LG; l++)
+#pragma unroll
+        for (int m = 0; m < 2; m++) foot2_init(ft[l][m]);
+    }
     const int lt = l0 + (j >> 1);                     // level of this lane's tap
     const bool tap_on = lt < a.d.levels;
     const int Wt = tap_on ? a.d.res[lt][axw] : 2, Ht = tap_on ? a.d.res[lt][axh] : 2;
@@ -843,8 +921,13 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
               static_assert(S3G_HEX_TSLAB == 0 || CPL == 1, "the T-slab walk is written for one channel per lane");
               const float* pl = a.d.planes[l0 + l][m ? i1 : i0] + c;
               const int Wm = a.d.res[l0 + l][PAIR0[m ? i1 : i0]];
-              if (UT && m == 1) foot2_add_t<true>(ft[l][m], t, lanes_of<T>::first(g[qq][l][0]), gp, pl, Wm, c);
-              else foot2_add_t<false>(ft[l][m], t, lanes_of<T>::first(g[qq][l][0]), gp, pl, Wm, c);
+              if constexpr (SCATTER_ONE_ENTRY) {
+                if (UT && m == 1) foot1_add_t<true>(f1[l][m], t, lanes_of<T>::first(g[qq][l][0]), gp, pl, Wm, c);
+                else foot1_add_t<false>(f1[l][m], t, lanes_of<T>::first(g[qq][l][0]), gp, pl, Wm, c);
+              } else {
+                if (UT && m == 1) foot2_add_t<true>(ft[l][m], t, lanes_of<T>::first(g[qq][l][0]), gp, pl, Wm, c);
+                else foot2_add_t<false>(ft[l][m], t, lanes_of<T>::first(g[qq][l][0]), gp, pl, Wm, c);
+              }
             } else {
               if (UT && m == 1) foot2_add<true>(ft[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[i1]], c);
               else foot2_add<false>(ft[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
@@ -861,9 +944,14 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
         float* gp = a.gplanes[l0 + l][m ? i1 : i0];
         if (gp == nullptr) continue;
         const int W = a.d.res[l0 + l][PAIR0[m ? i1 : i0]];
-        if constexpr (S3G_HEX_TSLAB != 0 && CPL == 1) foot2_unpack_t(ft[l][m]);
-        if (UT && m == 1) foot2_flush_all<true>(ft[l][m], gp, W, c);
-        else foot2_flush_all<false>(ft[l][m], gp, W, c);
+        if constexpr (SCATTER_ONE_ENTRY) {
+          if (UT && m == 1) foot1_flush_all<true>(f1[l][m], gp, W, c);
+          else foot1_flush_all<false>(f1[l][m], gp, W, c);
+        } else {
+          if constexpr (S3G_HEX_TSLAB != 0 && CPL == 1) foot2_unpack_t(ft[l][m]);
+          if (UT && m == 1) foot2_flush_all<true>(ft[l][m], gp, W, c);
+          else foot2_flush_all<false>(ft[l][m], gp, W, c);
+        }
       }
     }
   }
