@@ -632,6 +632,8 @@ def main(argv=None):
     pipe = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
     n_frames = 20
 
+    render_outliers = []
+
     def render_loop():
         """-> (wall ms per frame over n_frames frames, median stream ms per frame from one event pair per frame)."""
         for i in range(5):
@@ -645,7 +647,10 @@ def main(argv=None):
             evs[i + 1].record()
         torch.cuda.synchronize()
         wall = 1000.0 * (time.perf_counter() - t1) / n_frames
-        per = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(n_frames))
+        raw = [evs[k].elapsed_time(evs[k + 1]) for k in range(n_frames)]
+        per = sorted(raw)
+        if per[-1] > 3.0 * per[n_frames // 2]:     # a one-off stall inside the loop: say where, so that it can be explained
+            render_outliers.append({"frame": raw.index(per[-1]), "ms": round(per[-1], 3), "median_ms": round(per[n_frames // 2], 3)})
         return wall, per[n_frames // 2]
 
     with torch.no_grad():
@@ -827,7 +832,8 @@ def main(argv=None):
                        "render_ms_per_frame": round(render_ms, 3), "render_ms_per_frame_median": round(render_median_ms, 3),
                        "render_deform_infer_kernel_ms": round(infer_kernel_ms, 4) if infer_kernel_ms else None,
                        "render_ms_per_frame_bf16x3": round(render_split_ms, 3),
-                       "render_ms_per_frame_bf16x3_median": round(render_split_median_ms, 3)},
+                       "render_ms_per_frame_bf16x3_median": round(render_split_median_ms, 3),
+                       "render_loop_outliers": render_outliers},
             "roofline": roof,
         }
         if world > 1:

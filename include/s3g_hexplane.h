@@ -58,6 +58,21 @@ int s3g_hexplane_backward_scratch_rows(int levels);   /* 128-byte rows of scratc
  * 6 * levels + 1 words (25 at the reference's four levels); rounds 1-3 kept three orders (7 words). */
 int s3g_hexplane_sort_state_words(int levels);
 size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P, int have_features);
+/* Backward algorithms (s3g_hexplane_backward_algo; s3g_hexplane_backward selects SLAB for features == NULL, WALK otherwise):
+ *   S3G_HEX_SLAB      two passes: a per-point pass forms dL/d(sample) by the product rule, finishes dL/dxyz and stores ONE row per
+ *                     level, T = dL/dfeature * feature; sorted scatter walks divide T by the sample they re-derive.
+ *   S3G_HEX_WALK      no per-point pass (30 B of scratch per point): every walk derives its share of dL/dxyz too.  Needs `features`.
+ *   S3G_HEX_SLAB_DIV  (round 4, what s3gaussian_amd.hexplane uses) the two passes of SLAB, but the per-point pass takes
+ *                     T = dL/dfeature * feature from the forward's output (`features`, required) and dL/d(sample_i) = T / sample_i
+ *                     plane by plane, instead of keeping six samples live for the product rule: the forward's register count
+ *                     and occupancy.  Same exact fallback for samples that cannot be divided by. */
+#define S3G_HEX_SLAB 0
+#define S3G_HEX_WALK 1
+#define S3G_HEX_SLAB_DIV 2
+int s3g_hexplane_backward_algo(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
+                               const float* dL_dfeatures, const float* features, int algorithm, float* dL_dxyz,
+                               float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* workspace,
+                               unsigned int* sort_state, int sort_reuse, void* stream);
 int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
                           const float* dL_dfeatures,
                           const float* features /* [P, levels*32]: the OUTPUT of the matching s3g_hexplane_forward (same

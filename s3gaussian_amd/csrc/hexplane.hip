@@ -337,6 +337,128 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
   }
 }
 
+// ---- pass A, DIVISION form (round 4, `algorithm` S3G_HEX_SLAB_DIV: needs the forward's output `feat`) ----
+// The product-rule kernel above keeps six samples and their twelve derivative vectors live per level (252 VGPRs with the next
+// level's texels in flight: two waves per SIMD, parked on s_waitcnt 63 % of the time) only to form dL/ds_i = g * prod_{j != i} s_j.
+// With the forward's own output f = prod_j s_j at hand the level's row is T = g * f in ONE multiply, and dL/ds_i = T / s_i needs
+// nothing but plane i's own sample: the planes are processed one after the other like the forward does (texels, sample, two
+// derivative vectors, two dot products -- then everything but three scalars is dead), at the forward's register count and
+// occupancy, so that the 72 texel-line gathers per point hide behind other waves instead of behind nothing.  Same division and
+// same safety predicate as the scatter walk (tv * rcp(s), |s| in (1e-18, inf)); a sample that fails it gets its EXACT
+// g * prod_{j != i} s_j -- for the plane gradients through tslab_exact_scatter, for dL/dxyz through exact_du below -- re-derived
+// from the coordinates on a path that costs the hot loop no registers.
+__device__ __forceinline__ void exact_du(const HexArgs& a, int p, int l, int c0, f4v g, uint32_t badbits, float* du) {
+  float u[4];
+  point_coords(a, p, u);
+#pragma unroll 1
+  for (int i = 0; i < 6; i++) {
+    if (!((badbits >> i) & 1u)) continue;
+    const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
+    const Tap t = make_tap(u[PAIR0[i]], u[PAIR1[i]], W, H);
+    const float* pl = a.d.planes[l][i];
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+      const int c = c0 + k;
+      if (tslab_divisible(walk_sample(a, l, i, u, c))) continue;     // that channel went through the division
+      float gk = vget<f4v>(g, k);
+#pragma unroll 1
+      for (int jj = 0; jj < 6; jj++)
+        if (jj != i) gk *= walk_sample(a, l, jj, u, c);
+      const float v00 = fetch(pl, t.o00, c), v01 = fetch(pl, t.o01 >= 0 ? t.o01 : t.o00, c);
+      const float v10 = fetch(pl, t.o10 >= 0 ? t.o10 : t.o00, c);
+      const float v11 = fetch(pl, t.o11 >= 0 ? t.o11 : (t.o10 >= 0 ? t.o10 : (t.o01 >= 0 ? t.o01 : t.o00)), c);
+      const float dX = (v01 - v00) * (t.y1f - t.iy) + (v11 - v10) * (t.iy - t.y0f);
+      const float dY = (v10 - v00) * (t.x1f - t.ix) + (v11 - v01) * (t.ix - t.x0f);
+      if (PAIR0[i] < 3) du[PAIR0[i]] += t.mx * dX * gk;
+      if (PAIR1[i] < 3) du[PAIR1[i]] += t.my * dY * gk;
+    }
+  }
+}
+
+#ifndef S3G_HEX_POINTDIV_WAVES
+#define S3G_HEX_POINTDIV_WAVES 4
+#endif
+template <bool UT>
+__global__ void __launch_bounds__(256, S3G_HEX_POINTDIV_WAVES) hexplane_backward_pointdiv_kernel(const HexArgs a, const float* __restrict__ feat,
+                                                                                                  float* __restrict__ G) {
+  extern __shared__ float4 tapbuf[];   // [32 points][levels][TAP_SLOTS]
+  const int j = threadIdx.x & 7, c0 = j * 4, slot = threadIdx.x >> 3;
+  const int L = a.d.levels, F = L * HEXC;
+  float4* taps = tapbuf + (size_t)slot * tap_stride(L);
+  for (int p0 = xcd_group(blockIdx.x, gridDim.x) * 32; p0 < a.P; p0 += gridDim.x * 32) {  // uniform trip count: shuffles below need all lanes
+    const int pi = p0 + slot;
+    const bool live = pi < a.P;
+    const int p = live ? (a.proc_order ? (int)a.proc_order[pi] : pi) : 0;
+    const size_t gbase = (size_t)pi * (size_t)(L * HEXC);   // T rows of this PROCESSING position
+    float u[4];
+    point_coords(a, p, u);
+    wave_lds_sync();
+    produce_taps(a, u, j, taps);
+    wave_lds_sync();
+    const size_t row = (size_t)p * F + c0;
+    float du[3] = {0.f, 0.f, 0.f};
+    for (int l = 0; l < L; l++) {
+      const f4v g = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.gfeat + row + l * HEXC));
+      const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(feat + row + l * HEXC));
+      const f4v T = g * f;
+      if (live) __builtin_nontemporal_store(T, reinterpret_cast<f4v*>(G + gbase + (size_t)(l * HEXC + c0)));
+      uint32_t badbits = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
+        const float* pl = a.d.planes[l][i];
+        f4v sv, dX, dY;
+        float mx, my;
+        if (UT && IS_TIME_PLANE[i]) {
+          const PointTap t = read_tap<true>(taps, l, i, W, H, c0);
+          const f4v v00 = texelv<f4v>(pl, t.off), v01 = texelv<f4v>(pl, t.off + t.dx);
+          sv = v00 * t.gx;
+          sv = sv + v01 * t.fx;
+          dX = v01 - v00;
+          dY = vsplat<f4v>(0.f);
+          mx = t.mx; my = 0.f;
+        } else {
+          const PointTap t = read_tap<false>(taps, l, i, W, H, c0);
+          const f4v v00 = texelv<f4v>(pl, t.off), v01 = texelv<f4v>(pl, t.off + t.dx);
+          const f4v v10 = texelv<f4v>(pl, t.off + t.dy), v11 = texelv<f4v>(pl, t.off + t.dy + t.dx);
+          sv = v00 * (t.gx * t.gy);
+          sv = sv + v01 * (t.fx * t.gy);
+          sv = sv + v10 * (t.gx * t.fy);
+          sv = sv + v11 * (t.fx * t.fy);
+          dX = (v01 - v00) * t.gy + (v11 - v10) * t.fy;
+          dY = (v10 - v00) * t.gx + (v11 - v01) * t.fx;
+          mx = t.mx; my = t.my;
+        }
+        f4v gi;
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float sk = vget<f4v>(sv, k);
+          const bool okk = tslab_divisible(sk);
+          ok = ok && okk;
+          const float q = okk ? vget<f4v>(T, k) * __builtin_amdgcn_rcpf(sk) : 0.f;
+          if (k == 0) gi.x = q; else if (k == 1) gi.y = q; else if (k == 2) gi.z = q; else gi.w = q;
+        }
+        badbits |= ok ? 0u : (1u << i);
+        if (PAIR0[i] < 3) du[PAIR0[i]] += mx * vdot(dX, gi);
+        if (PAIR1[i] < 3) du[PAIR1[i]] += my * vdot(dY, gi);
+      }
+      if (badbits && live) {   // rare: a sample that is (nearly) zero or not finite
+        tslab_exact_scatter<f4v>(a, p, l, c0, g, badbits);
+        exact_du(a, p, l, c0, g, badbits, du);
+      }
+    }
+    // sum over the 32 channels (the 8 lanes of this point), then undo the aabb normalisation
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      float v = du[k];
+      for (int off = 4; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      du[k] = v;
+    }
+    if (live && j < 3) a.gxyz[3 * (size_t)p + j] = (j == 0 ? du[0] : (j == 1 ? du[1] : du[2])) * (2.0f / (a.d.aabb_min[j] - a.d.aabb_max[j]));
+  }
+}
+
 // ---- sort: point indices ordered by (major cell, minor cell) on a 512 x 512 grid, per orientation ----
 // orientation o: major axis MAJ[o], minor axis MIN_[o]; handles planes PLA[o] (spatial) and PLT[o] (the major axis vs time)
 constexpr int SORT_BINS = 512, SORT_NB = 256;
@@ -1313,10 +1435,39 @@ extern "C" size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc*
   return c.bytes();
 }
 
+static int hexplane_backward_impl(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
+                                  const float* dL_dfeatures, const float* features, int algorithm, float* dL_dxyz,
+                                  float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* workspace,
+                                  uint32_t* sort_state, int sort_reuse, void* stream_);
+
 extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
                                      const float* dL_dfeatures, const float* features, float* dL_dxyz,
                                      float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* workspace,
                                      uint32_t* sort_state, int sort_reuse, void* stream_) {
+  return hexplane_backward_impl(d, P, xyz, time, dL_dfeatures, features, features ? S3G_HEX_WALK : S3G_HEX_SLAB, dL_dxyz,
+                                dL_dplanes, workspace, sort_state, sort_reuse, stream_);
+}
+
+extern "C" int s3g_hexplane_backward_algo(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
+                                          const float* dL_dfeatures, const float* features, int algorithm, float* dL_dxyz,
+                                          float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* workspace,
+                                          uint32_t* sort_state, int sort_reuse, void* stream_) {
+  if (algorithm != S3G_HEX_SLAB && algorithm != S3G_HEX_WALK && algorithm != S3G_HEX_SLAB_DIV) {
+    set_error("s3g_hexplane_backward_algo: unknown algorithm %d", algorithm);
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (algorithm != S3G_HEX_SLAB && !features && P > 0) {
+    set_error("s3g_hexplane_backward_algo: this algorithm needs the forward's output `features`");
+    return S3G_ERR_INVALID_ARG;
+  }
+  return hexplane_backward_impl(d, P, xyz, time, dL_dfeatures, features, algorithm, dL_dxyz, dL_dplanes, workspace, sort_state,
+                                sort_reuse, stream_);
+}
+
+static int hexplane_backward_impl(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
+                                  const float* dL_dfeatures, const float* features, int algorithm, float* dL_dxyz,
+                                  float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* workspace,
+                                  uint32_t* sort_state, int sort_reuse, void* stream_) {
   if (int e = check_desc(d)) return e;
   if (P < 0 || (P > 0 && (!xyz || !time || !dL_dfeatures || !dL_dxyz || !dL_dplanes || !workspace)) ||
       (sort_reuse && !sort_state)) {
@@ -1325,7 +1476,7 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
   }
   if (P == 0) return S3G_OK;
   hipStream_t stream = (hipStream_t)stream_;
-  const bool walk = features != nullptr;
+  const bool walk = algorithm == S3G_HEX_WALK;
   HexArgs a;
   memset(&a, 0, sizeof a);
   a.d = *d; a.P = P; a.xyz = xyz; a.time = time; a.gfeat = dL_dfeatures; a.gxyz = dL_dxyz;
@@ -1381,7 +1532,12 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
     constexpr int ppw = 256 / (HEXC / vec_of<PointV>::N);   // points per workgroup
     const int pblocks = (P + ppw - 1) / ppw;
     const size_t lds = (size_t)ppw * tap_stride(d->levels) * sizeof(float4);
-    if (d->uniform_time && d->levels == 4) hipLaunchKernelGGL((hexplane_backward_point_kernel<true, PointV, 4>), dim3(pblocks), dim3(256), lds, stream, a, G);
+    if (algorithm == S3G_HEX_SLAB_DIV && S3G_HEX_TSLAB) {
+      const int dblocks = (P + 31) / 32;
+      const size_t dlds = (size_t)32 * tap_stride(d->levels) * sizeof(float4);
+      if (d->uniform_time) hipLaunchKernelGGL(hexplane_backward_pointdiv_kernel<true>, dim3(dblocks), dim3(256), dlds, stream, a, features, G);
+      else hipLaunchKernelGGL(hexplane_backward_pointdiv_kernel<false>, dim3(dblocks), dim3(256), dlds, stream, a, features, G);
+    } else if (d->uniform_time && d->levels == 4) hipLaunchKernelGGL((hexplane_backward_point_kernel<true, PointV, 4>), dim3(pblocks), dim3(256), lds, stream, a, G);
     else if (d->uniform_time) hipLaunchKernelGGL((hexplane_backward_point_kernel<true, PointV, 0>), dim3(pblocks), dim3(256), lds, stream, a, G);
     else hipLaunchKernelGGL((hexplane_backward_point_kernel<false, PointV, 0>), dim3(pblocks), dim3(256), lds, stream, a, G);
     profile_end(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream, (double)P, (double)d->levels);

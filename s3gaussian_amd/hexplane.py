@@ -37,7 +37,11 @@ def sort_state_words(levels: int) -> int:
 # three sorted scatter walks read it back and divide by the sample they re-derive from the footprint they are accumulating
 # (2.37 ms at 1.2 M points).  "walk" = no slab and no per-point pass at all: each scatter walk forms dL/d(sample) =
 # dL/dfeature * feature / sample from the forward's output and also derives its share of dL/dxyz (30 B of scratch per point; 3.36 ms).
+# Round 4: "slab" takes T = dL/dfeature * feature from the forward's saved output and dL/d(sample_i) = T / sample_i plane by plane in
+# the per-point pass too (S3G_HEX_SLAB_DIV: the forward's register count and occupancy instead of 252 VGPRs for the product rule);
+# "slab_product" = round 3's per-point pass (S3G_HEX_SLAB).
 BACKWARD_MODE = os.environ.get("S3G_HEX_BACKWARD", "slab")
+_ALGORITHM = {"slab_product": 0, "walk": 1, "slab": 2}     # S3G_HEX_SLAB, S3G_HEX_WALK, S3G_HEX_SLAB_DIV (include/s3g_hexplane.h)
 
 
 class _HexDesc(C.Structure):
@@ -61,6 +65,9 @@ def _bind():
         L.s3g_hexplane_forward_workspace_bytes.argtypes = [C.POINTER(_HexDesc)]
         L.s3g_hexplane_backward.restype = C.c_int
         L.s3g_hexplane_backward.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, vp, C.POINTER(_PlanePtrs), vp, vp, C.c_int, vp]
+        L.s3g_hexplane_backward_algo.restype = C.c_int
+        L.s3g_hexplane_backward_algo.argtypes = [C.POINTER(_HexDesc), C.c_int, vp, vp, vp, vp, C.c_int, vp, C.POINTER(_PlanePtrs), vp, vp,
+                                                 C.c_int, vp]
         L.s3g_hexplane_backward_workspace_bytes.restype = C.c_size_t
         L.s3g_hexplane_backward_workspace_bytes.argtypes = [C.POINTER(_HexDesc), C.c_int, C.c_int]
         L.s3g_hexplane_sort_state_words.restype = C.c_int
@@ -161,8 +168,10 @@ class _HexPlaneSample(torch.autograd.Function):
                 g = gplanes[l * 6 + i]
                 ptrs[l][i] = _channels_last_ptr(g) if g is not None else None
         d = _make_desc(planes, resolutions, aabb_host, uniform_time)
-        legacy = BACKWARD_MODE != "walk"
-        work = torch.empty(L.s3g_hexplane_backward_workspace_bytes(C.byref(d), P, 0 if legacy else 1), dtype=torch.uint8,
+        if BACKWARD_MODE not in _ALGORITHM:
+            raise RuntimeError(f"S3G_HEX_BACKWARD must be one of {sorted(_ALGORITHM)}, got {BACKWARD_MODE!r}")
+        algorithm = _ALGORITHM[BACKWARD_MODE]
+        work = torch.empty(L.s3g_hexplane_backward_workspace_bytes(C.byref(d), P, 1 if algorithm == 1 else 0), dtype=torch.uint8,
                            device=xyz_c.device)
         # the spatial walk orders live in the field's cache and are refreshed every SORT_REFRESH backward passes (or when
         # P changes): they steer the walk, not the result, and the points move slowly between iterations
@@ -180,11 +189,11 @@ class _HexPlaneSample(torch.autograd.Function):
                 else:
                     reuse = 1
         with torch.cuda.device(xyz_c.device):
-            _lib.check(L.s3g_hexplane_backward(C.byref(d), P, xyz_c.data_ptr(), t_c.data_ptr(), gfeat.data_ptr(),
-                                               None if legacy else feat.data_ptr(),
-                                               gxyz.data_ptr(), C.byref(ptrs), work.data_ptr(),
-                                               state.data_ptr() if state is not None else None, reuse,
-                                               torch.cuda.current_stream().cuda_stream))
+            _lib.check(L.s3g_hexplane_backward_algo(C.byref(d), P, xyz_c.data_ptr(), t_c.data_ptr(), gfeat.data_ptr(),
+                                                    None if algorithm == 0 else feat.data_ptr(), algorithm,
+                                                    gxyz.data_ptr(), C.byref(ptrs), work.data_ptr(),
+                                                    state.data_ptr() if state is not None else None, reuse,
+                                                    torch.cuda.current_stream().cuda_stream))
         if cache is not None:
             cache["order"] = state[(words - 1) * P:words * P]  # 3-D blocked processing order for the forwards
         return (gxyz if ctx.needs_input_grad[0] else None, None, None, *gplanes)

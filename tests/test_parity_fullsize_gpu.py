@@ -92,15 +92,15 @@ def _fields(dev, aabb, seed):
     return ref.double().to(dev), mine.to(dev)
 
 
-@pytest.mark.parametrize("backward", ["slab", "walk"])
+@pytest.mark.parametrize("backward", ["slab", "walk", "slab_product"])
 @pytest.mark.parametrize("tmode", ["uniform", "per_point"])
 @pytest.mark.parametrize("P", SIZES)
 def test_hexplane_sampler_at_baseline_size(gpu_device, street, monkeypatch, P, tmode, backward):
     """P = 1.2 M takes the 256-point scatter segments, the multi-workgroup counting sorts, the blocked order with XCD dealing and
     the point-major G slab at 3.7 GB; the second backward reuses the cached spatial orders (sort_age 1)."""
     import s3gaussian_amd.hexplane as hx
-    if P == 600_000 and backward == "walk":
-        pytest.skip("600 k covers the slab default; walk is checked at 70 k and 1.2 M")
+    if P == 600_000 and backward != "slab":
+        pytest.skip("600 k covers the slab default; the other algorithms are checked at 70 k and 1.2 M")
     monkeypatch.setattr(hx, "BACKWARD_MODE", backward)
     dev = gpu_device
     ref64, mine = _fields(dev, street["aabb"], seed=P % 1000)
