@@ -378,6 +378,7 @@ __device__ __forceinline__ void exact_du(const HexArgs& a, int p, int l, int c0,
 #ifndef S3G_HEX_POINTDIV_WAVES
 #define S3G_HEX_POINTDIV_WAVES 4
 #endif
+
 template <bool UT>
 __global__ void __launch_bounds__(256, S3G_HEX_POINTDIV_WAVES) hexplane_backward_pointdiv_kernel(const HexArgs a, const float* __restrict__ feat,
                                                                                                   float* __restrict__ G) {
@@ -397,6 +398,8 @@ __global__ void __launch_bounds__(256, S3G_HEX_POINTDIV_WAVES) hexplane_backward
     wave_lds_sync();
     const size_t row = (size_t)p * F + c0;
     float du[3] = {0.f, 0.f, 0.f};
+    // (requesting the NEXT level's two rows a level ahead costs the eight registers that keep this kernel at four waves per SIMD:
+    // 0.78 -> 1.12 ms with the spills, 0.88 ms at three waves -- measured, tools/variants/r04_pointdiv2.py)
     for (int l = 0; l < L; l++) {
       const f4v g = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.gfeat + row + l * HEXC));
       const f4v f = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(feat + row + l * HEXC));
