@@ -701,6 +701,8 @@ def main(argv=None):
         # because of how this implementation is split into kernels (G slab, activation stash, gradient signals) is counted
         # under implementation bytes and never enters `frac`.
         G_ROWS = float(L.s3g_hexplane_backward_scratch_rows(int(levels)))   # 128-byte rows of scratch per point (r2: 24, r3: 4)
+        from s3gaussian_amd import hexplane as _hx
+        POINT_KERNEL = ("s3g::hexplane_backward_pointdiv_kernel" if _hx.BACKWARD_MODE == "slab" else "s3g::hexplane_backward_point_kernel")
         RB = lambda R_, N_: (56.0 if pair else 44.0) * R_mean + (36.0 if pair else 24.0) * N_
         models = {
             # two-image pass (RGB+depth and feature image from one geometry): + colors2 per instance, + one image per pixel
@@ -709,12 +711,13 @@ def main(argv=None):
                 lambda R_, N_: RB(R_, N_) + (56.0 if pair else 40.0) * R_mean, None),
             2: ("s3g::hexplane_forward_kernel", lambda n, l: n * (16.0 + 4.0 * FEAT) + plane_bytes, None, None),
             # xyz,t 16 B + dL/dfeatures 4F B read, dL/dxyz 12 B written, planes read once; the scratch rows are implementation
-            3: ("s3g::hexplane_backward_point_kernel", lambda n, l: n * (28.0 + 4.0 * FEAT) + plane_bytes,
-                lambda n, l: n * (28.0 + 4.0 * FEAT + G_ROWS * 128.0) + plane_bytes, None),
-            # plane gradients written once; reading the scratch back is implementation
-            # (each of the three orientation walks reads the point's rows)
+            # (round 4: the division-form pass also reads the forward's feature rows, 4F B per point: implementation)
+            3: (POINT_KERNEL, lambda n, l: n * (28.0 + 4.0 * FEAT) + plane_bytes,
+                lambda n, l: n * (28.0 + 4.0 * FEAT + (4.0 * FEAT if POINT_KERNEL.endswith("pointdiv_kernel") else 0.0) + G_ROWS * 128.0) + plane_bytes, None),
+            # plane gradients written once; reading the scratch back is implementation: every (orientation, level) walk reads
+            # index + position (8 B), the coordinates (12 B) and the level's T row (128 B) of each point
             4: ("s3g::hexplane_scatter_kernel", lambda n, l: plane_bytes,
-                lambda n, l: n * (60.0 + (3.0 if G_ROWS < 24 else 1.0) * G_ROWS * 128.0) + plane_bytes, None),
+                lambda n, l: n * (3.0 * l * 20.0 + (3.0 if G_ROWS < 24 else 1.0) * G_ROWS * 128.0) + plane_bytes, None),
             # features in, three heads out; the 5 stashed activations are implementation
             # implementation: + 5 stashed activation planes (for the weight gradients) + 5 ReLU mask words per lane (40 B/point)
             5: ("s3g::mlp_forward_kernel", lambda n, _: n * (512.0 + 216.0), lambda n, _: n * (512.0 + 5 * 256.0 + 40.0 + 216.0),
@@ -797,7 +800,7 @@ def main(argv=None):
                          "timed_in": "a separate instrumented loop over the same steps (the headline loop runs with the brackets off)"})
         # the HexPlane backward is ONE operation split into two kernels by this implementation (per-point pass + scatter walks):
         # their combined figures, for information next to the per-kernel entries (the top-level fields stay per kernel)
-        hb = [k for k in kernels if k["kernel"] in ("s3g::hexplane_backward_point_kernel", "s3g::hexplane_scatter_kernel")]
+        hb = [k for k in kernels if k["kernel"] in (POINT_KERNEL, "s3g::hexplane_scatter_kernel")]
         if roof is not None and len(hb) == 2:
             ms = sum(k["avg_launch_ms"] for k in hb)
             nb = sum(k["algorithmic_bytes_per_launch"] for k in hb)

@@ -51,6 +51,9 @@ def collect(d, counter):
 def main():
     fdir, wdir, out = sys.argv[1], sys.argv[2], sys.argv[3]
     fetch, write = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
+    # optional fourth argument: a pass of the same command with SQ_INSTS_VALU (wave-level VALU instructions per launch): what
+    # bench.py prices the blend kernels' VALU roofline with (they are VALU / v_exp-bound, not HBM-bound)
+    valu = {k: v[1] for k, v in collect(sys.argv[4], "SQ_INSTS_VALU").items()} if len(sys.argv) > 4 else {}
     os.makedirs(out, exist_ok=True)
     rows, traffic = [], {}
     for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 0))[1] + write.get(k, (0, 0))[1])):
@@ -68,7 +71,9 @@ def main():
                "launches_per_bracket": launches,
                "formula": "hbm_bytes = (2 * FETCH_SIZE_KB + WRITE_SIZE_KB) * 1024  (gfx950 FETCH_SIZE correction, "
                           "MI355X_MICROARCH.md 'HBM'); wgrad: average over its template instances",
-               "hbm_bytes_per_launch": traffic}, open(os.path.join(out, "kernel_traffic.json"), "w"), indent=1)
+               "hbm_bytes_per_launch": traffic,
+               "valu_wave_instructions_per_launch": {k: int(round(v)) for k, v in valu.items()}},
+              open(os.path.join(out, "kernel_traffic.json"), "w"), indent=1)
     for k, n, f, w in rows[:12]:
         print(f"{k:45s} {n:4d} launches  fetch {f / 1024:9.1f} MB  write {w / 1024:9.1f} MB  -> hbm {traffic[k] / 1e6:9.1f} MB")
 
