@@ -26,6 +26,7 @@ MLP's activation stash, is `implementation_bytes_per_launch`, never algorithmic)
 same command, see `traffic_source`).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -460,11 +461,20 @@ def launch_ranks(a, argv):
     return subprocess.call(cmd, env=env)
 
 
-def timed_loop(step, indices, world, device, after_step=None):
+GC_PASSES = []     # generation-2 collections that ran inside each timed_loop call, in call order
+
+
+def timed_loop(step, indices, world, device, after_step=None, collect=True):
     """Enqueue step(i) for i in indices.  -> (wall seconds from the barrier before to the barrier after -- MAX over ranks is taken by
     the caller --, host seconds spent enqueuing, per-step stream milliseconds from one hipEvent pair per step).  Nothing in the
     loop waits for the device (the rasterizer forward is host-asynchronous by default); the events are read afterwards."""
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(indices) + 1)]
+    # pay the interpreter's collection debt BEFORE the clock starts: a generation-2 pass over this process's heap takes 50-90 ms
+    # (measured: one render frame of 89 ms in a loop of 1.5 ms frames, profiles/r04_headline_variance.txt), i.e. a quarter of a
+    # 20-step timed region if it happens to fall inside it.  The collector stays ENABLED during the loop; GC_PASSES counts what ran.
+    if collect:
+        gc.collect()
+    gen2_before = gc.get_stats()[2]["collections"]
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -481,6 +491,7 @@ def timed_loop(step, indices, world, device, after_step=None):
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     per_step = [evs[k].elapsed_time(evs[k + 1]) for k in range(len(indices))]
+    GC_PASSES.append(gc.get_stats()[2]["collections"] - gen2_before)
     return dt, t_enq, per_step
 
 
@@ -568,6 +579,11 @@ def main(argv=None):
                                   densify_stats=(world == 1), optimizer_step=optimizer_step if world > 1 else None)
         return loss, pkg
 
+    # everything built so far (scene, targets, modules, the torch / ctypes machinery) is long-lived: take it out of the collector's
+    # working set, so that a generation-2 pass during the loops below walks this step's garbage, not the whole heap
+    gc.collect()
+    gc.freeze()
+
     # ---- 1. the headline: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, with the
     #         in-library kernel brackets OFF (they are hipEventCreate + hipEventRecord pairs inside the timed region otherwise) ----
     L.s3g_profile_enable(0)
@@ -594,6 +610,7 @@ def main(argv=None):
         # a step whose forward overflowed its speculative arena did no work: the capacity has grown by now, time the loop again
         vis_masks.clear()
         losses.clear()
+        GC_PASSES.clear()
         comm.update(elems=0, events=[], sparse_rows=0)
         raster_C.async_reset_statistics(device)
         dt, t_enq, per_step = timed_loop(step, headline_idx, world, device, after_step=keep)
@@ -639,6 +656,7 @@ def main(argv=None):
         for i in range(5):
             render_fn(cams[views[i % len(views)]], pc, pipe, bg, stage="fine")
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_frames + 1)]
+        gc.collect()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         evs[0].record()
@@ -820,6 +838,7 @@ def main(argv=None):
             "gpu_ms_per_step": round(sum(per_step) / len(per_step), 3),
             "host_enqueue_ms_per_step": round(1000.0 * t_enq / a.steps, 3),
             "instrumented_loop_ms_per_step": round(sum(per_step_instrumented) / len(per_step_instrumented), 3),
+            "gc_gen2_passes_in_timed_loop": GC_PASSES[0] if GC_PASSES else None,
             "config": {"workload": workload_label(a, world) + f": {a.P} Gaussians, {a.height}x{a.width}, 3 cams x {a.frames} frames, fine stage "
                                    "(hexplane+deformation ON), RGB+depth render + feature render, L1+DSSIM+depthL2+featL2+regs, Adam",
                        "path": "fused", "gaussians": a.P, "image": [a.height, a.width], "views_per_step_per_rank": 1,

@@ -8,7 +8,8 @@ Weak #1.)  One process, BASELINE cfg3, the SAME training step timed in loops tha
                      `bench.py --steps 20 --warmup 5` times);  replay = the same 20 views again
 
 Per loop: wall ms/step, the host's enqueue ms/step (time until the last step is queued), stream ms/step from one event pair per
-step (median / max).  The order is cold first (it can only be first), then every combination twice, second time reversed.
+step (median / max), and the number of generation-2 garbage collections of the interpreter that ran inside the loop.  The order is
+cold first (it can only be first), then every combination twice, second time reversed, then six 60-step loops.
 
     python tools/headline_variance.py > gpurun_out/r04_headline_variance.txt
 """
@@ -49,21 +50,21 @@ def clear():
 rows = []
 
 
-def loop(label, asyn, brackets, idx, warm):
+def loop(label, asyn, brackets, idx, warm, collect=False):
     raster_C.set_async(asyn)
     L.s3g_profile_enable(0)
     for i in warm:
         step(i)
     clear()
     L.s3g_profile_enable(1 if brackets else 0)
-    dt, t_enq, per = bench.timed_loop(step, idx, 1, dev)
+    dt, t_enq, per = bench.timed_loop(step, idx, 1, dev, collect=collect)
     L.s3g_profile_enable(0)
     clear()
     per = sorted(per)
     rows.append((label, "async" if asyn else "sync", "on" if brackets else "off", 1e3 * dt / len(idx), 1e3 * t_enq / len(idx),
-                 per[len(per) // 2], per[-1]))
-    print("%-34s raster %-5s brackets %-3s  wall %7.3f  host-enqueue %7.3f  stream median %7.3f  max %7.3f  ms/step" % rows[-1],
-          flush=True)
+                 per[len(per) // 2], per[-1], bench.GC_PASSES[-1]))
+    print("%-36s raster %-5s brackets %-3s  wall %7.3f  host-enqueue %7.3f  stream median %7.3f  max %7.3f  ms/step  gen-2 GC passes inside: %d"
+          % rows[-1], flush=True)
 
 
 print(f"# BASELINE cfg3-shaped scene, P = {P}, 1066x1600; 20 timed steps per loop; torch {torch.__version__}; "
@@ -74,5 +75,15 @@ combos = [(a_, b_) for a_ in (False, True) for b_ in (True, False)]
 for rnd, order in enumerate((combos, combos[::-1])):
     for asyn, br in order:
         loop(f"replay #{rnd + 1}", asyn, br, cold, range(3))
+# the interpreter's generation-2 collections: a pass over this process's heap is a host stall of tens of milliseconds; with the
+# synchronous forward the GPU idles for all of it, with the asynchronous one only for what exceeds the host's lead
+import gc  # noqa: E402
+import time  # noqa: E402
+t0 = time.perf_counter()
+n = gc.collect()
+print(f"# one full gc.collect() of this process: {1e3 * (time.perf_counter() - t0):.1f} ms ({n} objects freed, {len(gc.get_objects())} tracked)")
+for rnd in range(3):
+    for asyn in (False, True):
+        loop(f"long loop #{rnd + 1} (60 steps, no pre-collect)", asyn, False, [5 + (i % 20) for i in range(60)], range(2), collect=False)
 st = raster_C.async_status(dev, block=True)
 print(f"# asynchronous forwards: {st['calls']} calls, overflows {st['overflows']}, capacity {st['capacity']}")
