@@ -742,15 +742,20 @@ __global__ void __launch_bounds__(NWAVE * 64) deform_infer_kernel(const InferArg
       }
       prod = prod * s;
     }
-    // SPLIT: wait states between the packed-fp32 multiplies that produce `prod` and the ds_write_b128 that stores it.  With the
-    // other wave of the SIMD issuing v_mfma_f32_32x32x16_bf16, hipcc's own spacing (ROCm 7.2: one SALU instruction) was measured
-    // NOT to be enough: about one step in 10^3, on the younger wave of the SIMD (waves 4..7), stored stale values for the LAST
-    // quarter of the wave (lanes 48..63 = two points: errors of 1e-1 in two adjacent rows, different rows every launch).  It never
-    // happens with one wave per SIMD, nor beside the fp32 MFMAs of the exact kernel; waiting for the texel loads, for the LDS queue
-    // or for the wave's own MFMAs does not help; 16 wait states here do (profiles/r03_split_hazard.jsonl).  (The
-    // per-component operands also make hipcc form the last products with plain v_mul_f32: the stored registers are no longer
-    // written by a packed instruction at all.  The tap slots are stored from v_mov copies, the coordinates by lanes 0..31 only.)
-    if (SPLIT) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(prod.x), "+v"(prod.y), "+v"(prod.z), "+v"(prod.w));
+    // SPLIT: the float4 stored below must not come straight out of a PACKED fp32 instruction.  hipcc forms `prod` with
+    // v_pk_mul_f32 and issues ds_write_b128 a few slots later; with the other wave of the SIMD issuing v_mfma_f32_32x32x16_bf16 the
+    // store then reads STALE data for the last quarter of the wave (lanes 48..63 = two points, errors of 1e-1 in two adjacent rows,
+    // different rows every launch): ~800 wrong rows per launch at 1.2 M points, 110 872 over 1000 launches
+    // (profiles/r04_split_hazard.jsonl, build `split_nopad`).  It never happens with one wave per SIMD, nor beside the fp32 MFMAs of
+    // the exact kernel; waiting for the texel loads, the LDS queue or the wave's own MFMAs does not help.  Round 3 papered over it
+    // with 16 wait states (which also happened to make hipcc form the products with plain v_mul_f32).  Round 4 isolates the cause:
+    // re-writing the four registers with an ordinary single-pass VALU instruction (v_mov_b32) and NO wait state at all is enough --
+    // 0 wrong rows in 1000 launches at 1.2 M points and 400 at 70 001 (build `split_vmov`, now the tree; the 16-wait-state build:
+    // also 0) -- i.e. the unsafe pair is "packed-fp32 VALU result -> DS store data" while XDL ops of another wave are in flight,
+    // and a real register dependency on a non-packed VALU write removes it independently of timing.  ISA of the three builds:
+    // profiles/r04_split_hazard_isa.txt; stress test: tests/test_infer_gpu.py::test_split_inference_is_bit_reproducible_1000_launches.
+    // (The tap slots are stored from v_mov copies, the coordinates by lanes 0..31 only.)
+    if (SPLIT) asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(prod.x), "+v"(prod.y), "+v"(prod.z), "+v"(prod.w));
     *reinterpret_cast<float4*>(stage + (8 * rr + slot) * STG_LD + c4) = prod;
   };
   for (int tile = blockIdx.x * NWAVE + wave; tile < ntiles; tile += gridDim.x * NWAVE) {

@@ -107,6 +107,37 @@ def test_split_bf16_inference_has_fp32_accuracy(gpu_device, P, tmode):
         assert st["bf16x3"][k] <= max(4.0 * st["exact"][k], 1e-6), st
 
 
+@pytest.mark.parametrize("tmode,launches", [("uniform", 1000), ("per_point", 200)])
+def test_split_inference_is_bit_reproducible_1000_launches(gpu_device, tmode, launches):
+    """The split kernel's staging store once read stale registers for the last quarter of a wave (packed-fp32 VALU result -> DS store
+    data while the other wave of the SIMD issues bf16 MFMAs; csrc/mlp.hip, profiles/r04_split_hazard_isa.txt): two wrong rows about
+    once per thousand (level, round) steps, different rows every launch -- ~800 rows per launch at 1.2 M points, which four launches
+    catch only sometimes at small P.  The stress form: 1000 launches at BASELINE size, each compared with the first ON THE DEVICE, bit
+    for bit (profiles/r04_split_hazard.jsonl: the unprotected build fails this with 110 872 wrong rows; the tree: 0).  The same
+    1000 launches also stay within the fp32 tolerance of the exact kernel."""
+    from s3gaussian_amd import synth
+    from s3gaussian_amd.mlp import deform_infer
+    dev = gpu_device
+    P = 1_200_000
+    sc = synth.street_scene(P=P, seed=3, n_frames=2)
+    d = _net(dev, sc["aabb"], seed=2)
+    xyz = sc["gaussians"]["xyz"].to(dev).contiguous()
+    g = torch.Generator().manual_seed(9)
+    time = (torch.rand(P, 1, generator=g).to(dev) * 1.2 - 0.1) if tmode == "per_point" else torch.full((P, 1), 0.63, device=dev)
+    ut = tmode == "uniform"
+    args = (d.grid, xyz, time, d.feature_out, d.pos_deform, d.shs_deform, d.dino_head)
+    with torch.no_grad():
+        exact = torch.cat(deform_infer(*args, uniform_time=ut), 1)
+        first = torch.cat(deform_infer(*args, uniform_time=ut, arithmetic="bf16x3"), 1)
+        wrong = torch.zeros((), dtype=torch.int64, device=dev)
+        for _ in range(launches - 1):
+            r = torch.cat(deform_infer(*args, uniform_time=ut, arithmetic="bf16x3"), 1)
+            wrong += (r != first).any(1).sum()
+        torch.cuda.synchronize()
+    assert int(wrong) == 0, f"{int(wrong)} rows differed from the first launch over {launches} launches"
+    assert float((first - exact).abs().max() / exact.abs().max()) < 5e-6
+
+
 def test_render_uses_the_fused_inference_path_and_is_unchanged(gpu_device, monkeypatch):
     from types import SimpleNamespace
     import s3gaussian_amd.deformation as dm

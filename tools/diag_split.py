@@ -33,10 +33,24 @@ with torch.no_grad():
     two = torch.cat(deform_mlp(d.grid(xyz, t, uniform_time=True), d.feature_out, d.pos_deform, d.shs_deform, d.dino_head, need_feat=False)[:2], 1)
     ex_runs = [torch.cat(deform_infer(*args, uniform_time=True), 1) for _ in range(reps)]
     exact_ok = bool(all(torch.equal(r, two) for r in ex_runs + [ex]))
-    runs = [torch.cat(deform_infer(*args, uniform_time=True, arithmetic="bf16x3"), 1) for _ in range(reps)]
-    torch.cuda.synchronize()
-    bad = [(r != runs[0]).any(1).nonzero().flatten().tolist() for r in runs[1:]]
-    rows = sorted({x for b in bad for x in b})
+    if reps <= 16:
+        runs = [torch.cat(deform_infer(*args, uniform_time=True, arithmetic="bf16x3"), 1) for _ in range(reps)]
+        torch.cuda.synchronize()
+        bad = [(r != runs[0]).any(1).nonzero().flatten().tolist() for r in runs[1:]]
+        rows = sorted({x for b in bad for x in b})
+    else:   # stress form (hundreds of launches at full size): every launch compared with the first on the device, nothing kept
+        first = torch.cat(deform_infer(*args, uniform_time=True, arithmetic="bf16x3"), 1)
+        runs = [first]
+        hit = torch.zeros(P, dtype=torch.int32, device=dev)
+        per = torch.zeros(reps - 1, dtype=torch.int32, device=dev)
+        for k in range(reps - 1):
+            r = torch.cat(deform_infer(*args, uniform_time=True, arithmetic="bf16x3"), 1)
+            m = (r != first).any(1)
+            hit += m
+            per[k] = m.sum()
+        torch.cuda.synchronize()
+        rows = hit.nonzero().flatten().tolist()
+        bad = [[None] * int(n) for n in per.tolist() if n][:64]
     L.s3g_profile_read(9, None, None, None)
     L.s3g_profile_enable(1)
     for _ in range(10):
