@@ -47,6 +47,11 @@ namespace s3g {
 #define S3G_POINT_PREFETCH 1
 constexpr float TSLAB_SAFE = 1e-18f;
 __device__ __forceinline__ bool tslab_divisible(float s) { return fabsf(s) > TSLAB_SAFE && fabsf(s) < __builtin_huge_valf(); }
+// GATE of the exact fallback in the per-point passes: wider than the predicate itself.  The passes that DIVIDE decide with
+// tslab_divisible on the sample they re-derive; the fallback (tslab_exact_scatter / exact_du) re-derives the sample the same way and
+// applies the same predicate per channel.  The gate only has to make sure the fallback is ENTERED whenever some pass might refuse
+// to divide: a sample within a factor of four of the threshold enters it even if this kernel's own evaluation sits on the safe side.
+__device__ __forceinline__ bool tslab_near_unsafe(float s) { return !(fabsf(s) > 4.f * TSLAB_SAFE && fabsf(s) < __builtin_huge_valf()); }
 
 template <bool UT>
 __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) {
@@ -259,7 +264,7 @@ __device__ __forceinline__ void finish_level(const HexArgs& a, int p, int l, int
         else *grow = gi;
       } else {
 #pragma unroll
-        for (int k = 0; k < vec_of<V>::N; k++) badbits |= tslab_divisible(vget<V>(S.s[i], k)) ? 0u : (1u << i);
+        for (int k = 0; k < vec_of<V>::N; k++) badbits |= tslab_near_unsafe(vget<V>(S.s[i], k)) ? (1u << i) : 0u;
       }
       if (PAIR0[i] < 3) du[PAIR0[i]] += S.mx[i] * vdot(S.dX[i], gi);
       if (PAIR1[i] < 3) du[PAIR1[i]] += S.my[i] * vdot(S.dY[i], gi);
@@ -438,7 +443,7 @@ __global__ void __launch_bounds__(256, S3G_HEX_POINTDIV_WAVES) hexplane_backward
         for (int k = 0; k < 4; k++) {
           const float sk = vget<f4v>(sv, k);
           const bool okk = tslab_divisible(sk);
-          ok = ok && okk;
+          ok = ok && !tslab_near_unsafe(sk);
           const float q = okk ? vget<f4v>(T, k) * __builtin_amdgcn_rcpf(sk) : 0.f;
           if (k == 0) gi.x = q; else if (k == 1) gi.y = q; else if (k == 2) gi.z = q; else gi.w = q;
         }

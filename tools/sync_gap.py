@@ -1,6 +1,7 @@
 """How long the GPU idles around the rasterizer forward's one host synchronisation (the D2H read of the instance count that
 sizes the binning arena, csrc/raster_forward.hip; the reference has the same sync, rasterizer_impl.cu:281-282).
-From a rocprofv3 --kernel-trace CSV: gap between the end of scan_tiles_kernel and the start of the next bin_kernel<true>.
+From a rocprofv3 --kernel-trace CSV: gap between the end of scan_tiles_kernel and the start of the next bin_kernel<true>
+(round 4: with the host-asynchronous forward the two are separated by a 32-byte copy and fill_slots_kernel only -- no host wait).
 
     python tools/sync_gap.py <rocprof output dir>"""
 import csv
@@ -19,6 +20,8 @@ for i, (s, e, n) in enumerate(rows):
             if "bin_kernel<true>" in n2:
                 gaps.append((s2 - e) / 1e3)
                 break
+            if "fill_slots_kernel" in n2:   # round 4, asynchronous forward: the slot fill sits between the two (no host wait any more)
+                continue
             if not n2.startswith("__amd") and "rocclr" not in n2:   # another kernel ran in between (no instances to bin)
                 break
 if gaps:
