@@ -364,7 +364,7 @@ __device__ __forceinline__ void exact_du(const HexArgs& a, int p, int l, int c0,
 #pragma unroll 1
     for (int k = 0; k < 4; k++) {
       const int c = c0 + k;
-      if (tslab_divisible(walk_sample(a, l, i, u, c))) continue;     // that channel went through the division
+      if (!tslab_near_unsafe(walk_sample(a, l, i, u, c))) continue;     // that channel went through the division (same wide predicate)
       float gk = vget<f4v>(g, k);
 #pragma unroll 1
       for (int jj = 0; jj < 6; jj++)
@@ -442,8 +442,12 @@ __global__ void __launch_bounds__(256, S3G_HEX_POINTDIV_WAVES) hexplane_backward
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const float sk = vget<f4v>(sv, k);
-          const bool okk = tslab_divisible(sk);
-          ok = ok && !tslab_near_unsafe(sk);
+          // ONE predicate per channel, the WIDE one: this pass divides only where |s| clears the threshold by a factor of four and
+          // hands everything else to the exact fallback (exact_du applies the same wide predicate to the same bits; the plane
+          // gradients' fallback, tslab_exact_scatter, applies the strict one the scatter walk uses).  A second, strict compare per
+          // channel here cost the two registers that keep the kernel at four waves per SIMD: 0.76 -> 0.92 ms with the spills.
+          const bool okk = !tslab_near_unsafe(sk);
+          ok = ok && okk;
           const float q = okk ? vget<f4v>(T, k) * __builtin_amdgcn_rcpf(sk) : 0.f;
           if (k == 0) gi.x = q; else if (k == 1) gi.y = q; else if (k == 2) gi.z = q; else gi.w = q;
         }

@@ -1,0 +1,56 @@
+"""CPU-only: register / scratch budgets of the kernels whose speed hangs on an occupancy step (read from the gfx950 code objects
+hipcc cross-compiled into s3gaussian_amd/lib/*.o).  Round 4 lost 0.16 ms when a two-line change pushed the division-form per-point
+pass from 126 to 128 VGPRs + 64 B of scratch -- still "four waves per SIMD" on paper, 0.76 -> 0.92 ms on the GPU -- and only a
+bench line showed it.  This is the cheap guard: the budgets DESIGN.md quotes, asserted on the build."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _resources(obj):
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "kernel_resources.sh"), os.path.join(ROOT, "s3gaussian_amd", "lib", obj)],
+                         capture_output=True, text=True, timeout=300).stdout
+    res = {}
+    for line in out.splitlines():
+        m = re.match(r"(\S+)\s+vgpr\s+(\d+).*?lds\s+(\d+)\s+scratch\s+(\d+)", line)
+        if m:
+            res[m.group(1)] = (int(m.group(2)), int(m.group(4)))
+    return res
+
+
+@pytest.fixture(scope="module")
+def built():
+    from s3gaussian_amd import _lib
+    _lib.build()
+    return True
+
+
+def _one(res, needle):
+    hits = [(k, v) for k, v in res.items() if needle in k]
+    assert len(hits) == 1, (needle, [k for k, _ in hits])
+    return hits[0][1]
+
+
+def test_hexplane_kernels_keep_their_occupancy(built):
+    res = _resources("hexplane.o")
+    assert res, "tools/kernel_resources.sh found no kernels (llvm-objcopy / clang-offload-bundler / llvm-readelf)"
+    vgpr, scratch = _one(res, "hexplane_backward_pointdiv_kernelILb1E")        # uniform time: four waves per SIMD, no spills
+    assert vgpr <= 128 and scratch == 0, (vgpr, scratch)
+    vgpr, scratch = _one(res, "hexplane_scatter_kernelILb1Ef")                 # single-entry footprint, one level per walk: eight waves
+    assert vgpr <= 64 and scratch == 0, (vgpr, scratch)
+    vgpr, scratch = _one(res, "hexplane_forward_kernelILb1E")
+    assert vgpr <= 102 and scratch == 0, (vgpr, scratch)                       # five waves per SIMD
+
+
+def test_mlp_and_raster_kernels_do_not_spill(built):
+    mlp = _resources("mlp.o")
+    for needle in ("mlp_forward_kernelILb0E", "mlp_backward_kernelILb0E", "mlp_wgrad_all_kernel", "deform_infer_kernelILb1ELb0E"):
+        vgpr, scratch = _one(mlp, needle)
+        assert vgpr <= 256 and scratch == 0, (needle, vgpr, scratch)
+    bwd = _resources("raster_backward.o")
+    for k, (vgpr, scratch) in bwd.items():
+        assert scratch == 0, (k, vgpr, scratch)
