@@ -752,7 +752,9 @@ __global__ void __launch_bounds__(NWAVE * 64) deform_infer_kernel(const InferArg
     // re-writing the four registers with an ordinary single-pass VALU instruction (v_mov_b32) and NO wait state at all is enough --
     // 0 wrong rows in 1000 launches at 1.2 M points and 400 at 70 001 (build `split_vmov`, now the tree; the 16-wait-state build:
     // also 0) -- i.e. the unsafe pair is "packed-fp32 VALU result -> DS store data" while XDL ops of another wave are in flight,
-    // and a real register dependency on a non-packed VALU write removes it independently of timing.  ISA of the three builds:
+    // and a real register dependency on a non-packed VALU write removes it independently of timing (forming the products with plain
+    // v_mul_f32 is already enough -- build `split_scalarized`, 0 wrong rows --; the v_mov makes that independent of how hipcc chooses
+    // to multiply).  ISA of the builds:
     // profiles/r04_split_hazard_isa.txt; stress test: tests/test_infer_gpu.py::test_split_inference_is_bit_reproducible_1000_launches.
     // (The tap slots are stored from v_mov copies, the coordinates by lanes 0..31 only.)
     if (SPLIT) asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(prod.x), "+v"(prod.y), "+v"(prod.z), "+v"(prod.w));

@@ -23,22 +23,23 @@ for name, (_, edits) in V.items():
     finally:
         os.remove(p)
 PY
-for v in split_nopad split_nops; do dump $T/$v.o $T/$v.s; done
+for v in split_nopad split_nops split_scalarized; do dump $T/$v.o $T/$v.s; done
 python - "$T" > "$ROOT/profiles/r04_split_hazard_isa.txt" <<'PY'
 import re, sys
 T = sys.argv[1]
 print("""# ISA of the split-arithmetic inference kernel deform_infer_kernel<true, true> around its staging store (VERDICT r3 Weak #6 / ADVICE r3).
-# llvm-objdump (hipcc 7.2, gfx950) of three builds of csrc/mlp.hip; measured behaviour of each in profiles/r04_split_hazard.jsonl
+# llvm-objdump (hipcc 7.2, gfx950) of four builds of csrc/mlp.hip; measured behaviour of each in profiles/r04_split_hazard.jsonl
 # (tools/diag_split.py: every launch compared bit for bit with the first, 1000 launches at 1.2 M points, 400 at 70 001):
 #   split_nopad  nothing between the products and the store           -> 110 872 wrong rows / 1000 launches (lanes 48..63 of a wave)
 #   split_nops   16 wait states (round 3)                             -> 0
-#   tree         4 x v_mov_b32 re-writing the stored registers, NO wait state (round 4) -> 0
+#   split_scalarized  an empty asm statement with per-component operands: products by v_mul_f32, no wait state, no copy -> 0
+#   tree         4 x v_mov_b32 re-writing the stored registers on top of that, NO wait state (round 4) -> 0
 # Without the pad the float4 handed to ds_write_b128 is the result of v_pk_mul_f32 (a packed, multi-pass fp32 instruction) issued a few
 # slots earlier; the store reads it before the last quarter of the wave has been written when the OTHER wave of the SIMD is issuing
 # v_mfma_f32_32x32x16_bf16 (never beside the fp32 MFMAs of the exact kernel, never with one wave per SIMD).  A register dependency on
 # a single-pass VALU write (v_mov_b32) in front of the store is sufficient, independent of timing: the unsafe pair is
 # "packed-fp32 VALU result -> DS store data" with XDL ops of another wave in flight.""")
-for tag, f in (("split_nopad", "split_nopad.s"), ("split_nops", "split_nops.s"), ("tree (v_mov dependency)", "tree.s")):
+for tag, f in (("split_nopad", "split_nopad.s"), ("split_nops", "split_nops.s"), ("split_scalarized", "split_scalarized.s"), ("tree (v_mov dependency)", "tree.s")):
     txt = open(f"{T}/{f}").read()
     name = "_ZN3s3g19deform_infer_kernelILb1ELb1EEEvNS_9InferArgsE"
     i = txt.index(name + ">:")
