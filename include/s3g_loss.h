@@ -60,6 +60,13 @@ typedef struct s3g_plane_reg_desc {
 /* value: slotted accumulator (S3G_SUM_DOUBLES doubles). */
 int s3g_plane_regulation(int nplanes, const s3g_plane_reg_desc* planes, double* value, void* stream);
 
+/* x[0..n) *= *scale (device fp32 scalar) -- unless *scale == 1.0f, which the kernel finds out on the device and then touches
+ * nothing.  The plane regulariser's gradient (143 MB at the reference's resolutions) is written with the forward and has to be
+ * multiplied by the upstream gradient of its scalar in the backward (autograd's `grad * upstream`): in a training step that
+ * upstream is the implicit seed of ones times a unit weight, known only on the device; multiplying by it anyway was a 50 us
+ * read-modify-write per iteration. */
+int s3g_scale_unless_one(float* x, size_t n, const float* scale /* device */, void* stream);
+
 /*
  *   s3g_pixel_losses_*  <- the per-pixel terms of the training loss, /root/reference/train.py:395-425:
  *       l1_loss(image, gt[:3])                 utils/loss_utils.py:50-51

@@ -334,6 +334,34 @@ __global__ void __launch_bounds__(256) plane_reg_kernel(const PlaneRegArgs a) {
 
 }  // namespace s3g
 
+// x[i] *= *scale unless *scale == 1 (read on the device): x * 1.0f is x bit for bit, so the common case -- a loss that is
+// back-propagated with the implicit seed of ones through a unit weight -- costs a launch instead of a read-modify-write of the array.
+__global__ void __launch_bounds__(256) scale_unless_one_kernel(float* __restrict__ x, size_t n4, size_t n, const float* __restrict__ scale) {
+  const float s = *scale;
+  if (s == 1.0f) return;   // uniform
+  float4* x4 = reinterpret_cast<float4*>(x);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 v = x4[i];
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    x4[i] = v;
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] *= s;
+}
+
+extern "C" int s3g_scale_unless_one(float* x, size_t n, const float* scale, void* stream_) {
+  if (n > 0 && (!x || !scale)) {
+    set_error("s3g_scale_unless_one: NULL argument");
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (n == 0) return S3G_OK;
+  const size_t n4 = (((uintptr_t)x & 15) == 0) ? n / 4 : 0;
+  const size_t want = (n / 4 + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  hipLaunchKernelGGL(scale_unless_one_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, n4, n, scale);
+  S3G_HIP_CHECK(hipGetLastError());
+  return S3G_OK;
+}
+
 extern "C" int s3g_plane_regulation(int nplanes, const s3g_plane_reg_desc* planes, double* value, void* stream_) {
   using namespace s3g;
   if (nplanes < 0 || nplanes > S3G_MAX_REG_PLANES || (nplanes > 0 && (!planes || !value))) {

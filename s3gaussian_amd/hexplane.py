@@ -70,6 +70,8 @@ def _bind():
                                                  C.c_int, vp]
         L.s3g_hexplane_backward_workspace_bytes.restype = C.c_size_t
         L.s3g_hexplane_backward_workspace_bytes.argtypes = [C.POINTER(_HexDesc), C.c_int, C.c_int]
+        L.s3g_scale_unless_one.restype = C.c_int
+        L.s3g_scale_unless_one.argtypes = [vp, C.c_size_t, vp, vp]
         L.s3g_hexplane_sort_state_words.restype = C.c_int
         L.s3g_hexplane_sort_state_words.argtypes = [C.c_int]
         _bound = True
@@ -152,7 +154,13 @@ class _HexPlaneSample(torch.autograd.Function):
         need = [ctx.needs_input_grad[3 + i] for i in range(len(planes))]
         if ctx.reg_flat is not None:
             # every plane needs its gradient on this path (checked by the caller): regulariser gradient x upstream scalar
-            flat = ctx.reg_flat.mul_(g_reg) if g_reg is not None else ctx.reg_flat.zero_()
+            if g_reg is not None:
+                flat = ctx.reg_flat
+                g32 = g_reg.detach().reshape(-1)[:1].contiguous().float()
+                with torch.cuda.device(flat.device):    # in place; a no-op decided on the device when the upstream gradient is 1
+                    _lib.check(L.s3g_scale_unless_one(flat.data_ptr(), flat.numel(), g32.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            else:
+                flat = ctx.reg_flat.zero_()
             ctx.reg_flat = None
             gplanes = _flat_plane_views(flat, planes)
         else:
