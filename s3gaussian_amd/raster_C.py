@@ -181,10 +181,13 @@ def async_skip_flag(device=None):
 def async_status(device=None, block=False) -> dict:
     """Counters of the asynchronous forwards on `device`: calls issued / drained, overflowed calls, mean true instance count of
     the drained calls, capacities per image size.  block=True waits for every outstanding status row first."""
+    empty = {"enabled": ASYNC, "calls": 0, "drained": 0, "overflows": [], "mean_instances": None, "capacity": {}}
+    if not _async_states:     # nothing issued yet (or a CPU-only process): do not touch the device runtime
+        return empty
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     st = _async_states.get(dev.index if dev.index is not None else torch.cuda.current_device())
     if st is None:
-        return {"enabled": ASYNC, "calls": 0, "drained": 0, "overflows": [], "mean_instances": None, "capacity": {}}
+        return empty
     st.drain(block=block)
     return {"enabled": ASYNC, "calls": st.seq, "drained": st.drained, "overflows": list(st.overflows),
             "mean_instances": (st.sum_instances / st.drained) if st.drained else None,
@@ -193,6 +196,8 @@ def async_status(device=None, block=False) -> dict:
 
 def async_reset_statistics(device=None) -> None:
     """Forget the drained-call counters (not the capacities): bench.py brackets its timed regions with this."""
+    if not _async_states:
+        return
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     st = _async_states.get(dev.index if dev.index is not None else torch.cuda.current_device())
     if st is not None:

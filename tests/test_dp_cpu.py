@@ -243,3 +243,12 @@ def test_single_process_is_a_noop():
     assert dp.GradAllReducer([p])() == 0
     assert torch.equal(p.grad, torch.ones(4))
     assert dp.shard_views(10, 0, 1) == dp.shard_views(10, 0, 1)
+
+
+def test_reduce_skip_flag_is_a_no_op_without_an_asynchronous_forward():
+    """dp.reduce_skip_flag() all-reduces the asynchronous rasterizer's overflow flag; a process that has issued no such forward
+    (CPU tests, coarse debugging runs with S3G_RASTER_ASYNC=0) has nothing to reduce and must not touch the process group."""
+    from s3gaussian_amd import dp, raster_C
+    assert not raster_C._async_states
+    assert dp.reduce_skip_flag() is None
+    assert raster_C.async_status()["calls"] == 0 and raster_C.async_status()["overflows"] == []
