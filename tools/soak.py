@@ -2,7 +2,7 @@
 count, so the arena capacities and the allocator see the whole range), the interpreter's collector running normally (no freeze,
 no pre-collect), re-sorts of the HexPlane walk orders every 16 steps included.  One JSON line.
 
-    python tools/soak.py [steps=600] [sync]"""
+    python tools/soak.py [steps=600] [sync] [P=2500000] [scale=3.5]"""
 import gc
 import json
 import sys
@@ -18,8 +18,10 @@ from s3gaussian_amd.pipeline import training_step  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 if "sync" in sys.argv[2:]:
     raster_C.set_async(False)
+P = next((int(a[2:]) for a in sys.argv[2:] if a.startswith("P=")), 1_200_000)            # P=2500000: BASELINE cfg5 size
+SCALE = next((float(a[6:]) for a in sys.argv[2:] if a.startswith("scale=")), 1.0)         # scale=3.5: ~10 M instances per view
 dev = torch.device("cuda", 0)
-pc, cams, hyper, opt, bg = bench.build_scene(1_200_000, 1600, 1066, 50, dev)
+pc, cams, hyper, opt, bg = bench.build_scene(P, 1600, 1066, 50, dev, scale_mult=SCALE)
 targets = {v: bench.make_targets(pc, cams[v], bg, hyper, seed=1000 + v) for v in range(0, len(cams), 13)}
 tk = list(targets)
 g = torch.Generator().manual_seed(0)
@@ -50,7 +52,7 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 per = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(N))
 st = raster_C.async_status(dev, block=True)
-print(json.dumps({"what": "sustained fused training step, BASELINE cfg3, all 150 views in random order", "steps": N,
+print(json.dumps({"what": f"sustained fused training step, {P} Gaussians (scale x{SCALE}), 1066x1600, all 150 views in random order", "steps": N,
                   "rasterizer_forward": "asynchronous" if st["enabled"] else "synchronous",
                   "iters_per_s": round(N / dt, 2), "ms_per_step": round(1e3 * dt / N, 3), "host_enqueue_ms_per_step": round(1e3 * t_enq / N, 3),
                   "step_ms_min": round(per[0], 3), "step_ms_median": round(per[N // 2], 3), "step_ms_p99": round(per[int(N * 0.99)], 3),
