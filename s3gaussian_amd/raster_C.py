@@ -67,8 +67,8 @@ def _inputs(P, D, M, W, H, bg, means3D, sh, colors, opacity, scales, scale_modif
 # binning arena (rasterizer_impl.cu:281-282).  That one wait caps the host's run-ahead at a single iteration, so any hiccup of
 # the host (a slow core, a busy box, an allocator call) becomes GPU idle time.  With ASYNC on, the callers that never hand R
 # to anybody (the autograd nodes of rasterizer.py) size the arenas for a speculative capacity instead -- four times the largest
-# count seen so far for this image size (and never fewer than 16 M instances), quantised so that the allocation sizes repeat -- and the true counts arrive later
-# through a pinned ring that is polled, never waited for.  An overflow (counts above the capacity) is a well-defined no-op on
+# count seen so far for this image size (and never fewer than 16 M instances), quantised so that the allocation sizes repeat --
+# and the true counts arrive later through a pinned ring that is polled, never waited for.  An overflow (counts above the capacity) is a well-defined no-op on
 # the device (background-only image, zero gradients, no densification bookkeeping, optimizer step dropped through
 # `async_skip_flag`), is reported here one or more calls later (warning + `async_status()["overflows"]`), and raises the
 # capacity.  `rasterize_gaussians` called without allow_async -- the reference's `_C` signature, which returns R -- stays
@@ -119,8 +119,9 @@ class _AsyncState:
         h = self.hist.get(key)
         if h is None:
             return None
-        cap_r = _quantise(max(_ASYNC_HEADROOM * h[0], _ASYNC_MIN_INSTANCES))
-        cap_s = max(_quantise(max(_ASYNC_HEADROOM * h[1], 2 * _ASYNC_MIN_INSTANCES)), cap_r)
+        # (the C ABI carries both as uint32; instance positions are int32 inside the library, like the reference's num_rendered)
+        cap_r = min(_quantise(max(_ASYNC_HEADROOM * h[0], _ASYNC_MIN_INSTANCES)), 0x7fffffff)
+        cap_s = min(max(_quantise(max(_ASYNC_HEADROOM * h[1], 2 * _ASYNC_MIN_INSTANCES)), cap_r), 0xffffffff)
         longest = 2 * h[2]
         lds = 256
         while lds < min(longest, 4096):

@@ -41,3 +41,11 @@ def test_capacities_follow_the_largest_counts_seen():
     assert lds == 256 and long_lists == 0
     st.hist[(64, 64)] = [40_000_000, 70_000_000, 3]              # beyond the floor: the capacity follows the counts
     assert st.caps((64, 64))[0] >= 160_000_000
+
+
+def test_capacities_stay_inside_the_abi_integer_types():
+    from s3gaussian_amd import raster_C
+    st = object.__new__(raster_C._AsyncState)
+    st.hist = {(8, 8): [1_500_000_000, 3_000_000_000, 100_000]}      # absurd counts: the capacities saturate instead of wrapping
+    cap_r, cap_s, lds, long_lists = st.caps((8, 8))
+    assert cap_r == 0x7fffffff and cap_s == 0xffffffff and lds == 4096 and long_lists == 1
