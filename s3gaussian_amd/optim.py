@@ -81,6 +81,9 @@ class Adam(torch.optim.Adam):
             # host-asynchronous rasterizer (raster_C.ASYNC): if the last forward on this device overflowed its speculative
             # arena -- it then rendered nothing and back-propagated zeros -- the device drops this step too; the host finds out
             # later without having waited (raster_C.async_status()).  None: no such forward, plain step.
+            # The flag belongs to the most recent asynchronous forward on this device and applies to every optimizer step issued
+            # before the next one (a two-phase data-parallel step calls step() twice per iteration).  A process that trains two
+            # independent models on one device with interleaved forwards should switch the mechanism off (S3G_RASTER_ASYNC=0).
             flag = raster_C.async_skip_flag(dev)   # data parallel: dp.reduce_skip_flag() has all-reduced it in place
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream().cuda_stream

@@ -142,7 +142,8 @@ def test_training_steps_are_enqueued_ahead_of_the_device(gpu_device):
     from s3gaussian_amd import raster_C, synth
     from s3gaussian_amd.pipeline import GaussianParams, default_hyper, default_opt, training_step
     dev = gpu_device
-    scn = synth.street_scene(P=400_000, seed=0, width=1600, height=1066, n_frames=4)
+    # BASELINE-size scene: the device needs ~7 ms per step, several times what the host needs to enqueue one even on a slow box
+    scn = synth.street_scene(P=1_200_000, seed=0, width=1600, height=1066, n_frames=4)
     hyper, opt = default_hyper(), default_opt()
     pc = GaussianParams(3, hyper)
     gs = scn["gaussians"]
