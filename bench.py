@@ -839,6 +839,8 @@ def main(argv=None):
             "host_enqueue_ms_per_step": round(1000.0 * t_enq / a.steps, 3),
             "instrumented_loop_ms_per_step": round(sum(per_step_instrumented) / len(per_step_instrumented), 3),
             "gc_gen2_passes_in_timed_loop": GC_PASSES[0] if GC_PASSES else None,
+            "gc_policy": "gc.collect() + gc.freeze() after the warm-up and gc.collect() before each timed loop; the collector stays enabled "
+                         "inside the loops (tools/soak.py times 600 steps with no such care: profiles/r04_soak.jsonl)",
             "config": {"workload": workload_label(a, world) + f": {a.P} Gaussians, {a.height}x{a.width}, 3 cams x {a.frames} frames, fine stage "
                                    "(hexplane+deformation ON), RGB+depth render + feature render, L1+DSSIM+depthL2+featL2+regs, Adam",
                        "path": "fused", "gaussians": a.P, "image": [a.height, a.width], "views_per_step_per_rank": 1,
