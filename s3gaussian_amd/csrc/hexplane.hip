@@ -12,18 +12,22 @@
 //
 // Backward without an atomic storm.  A direct scatter is 96 line-coalesced float atomics per point; MI355X retires
 // ~10 G such line-ops/s whatever the contention (tools/ubench/atomic_lines.hip), i.e. 11.5 ms at 1.2 M points.  So:
-//   pass A  (blocked order) re-gathers the taps, applies the product rule, finishes dL/dxyz and writes to the scratch G ONE row
-//                           per level, T = dL/dfeature * feature (point-major, 512 B per point, streamed; rounds 1-2 wrote
-//                           dL/ds for all 24 plane-levels = 3 KB per point: see S3G_HEX_TSLAB below);
-//   sort    four 2-level counting sorts of the point indices -- by (major, minor) finest-level texel cell, one per plane
-//           orientation, and the blocked processing order -- with LDS histograms (no global atomics, no library sort); the
-//           orders only steer the walks, so the caller may keep them for several iterations (sort_state / sort_reuse);
-//   pass B  (sorted order, one launch for the three orientations = 2 plane kinds x all levels each): a half-wave (32
-//           lanes = the 32 channels) walks a run of spatially consecutive points keeping two bilinear footprints per
-//           (level, plane) in registers and only issues atomics when a footprint is evicted (two instead of four when the
-//           walk just steps to the neighbouring footprint) -- consecutive points share texels, so the 96 line-ops per point
-//           drop to ~5.  Taps are computed cooperatively (lane = point x tap) and
-//           shared through LDS; index, coordinate and tap computation run one to two groups ahead of the accumulation.
+//   pass A  (blocked order) re-gathers the taps, finishes dL/dxyz and writes to the scratch G ONE row per level,
+//                           T = dL/dfeature * feature (point-major, 512 B per point, streamed).  Round 4 (S3G_HEX_SLAB_DIV,
+//                           hexplane_backward_pointdiv_kernel): T straight from the forward's saved output, dL/ds_i = T / s_i plane by
+//                           plane at four waves per SIMD; rounds 1-3 (hexplane_backward_point_kernel): the product rule with six
+//                           samples live at two waves per SIMD (rounds 1-2 also wrote dL/ds of all 24 plane-levels, 3 KB per point);
+//   sort    2-level counting sorts of the point indices with LDS histograms (no global atomics, no library sort) -- round 4: ONE
+//           ORDER PER (orientation, LEVEL), by (major, minor) texel cell of THAT level (thirteen sorts with the blocked processing
+//           order; rounds 1-3: the finest level's cells only, four sorts); the orders only steer the walks, so the caller may keep
+//           them for several iterations (sort_state / sort_reuse);
+//   pass B  (sorted orders, one launch: blockIdx.y = orientation * levels + level): a half-wave (32 lanes = the 32 channels) walks
+//           a run of consecutive points of ITS order keeping one bilinear footprint per plane kind (the spatial plane and the
+//           (major, t) plane of the orientation) in registers -- sums AND texel values -- and only issues atomics when the footprint
+//           changes (two instead of four when the walk just steps to the neighbouring footprint): the 96 line-ops per point
+//           drop to ~2 (rounds 1-3, every level in the finest order with a two-entry cache: ~5-6).  Taps are computed
+//           cooperatively (lane = point x tap) and shared through LDS; index, coordinate and tap computation run one to two groups
+//           ahead of the accumulation.
 #include "hexplane_dev.hpp"
 
 namespace s3g {

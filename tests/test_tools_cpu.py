@@ -59,3 +59,20 @@ def test_pmc_summary_and_step_trace(tmp_path):
                        check=True, capture_output=True, text=True)
     last = r.stdout.strip().splitlines()[-1]
     assert "span 8.0 us" in last and "kernel-busy 6.0 us" in last and "non-s3g kernels 1.0 us" in last and "launches 3" in last
+
+
+def test_variant_specs_still_apply_to_the_tree():
+    """tools/variants/*.py are the A/B specs behind the numbers DESIGN.md quotes (tools/mkvariants.py: exact-once string edits of a
+    source file).  A spec whose pattern no longer occurs exactly once has rotted: the experiment could not be repeated."""
+    import glob
+    import os
+    import runpy
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    specs = sorted(glob.glob(os.path.join(root, "tools", "variants", "*.py")))
+    assert specs
+    for spec in specs:
+        for name, (hip, edits) in runpy.run_path(spec)["VARIANTS"].items():
+            src = open(os.path.join(root, "s3gaussian_amd", "csrc", hip)).read()
+            for old, new in edits:
+                assert src.count(old) == 1, (os.path.basename(spec), name, old[:60])
+                src = src.replace(old, new)

@@ -15,6 +15,8 @@ from s3gaussian_amd import synth  # noqa: E402
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 1_200_000
 SIM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "flush_sim")
+if not os.path.exists(SIM) or os.path.getmtime(SIM) < os.path.getmtime(SIM + ".c"):
+    subprocess.check_call(["gcc", "-O2", "-o", SIM, SIM + ".c"])
 sc = synth.street_scene(P=P, seed=0, width=1600, height=1066, n_frames=2)
 xyz = sc["gaussians"]["xyz"].numpy().astype(np.float32)
 amax, amin = (np.asarray(v, np.float32) for v in sc["aabb"])
