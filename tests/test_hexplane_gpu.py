@@ -284,3 +284,53 @@ def test_walk_backward_matches_the_slab_backward(gpu_device, tmode, monkeypatch)
         assert rel_l2(res[other][0].cpu().numpy(), res["slab"][0].cpu().numpy()) < 1e-5, other
         for a, b in zip(res[other][1], res["slab"][1]):
             assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, other
+
+
+def test_every_walk_order_is_sorted_by_its_own_levels_cells(gpu_device):
+    """Round 4: the scatter walks every (orientation, level) in an order sorted by THAT level's (major, minor) texel cells
+    (csrc/hexplane.hip::sort_cell / order_key; sort_state layout in include/s3g_hexplane.h).  A wrong key would not change any result
+    -- the orders only steer the walks -- it would silently bring back the flush storm, so the orders themselves are checked: keys
+    recomputed here in the kernel's fp32 arithmetic must be non-decreasing along every order, every order must be a permutation,
+    and comp must be the composition with the processing order."""
+    from s3gaussian_amd import hexplane as hx
+    torch.manual_seed(3)
+    cfg = dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32, resolution=[64, 64, 64, 25])
+    f = hx.HexPlaneField(1.6, cfg, [1, 2, 4, 8])
+    f.set_aabb([30.0, 12.0, 6.0], [-10.0, -12.0, -2.0])
+    f = f.to(gpu_device)
+    P = 200_000
+    g = torch.Generator().manual_seed(1)
+    xyz = (torch.rand(P, 3, generator=g) * torch.tensor([44.0, 26.0, 9.0]) + torch.tensor([-12.0, -13.0, -2.5])).to(gpu_device)   # some outside
+    x = xyz.clone().requires_grad_(True)
+    (f(x, torch.full((P, 1), 0.4, device=gpu_device), uniform_time=True) ** 2).sum().backward()
+    L = len(f.resolutions)
+    words = hx.sort_state_words(L)
+    assert words == 6 * L + 1
+    st = f._order_cache["sort_state"].view(words, P).long()
+    order, comp, proc = st[:3 * L], st[3 * L:6 * L], st[6 * L]
+    everyone = torch.arange(P, device=gpu_device)
+    assert torch.equal(torch.sort(proc).values, everyone)
+    procrank = torch.empty_like(proc)
+    procrank[proc] = everyone
+    amax, amin = f.aabb[0].float(), f.aabb[1].float()
+    u = (xyz - amax) * (2.0 / (amin - amax)) - 1.0                         # point_coords(), fp32 like the kernel
+
+    def cell(axis, W):
+        ix = ((u[:, axis] + 1.0) / 2.0) * float(W - 1)
+        return torch.clamp(ix, 0.0, float(W - 1)).floor().long()
+
+    MAJ, MIN_ = [0, 1, 2], [1, 2, 0]
+    for o in range(3):
+        for l in range(L):
+            oi = o * L + l
+            W_major, W_minor = f.resolutions[l][MAJ[o]], f.resolutions[l][MIN_[o]]
+            key = cell(MAJ[o], W_major) * 512 + cell(MIN_[o], W_minor)
+            k = key[order[oi]]
+            assert torch.equal(torch.sort(order[oi]).values, everyone), (o, l)
+            assert int((k[1:] < k[:-1]).sum()) == 0, (o, l)                   # monotone in its OWN level's cells
+            assert torch.equal(comp[oi], procrank[order[oi]]), (o, l)
+    # and the coarse levels are NOT monotone in the finest level's order: that is what rounds 1-3 walked
+    fine = cell(0, f.resolutions[L - 1][0]) * 512 + cell(1, f.resolutions[L - 1][1])
+    coarse_in_fine_order = (cell(0, f.resolutions[0][0]) * 512 + cell(1, f.resolutions[0][1]))[order[L - 1]]
+    assert int((fine[order[L - 1]][1:] < fine[order[L - 1]][:-1]).sum()) == 0
+    assert int((coarse_in_fine_order[1:] < coarse_in_fine_order[:-1]).sum()) > 100
