@@ -13,7 +13,6 @@ cold first (it can only be first), then every combination twice, second time rev
 
     python tools/headline_variance.py > gpurun_out/r04_headline_variance.txt
 """
-import ctypes as C
 import os
 import sys
 
