@@ -36,21 +36,8 @@ __device__ __forceinline__ void load_sh(const GlueArgs& a, int p, float (&sh)[16
   }
 }
 
-__global__ void __launch_bounds__(256) glue_forward_kernel(const GlueArgs a) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (a.dshs_abs_sum != nullptr && a.dshs != nullptr) {  // coalesced sweep over this block's 256 x 48 slice of dshs
-    __shared__ double part[4];
-    const size_t lo = (size_t)blockIdx.x * 256 * 48, hi = min(lo + (size_t)256 * 48, (size_t)a.P * 48);
-    float s = 0.f;
-    for (size_t e = lo + threadIdx.x; e < hi; e += 256) s += fabsf(a.dshs[e]);
-    double d = (double)s;
-    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = d;
-    __syncthreads();
-    if (threadIdx.x == 0)
-      atomicAdd(&a.dshs_abs_sum[(blockIdx.x % S3G_SUM_SLOTS) * S3G_SUM_STRIDE], part[0] + part[1] + part[2] + part[3]);
-  }
-  if (p >= a.P) return;
+// thread = Gaussian: activations, then SH -> RGB from the summed coefficient rows sh (registers)
+__device__ __forceinline__ void glue_forward_point(const GlueArgs& a, int p, const float (&sh)[16][3]) {
   // activations
 #pragma unroll
   for (int k = 0; k < 3; k++) a.scales[3 * (size_t)p + k] = expf(a.log_scales[3 * (size_t)p + k]);
@@ -59,8 +46,6 @@ __global__ void __launch_bounds__(256) glue_forward_kernel(const GlueArgs a) {
   reinterpret_cast<float4*>(a.rot)[p] = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
   a.opacity[p] = 1.0f / (1.0f + expf(-a.opacity_logit[p]));
   // SH -> RGB (utils/sh_utils.py:57-112; same polynomial order as the rasterizer's in-kernel path)
-  float sh[16][3];
-  load_sh(a, p, sh);
   float dx = a.xyz[3 * (size_t)p] - a.campos[0], dy = a.xyz[3 * (size_t)p + 1] - a.campos[1], dz = a.xyz[3 * (size_t)p + 2] - a.campos[2];
   const float len = sqrtf(dx * dx + dy * dy + dz * dz);
   const float x = dx / len, y = dy / len, z = dz / len;
@@ -84,6 +69,70 @@ __global__ void __launch_bounds__(256) glue_forward_kernel(const GlueArgs a) {
     }
     a.colors[3 * (size_t)p + c] = fmaxf(v + 0.5f, 0.f);
   }
+}
+
+// Forward with a deformation (dshs present).  Phase 1 (workgroup, coalesced): the block's 256 coefficient rows of dshs go through
+// LDS as contiguous sweeps -- a wave instruction covers 256 consecutive bytes -- and pick up (f_dc | f_rest) on the way: element
+// e = 48 q + r of the slice is f_rest[45 q + r - 3] = rest[e - 3 (q + 1)], contiguous but for a three-float step per row; the
+// three f_dc columns follow in a short second sweep.  (Read per lane as 45- / 48-float rows, every load instruction touched 64
+// different lines: 24 x dwordx4 per lane, 151 us for 0.57 GB -- the address path, not HBM.  Without dshs the 12 row loads that are
+// left run at the HBM rate and that kernel is kept: glue_forward_rows_kernel.)  The |dshs| sum of the regulariser is taken from
+// the same registers instead of a second sweep.  Phase 2 (thread = Gaussian): rows read back at an odd stride (conflict-free),
+// same polynomial, and every coefficient is the same single addition f + d as before: colours are bit-identical.
+constexpr int GLUE_ROW = 49;
+
+template <bool FULL>   // FULL: all 256 rows of the block exist (compile-time trip counts: the loads of a sweep are issued back to back)
+__device__ __forceinline__ float glue_stage_rows(const GlueArgs& a, int p0, int nrows, float* rows) {
+  const float* dc = a.f_dc + (size_t)p0 * 3;
+  const float* rest = a.f_rest + (size_t)p0 * 45;
+  const float* d = a.dshs + (size_t)p0 * 48;
+  const int n48 = FULL ? 256 * 48 : nrows * 48, n3 = FULL ? 256 * 3 : nrows * 3;
+  // e = tid + 256 i; 256 = 5 * 48 + 16: (q, r) advance by (5, 16) with one carry; LDS word q * 49 + r, rest index e - 3 (q + 1)
+  int r = threadIdx.x % 48, q = threadIdx.x / 48;
+  int word = q * GLUE_ROW + r, src = (int)threadIdx.x - 3 * (q + 1);
+  float s = 0.f;
+#pragma unroll 16
+  for (int e = threadIdx.x; e < n48; e += 256) {
+    const float v = d[e];
+    const float f = rest[src < 0 ? 0 : src];   // unconditional (no branch around the load): r < 3 reads a neighbour it does not use
+    s += fabsf(v);
+    rows[word] = r >= 3 ? f + v : v;
+    r += 16; word += 5 * GLUE_ROW + 16; src += 256 - 15;
+    if (r >= 48) { r -= 48; word += GLUE_ROW - 48; src -= 3; }
+  }
+  __syncthreads();   // the f_dc columns are added by other threads than the ones that stored dshs there
+  for (int e = threadIdx.x; e < n3; e += 256) rows[(e / 3) * GLUE_ROW + e % 3] += dc[e];
+  return s;
+}
+
+__global__ void __launch_bounds__(256) glue_forward_kernel(const GlueArgs a) {   // a.dshs != nullptr
+  __shared__ float rows[256 * GLUE_ROW];
+  __shared__ double part[4];
+  const int p0 = blockIdx.x * 256, p = p0 + threadIdx.x, nrows = min(256, a.P - p0);
+  const float s = nrows == 256 ? glue_stage_rows<true>(a, p0, nrows, rows) : glue_stage_rows<false>(a, p0, nrows, rows);
+  if (a.dshs_abs_sum != nullptr) {
+    double t = (double)s;
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+  }
+  __syncthreads();
+  if (a.dshs_abs_sum != nullptr && threadIdx.x == 0)
+    atomicAdd(&a.dshs_abs_sum[(blockIdx.x % S3G_SUM_SLOTS) * S3G_SUM_STRIDE], part[0] + part[1] + part[2] + part[3]);
+  if (p >= a.P) return;
+  float sh[16][3];
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) sh[k][c] = rows[threadIdx.x * GLUE_ROW + 3 * k + c];
+  glue_forward_point(a, p, sh);
+}
+
+__global__ void __launch_bounds__(256) glue_forward_rows_kernel(const GlueArgs a) {   // no dshs (coarse stage): 12 row loads per lane
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.P) return;
+  float sh[16][3];
+  load_sh(a, p, sh);
+  glue_forward_point(a, p, sh);
 }
 
 // Phase 1 (thread = Gaussian): everything but the SH coefficient gradients; the 16 basis values and the 3 colour gradients
@@ -224,7 +273,8 @@ extern "C" int s3g_glue_forward(int P, int deg, const float* f_dc, const float* 
   a.log_scales = log_scales; a.rot_raw = rot_raw; a.opacity_logit = opacity_logit;
   a.colors = colors; a.scales = scales; a.rot = rot; a.opacity = opacity;
   a.dshs_abs_sum = dshs_abs_sum;
-  hipLaunchKernelGGL(glue_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
+  if (dshs != nullptr) hipLaunchKernelGGL(glue_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
+  else hipLaunchKernelGGL(glue_forward_rows_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }
