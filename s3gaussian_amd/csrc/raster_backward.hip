@@ -293,24 +293,47 @@ struct GeomBwdArgs {
   float* dens_max_radii;    // [P] max_radii2D = max(max_radii2D, radii) where visible
 };
 
-// Sum the records of the tiles k = k0, k0+stride, ... of one Gaussian's rect (row-major inside the rect).
+// Sum the records of the tiles k = k0, k0+stride, ... of one Gaussian's rect (row-major inside the rect), in that order.
+// The walk is a chain of dependent loads (slot_pos -> record; tile_hi beside it) and the kernel is bound by that latency, not by
+// bytes: GATHER_BATCH tiles are therefore in flight at a time -- all their positions and tile ends are requested first, then all
+// their records, then the sums are taken in ascending k exactly as a one-at-a-time walk would take them (a tile that contributes
+// nothing adds +0: the totals are bit-identical).
+#ifndef S3G_GATHER_BATCH
+#define S3G_GATHER_BATCH 3   // cfg3, two-image pass: 192 / 164 / 145 / 154 / 160 / 158 us for 1 / 2 / 3 / 4 / 6 / 8 (profiles/r04_gather.txt)
+#endif
 template <int NR>
 __device__ __forceinline__ void gather_records(const GeomBwdArgs& a, const ushort4 r, uint32_t o, int k0, int stride,
                                                float* acc) {
+  constexpr int B = S3G_GATHER_BATCH;
   const int w = (int)r.z - (int)r.x, n = w * ((int)r.w - (int)r.y);
-  for (int k = k0; k < n; k += stride) {
-    const int ty = (int)r.y + k / w, tx = (int)r.x + k % w;
-    const int t = ty * a.gx + tx;
-    const uint32_t pos = a.slot_pos[o + k];
-    if (pos < a.tile_hi[t]) {  // tile_hi = absolute end of the positions the blend backward wrote
-      const float2* rec = reinterpret_cast<const float2*>(a.records + (size_t)pos * NR);
+  for (int k = k0; k < n; k += B * stride) {
+    uint32_t pos[B], hi[B];
 #pragma unroll
-      for (int q = 0; q < NR / 2; q++) {
-        const float2 v = rec[q];
-        acc[2 * q] += v.x;
-        acc[2 * q + 1] += v.y;
+    for (int j = 0; j < B; j++) {
+      const int kk = k + j * stride;
+      const int kc = kk < n ? kk : k;   // past the rect: a valid address whose value is not used
+      const int ty = (int)r.y + kc / w, tx = (int)r.x + kc % w;
+      pos[j] = a.slot_pos[o + kc];
+      hi[j] = a.tile_hi[ty * a.gx + tx];  // tile_hi = absolute end of the positions the blend backward wrote
+    }
+    float2 v[B][NR / 2];
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+#pragma unroll
+      for (int q = 0; q < NR / 2; q++) v[j][q] = make_float2(0.f, 0.f);
+      if (k + j * stride < n && pos[j] < hi[j]) {
+        const float2* rec = reinterpret_cast<const float2*>(a.records + (size_t)pos[j] * NR);
+#pragma unroll
+        for (int q = 0; q < NR / 2; q++) v[j][q] = rec[q];
       }
     }
+#pragma unroll
+    for (int j = 0; j < B; j++)
+#pragma unroll
+      for (int q = 0; q < NR / 2; q++) {
+        acc[2 * q] += v[j][q].x;
+        acc[2 * q + 1] += v[j][q].y;
+      }
   }
 }
 
