@@ -136,6 +136,10 @@ typedef struct s3g_raster_async {
   void* image_arena;
   uint32_t* status_device;
   uint32_t* status_host;
+  int forward_only;             /* != 0: no backward will follow (inference): the instance -> list-position map that only the
+                                 * backward gather reads is not built (no slot fill, no rect / offset gathers and no scattered
+                                 * store per instance in the per-tile sort).  The arenas then serve s3g_raster_forward_reuse and
+                                 * s3g_raster_forward_decompose, NOT s3g_raster_backward*. */
 } s3g_raster_async;
 int s3g_raster_arena_bytes(int P, int width, int height, uint32_t capacity_instances, uint32_t capacity_slots,
                            size_t* geometry_bytes, size_t* binning_bytes, size_t* image_bytes);

@@ -43,7 +43,7 @@ inline int bin_blocks(int P) {
 inline int bin_chunk(int P) {
   const int nb = bin_blocks(P);
   const int per = (P + nb - 1) / nb;
-  return ((per + 255) / 256) * 256;
+  return ((per + 63) / 64) * 64;   // whole waves; the binning workgroups step through their chunk with a guarded tail
 }
 
 // ---- error plumbing ------------------------------------------------------------------------------------

@@ -207,10 +207,22 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreprocessArgs a)
 //    launched once per band and only handle the instances whose tile lies in it (an 8K image is 4 bands).
 //    (*) order inside a tile is arbitrary here; the per-tile sort fixes it.
 // =========================================================================================================
-constexpr int BIN_THREADS = 256;
+#ifndef S3G_BIN_THREADS
+#define S3G_BIN_THREADS 512
+#endif
+#ifndef S3G_BIN_PREFETCH
+#define S3G_BIN_PREFETCH 1
+#endif
+// Both walks are chains of dependent global loads (rect -> tile mask / depth) in front of LDS work, run by 2 workgroups per CU
+// (the histogram of ALL tiles lives in LDS: more workgroups would mean more table rows for bin_scan).  What hides the latency is
+// (i) more waves per workgroup -- the histogram is shared, so threads are free -- and (ii) the next step's three loads requested
+// before this step's walk; the block-wide scan of bin_write therefore synchronises on LDS only (an ordinary __syncthreads()
+// would also wait for the prefetch).
+constexpr int BIN_THREADS = S3G_BIN_THREADS, BIN_WAVES = BIN_THREADS / 64, BIN_SCRATCH = 2 * BIN_WAVES + 8;
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct BinArgs {
-  int P, gx, tiles, chunk;         // chunk = Gaussians per workgroup (multiple of BIN_THREADS)
+  int P, gx, tiles, chunk;         // chunk = Gaussians per workgroup
   int tile_lo, tile_n;             // the band of tiles this launch handles: [tile_lo, tile_lo + tile_n)
   const ushort4* rect;
   const float* depths;
@@ -229,9 +241,9 @@ struct BinArgs {
 
 template <bool WRITE>
 __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [tiles] histogram / cursors, then 8 words of scratch
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [tiles] histogram / cursors, then BIN_SCRATCH words
   uint32_t* cell = lds;
-  uint32_t* wsum = lds + a.tile_n;  // [4] wave totals + [1] carry
+  uint32_t* wsum = lds + a.tile_n;  // [2][BIN_WAVES] wave totals, alternating by step: ONE barrier per step
   if (WRITE && a.ctrl[4] != 0u) return;  // host-asynchronous forward: the instances do not fit the arena (see scan_tiles_kernel)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t* trow = a.table + (size_t)blockIdx.x * a.tiles;
@@ -241,10 +253,32 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
   uint32_t my_total = 0;
   __syncthreads();
   const int g0 = blockIdx.x * a.chunk, g1 = min(a.P, g0 + a.chunk);
-  for (int base = g0; base < g1; base += BIN_THREADS) {
+  // what a step needs of its Gaussian: rect, the mask of tiles that survive the exact cull (meaningful for 0 < area <= BIG_RECT
+  // only; whatever the word holds otherwise is not used) and the depth bits of the key
+  ushort4 r_next = make_ushort4(0, 0, 0, 0);
+  uint32_t mask_next = 0xffffffffu, depth_next = 0u;
+  if (S3G_BIN_PREFETCH && g0 + tid < g1) {
+    r_next = a.rect[g0 + tid];
+    if (a.cull) mask_next = a.tile_mask[g0 + tid];
+    if (WRITE) depth_next = __float_as_uint(a.depths[g0 + tid]);
+  }
+  int step = 0;
+  for (int base = g0; base < g1; base += BIN_THREADS, step ^= 1) {
     const int g = base + tid;
     ushort4 r = make_ushort4(0, 0, 0, 0);
-    if (g < g1) r = a.rect[g];
+    uint32_t mask = 0xffffffffu, dbits = 0u;
+    if (S3G_BIN_PREFETCH) {
+      r = r_next; mask = mask_next; dbits = depth_next;
+      const int gn = g + BIN_THREADS;
+      r_next = make_ushort4(0, 0, 0, 0);
+      if (gn < g1) {
+        r_next = a.rect[gn];
+        if (a.cull) mask_next = a.tile_mask[gn];
+        if (WRITE) depth_next = __float_as_uint(a.depths[gn]);
+      }
+    } else if (g < g1) {
+      r = a.rect[g];
+    }
     const int w = (int)r.z - (int)r.x, h = (int)r.w - (int)r.y;
     const uint32_t area = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
     uint64_t key = 0;
@@ -259,24 +293,24 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
         const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
         if (lane >= off) incl += t;
       }
-      if (lane == 63) wsum[wave] = incl;
-      __syncthreads();
+      uint32_t* ws = wsum + step * BIN_WAVES;
+      if (lane == 63) ws[wave] = incl;
+      lds_barrier();
       uint32_t wbase = 0, tot = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t v = wsum[k];
+      for (int k = 0; k < BIN_WAVES; k++) {
+        const uint32_t v = ws[k];
         if (k < wave) wbase += v;
         tot += v;
       }
       if (g < g1 && first_band) a.gauss_off[g] = carry + wbase + incl - area;
       carry += tot;
-      __syncthreads();  // wsum reused next iteration
-      if (area) key = ((uint64_t)__float_as_uint(a.depths[g]) << 32) | (uint32_t)g;
+      if (area) key = ((uint64_t)(S3G_BIN_PREFETCH ? dbits : __float_as_uint(a.depths[g])) << 32) | (uint32_t)g;
     } else {
       my_total += area;
     }
     if (area != 0 && area <= BIG_RECT) {
-      const uint32_t mask = a.cull ? a.tile_mask[g] : 0xffffffffu;  // computed by preprocess_kernel
+      if (!S3G_BIN_PREFETCH) mask = a.cull ? a.tile_mask[g] : 0xffffffffu;  // computed by preprocess_kernel
       uint32_t bit = 1u;
       for (int y = r.y; y < r.w; y++)
         for (int x = r.x; x < r.z; x++, bit <<= 1) {
@@ -315,7 +349,11 @@ __global__ void __launch_bounds__(BIN_THREADS) bin_kernel(const BinArgs a) {
     for (int off = 32; off >= 1; off >>= 1) my_total += (uint32_t)__shfl_xor((int)my_total, off);
     if (lane == 0) wsum[wave] = my_total;
     __syncthreads();
-    if (tid == 0 && first_band) a.chunk_total[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0 && first_band) {
+      uint32_t tot = 0;
+      for (int k = 0; k < BIN_WAVES; k++) tot += wsum[k];
+      a.chunk_total[blockIdx.x] = tot;
+    }
   }
 }
 
@@ -340,25 +378,32 @@ __global__ void __launch_bounds__(256) bin_scan_kernel(int tiles, int nb, uint32
   tile_count[t] = run;
 }
 
-// Exclusive scan over tiles: ranges[t] = [start, end); ctrl[0] = R, ctrl[1] = longest tile list, ctrl[3] = slots; also turns
-// chunk_total[nb] into its exclusive prefix.  One 1024-thread workgroup; tiles is O(10^3..10^4), nb <= 1024.
-__device__ __forceinline__ uint32_t block_inclusive_scan_1024(uint32_t v, uint32_t (*buf)[1024], int tid, uint32_t* total) {
-  int cur = 0;
-  buf[0][tid] = v;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele
-    uint32_t x = buf[cur][tid];
-    if (tid >= off) x += buf[cur][tid - off];
-    buf[cur ^ 1][tid] = x;
-    cur ^= 1;
-    __syncthreads();
+// Inclusive scan of one value per thread over the 1024 threads: shuffles inside a wave, the 16 wave totals through LDS (three
+// barriers; a Hillis-Steele scan in LDS costs twenty, and scan_tiles_kernel is ONE workgroup on an otherwise idle device: 13 -> 4 us).
+__device__ __forceinline__ uint32_t block_inclusive_scan_waves(uint32_t v, uint32_t* wtot, int tid, uint32_t* total) {
+  const int lane = tid & 63, wave = tid >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+    if (lane >= off) incl += t;
   }
-  const uint32_t incl = buf[cur][tid];
-  *total = buf[cur][1023];
+  __syncthreads();   // wtot may still be read from a previous call
+  if (lane == 63) wtot[wave] = incl;
   __syncthreads();
-  return incl;
+  uint32_t wbase = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const uint32_t x = wtot[k];
+    if (k < wave) wbase += x;
+    tot += x;
+  }
+  *total = tot;
+  return wbase + incl;
 }
 
+// Exclusive scan over tiles: ranges[t] = [start, end); ctrl[0] = R, ctrl[1] = longest tile list, ctrl[3] = slots; also turns
+// chunk_total[nb] into its exclusive prefix.  One 1024-thread workgroup; tiles is O(10^3..10^4), nb <= 1024.
 // Host-asynchronous forward (s3g_raster_forward_async): the binning arena was sized BEFORE this kernel knew R.  cap_R != 0
 // turns the capacity check on: if R > cap_R, S > cap_S or the longest list > cap_tile, ctrl[4] = 1, every range is emptied and
 // R / S read as 0, so that every later kernel of the forward AND of the backward finds nothing to do (bin_write and the
@@ -369,24 +414,28 @@ __global__ void __launch_bounds__(1024) scan_tiles_kernel(int tiles, const uint3
                                                           uint2* __restrict__ ranges, uint32_t* __restrict__ ctrl,
                                                           int nb, uint32_t* __restrict__ chunk_total, uint32_t cap_R,
                                                           uint32_t cap_S, uint32_t cap_tile, uint32_t* __restrict__ status) {
-  __shared__ uint32_t buf[2][1024];
+  __shared__ uint32_t wtot[16];
   __shared__ uint32_t wmax[16];
   const int tid = threadIdx.x;
-  uint32_t carry = 0, vmax = 0, total;
-  for (int base = 0; base < tiles; base += 1024) {
-    const int i = base + tid;
-    const uint32_t v = i < tiles ? tile_count[i] : 0u;
+  // thread t owns the tiles [t * per, (t + 1) * per): a serial sum, ONE block scan of the 1024 sums, a serial pass for the ranges
+  const int per = (tiles + 1023) / 1024, t0 = tid * per, t1 = min(tiles, t0 + per);
+  uint32_t vmax = 0, mine = 0, total, carry;
+  for (int i = t0; i < t1; i++) {
+    const uint32_t v = tile_count[i];
     vmax = max(vmax, v);
-    const uint32_t incl = block_inclusive_scan_1024(v, buf, tid, &total);
-    if (i < tiles) {
-      const uint32_t start = carry + incl - v;
+    mine += v;
+  }
+  {
+    uint32_t start = block_inclusive_scan_waves(mine, wtot, tid, &carry) - mine;   // carry = R
+    for (int i = t0; i < t1; i++) {
+      const uint32_t v = tile_count[i];
       ranges[i] = make_uint2(start, start + v);
+      start += v;
     }
-    carry += total;
   }
   {
     const uint32_t v = tid < nb ? chunk_total[tid] : 0u;
-    const uint32_t incl = block_inclusive_scan_1024(v, buf, tid, &total);
+    const uint32_t incl = block_inclusive_scan_waves(v, wtot, tid, &total);
     if (tid < nb) chunk_total[tid] = incl - v;
     if (tid == 0) ctrl[3] = total;  // S: slots = sum of rect areas (== R without culling)
   }
@@ -461,6 +510,7 @@ __device__ __forceinline__ void emit_instance(uint32_t pos, uint32_t g, int tx, 
                                               const uint32_t* __restrict__ gauss_off, uint32_t* __restrict__ point_list,
                                               uint32_t* __restrict__ slot_pos) {
   point_list[pos] = g;
+  if (slot_pos == nullptr) return;   // forward-only render: nobody will gather through the map
   const ushort4 r = rect[g];
   const uint32_t local = (uint32_t)(ty - (int)r.y) * (uint32_t)((int)r.z - (int)r.x) + (uint32_t)(tx - (int)r.x);
   slot_pos[gauss_off[g] + local] = pos;
@@ -715,7 +765,7 @@ static inline uint32_t round_up8(uint32_t v) { return (v + 7u) & ~7u; }
 using namespace s3g;
 
 extern "C" const char* s3g_last_error(void) { return g_err; }
-extern "C" int s3g_abi_version(void) { return 10; }
+extern "C" int s3g_abi_version(void) { return 11; }
 
 // as != NULL: the host-asynchronous variant (s3g_raster_forward_async) -- arenas are the caller's, sized for a speculative
 // capacity, and nothing below waits for the device.
@@ -795,13 +845,13 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   S3G_KERNEL_CHECK(stream, debug);
 
   // atomic-free binning, counting half
-  const size_t bin_lds = ((size_t)band + 8) * sizeof(uint32_t);
+  const size_t bin_lds = ((size_t)band + BIN_SCRATCH) * sizeof(uint32_t);
   static std::atomic<uint64_t> bin_attr_set{0};
   if (device_needs_setup(bin_attr_set)) {
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)bin_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (MAX_TILES_LDS + 8) * 4));
+                                      (MAX_TILES_LDS + BIN_SCRATCH) * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)bin_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (MAX_TILES_LDS + 8) * 4));
+                                      (MAX_TILES_LDS + BIN_SCRATCH) * 4));
     device_setup_done(bin_attr_set);
   }
   BinArgs ba;
@@ -860,10 +910,12 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
     if (num_rendered) *num_rendered = (int)R;
   }
   BinningState b = BinningState::carve(bin_p, R, S, nullptr);
-  if (as) {
+  const bool forward_only = as && as->forward_only != 0;
+  uint32_t* const slot_map = forward_only ? nullptr : b.slot_pos;
+  if (as && !forward_only) {
     hipLaunchKernelGGL(fill_slots_kernel, dim3(1024), dim3(256), 0, stream, b.slot_pos, (const uint32_t*)im.ctrl);
     S3G_KERNEL_CHECK(stream, debug);
-  } else if (S > 0) {
+  } else if (!as && S > 0) {
     S3G_HIP_CHECK(hipMemsetAsync(b.slot_pos, 0xff, (size_t)S * sizeof(uint32_t), stream));  // culled slots
   }
 
@@ -878,8 +930,11 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
     // short lists: <= 32 KiB of LDS per workgroup (5 workgroups/CU); long lists: up to 128 KiB, beyond that in global
     // (asynchronous: max_tile is the caller's estimate; a list longer than the LDS buffer is sorted in global memory)
     const uint32_t small_cap = max_tile < SMALL ? max_tile : SMALL;
+    // (a separate launch with a 2-8 KiB buffer for the lists of <= 256 / 512 / 1024 keys -- eight workgroups per CU instead of
+    // five -- changes nothing: 136 / 127 / 122 us per frame against 123 with one launch, profiles/r04_sort.txt; the network's
+    // LDS traffic bounds the kernel, not the workgroups in flight)
     hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)small_cap * 8, stream, tiles, gx,
-                       im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, b.slot_pos, 0u, SMALL, small_cap);
+                       im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, slot_map, 0u, SMALL, small_cap);
     S3G_KERNEL_CHECK(stream, debug);
     if (as ? as->long_lists != 0 : max_tile > SMALL) {
       const uint32_t large_cap = as ? LARGE : (max_tile < LARGE ? max_tile : LARGE);
@@ -890,7 +945,7 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
         device_setup_done(attr_set);
       }
       hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)large_cap * 8, stream, tiles, gx,
-                         im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, b.slot_pos, SMALL, 0xffffffffu, large_cap);
+                         im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, slot_map, SMALL, 0xffffffffu, large_cap);
       S3G_KERNEL_CHECK(stream, debug);
     }
   }

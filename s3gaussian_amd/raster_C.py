@@ -206,7 +206,7 @@ def async_reset_statistics(device=None) -> None:
         st.sum_instances, st.drained, st.overflows = 0, 0, []
 
 
-def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_depth, out_color2, radii):
+def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_depth, out_color2, radii, forward_only=False):
     """One s3g_raster_forward_async call (or several while the capacity is being learnt).  -> (R capacity, geom, binning, img)"""
     key = (W, H)
     st.drain()
@@ -223,7 +223,7 @@ def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_
         if st.events[slot] is not None and any(s == slot for s, _, _ in st.pending):
             st.drain(block=True)            # the host is a whole ring ahead of the device: let the oldest rows land
         desc = _lib.RasterAsync(cap_r, cap_s, lds, long_lists, geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
-                                st.status_dev.data_ptr() + 4 * slot, st.status_host.data_ptr() + 32 * slot)
+                                st.status_dev.data_ptr() + 4 * slot, st.status_host.data_ptr() + 32 * slot, 1 if forward_only else 0)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
             code = L.s3g_raster_forward_async(C.byref(inp), col2_.data_ptr() if col2_ is not None else None, C.byref(desc),
@@ -254,7 +254,11 @@ def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_
 # ---- geometry cache: the feature render of an iteration reuses the RGB render's preprocess / binning / sort ------------
 _GEOM_CACHE_ON = os.environ.get("S3G_GEOMETRY_CACHE", "1") != "0"
 _geom_cache = None  # (key, tensors kept alive, outputs)
+_geom_cache_forward_only = False  # the cached arenas come from a forward_only render: no instance -> position map for a backward
 _geom_cache_hits = 0  # number of renders served from the cache (tests, diagnostics)
+
+
+FORWARD_ONLY = os.environ.get("S3G_RASTER_FORWARD_ONLY", "1") != "0"   # 0: always build the backward's map (A/B, diagnostics)
 
 
 def invalidate_geometry_cache() -> None:
@@ -273,14 +277,18 @@ def _geom_key(tensors, scalars):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug, colors2=None, allow_async=False):
+                        prefiltered, debug, colors2=None, allow_async=False, forward_only=False):
     """-> (num_rendered, color[3,H,W], depth[1,H,W], radii[P] int32, geomBuffer, binningBuffer, imgBuffer).
     colors2 [P,3] (extension): a second image with these colours is blended in the same pass (s3g_raster_forward2) and
     appended to the result tuple.
     allow_async (extension): the caller only needs `num_rendered` as the key that goes back into the backward / reuse /
     decomposition entry points with these arenas, not as a count -- with ASYNC on the call then does not wait for the device and
-    returns the arena's instance CAPACITY in its place (see the block comment above; `async_status()` has the true counts)."""
-    global _geom_cache, _geom_cache_hits
+    returns the arena's instance CAPACITY in its place (see the block comment above; `async_status()` has the true counts).
+    forward_only (extension, honoured by the asynchronous forward): the caller promises that no backward will run on the arenas
+    of this call (a render under no_grad): the instance -> list-position map that only the backward gather reads is not built
+    (s3g_raster_async.forward_only).  Such arenas still serve the reuse / decomposition entry points."""
+    global _geom_cache, _geom_cache_hits, _geom_cache_forward_only
+    forward_only = bool(forward_only) and FORWARD_ONLY
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _require_gpu(means3D, "means3D")
@@ -291,7 +299,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     key = None
     if _GEOM_CACHE_ON and P != 0 and sh.numel() == 0 and colors.numel() != 0 and not debug and colors2 is None:
         key = _geom_key(geo_tensors, (float(scale_modifier), float(tan_fovx), float(tan_fovy), H, W, bool(prefiltered)))
-        if _geom_cache is not None and _geom_cache[0] == key:
+        if _geom_cache is not None and _geom_cache[0] == key and (forward_only or not _geom_cache_forward_only):
             R, radii_c, geom_c, binning_c, img_c = _geom_cache[2]
             _geom_cache_hits += 1
             out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
@@ -327,9 +335,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             raise RuntimeError("colors2 must have shape (num_points, 3)")
         if allow_async and ASYNC and not debug and not prefiltered:   # a `prefiltered` violation must raise from THIS call
             R_cap, geom_t, binning_t, img_t = _forward_async(L, _async_state(dev), inp, col2_, P, W, H, dev, out_color, out_depth,
-                                                             out_color2, radii)
+                                                             out_color2, radii, forward_only)
             if key is not None:
                 _geom_cache = (key, geo_tensors, (R_cap, radii, geom_t, binning_t, img_t))
+                _geom_cache_forward_only = forward_only
             if colors2 is not None:
                 return R_cap, out_color, out_depth, radii, geom_t, binning_t, img_t, out_color2
             return R_cap, out_color, out_depth, radii, geom_t, binning_t, img_t
@@ -349,6 +358,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         _lib.check(code)
         if key is not None:  # remember this geometry (inputs are kept alive so the id()/version key stays meaningful)
             _geom_cache = (key, geo_tensors, (rendered.value, radii, geom.tensor, binning.tensor, img.tensor))
+            _geom_cache_forward_only = False
     if colors2 is not None:
         return rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor, out_color2
     return rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor

@@ -37,7 +37,8 @@ class _RasterizeGaussians(torch.autograd.Function):
     """autograd node; forward keeps the three private arenas alive for backward (reference :44-156)."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                forward_only=False):
         rs = raster_settings
         native_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
@@ -52,7 +53,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise
         else:
             # num_rendered only travels to the backward below as the key of the arenas: the call may run host-asynchronously
-            out = _C.rasterize_gaussians(*native_args, allow_async=True)
+            out = _C.rasterize_gaussians(*native_args, allow_async=True, forward_only=forward_only)
         num_rendered, color, depth, radii, geom, binning, img = out
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
@@ -83,7 +84,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             grads = _C.rasterize_gaussians_backward(*native_args)
         g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot = grads
         # order of forward's inputs: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
-        return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rot, g_cov3D, None
+        return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rot, g_cov3D, None, None
 
 
 class _RasterizeGaussiansPair(torch.autograd.Function):
@@ -93,13 +94,13 @@ class _RasterizeGaussiansPair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, colors_a, colors_b, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                densify_accum=None):
+                densify_accum=None, forward_only=False):
         rs = raster_settings
         empty = torch.Tensor([])
         common = (opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
                   rs.tanfovy, rs.image_height, rs.image_width, empty, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
         num_rendered, color, depth, radii, geom, binning, img, color2 = _C.rasterize_gaussians(
-            rs.bg, means3D, colors_a, *common, colors2=colors_b, allow_async=True)
+            rs.bg, means3D, colors_a, *common, colors2=colors_b, allow_async=True, forward_only=forward_only)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.densify_accum = densify_accum
@@ -119,12 +120,18 @@ class _RasterizeGaussiansPair(torch.autograd.Function):
             rs.bg, means3D, radii, colors_a, colors_b, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_color2, rs.campos, geom, ctx.num_rendered,
             binning, img, rs.debug, densify_accum=ctx.densify_accum)
-        return g_means3D, g_means2D, g_col_a, g_col_b, g_opac, g_scales, g_rot, g_cov3D, None, None
+        return g_means3D, g_means2D, g_col_a, g_col_b, g_opac, g_scales, g_rot, g_cov3D, None, None, None
+
+
+def _no_backward(*tensors) -> bool:
+    """True when autograd will record nothing for a node over these inputs (no_grad, or no input requires a gradient): the
+    forward may then skip what only a backward would read (raster_C.rasterize_gaussians: forward_only)."""
+    return not (torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors))
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings)
+    tensors = (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+    return _RasterizeGaussians.apply(*tensors, raster_settings, _no_backward(*tensors))
 
 
 class GaussianRasterizer(nn.Module):
@@ -173,7 +180,7 @@ class GaussianRasterizer(nn.Module):
         R, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
             rs.bg, means3D, n(colors_precomp), opacities, n(scales), n(rotations), rs.scale_modifier, n(cov3D_precomp),
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, n(shs), rs.sh_degree,
-            rs.campos, rs.prefiltered, rs.debug, allow_async=True)
+            rs.campos, rs.prefiltered, rs.debug, allow_async=True, forward_only=True)
         if P == 0:
             z3, z1 = torch.zeros_like(color), torch.zeros_like(depth)
             return dict(render=color, radii=radii, depth=depth, render_d=z3, depth_d=z1, render_s=z3.clone(), depth_s=z1.clone())
@@ -205,5 +212,5 @@ class GaussianRasterizer(nn.Module):
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
-        return _RasterizeGaussiansPair.apply(means3D, means2D, colors_a, colors_b, opacities, scales, rotations, cov3D_precomp,
-                                             self.raster_settings, densify_accum)
+        tensors = (means3D, means2D, colors_a, colors_b, opacities, scales, rotations, cov3D_precomp)
+        return _RasterizeGaussiansPair.apply(*tensors, self.raster_settings, densify_accum, _no_backward(*tensors))

@@ -8,7 +8,7 @@ from tests.test_abi_cpu import _struct_fields
 def test_async_descriptor_matches_the_header():
     from s3gaussian_amd import _lib
     assert _struct_fields("s3g_raster.h", "s3g_raster_async") == [f[0] for f in _lib.RasterAsync._fields_]
-    assert ctypes.sizeof(_lib.RasterAsync) == 4 * 4 + 5 * 8
+    assert ctypes.sizeof(_lib.RasterAsync) == 4 * 4 + 5 * 8 + 8   # + forward_only (int) and its tail padding
 
 
 def test_capacity_ladder_is_monotone_tight_and_repeats():

@@ -173,3 +173,52 @@ def test_training_steps_are_enqueued_ahead_of_the_device(gpu_device):
         assert torch.isfinite(loss)
     finally:
         raster_C.set_async(prev)
+
+
+@pytest.mark.parametrize("pair", [False, True])
+def test_forward_only_render_is_bit_identical_and_never_feeds_a_backward(gpu_device, pair):
+    """A render under no_grad takes the forward_only form of the asynchronous forward (s3g_raster_async.forward_only: the
+    instance -> position map of the backward gather is not built).  Same image / depth / radii bit for bit; and arenas cached
+    from such a render must not serve a later render of the SAME geometry that does need gradients."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from s3gaussian_amd import raster_C
+    dev = gpu_device
+    s = tiny_scene(P=20_000, W=320, H=208, seed=4)
+    assert raster_C.ASYNC and raster_C.FORWARD_ONLY
+    raster_C.invalidate_geometry_cache()
+    o_ref, g_ref = _render_and_grads(s, dev, pair)
+    # (1) the same inputs under no_grad
+    rast = GaussianRasterizer(raster_settings=settings_from(s, dev))
+    k = lambda n: s[n].to(dev).clone()
+    m3, op, sc, rot, col = k("means3D"), k("opacities"), k("scales"), k("rotations"), k("colors_precomp")
+    col2 = s["colors_precomp"].flip(0).to(dev).clone()
+    raster_C.invalidate_geometry_cache()
+    with torch.no_grad():
+        if pair:
+            color, radii, depth, color2 = rast.forward_pair(means3D=m3, means2D=torch.zeros_like(m3), opacities=op, colors_a=col,
+                                                            colors_b=col2, scales=sc, rotations=rot)
+            outs = [color, depth, color2, radii]
+        else:
+            color, radii, depth = rast(means3D=m3, means2D=torch.zeros_like(m3), opacities=op, colors_precomp=col, scales=sc, rotations=rot)
+            outs = [color, depth, radii]
+    for a, b in zip(o_ref, outs):
+        assert torch.equal(a, b)
+    if not pair:
+        # (2) the single-image node caches its geometry: the arenas of the no_grad render above are in the cache now and flagged
+        assert raster_C._geom_cache is not None and raster_C._geom_cache_forward_only
+        hits = raster_C._geom_cache_hits
+        for x in (m3, op, sc, rot, col):
+            x.requires_grad_(True)
+        m2 = torch.zeros_like(m3, requires_grad=True)
+        H, W = s["cam"]["image_height"], s["cam"]["image_width"]
+        g = torch.Generator().manual_seed(5)
+        gc, gd = (torch.randn(c, H, W, generator=g).to(dev) for c in (3, 1))
+        color, radii, depth = rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=col, scales=sc, rotations=rot)
+        assert raster_C._geom_cache_hits == hits and not raster_C._geom_cache_forward_only    # rendered afresh, with the map
+        ((color * gc).sum() + (depth * gd).sum()).backward()
+        for a, b in zip(g_ref, [x.grad for x in (m3, m2, op, sc, rot, col)]):
+            assert torch.equal(a, b)
+        # (3) and a no_grad render of that geometry may reuse the arenas that DO have the map
+        with torch.no_grad():
+            rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=col, scales=sc, rotations=rot)
+        assert raster_C._geom_cache_hits == hits + 1
