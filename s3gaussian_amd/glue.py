@@ -43,7 +43,8 @@ class _Glue(torch.autograd.Function):
         scales = torch.empty((P, 3), dtype=torch.float32, device=dev)
         rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
         opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
-        want_dshs_l1 = bool(want_dshs_l1) and dshs is not None and P > 0
+        asked_l1 = bool(want_dshs_l1)
+        want_dshs_l1 = asked_l1 and dshs is not None and P > 0
         abs_sum = torch.zeros(64 * 16, dtype=torch.float64, device=dev) if want_dshs_l1 else None   # S3G_SUM_DOUBLES
         with torch.cuda.device(dev):
             _lib.check(L.s3g_glue_forward(P, int(deg), _p(f_dc), _p(f_rest), _p(dshs), _p(xyz_c), _p(campos_c), _p(ls), _p(rr),
@@ -54,7 +55,12 @@ class _Glue(torch.autograd.Function):
         ctx.save_for_backward(f_dc, f_rest, dshs if dshs is not None else torch.empty(0, device=dev), xyz_c, campos_c, rr,
                               colors, scales, rot, opac)
         ctx.want_dshs_l1 = want_dshs_l1
-        dshs_l1 = (abs_sum.sum() / (48.0 * P)).float() if want_dshs_l1 else torch.zeros((), dtype=torch.float32, device=dev)
+        if want_dshs_l1:
+            dshs_l1 = (abs_sum.sum() / (48.0 * P)).float()
+        elif asked_l1:
+            dshs_l1 = torch.zeros((), dtype=torch.float32, device=dev)     # asked for, nothing to sum (no dshs / P == 0)
+        else:
+            dshs_l1 = torch.empty((), dtype=torch.float32, device=dev)     # not asked for: dropped by the wrapper, no fill launch
         return colors, scales, rot, opac, dshs_l1
 
     @staticmethod
