@@ -19,7 +19,11 @@ def _resources(obj):
         m = re.match(r"(\S+)\s+vgpr\s+(\d+).*?lds\s+(\d+)\s+scratch\s+(\d+)", line)
         if m:
             res[m.group(1)] = (int(m.group(2)), int(m.group(4)))
+            LDS[m.group(1)] = int(m.group(3))
     return res
+
+
+LDS = {}    # kernel -> static LDS bytes, filled by _resources
 
 
 @pytest.fixture(scope="module")
@@ -54,3 +58,20 @@ def test_mlp_and_raster_kernels_do_not_spill(built):
     bwd = _resources("raster_backward.o")
     for k, (vgpr, scratch) in bwd.items():
         assert scratch == 0, (k, vgpr, scratch)
+
+
+def test_round4_latency_fixes_keep_their_occupancy(built):
+    """The three late fixes of round 4 bought latency hiding with registers / LDS; each has a step it must stay under."""
+    bwd = _resources("raster_backward.o")
+    for needle in ("geometry_backward_kernelILi0E", "geometry_backward_kernelILi3E"):
+        vgpr, scratch = _one(bwd, needle)          # three tiles of a rect in flight: still five waves per SIMD (four tiles: 105)
+        assert vgpr <= 96 and scratch == 0, (needle, vgpr, scratch)
+    fwd = _resources("raster_forward.o")
+    for needle in ("bin_kernelILb0E", "bin_kernelILb1E"):
+        vgpr, scratch = _one(fwd, needle)          # 512 threads x 2 workgroups per CU = four waves per SIMD
+        assert vgpr <= 128 and scratch == 0, (needle, vgpr, scratch)
+    glue = _resources("glue.o")
+    vgpr, scratch = _one(glue, "glue_forward_kernelE")
+    assert vgpr <= 128 and scratch == 0, (vgpr, scratch)
+    lds = [v for k, v in LDS.items() if "glue_forward_kernelE" in k][0]
+    assert 3 * lds <= 160 * 1024, lds              # 256 rows x 49 floats: three workgroups per CU
