@@ -88,3 +88,4 @@ def test_no_backward_predicate_of_the_autograd_nodes():
     with torch.no_grad():
         assert _no_backward(a, b)
     assert not _no_backward(b.detach().requires_grad_(True))
+
