@@ -81,20 +81,39 @@ def make_targets(pc, cam, bg, hyper, seed):
     return pkg["render"].clamp(0, 1).clone(), pkg["depth"].clone(), pkg["feat"].clone()
 
 
-def _oracle_iteration_factory(P, width, height, seed, point_splat):
+def _oracle_iteration_factory(P, width, height, seed, point_splat, ref=None):
     """One training iteration on the host cores at P Gaussians and the full image.  point_splat=False: the oracle path
     (plain-PyTorch restatement of the reference's hexplane+MLP+glue+losses, C/OpenMP restatement of the tile rasterizer,
     fwd+bwd x2).  point_splat=True: the north_star's baseline -- the same PyTorch hexplane+MLP+glue+losses with the
     rasterizer stubbed to a point splat (each Gaussian -> its nearest pixel, depth-sorted alpha = opacity compositing)."""
     import numpy as np
+    from types import SimpleNamespace
     from oracle import hexplane_ref as hr
     from oracle.oracle import RasterOracle
     from s3gaussian_amd import synth
     sc = synth.street_scene(P=P, seed=seed, width=width, height=height, n_frames=2)
     gs, cam = sc["gaussians"], sc["cameras"][0]
     torch.manual_seed(seed)
-    net = hr.deform_network(hr.default_hyper())
-    net.deformation_net.grid.set_aabb(*sc["aabb"])
+    if ref is not None:
+        # the reference's OWN modules on the host cores (oracle/_ref/reference_py.tar.gz: scene/deformation.py + scene/hexplane.py,
+        # utils/sh_utils.py::eval_sh, utils/loss_utils.py, GaussianModel.compute_regulation) -- `kind: "reference"`
+        from oracle import ref_py
+        _, _, ref_hyper, _, _ = ref_py.default_arguments(ref)
+        gm = ref.gaussian_model.GaussianModel(3, ref_hyper)          # constructor only: nothing is moved to a GPU
+        net = gm._deformation
+        net.deformation_net.set_aabb(*sc["aabb"])
+        LU = ref.loss_utils
+
+        def _colors(deg, shs, xyz, campos):                           # gaussian_renderer/__init__.py:104-110 on the reference's eval_sh
+            d = xyz - campos.repeat(xyz.shape[0], 1)
+            return torch.clamp_min(ref.sh_utils.eval_sh(deg, shs.transpose(1, 2).view(-1, 3, 16), d / d.norm(dim=1, keepdim=True)) + 0.5, 0.0)
+
+        hr = SimpleNamespace(shs_to_colors=_colors, l1_loss=LU.l1_loss, ssim=LU.ssim, l2_loss=LU.l2_loss,
+                             depth_l2=lambda a, b: LU.compute_depth("l2", a, b),
+                             plane_regulation=lambda grids, tw, l1w, pw: gm.compute_regulation(tw, l1w, pw))
+    else:
+        net = hr.deform_network(hr.default_hyper())
+        net.deformation_net.grid.set_aabb(*sc["aabb"])
     orc = None if point_splat else RasterOracle(np.float32)
     leaves = {k: v.clone().requires_grad_(True) for k, v in
               dict(xyz=gs["xyz"], sc=gs["log_scales"], rot=gs["rotations_raw"], op=gs["opacity_logit"], shs=gs["shs"]).items()}
@@ -171,8 +190,8 @@ def _oracle_iteration_factory(P, width, height, seed, point_splat):
     return one_iter
 
 
-def _time_iteration(P, width, height, seed, point_splat, repeats=1, warm=True):
-    it = _oracle_iteration_factory(P, width, height, seed, point_splat)
+def _time_iteration(P, width, height, seed, point_splat, repeats=1, warm=True, ref=None):
+    it = _oracle_iteration_factory(P, width, height, seed, point_splat, ref=ref)
     if warm:
         it()                                   # warm-up (allocator, OpenMP team, lazy inits)
     t0 = time.perf_counter()
@@ -206,13 +225,28 @@ def cpu_baseline(P_full, width, height, seed=0):
       "tile_rasterizer_port": the oracle path proper (same PyTorch front end, C/OpenMP restatement of the tile rasterizer
           fwd+bwd x2) sampled at THREE sizes of P up to P_full/4 at the full image, least-squares t = a + b*P with the residuals."""
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads = min(cores, 64)     # intra-op parallelism of these element-wise / gather ops stops paying beyond ~64 threads on this host
     torch.set_num_threads(threads)
-    _time_iteration(max(2000, P_full // 40), width, height, seed, True, repeats=1, warm=False)
-    t_full = _time_iteration(P_full, width, height, seed, True, repeats=1, warm=False)
-    out = {"value": round(1.0 / t_full, 5), "unit": "iters/s", "cores": cores, "kind": "port", "what": "point_splat",
+    ref = None
+    try:
+        from oracle import ref_py
+        if ref_py.available():
+            ref = ref_py.load(patch=False)
+    except Exception:
+        ref = None
+    try:
+        _time_iteration(max(2000, P_full // 40), width, height, seed, True, repeats=1, warm=False, ref=ref)
+        t_full = _time_iteration(P_full, width, height, seed, True, repeats=1, warm=False, ref=ref)
+    finally:
+        if ref is not None:
+            ref_py.unload()
+    front = ("the reference's OWN scene/deformation.py + scene/hexplane.py + utils/sh_utils.py + utils/loss_utils.py + "
+             "GaussianModel.compute_regulation (oracle/_ref/reference_py.tar.gz)" if ref is not None else
+             "reference-architecture PyTorch hexplane+MLP+glue+losses (oracle/hexplane_ref.py)")
+    out = {"value": round(1.0 / t_full, 5), "unit": "iters/s", "cores": threads, "host_cores": cores,
+           "kind": "reference" if ref is not None else "port", "what": "point_splat",
            "sample": f"measured, not extrapolated: ONE full iteration of the workload itself ({P_full} Gaussians, {width}x{height}) in "
-                     f"{t_full:.2f} s -- reference-architecture PyTorch hexplane+MLP+glue+losses, rasterizer stubbed to a nearest-pixel "
+                     f"{t_full:.2f} s -- {front}, rasterizer stubbed to a nearest-pixel "
                      f"point splat (torch threads {threads} of {cores} cores)"}
     try:
         sizes = (max(2000, P_full // 120), max(6000, P_full // 40), max(20000, P_full // 4))
@@ -364,7 +398,8 @@ def patched_reference_step(gaussians, viewpoint_cam, hyper, opt, background, pip
 
 
 def time_alt_paths(pc, cams, views, targets, tkeys, hyper, opt, bg, steps=4, warmup=1):
-    """-> {"zero_diff": {...}, "import_swap": {...}}: ms/step and it/s of the two slower call paths on the same scene."""
+    """FALLBACK when oracle/_ref/reference_py.tar.gz is absent (see time_reference_paths): restatements of train.py's iteration body.
+    -> {"patched": {...}, "import_swap": {...}, "zero_diff": {...}}: ms/step and it/s of the slower call paths on the same scene."""
     groups = [{"params": g["params"], "lr": g["lr"], "name": g.get("name", "")} for g in pc.optimizer.param_groups]
     torch_adam = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
     out = {}
@@ -391,9 +426,58 @@ def time_alt_paths(pc, cams, views, targets, tkeys, hyper, opt, bg, steps=4, war
                     one(i)
                 torch.cuda.synchronize()
                 ms = 1000.0 * (time.perf_counter() - t0) / n
-            out[path] = {"ms_per_step": round(ms, 2), "iters_per_s": round(1000.0 / ms, 2), "steps": n}
+            out[path] = {"ms_per_step": round(ms, 2), "iters_per_s": round(1000.0 / ms, 2), "steps": n, "executed": "restatement in bench.py"}
         except Exception as ex:   # never take the headline down
             out[path] = {"ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"}
+    return out
+
+
+def time_reference_paths(pc, cams, targets, bg, aabb):
+    """The reference's OWN `train.py::scene_reconstruction` (train.py:216-560: update_learning_rate, the view stack, render(), the loss
+    assembly one `loss +=` at a time, psnr, the NaN check, `loss.item()`, max_radii2D / add_densification_stats, the optimizer step),
+    UNCHANGED, on real `scene.cameras.Camera` objects and a real `scene.gaussian_model.GaussianModel` holding this bench's scene --
+    executed from oracle/_ref/reference_py.tar.gz (the reference's files packed by oracle/ref_py.py; /root/reference itself does not
+    exist on the GPU box).  The reference's Python is the CALLER here; what is timed underneath is the product (libs3g.so).
+      "zero_diff"    nothing but the two drop-in packages: the reference's own plain-PyTorch HexPlane / MLP / glue / SSIM / Adam
+      "import_swap"  + `scene.gaussian_model.deform_network` bound to s3gaussian_amd.deformation.deform_network
+      "patched"      `s3gaussian_amd.patch.patch_reference()` before train.py is imported, zero file edits
+    ms/step = host time between the iteration body's own `timer.pause()` calls (train.py:469) after a warm-up; the body waits for the
+    device once per iteration (`loss.item()`), so host time is step time.  No densify / prune event falls into these short runs
+    (densify_from_iter = 500); tests/test_reference_py_gpu.py runs the body through such events."""
+    from oracle import ref_py
+    out = {}
+    tk = list(targets)[:6]
+    state = {k: v.detach().clone() for k, v in pc._deformation.state_dict().items()}
+    gs = dict(xyz=pc._xyz.detach(), log_scales=pc._scaling.detach(), rotations_raw=pc._rotation.detach(),
+              opacity_logit=pc._opacity.detach(), shs=torch.cat([pc._features_dc.detach(), pc._features_rest.detach()], dim=1))
+    for route, (warm, n) in (("patched", (5, 60)), ("import_swap", (2, 8)), ("zero_diff", (1, 3))):
+        gm = None
+        try:
+            ref = ref_py.load(patch=(route == "patched"))
+            if route == "import_swap":
+                from s3gaussian_amd import deformation as _deformation
+                ref.gaussian_model.deform_network = _deformation.deform_network
+            args, dataset, hyper, opt, pipe = ref_py.default_arguments(ref)
+            dataset.render_process = False
+            gm = ref_py.make_gaussians(ref, gs, aabb, hyper)
+            gm._deformation.load_state_dict(state)
+            cam_objs = [ref_py.make_camera(ref, cams[v], targets[v], uid=v) for v in tk]
+            timer = ref_py.RecordingTimer(record_locals=False)
+            ref_py.run_scene_reconstruction(ref, gm, ref_py.SceneStub(cam_objs), dataset, hyper, opt, pipe, warm + n, "fine", timer)
+            torch.cuda.synchronize()
+            st = timer.stamps
+            ms = 1000.0 * (st[-1] - st[warm - 1]) / n
+            out[route] = {"ms_per_step": round(ms, 2), "iters_per_s": round(1000.0 / ms, 2), "steps": n,
+                          "executed": "the reference's train.py::scene_reconstruction, unchanged (oracle/_ref/reference_py.tar.gz)",
+                          "optimizer": type(gm.optimizer).__module__ + "." + type(gm.optimizer).__name__,
+                          "deformation": type(gm._deformation).__module__}
+        except Exception as ex:   # never take the headline down
+            out[route] = {"ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"}
+        finally:
+            del gm
+            ref_py.unload()
+            gc.collect()
+            torch.cuda.empty_cache()
     return out
 
 
@@ -431,6 +515,8 @@ def parse_args(argv=None):
     ap.add_argument("--reorder", action="store_true",
                     help="keep the Gaussians themselves in Morton order (GaussianParams.reorder_spatially() once after the scene is "
                          "built; a real run repeats it after every densification)")
+    ap.add_argument("--sustain-steps", type=int, default=300,
+                    help="after the K timed steps: this many more in one untended loop -> sustained_iters_per_s, step_ms_p99 (0: skip)")
     ap.add_argument("--sync-raster", action="store_true",
                     help="rasterizer forward with the reference's one host wait per call (default: host-asynchronous, raster_C.ASYNC)")
     return ap.parse_args(argv)
@@ -508,6 +594,7 @@ def main(argv=None):
     rank, world, local = dp.init_from_env()
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: the label would not match the run")
+    dist_on = dp.active()      # world > 1, or a process group of ONE rank under S3G_FORCE_DIST=1 (executes the RCCL path on a one-GPU lease)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # one rank per GPU; the modulo only matters for functional tests that oversubscribe one GPU (S3G_DIST_BACKEND=gloo)
@@ -526,6 +613,7 @@ def main(argv=None):
     pc, cams, hyper, opt, bg = build_scene(a.P, a.width, a.height, a.frames, device, scale_mult=a.scale_mult)
     if a.reorder:
         pc.reorder_spatially()
+    scene_aabb = tuple(pc._deformation.deformation_net.grid.aabb.detach().cpu().tolist())     # (xyz_max, xyz_min) as set_aabb takes them
     my_views = dp.shard_views(len(cams), rank, world, seed=0)
     n_needed = a.steps + a.warmup
     views = [my_views[i % len(my_views)] for i in range(n_needed)]
@@ -538,7 +626,7 @@ def main(argv=None):
     SPARSE = ("f_dc", "f_rest", "opacity", "scaling", "rotation")   # gradients that are exactly zero for Gaussians no rank sees
     reducer = sparse = None
     comm = {"elems": 0, "events": [], "sparse_rows": 0}
-    if world > 1:
+    if dist_on:
         if a.sparse_rows:
             dense = lambda: [p for g in pc.optimizer.param_groups if g.get("name") not in SPARSE for p in g["params"]]
             reducer = dp.OverlappedGradAllReducer(dense, average=False)
@@ -552,7 +640,8 @@ def main(argv=None):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()            # backward's last kernel is queued: from here on the stream waits for collectives + steps
             comm["events"].append([ev])
-            dp.reduce_skip_flag(device)     # a rank whose asynchronous forward overflowed makes EVERY replica drop this step
+            # (a rank whose asynchronous forward overflowed makes EVERY replica drop this step: the reducer's finish() /
+            #  finish_and_step() all-reduce the flag themselves since round 5)
             g_xy, any_vis, rmax = dp.reduce_densification_stats(pkg["viewspace_points"].grad, pkg["visibility_filter"], pkg["radii"])
             dp.add_densification_stats(pc_.xyz_gradient_accum, pc_.denom, pc_.max_radii2D, g_xy, any_vis, rmax)
             if sparse is not None:
@@ -576,7 +665,7 @@ def main(argv=None):
         # densification bookkeeping (train.py:489-493) is part of every iteration below densify_until_iter: single GPU ->
         # inside the rasterizer's per-Gaussian backward; data parallel -> after the all-reduce of the statistics (hook)
         loss, pkg = training_step(pc, cams[v], gt_img, gt_depth, gt_feat, hyper, opt, bg, stage="fine", grad_hook=hook,
-                                  densify_stats=(world == 1), optimizer_step=optimizer_step if world > 1 else None)
+                                  densify_stats=(not dist_on), optimizer_step=optimizer_step if dist_on else None)
         return loss, pkg
 
     # everything built so far (scene, targets, modules, the torch / ctypes machinery) is long-lived: take it out of the collector's
@@ -631,6 +720,27 @@ def main(argv=None):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt, t_enq = float(t[0].item()), float(t[1].item())
     comm_timed = {"elems": comm["elems"], "events": list(comm["events"]), "sparse_rows": comm["sparse_rows"]}
+
+    # ---- 1b. sustained throughput: a.sustain_steps more steps (default 300, ~2.3 s) over the same views, the interpreter's collector
+    #          running as it pleases (no collect before, nothing frozen anew), walk-order re-sorts included -- the 20-step headline is a
+    #          0.15-s burst; this is the number a long training run sees (tools/soak.py is the 600 / 3000-step form) ----------------
+    sustained = None
+    if a.sustain_steps > 0:
+        s_idx = [(a.warmup + k) % n_needed for k in range(a.sustain_steps)]
+        raster_C.async_reset_statistics(device)
+        dts, t_enq_s, per_s = timed_loop(step, s_idx, world, device, collect=False)
+        s_over = len(raster_C.async_status(device, block=True)["overflows"])
+        if world > 1:
+            t = torch.tensor([dts, float(s_over)], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dts, s_over = float(t[0].item()), int(t[1].item())
+        ps = sorted(per_s)
+        sustained = {"steps": a.sustain_steps, "iters_per_s": round(world * a.sustain_steps / dts, 3),
+                     "ms_per_step": round(1000.0 * dts / a.sustain_steps, 3), "step_ms_median": round(ps[len(ps) // 2], 3),
+                     "step_ms_p99": round(ps[min(len(ps) - 1, int(0.99 * len(ps)))], 3), "step_ms_max": round(ps[-1], 3),
+                     "host_enqueue_ms_per_step": round(1000.0 * t_enq_s / a.sustain_steps, 3),
+                     "gc_gen2_passes": GC_PASSES[-1], "arena_overflows": s_over}
+        comm.update(elems=0, events=[], sparse_rows=0)
 
     # ---- 2. roofline leg: the SAME steps again with the nine hot kernels bracketed by hipEvent pairs inside libs3g.so -------
     clear_profile_slots()
@@ -694,7 +804,7 @@ def main(argv=None):
             _deformation.INFER_ARITHMETIC = _arith
 
     dev_ids = None
-    if world > 1:     # collectives are called by EVERY rank, never inside the rank-0 block below
+    if dist_on:     # collectives are called by EVERY rank, never inside the rank-0 block below
         dev_ids = [None] * world
         torch.distributed.all_gather_object(dev_ids, f"{os.uname().nodename}:cuda:{device.index}")
     if rank == 0:
@@ -839,6 +949,9 @@ def main(argv=None):
             "host_enqueue_ms_per_step": round(1000.0 * t_enq / a.steps, 3),
             "instrumented_loop_ms_per_step": round(sum(per_step_instrumented) / len(per_step_instrumented), 3),
             "gc_gen2_passes_in_timed_loop": GC_PASSES[0] if GC_PASSES else None,
+            "sustained_iters_per_s": sustained["iters_per_s"] if sustained else None,
+            "step_ms_p99": sustained["step_ms_p99"] if sustained else None,
+            "sustained": sustained,
             "gc_policy": "gc.collect() + gc.freeze() after the warm-up and gc.collect() before each timed loop; the collector stays enabled "
                          "inside the loops (tools/soak.py times 600 steps with no such care: profiles/r04_soak.jsonl)",
             "config": {"workload": workload_label(a, world) + f": {a.P} Gaussians, {a.height}x{a.width}, 3 cams x {a.frames} frames, fine stage "
@@ -860,7 +973,7 @@ def main(argv=None):
                        "render_loop_outliers": render_outliers},
             "roofline": roof,
         }
-        if world > 1:
+        if dist_on:
             # what the all-reduce cost this rank: stream time from "backward queued" to "optimizer step queued" minus the Adam
             # kernel itself = waiting for collectives + the small statistics reduces.  NO multi-GPU run has been measured in the
             # build sandbox (one GPU per lease); these fields exist so that the first SCALE run explains itself.
@@ -879,13 +992,23 @@ def main(argv=None):
                            "optimizer_step": "single phase" if (a.single_phase_step or a.sparse_rows) else "two phases (dp.finish_and_step)",
                            "sparse_row_exchange": bool(a.sparse_rows),
                            "sparse_rows_per_step": round(comm_timed["sparse_rows"] / max(a.steps, 1)) if a.sparse_rows else None,
+                           "forced_single_rank_group": bool(dp.force_dist() and world == 1),
+                           "collectives_executed_in_this_run": True,
                            "scaling_curve_measured_by_the_builder": False}
-        if world == 1 and not a.no_alt_paths:
+        if world == 1 and not dist_on and not a.no_alt_paths:
             out["config"]["paths"] = {"fused": {"ms_per_step": out["ms_per_step"], "iters_per_s": out["value"]}}
-            out["config"]["paths"].update(time_alt_paths(pc, cams, views, targets, tkeys, hyper, opt, bg))
-            out["config"]["paths_note"] = ("`patched` / `import_swap` / `zero_diff` are restatements of train.py's iteration body inside "
-                                           "bench.py (the reference tree does not exist on the GPU box); the reference's own render() / "
-                                           "train.py have not been executed against the drop-ins on a GPU")
+            from oracle import ref_py as _ref_py     # the reference's own files as the CALLER of the product (never the other way round)
+            if _ref_py.available():
+                import contextlib
+                with contextlib.redirect_stdout(sys.stderr):      # train.py and the reference's modules print; stdout carries ONE JSON line
+                    out["config"]["paths"].update(time_reference_paths(pc, cams, targets, bg, scene_aabb))
+                out["config"]["paths_note"] = ("`patched` / `import_swap` / `zero_diff` EXECUTE the reference's own train.py::scene_reconstruction "
+                                               "(train.py:216-560), unchanged, from oracle/_ref/reference_py.tar.gz on real Camera / GaussianModel "
+                                               "objects; see each entry's `executed`")
+            else:
+                out["config"]["paths"].update(time_alt_paths(pc, cams, views, targets, tkeys, hyper, opt, bg))
+                out["config"]["paths_note"] = ("oracle/_ref/reference_py.tar.gz absent: `patched` / `import_swap` / `zero_diff` are RESTATEMENTS of "
+                                               "train.py's iteration body inside bench.py")
             try:   # the fused step again with the MLP kernels' per-point GEMM chains on the bf16 matrix pipe (opt-in, fp32 accuracy)
                 from s3gaussian_amd import mlp as _mlp
                 _mlp.set_mlp_arithmetic("bf16x3")
@@ -910,14 +1033,16 @@ def main(argv=None):
                 out["config"]["psnr_parity_source"] = "profiles/psnr_parity.json: " + pj.get("what", "")
             except Exception:
                 pass
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not dist_on and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(a.P, a.width, a.height)
+                import contextlib
+                with contextlib.redirect_stdout(sys.stderr):      # the reference's modules print; stdout carries ONE JSON line
+                    out["cpu_baseline"] = cpu_baseline(a.P, a.width, a.height)
             except Exception as ex:  # the baseline must never take the headline number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(ex).__name__}: {ex}"}
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -28,12 +28,27 @@ import torch
 import torch.distributed as dist
 
 
+def force_dist() -> bool:
+    """S3G_FORCE_DIST=1: run every collective of this module even at world size 1 (a process group of ONE rank).  That is how the
+    RCCL code path -- library load, communicator init, in-place all-reduces on channels_last views, the post-accumulate hooks,
+    stream ordering against the optimizer kernel -- is executed on a one-GPU lease (tests/test_rccl_gpu.py, `bench.py --gpus 1`
+    under the flag); the results equal the non-distributed step bit for bit because a sum over one rank is the identity."""
+    return os.environ.get("S3G_FORCE_DIST", "0") == "1"
+
+
+def active() -> bool:
+    """True when the collectives below should run: an initialised process group of more than one rank, or of one rank under
+    S3G_FORCE_DIST=1."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or force_dist())
+
+
 def init_from_env(backend: Optional[str] = None) -> tuple:
-    """(rank, world_size, local_rank) from torchrun's environment; single-process when WORLD_SIZE is unset/1."""
+    """(rank, world_size, local_rank) from torchrun's environment; single-process when WORLD_SIZE is unset/1 (unless
+    S3G_FORCE_DIST=1 asks for a process group of one rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_dist()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -109,8 +124,10 @@ class GradAllReducer:
 
     @torch.no_grad()
     def __call__(self) -> int:
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not active():
             return 0
+        if self._only is None:
+            reduce_skip_flag()       # replicas drop the same optimizer steps (see OverlappedGradAllReducer._agree_on_skip)
         world = dist.get_world_size()
         grads = [p.grad for p in (self._only if self._only is not None else self.params) if p.grad is not None]
         total = 0
@@ -162,6 +179,7 @@ class OverlappedGradAllReducer(GradAllReducer):
         # bytes, ~35 collectives); the rest (MLP weights, 64x64 planes) goes in one flat bucket in finish()
         super().__init__(params, bucket_mb, inplace_mb, average)
         self._inflight = []   # (work handle, flat view)
+        self._skip_agreed = False
         self._started = set()
         self._hooks = {}      # id(param) -> (param, hook handle)
         self.rebinds = 0      # how often the hooked set had to follow replaced parameters (diagnostics / tests)
@@ -172,7 +190,7 @@ class OverlappedGradAllReducer(GradAllReducer):
         replaced) are removed.  finish() calls this itself when it sees the optimizer's parameters changed, so a missed
         rebind costs one iteration of non-overlapped reduction, never a silent divergence."""
         super().rebind(params)
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if not active():
             return
         want = {id(p): p for p in self.params if p.requires_grad and p.numel() >= self.inplace_elems}
         for k in [k for k in self._hooks if k not in want]:
@@ -194,10 +212,22 @@ class OverlappedGradAllReducer(GradAllReducer):
             h.remove()
         self._hooks = {}
 
+    def _agree_on_skip(self) -> None:
+        """Every replica must drop the SAME optimizer steps: the overflow word of the host-asynchronous rasterizer forward is
+        all-reduced (MAX, 4 bytes, no host wait) before the first optimizer kernel of the iteration can read it.  Called once per
+        iteration by finish() / finish_and_step() -- a data-parallel user of this class cannot forget it (only
+        bench.py's hook used to call dp.reduce_skip_flag, so one replica could skip a step the others applied)."""
+        if self._skip_agreed:
+            return
+        self._skip_agreed = True
+        reduce_skip_flag()
+
     @torch.no_grad()
     def finish(self) -> int:
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not active():
             return 0
+        self._agree_on_skip()
+        self._skip_agreed = False            # the next iteration agrees anew
         world = dist.get_world_size()
         total = 0
         for work, v in self._inflight:
@@ -233,9 +263,10 @@ class OverlappedGradAllReducer(GradAllReducer):
         those parameters; phase 2 waits for the rest, reduces what no hook covered, and steps the remaining parameters.  Every
         parameter is stepped exactly once with its fully reduced gradient: the result equals finish(); optimizer.step()
         (tests/test_dp_cpu.py).  Group names are the reference's (scene/gaussian_model.py:177-187)."""
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not active():
             optimizer.step()
             return 0
+        self._agree_on_skip()                # before the FIRST of the two optimizer launches reads the word
         world = dist.get_world_size()
         late_ids = {id(p) for g in optimizer.param_groups if g.get("name") in late_groups for p in g["params"]}
         early_params = [p for p in self.params if p.grad is not None and id(p) in self._started and id(p) not in late_ids]
@@ -290,7 +321,7 @@ def reduce_densification_stats(viewspace_grad: torch.Tensor, visibility: torch.T
     g = viewspace_grad[:, :2].contiguous().clone()
     any_vis = visibility.to(torch.int32).clone()
     rmax = radii.clone()
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         dist.all_reduce(any_vis, op=dist.ReduceOp.MAX)
         dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
@@ -311,7 +342,7 @@ def reduce_skip_flag(device=None):
     flag = raster_C.async_skip_flag(device)
     if flag is None:
         return None
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)     # in place: the view into the status ring now holds the batch's verdict
     return flag
 
@@ -345,7 +376,7 @@ class SparseRowExchange:
 
     @torch.no_grad()
     def __call__(self, params: Sequence[torch.nn.Parameter], visibility: torch.Tensor) -> int:
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not active():
             return 0
         world = dist.get_world_size()
         grads = [p.grad for p in params if p.grad is not None]

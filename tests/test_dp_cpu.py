@@ -252,3 +252,88 @@ def test_reduce_skip_flag_is_a_no_op_without_an_asynchronous_forward():
     assert not raster_C._async_states
     assert dp.reduce_skip_flag() is None
     assert raster_C.async_status()["calls"] == 0 and raster_C.async_status()["overflows"] == []
+
+
+def _skip_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from s3gaussian_amd import dp, raster_C
+    dp.init_from_env(backend="gloo")
+    ok = True
+    # rank 0's asynchronous forward "overflowed", rank 1's did not: after finish() / finish_and_step() / the plain reducer BOTH
+    # replicas hold 1 in the word their guarded optimizer step reads -- without the caller doing anything
+    for mode in ("finish", "finish_and_step", "plain"):
+        word = torch.tensor([1 if rank == 0 else 0], dtype=torch.int32)
+        seen = []
+        raster_C.async_skip_flag = lambda device=None, _w=word: _w
+        torch.manual_seed(0)
+        p = torch.nn.Parameter(torch.randn(3000, 3))
+        small = torch.nn.Parameter(torch.randn(5))
+
+        class Opt(torch.optim.SGD):
+            def step(self, closure=None):
+                seen.append(int(word.item()))     # what a guarded step would see
+                return super().step(closure)
+
+        opt = Opt([{"params": [p], "name": "f_dc"}, {"params": [small], "name": "xyz"}], lr=0.1)
+        red = (dp.GradAllReducer(opt) if mode == "plain" else dp.OverlappedGradAllReducer(opt, bucket_mb=0.001, inplace_mb=0.004))
+        for it in range(2):
+            word.fill_(1 if (rank == 0 and it == 0) else 0)     # second iteration: nobody overflowed
+            opt.zero_grad(set_to_none=True)
+            ((p * float(rank + 1)).sum() + small.sum()).backward()
+            if mode == "finish_and_step":
+                red.finish_and_step(opt)
+            else:
+                red()
+                opt.step()
+            ok = ok and int(word.item()) == (1 if it == 0 else 0)
+        ok = ok and all(s == 1 for s in seen[:len(seen) // 2]) and all(s == 0 for s in seen[len(seen) // 2:]) and len(seen) >= 2
+        if hasattr(red, "remove_hooks"):
+            red.remove_hooks()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_reducers_agree_on_the_skip_flag_before_any_optimizer_step_world_size_2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_skip_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert results == {0: True, 1: True}
+
+
+def _forced_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", S3G_FORCE_DIST="1")
+    from s3gaussian_amd import dp
+    r, w, _ = dp.init_from_env(backend="gloo")
+    ok = (r, w) == (0, 1) and dist.is_initialized() and dp.active()
+    torch.manual_seed(0)
+    p = torch.nn.Parameter(torch.randn(3000, 3))
+    plane = torch.nn.Parameter(torch.randn(1, 32, 8, 16).contiguous(memory_format=torch.channels_last))
+    opt = torch.optim.Adam([{"params": [p], "name": "f_dc"}, {"params": [plane], "name": "grid"}], lr=0.01)
+    red = dp.OverlappedGradAllReducer(opt, bucket_mb=0.001, inplace_mb=0.004, average=False)
+    ok = ok and len(red._hooks) == 2
+    ((p ** 2).sum() + (plane * 3.0).sum()).backward()
+    want = (p.grad.clone(), plane.grad.clone())
+    n = red.finish_and_step(opt)
+    ok = ok and n == p.numel() + plane.numel() and torch.equal(p.grad, want[0]) and torch.equal(plane.grad, want[1])
+    g, vis, rmax = dp.reduce_densification_stats(torch.ones(6, 3), torch.arange(6) % 2 == 0, torch.arange(6, dtype=torch.int32))
+    ok = ok and torch.equal(g, torch.ones(6, 2)) and torch.equal(rmax, torch.arange(6, dtype=torch.int32))
+    red.remove_hooks()
+    q.put((0, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_forced_single_rank_group_executes_the_collectives():
+    """S3G_FORCE_DIST=1: a process group of ONE rank runs every collective of dp.py (here over gloo; tests/test_rccl_gpu.py is the
+    same thing over RCCL on the GPU box)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_forced_worker, args=(_free_port(), q))
+    pr.start()
+    assert q.get(timeout=120) == (0, True)
+    pr.join(timeout=60)
