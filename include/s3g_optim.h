@@ -54,6 +54,11 @@ int s3g_adam_step_guarded(int n, const s3g_adam_tensor* tensors /* host array */
  * the rasterizer's per-Gaussian backward when one call produces the whole viewspace gradient. */
 int s3g_densify_stats(int P, const float* grad_xy, int grad_stride, const int* radii, const unsigned char* visible,
                       float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream);
+/* The same behind a device word (the `status_device` word of the asynchronous rasterizer forward that rendered the view, or the
+ * all-reduced verdict of a data-parallel batch): skip_flag != NULL and *skip_flag != 0 at run time -> the launch changes nothing
+ * (the view rendered nothing; its radii say "visible" but no gradient exists).  skip_flag == NULL: identical to s3g_densify_stats. */
+int s3g_densify_stats_guarded(int P, const float* grad_xy, int grad_stride, const int* radii, const unsigned char* visible,
+                              float* xyz_gradient_accum, float* denom, float* max_radii2D, const uint32_t* skip_flag, void* stream);
 
 #ifdef __cplusplus
 }

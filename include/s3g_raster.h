@@ -140,6 +140,13 @@ typedef struct s3g_raster_async {
                                  * backward gather reads is not built (no slot fill, no rect / offset gathers and no scattered
                                  * store per instance in the per-tile sort).  The arenas then serve s3g_raster_forward_reuse and
                                  * s3g_raster_forward_decompose, NOT s3g_raster_backward*. */
+  uint32_t* sticky_device;      /* optional (NULL: off; ignored when forward_only != 0).  One device word shared by the calls of a
+                                 * training loop: the call that overflows sets it, and every later call that is handed the same
+                                 * word renders nothing either (status bit 0 set, status_host[7] = 1 "frozen by an earlier call")
+                                 * until the host stores 0 into it.  With s3g_adam_step_guarded this freezes the model from the
+                                 * overflowed iteration on; the host, which reads the status rows late, raises the capacity, clears
+                                 * the word and re-issues the iterations from the overflowed one -- no (view, step) pair is dropped
+                                 * or reordered w.r.t. the reference's synchronous loop (train.py:291-522). */
 } s3g_raster_async;
 int s3g_raster_arena_bytes(int P, int width, int height, uint32_t capacity_instances, uint32_t capacity_slots,
                            size_t* geometry_bytes, size_t* binning_bytes, size_t* image_bytes);

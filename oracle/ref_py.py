@@ -43,7 +43,10 @@ REF = os.environ.get("S3G_REFERENCE", "/root/reference")
 ARCHIVE = os.path.join(HERE, "_ref", "reference_py.tar.gz")
 PACKED = ("arguments", "gaussian_renderer", "scene", "utils")          # every *.py below these, + train.py
 TOP_LEVEL = PACKED + ("train",)
-STUBBED = ("plyfile", "open3d", "cv2", "imageio", "skimage", "torchvision", "tkinter", "lpips", "lpipsPyTorch", "mmcv", "timm")
+# served as stubs ONLY where the real package cannot be found (the GPU boxes of the pool do not all carry the same wheels: the first
+# run of this module there found no sklearn, which utils/loss_utils.py imports for a DBSCAN helper the hot path never calls)
+STUBBED = ("plyfile", "open3d", "cv2", "imageio", "skimage", "torchvision", "tkinter", "lpips", "lpipsPyTorch", "mmcv", "timm",
+           "sklearn", "matplotlib", "plotly", "scipy", "PIL", "tqdm")
 
 
 def reference_present() -> bool:
@@ -83,8 +86,9 @@ def pack(force: bool = False) -> str | None:
 
 # ---- stub modules for what the image lacks --------------------------------------------------------------------------------------
 class _Stub(types.ModuleType):
-    """Permissive placeholder: any attribute is another placeholder (so `from plyfile import PlyData, PlyElement` binds), calling
-    one raises.  Nothing on the hot path touches them."""
+    """Permissive placeholder: any attribute, item or call result is another placeholder (so `from plyfile import PlyData,
+    PlyElement` binds and import-time set-up lines run); nothing on the hot path touches them, and a placeholder that did reach
+    the numerics would fail loudly in the first tensor operation."""
     __path__: list = []
 
     def __getattr__(self, name):
@@ -94,11 +98,36 @@ class _Stub(types.ModuleType):
         object.__setattr__(self, name, sub)
         return sub
 
-    def __call__(self, *a, **k):
-        raise RuntimeError(f"{self.__name__} is a stub: the package is not installed in this image")
+    def __call__(self, *a, **k):            # utils/visualization_tools.py:28 calls `cm.get_cmap("turbo")` at import time
+        return _Stub(f"{self.__name__}()")
 
     def __mro_entries__(self, bases):      # `class X(stub.Base):` in code that is never instantiated
         return (object,)
+
+    def __setitem__(self, key, value):      # utils/scene_utils.py:5 `plt.rcParams[...] = ...` at import time
+        pass
+
+    def __getitem__(self, key):
+        return _Stub(f"{self.__name__}[{key!r}]")
+
+
+class _Progress:
+    """What train.py uses of tqdm.tqdm when tqdm itself is absent: iteration, set_postfix, update, close."""
+
+    def __init__(self, iterable=None, *a, **k):
+        self.iterable = iterable
+
+    def __iter__(self):
+        return iter(self.iterable)
+
+    def set_postfix(self, *a, **k):
+        pass
+
+    def update(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
 
 
 class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
@@ -114,6 +143,8 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         m = _Stub(spec.name)
         if spec.name == "tkinter":
             m.W = "w"                       # scene/deformation.py:7 `from tkinter import W`
+        if spec.name == "tqdm":             # train.py:272 wraps its iteration range in a progress bar and calls these on it
+            m.tqdm, m.trange = _Progress, (lambda *a, **k: _Progress(range(*a), **k))
         return m
 
     def exec_module(self, module):

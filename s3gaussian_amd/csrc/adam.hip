@@ -58,9 +58,10 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamArgs a) {
 __global__ void __launch_bounds__(256) densify_stats_kernel(int P, const float* __restrict__ g, int stride,
                                                             const int* __restrict__ radii, const unsigned char* __restrict__ visible,
                                                             float* __restrict__ accum, float* __restrict__ denom,
-                                                            float* __restrict__ max_radii) {
+                                                            float* __restrict__ max_radii, const uint32_t* __restrict__ skip) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
+  if (skip && *skip != 0u) return;   // the view's asynchronous forward overflowed: its statistics do not exist (uniform load)
   const int r = radii[i];
   if (!(visible ? visible[i] != 0 : r > 0)) return;
   const float gx = g[(size_t)i * stride], gy = g[(size_t)i * stride + 1];
@@ -73,15 +74,28 @@ __global__ void __launch_bounds__(256) densify_stats_kernel(int P, const float* 
 
 using namespace s3g;
 
+static int densify_stats_impl(int P, const float* grad_xy, int grad_stride, const int* radii, const unsigned char* visible,
+                              float* xyz_gradient_accum, float* denom, float* max_radii2D, const uint32_t* skip, void* stream_);
+
 extern "C" int s3g_densify_stats(int P, const float* grad_xy, int grad_stride, const int* radii, const unsigned char* visible,
                                  float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream_) {
+  return densify_stats_impl(P, grad_xy, grad_stride, radii, visible, xyz_gradient_accum, denom, max_radii2D, nullptr, stream_);
+}
+extern "C" int s3g_densify_stats_guarded(int P, const float* grad_xy, int grad_stride, const int* radii, const unsigned char* visible,
+                                         float* xyz_gradient_accum, float* denom, float* max_radii2D, const uint32_t* skip_flag,
+                                         void* stream_) {
+  return densify_stats_impl(P, grad_xy, grad_stride, radii, visible, xyz_gradient_accum, denom, max_radii2D, skip_flag, stream_);
+}
+
+static int densify_stats_impl(int P, const float* grad_xy, int grad_stride, const int* radii, const unsigned char* visible,
+                              float* xyz_gradient_accum, float* denom, float* max_radii2D, const uint32_t* skip, void* stream_) {
   if (P < 0 || grad_stride < 2 || (P > 0 && (!grad_xy || !radii || !xyz_gradient_accum || !denom || !max_radii2D))) {
     set_error("s3g_densify_stats: bad argument");
     return S3G_ERR_INVALID_ARG;
   }
   if (P == 0) return S3G_OK;
   hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, grad_xy, grad_stride,
-                     radii, visible, xyz_gradient_accum, denom, max_radii2D);
+                     radii, visible, xyz_gradient_accum, denom, max_radii2D, skip);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }

@@ -437,10 +437,16 @@ __device__ __forceinline__ uint32_t block_inclusive_scan_waves(uint32_t v, uint3
 // per-Gaussian backward also look at ctrl[4] themselves); the true counts stay in ctrl[5..6] for the host, which reads them
 // late, without stalling.  *status (optional device word, written on every call): bit 0 = overflow, bit 1 = a Gaussian was
 // culled although `prefiltered` was set.
+// *sticky (optional device word, s3g_raster_async.sticky_device): set by the call that overflows and then honoured by every
+// later call that is handed the same word -- they render nothing either (ctrl[4] = 1, ctrl[7] = 1 "because of an earlier call")
+// until the host clears it.  With the guarded optimizer step this freezes the model from the overflowed iteration on, so that the
+// host, which learns of the overflow a few iterations late, can raise the capacity, clear the word and RE-ISSUE the iterations
+// from the overflowed one: the sequence of (view, optimizer step) pairs the model sees is then the reference's, none dropped.
 __global__ void __launch_bounds__(1024) scan_tiles_kernel(int tiles, const uint32_t* __restrict__ tile_count,
                                                           uint2* __restrict__ ranges, uint32_t* __restrict__ ctrl,
                                                           int nb, uint32_t* __restrict__ chunk_total, uint32_t cap_R,
-                                                          uint32_t cap_S, uint32_t cap_tile, uint32_t* __restrict__ status) {
+                                                          uint32_t cap_S, uint32_t cap_tile, uint32_t* __restrict__ status,
+                                                          uint32_t* __restrict__ sticky) {
   __shared__ uint32_t wtot[16];
   __shared__ uint32_t wmax[16];
   const int tid = threadIdx.x;
@@ -471,7 +477,9 @@ __global__ void __launch_bounds__(1024) scan_tiles_kernel(int tiles, const uint3
   __syncthreads();
   uint32_t m = 0;
   for (int w = 0; w < 16; w++) m = max(m, wmax[w]);
-  const bool overflow = cap_R != 0u && (carry > cap_R || total > cap_S || m > cap_tile);   // `total` = S (last scan above)
+  const bool own = cap_R != 0u && (carry > cap_R || total > cap_S || m > cap_tile);   // `total` = S (last scan above)
+  const bool frozen = cap_R != 0u && sticky != nullptr && *sticky != 0u;               // an EARLIER call overflowed (uniform load)
+  const bool overflow = own || frozen;
   if (overflow)
     for (int i = tid; i < tiles; i += 1024) ranges[i] = make_uint2(0u, 0u);
   if (tid == 0) {
@@ -481,6 +489,8 @@ __global__ void __launch_bounds__(1024) scan_tiles_kernel(int tiles, const uint3
     ctrl[4] = overflow ? 1u : 0u;
     ctrl[5] = carry;
     ctrl[6] = total;
+    ctrl[7] = (frozen && !own) ? 1u : 0u;
+    if (sticky && own) *sticky = 1u;
     if (status) *status = (overflow ? 1u : 0u) | ((ctrl[2] & 1u) ? 2u : 0u);
   }
 }
@@ -792,7 +802,7 @@ static inline uint32_t round_up8(uint32_t v) { return (v + 7u) & ~7u; }
 using namespace s3g;
 
 extern "C" const char* s3g_last_error(void) { return g_err; }
-extern "C" int s3g_abi_version(void) { return 11; }
+extern "C" int s3g_abi_version(void) { return 12; }
 
 // as != NULL: the host-asynchronous variant (s3g_raster_forward_async) -- arenas are the caller's, sized for a speculative
 // capacity, and nothing below waits for the device.
@@ -896,7 +906,8 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
   constexpr uint32_t SMALL = 4096, LARGE = 16384;  // per-tile sort: lists <= SMALL in <= 32 KiB of LDS, <= LARGE in 128 KiB
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, tiles, im.tile_count, im.ranges, im.ctrl, nb,
                      im.chunk_total, as ? as->capacity_instances : 0u, as ? as->capacity_slots : 0u,
-                     as ? (as->long_lists ? 0xffffffffu : SMALL) : 0u, as ? as->status_device : nullptr);
+                     as ? (as->long_lists ? 0xffffffffu : SMALL) : 0u, as ? as->status_device : nullptr,
+                     (as && !as->forward_only) ? as->sticky_device : nullptr);
   S3G_KERNEL_CHECK(stream, debug);
 
   uint32_t R, max_tile, S;

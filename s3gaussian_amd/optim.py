@@ -33,6 +33,18 @@ class Adam(torch.optim.Adam):
                                 # 1 / world_size after a SUM all-reduce instead of spending a pass on the average
 
     @torch.no_grad()
+    def rewind(self, iterations: int) -> None:
+        """The last `iterations` iterations were dropped ON THE DEVICE (guarded step, skip word set: the asynchronous rasterizer's
+        overflow in replay mode, raster_C.set_async_replay) and are about to be issued again: take the host-side step counts --
+        which feed the bias corrections -- back, so that the re-issued steps compute exactly what the dropped ones would have.
+        The moments and parameters were never touched by the dropped launches."""
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] -= float(iterations)
+                if float(st["step"]) < 0:
+                    st["step"].zero_()
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
@@ -121,9 +133,12 @@ def densify_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_rad
         else viewspace_grad.float().contiguous()
     r = radii if radii.dtype == torch.int32 and radii.is_contiguous() else radii.to(torch.int32).contiguous()
     v = None if visible is None else visible.to(torch.uint8).contiguous()
+    from . import raster_C
+    flag = raster_C.async_skip_flag(radii.device)     # the view's asynchronous forward overflowed -> no statistics
     with torch.cuda.device(radii.device):
-        _lib.check(L.s3g_densify_stats(P, g.data_ptr(), int(g.stride(0)), r.data_ptr(), v.data_ptr() if v is not None else None,
-                                       xyz_gradient_accum.data_ptr(), denom.data_ptr(), max_radii2D.data_ptr(),
-                                       torch.cuda.current_stream().cuda_stream))
+        _lib.check(L.s3g_densify_stats_guarded(P, g.data_ptr(), int(g.stride(0)), r.data_ptr(), v.data_ptr() if v is not None else None,
+                                               xyz_gradient_accum.data_ptr(), denom.data_ptr(), max_radii2D.data_ptr(),
+                                               flag.data_ptr() if flag is not None else None,
+                                               torch.cuda.current_stream().cuda_stream))
     for t_ in (xyz_gradient_accum, denom, max_radii2D):
         torch.autograd.graph.increment_version(t_)

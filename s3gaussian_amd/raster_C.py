@@ -83,6 +83,20 @@ _ASYNC_MIN_INSTANCES = int(os.environ.get("S3G_RASTER_ASYNC_MIN_INSTANCES", str(
 _ASYNC_HEADROOM = 4
 
 
+# Replay mode (round 5; opt-in through pipeline.run_training_steps): instead of DROPPING the iteration whose forward overflowed, the
+# device freezes the model from that iteration on (a sticky word that scan_tiles_kernel sets and every later training forward
+# honours, s3g_raster_async.sticky_device) and the host re-issues the iterations from the overflowed one once it has learnt of it.
+REPLAY = False
+
+
+def set_async_replay(on: bool) -> bool:
+    """Sticky overflow word for the training forwards (see the block comment above); returns the previous setting.  Only a loop
+    that polls `async_replay_pending()` and calls `async_acknowledge()` may switch this on: nobody else would ever thaw the model."""
+    global REPLAY
+    prev, REPLAY = REPLAY, bool(on)
+    return prev
+
+
 def set_async(on: bool) -> bool:
     """Host-asynchronous forwards for the autograd nodes; returns the previous setting."""
     global ASYNC
@@ -110,7 +124,11 @@ class _AsyncState:
         self.pending = []          # [(slot, seq, key)] in issue order
         self.seq = 0
         self.hist = {}             # (W, H) -> [max instances, max slots, longest list] observed
-        self.overflows = []        # seq numbers of the calls that rendered nothing
+        self.overflows = []        # seq numbers of the calls that rendered nothing because THEY overflowed
+        self.frozen = []           # seq numbers of the calls that rendered nothing because an EARLIER call had (replay mode)
+        self.sticky_dev = torch.zeros(1, dtype=torch.int32, device=device)   # the sticky word of replay mode
+        self.replay_from = None    # seq of the earliest overflowed call the host has not acknowledged yet
+        self.ack_seq = 0           # calls issued before the last acknowledgement are covered by that rewind
         self.sum_instances = 0     # over the drained calls (workload statistics)
         self.drained = 0
         self.last_slot = None
@@ -145,7 +163,14 @@ class _AsyncState:
             h[0], h[1], h[2] = max(h[0], r_true), max(h[1], s_true), max(h[2], longest & 0xffffffff)
             self.sum_instances += 0 if overflow else r_true
             self.drained += 1
-            if overflow:
+            if overflow and (row[7] & 1):
+                self.frozen.append(seq)     # did nothing because an earlier call overflowed: the replay covers it
+            elif overflow and REPLAY and seq < self.ack_seq:
+                pass                        # overflowed on its own, but inside a window that is being re-issued anyway
+            elif overflow and REPLAY:
+                self.overflows.append(seq)
+                self.replay_from = seq if self.replay_from is None else min(self.replay_from, seq)
+            elif overflow:
                 self.overflows.append(seq)
                 warnings.warn(f"s3gaussian_amd: asynchronous rasterizer forward #{seq} exceeded its arena ({r_true} instances, "
                               f"{s_true} slots, longest list {longest}): that call rendered nothing and its optimizer step was "
@@ -190,9 +215,47 @@ def async_status(device=None, block=False) -> dict:
     if st is None:
         return empty
     st.drain(block=block)
-    return {"enabled": ASYNC, "calls": st.seq, "drained": st.drained, "overflows": list(st.overflows),
+    return {"enabled": ASYNC, "calls": st.seq, "drained": st.drained, "overflows": list(st.overflows), "frozen": list(st.frozen),
+            "replay": REPLAY,
             "mean_instances": (st.sum_instances / st.drained) if st.drained else None,
             "capacity": {k: st.caps(k) for k in st.hist}}
+
+
+def _state_of(device):
+    if not _async_states:
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    return _async_states.get(dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+def async_issued(device=None) -> int:
+    """Number of asynchronous forwards issued on `device` so far (= the sequence number the NEXT one will get): a training loop
+    notes it before each iteration to map a late overflow report back to the iteration that issued the call."""
+    st = _state_of(device)
+    return 0 if st is None else st.seq
+
+
+def async_replay_pending(device=None, block: bool = False):
+    """Replay mode: sequence number of the earliest asynchronous forward that overflowed and has not been acknowledged, else None.
+    Never waits unless block=True (then every outstanding status row is awaited first: the end of a training loop)."""
+    st = _state_of(device)
+    if st is None:
+        return None
+    st.drain(block=block)
+    return st.replay_from
+
+
+def async_acknowledge(device=None) -> None:
+    """Replay mode: the caller is about to re-issue its iterations from the overflowed one.  Enqueues the store that thaws the
+    model (ordered behind every forward issued so far, all of which did nothing) and forgets the report; the capacity has already
+    been raised from the true counts of the rows read so far."""
+    st = _state_of(device)
+    if st is None:
+        return
+    with torch.cuda.device(st.device):
+        st.sticky_dev.zero_()
+    st.replay_from = None
+    st.ack_seq = st.seq
 
 
 def async_reset_statistics(device=None) -> None:
@@ -203,7 +266,7 @@ def async_reset_statistics(device=None) -> None:
     st = _async_states.get(dev.index if dev.index is not None else torch.cuda.current_device())
     if st is not None:
         st.drain(block=True)
-        st.sum_instances, st.drained, st.overflows = 0, 0, []
+        st.sum_instances, st.drained, st.overflows, st.frozen = 0, 0, [], []
 
 
 def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_depth, out_color2, radii, forward_only=False):
@@ -223,7 +286,8 @@ def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_
         if st.events[slot] is not None and any(s == slot for s, _, _ in st.pending):
             st.drain(block=True)            # the host is a whole ring ahead of the device: let the oldest rows land
         desc = _lib.RasterAsync(cap_r, cap_s, lds, long_lists, geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
-                                st.status_dev.data_ptr() + 4 * slot, st.status_host.data_ptr() + 32 * slot, 1 if forward_only else 0)
+                                st.status_dev.data_ptr() + 4 * slot, st.status_host.data_ptr() + 32 * slot, 1 if forward_only else 0,
+                                st.sticky_dev.data_ptr() if (REPLAY and not forward_only and not learn) else None)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
             code = L.s3g_raster_forward_async(C.byref(inp), col2_.data_ptr() if col2_ is not None else None, C.byref(desc),
@@ -236,7 +300,8 @@ def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_
             ev.record()
         st.pending.append((slot, st.seq, key))
         st.seq += 1
-        st.last_slot = slot
+        if not forward_only:     # a render under no_grad between backward and optimizer step must not replace the training
+            st.last_slot = slot  # forward's verdict: the guarded step reads the word of the last forward WITH a backward
         if not learn:
             return cap_r, geom, binning, img
         import warnings

@@ -8,7 +8,7 @@ from tests.test_abi_cpu import _struct_fields
 def test_async_descriptor_matches_the_header():
     from s3gaussian_amd import _lib
     assert _struct_fields("s3g_raster.h", "s3g_raster_async") == [f[0] for f in _lib.RasterAsync._fields_]
-    assert ctypes.sizeof(_lib.RasterAsync) == 4 * 4 + 5 * 8 + 8   # + forward_only (int) and its tail padding
+    assert ctypes.sizeof(_lib.RasterAsync) == 4 * 4 + 5 * 8 + 8 + 8   # + forward_only (int, padded) + sticky_device (round 5)
 
 
 def test_capacity_ladder_is_monotone_tight_and_repeats():
@@ -49,3 +49,48 @@ def test_capacities_stay_inside_the_abi_integer_types():
     st.hist = {(8, 8): [1_500_000_000, 3_000_000_000, 100_000]}      # absurd counts: the capacities saturate instead of wrapping
     cap_r, cap_s, lds, long_lists = st.caps((8, 8))
     assert cap_r == 0x7fffffff and cap_s == 0xffffffff and lds == 4096 and long_lists == 1
+
+
+def test_run_training_steps_rewinds_to_the_overflowed_iteration(monkeypatch):
+    """Host logic of pipeline.run_training_steps with the rasterizer's status ring mocked: iteration 4 issues the forward that
+    overflows (two forwards per iteration here), the report arrives while iteration 6 is being issued, the loop takes three
+    iterations of optimizer step counts back, acknowledges, re-issues 4, 5, 6 and carries on; a second report lands only in the
+    blocking drain at the end and sends the loop back once more."""
+    from s3gaussian_amd import pipeline, raster_C
+    issued_calls = {"n": 0}
+    # once iteration 7 has issued its forwards (#12, #13), forward #6 is reported (iteration 4 issued forwards #6 and #7)
+    state = {"pending": None, "acks": 0, "late": False}
+
+    def fake_issued(device=None):
+        return issued_calls["n"]
+
+    def fake_pending(device=None, block=False):
+        if state["pending"] is None and issued_calls["n"] >= 14 and state["acks"] == 0:
+            state["pending"] = 6
+        if block and state["acks"] == 1 and not state["late"]:
+            state["late"], state["pending"] = True, issued_calls["n"] - 2      # the first forward of the last iteration
+        return state["pending"]
+
+    def fake_ack(device=None):
+        state["pending"], state["acks"] = None, state["acks"] + 1
+
+    monkeypatch.setattr(raster_C, "async_issued", fake_issued)
+    monkeypatch.setattr(raster_C, "async_replay_pending", fake_pending)
+    monkeypatch.setattr(raster_C, "async_acknowledge", fake_ack)
+
+    class Opt:
+        rewound = []
+
+        def rewind(self, n):
+            self.rewound.append(n)
+
+    log = []
+
+    def issue(i):
+        issued_calls["n"] += 2
+
+    out = pipeline.run_training_steps(issue, 1, 8, optimizer=Opt(), log=log)
+    # forwards: it1 = #0,1  it2 = #2,3  it3 = #4,5  it4 = #6,7 ...  it7 = #12,13
+    assert log[:7] == [1, 2, 3, 4, 5, 6, 7] and log[7:12] == [4, 5, 6, 7, 8] and log[12:] == [8]
+    assert out["rewinds"] == [(4, 7), (8, 8)] and Opt.rewound == [4, 1] and out["issued"] == len(log) == 13
+    assert raster_C.REPLAY is False
