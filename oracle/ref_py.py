@@ -43,6 +43,9 @@ REF = os.environ.get("S3G_REFERENCE", "/root/reference")
 ARCHIVE = os.path.join(HERE, "_ref", "reference_py.tar.gz")
 PACKED = ("arguments", "gaussian_renderer", "scene", "utils")          # every *.py below these, + train.py
 TOP_LEVEL = PACKED + ("train",)
+# the reference's Python wrapper of its rasterizer (autograd Function, settings tuple, module): packed under its own path and only
+# used by load(rasterizer="reference"), where it is put on top of the reference's own KERNELS (oracle/ref_diff_raster_C.py)
+RAST_WRAPPER = "submodules/depth-diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py"
 # served as stubs ONLY where the real package cannot be found (the GPU boxes of the pool do not all carry the same wheels: the first
 # run of this module there found no sklearn, which utils/loss_utils.py imports for a DBSCAN helper the hot path never calls)
 STUBBED = ("plyfile", "open3d", "cv2", "imageio", "skimage", "torchvision", "tkinter", "lpips", "lpipsPyTorch", "mmcv", "timm",
@@ -58,7 +61,7 @@ def available() -> bool:
 
 
 def _members():
-    out = [os.path.join(REF, "train.py")]
+    out = [os.path.join(REF, "train.py"), os.path.join(REF, RAST_WRAPPER)]
     for d in PACKED:
         out += sorted(glob.glob(os.path.join(REF, d, "**", "*.py"), recursive=True))
     return out
@@ -151,7 +154,8 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         pass
 
 
-_state = {"dir": None, "finder": None, "path_entry": None}
+_state = {"dir": None, "finder": None, "path_entry": None, "pkg_entry": None, "saved_modules": {}}
+_DROPIN_NAMES = ("diff_gaussian_rasterization", "simple_knn")
 
 
 def _missing(name: str) -> bool:
@@ -161,10 +165,15 @@ def _missing(name: str) -> bool:
         return True
 
 
-def load(patch: bool = False, verbose: bool = False) -> types.SimpleNamespace:
+def load(patch: bool = False, verbose: bool = False, rasterizer: str = "dropin") -> types.SimpleNamespace:
     """-> namespace(root, train, gaussian_renderer, gaussian_model, cameras, arguments, loss_utils, image_utils, general_utils,
     graphics_utils, patched: dict).  patch=True calls s3gaussian_amd.patch.patch_reference() BEFORE train.py is imported, the way
-    `python -m s3gaussian_amd.patch train.py ...` does."""
+    `python -m s3gaussian_amd.patch train.py ...` does.
+    rasterizer="dropin" (default): `diff_gaussian_rasterization` / `simple_knn` resolve to this repo's drop-in packages.
+    rasterizer="reference": they resolve to the REFERENCE's own Python wrapper on the REFERENCE's own kernels (oracle/_ref/*.so
+    through oracle/ref_diff_raster_C.py): the whole reference, end to end, with no product code underneath -- the oracle trainer of
+    the PSNR-parity experiment.  Not combinable with patch=True."""
+    assert rasterizer in ("dropin", "reference") and not (patch and rasterizer == "reference")
     if not available():
         raise FileNotFoundError(f"{ARCHIVE} missing: run oracle/ref_py.py (or __graft_entry__.build()) where /root/reference exists")
     unload()
@@ -178,6 +187,21 @@ def load(patch: bool = False, verbose: bool = False) -> types.SimpleNamespace:
         sys.path.insert(0, ROOT)            # diff_gaussian_rasterization / simple_knn = the drop-in packages of this repo
     sys.path.insert(0, d)
     _state.update(dir=d, finder=finder, path_entry=d)
+    if rasterizer == "reference":
+        pk = os.path.join(d, "_reference_packages")
+        os.makedirs(os.path.join(pk, "diff_gaussian_rasterization"))
+        os.makedirs(os.path.join(pk, "simple_knn"))
+        shutil.copy(os.path.join(d, RAST_WRAPPER), os.path.join(pk, "diff_gaussian_rasterization", "__init__.py"))   # unchanged
+        with open(os.path.join(pk, "diff_gaussian_rasterization", "_C.py"), "w") as f:       # stands where the pybind module stood
+            f.write("from oracle.ref_diff_raster_C import mark_visible, rasterize_gaussians, rasterize_gaussians_backward  # noqa: F401\n")
+        open(os.path.join(pk, "simple_knn", "__init__.py"), "w").close()
+        with open(os.path.join(pk, "simple_knn", "_C.py"), "w") as f:
+            f.write("from oracle.ref_diff_raster_C import distCUDA2  # noqa: F401\n")
+        for name in list(sys.modules):      # the drop-in packages may already be imported under these names: set them aside
+            if name.split(".")[0] in _DROPIN_NAMES:
+                _state["saved_modules"][name] = sys.modules.pop(name)
+        sys.path.insert(0, pk)
+        _state["pkg_entry"] = pk
     bound = {}
     if patch:
         from s3gaussian_amd import patch as _patch
@@ -187,11 +211,14 @@ def load(patch: bool = False, verbose: bool = False) -> types.SimpleNamespace:
              "scene.cameras", "scene.gaussian_model", "gaussian_renderer", "train")}
     for m in mods.values():                 # the files that run are the archive's, which are the reference's
         assert os.path.realpath(m.__file__).startswith(os.path.realpath(d)), m.__file__
+    rast_file = os.path.realpath(sys.modules["diff_gaussian_rasterization"].__file__)
+    assert rast_file.startswith(os.path.realpath(d) if rasterizer == "reference" else os.path.realpath(ROOT)), rast_file
     return types.SimpleNamespace(root=d, train=mods["train"], gaussian_renderer=mods["gaussian_renderer"],
                                  gaussian_model=mods["scene.gaussian_model"], cameras=mods["scene.cameras"],
                                  arguments=mods["arguments"], loss_utils=mods["utils.loss_utils"],
                                  image_utils=mods["utils.image_utils"], general_utils=mods["utils.general_utils"],
-                                 graphics_utils=mods["utils.graphics_utils"], sh_utils=mods["utils.sh_utils"], patched=bound)
+                                 graphics_utils=mods["utils.graphics_utils"], sh_utils=mods["utils.sh_utils"], patched=bound,
+                                 rasterizer=rasterizer)
 
 
 def unload() -> None:
@@ -202,9 +229,16 @@ def unload() -> None:
         sys.meta_path.remove(_state["finder"])
     if _state["path_entry"] in sys.path:
         sys.path.remove(_state["path_entry"])
+    if _state["pkg_entry"]:
+        if _state["pkg_entry"] in sys.path:
+            sys.path.remove(_state["pkg_entry"])
+        for name in list(sys.modules):
+            if name.split(".")[0] in _DROPIN_NAMES:
+                del sys.modules[name]
+        sys.modules.update(_state["saved_modules"])
     if _state["dir"]:
         shutil.rmtree(_state["dir"], ignore_errors=True)
-    _state.update(dir=None, finder=None, path_entry=None)
+    _state.update(dir=None, finder=None, path_entry=None, pkg_entry=None, saved_modules={})
     p = sys.modules.get("s3gaussian_amd.patch")
     if p is not None:                       # the bindings lived in the modules just dropped
         p._PATCHED = False

@@ -241,4 +241,53 @@ void ref_mark_visible(int P, const float* means3D, const float* viewmatrix, cons
     down((bool*)present, out, (size_t)P);
 }
 
+
+/* ---- device-pointer entry points: RAST/rasterize_points.cu:35-202 without torch ------------------------------------------
+ * Everything below takes DEVICE pointers and copies nothing: the three arenas come from caller callbacks (the reference's
+ * std::function<char*(size_t)> resize functions, rasterize_points.cu:27-33 -- here plain C function pointers that a torch
+ * caller backs with uint8 tensors), outputs are caller-allocated and caller-zeroed exactly like the `torch::full(..., 0.0)`
+ * / `torch::zeros` of the reference.  oracle/ref_diff_raster_C.py binds these with the `_C` signatures of
+ * RAST/rasterize_points.h:18-68, so that the reference's OWN Python wrapper (diff_gaussian_rasterization/__init__.py) and the
+ * reference's OWN train.py run on the reference's OWN kernels on this GPU: the end-to-end oracle of the PSNR-parity test.
+ * The kernels run on the legacy default stream (the reference launches everything there): callers synchronise. */
+typedef char* (*ref_resize_fn)(void* user, size_t bytes);
+
+int ref_forward_dev(const Inputs* in, ref_resize_fn geom, void* geom_user, ref_resize_fn binning, void* binning_user,
+                    ref_resize_fn img, void* img_user, float* out_color, float* out_depth, int* radii, int prefiltered, int debug) {
+    if (in->P == 0) return 0;
+    std::function<char*(size_t)> g = [=](size_t n) { return geom(geom_user, n); };
+    std::function<char*(size_t)> b = [=](size_t n) { return binning(binning_user, n); };
+    std::function<char*(size_t)> i = [=](size_t n) { return img(img_user, n); };
+    HIPCHK(hipDeviceSynchronize());   /* inputs were produced on the caller's stream */
+    const int R = CudaRasterizer::Rasterizer::forward(g, b, i, in->P, in->D, in->M, in->background, in->W, in->H, in->means3D,
+                                                      in->shs, in->colors_precomp, in->opacities, in->scales, in->scale_modifier,
+                                                      in->rotations, in->cov3D_precomp, in->viewmatrix, in->projmatrix, in->cam_pos,
+                                                      in->tan_fovx, in->tan_fovy, prefiltered != 0, out_color, out_depth, radii,
+                                                      debug != 0);
+    HIPCHK(hipDeviceSynchronize());
+    return R;
+}
+
+void ref_backward_dev(const Inputs* in, int R, const int* radii, char* geom, char* binning, char* img, const float* dL_dout_color,
+                      const float* dL_dout_depth, float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors,
+                      float* dL_ddepths, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+                      float* dL_drotations, int debug) {
+    if (in->P == 0) return;
+    HIPCHK(hipDeviceSynchronize());
+    CudaRasterizer::Rasterizer::backward(in->P, in->D, in->M, R, in->background, in->W, in->H, in->means3D, in->shs,
+                                         in->colors_precomp, in->scales, in->scale_modifier, in->rotations, in->cov3D_precomp,
+                                         in->viewmatrix, in->projmatrix, in->cam_pos, in->tan_fovx, in->tan_fovy, radii, geom,
+                                         binning, img, dL_dout_color, dL_dout_depth, dL_dmeans2D, dL_dconic, dL_dopacity,
+                                         dL_dcolors, dL_ddepths, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
+                                         debug != 0);
+    HIPCHK(hipDeviceSynchronize());
+}
+
+void ref_mark_visible_dev(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present) {
+    if (P == 0) return;
+    HIPCHK(hipDeviceSynchronize());
+    CudaRasterizer::Rasterizer::markVisible(P, (float*)means3D, (float*)viewmatrix, (float*)projmatrix, (bool*)present);
+    HIPCHK(hipDeviceSynchronize());
+}
+
 }  // extern "C"

@@ -18,7 +18,8 @@ def test_archive_is_the_reference_byte_for_byte_and_nothing_else():
     with tarfile.open(ref_py.ARCHIVE, "r:gz") as tar:
         names = tar.getnames()
         assert "train.py" in names and "gaussian_renderer/__init__.py" in names and "scene/gaussian_model.py" in names
-        assert all(n.endswith(".py") and n.split("/")[0] in ref_py.TOP_LEVEL + ("train.py",) for n in names)
+        assert ref_py.RAST_WRAPPER in names
+        assert all(n.endswith(".py") and (n.split("/")[0] in ref_py.TOP_LEVEL + ("train.py",) or n == ref_py.RAST_WRAPPER) for n in names)
         for n in names:
             want = hashlib.sha256(open(os.path.join(ref_py.REF, n), "rb").read()).hexdigest()
             assert hashlib.sha256(tar.extractfile(n).read()).hexdigest() == want, n
@@ -72,3 +73,24 @@ def test_patch_reference_binds_to_the_real_modules_before_train_is_imported():
         assert ref.train.render.__module__ == "gaussian_renderer" and ref.train.ssim.__module__ == "utils.loss_utils"
     finally:
         ref_py.unload()
+
+
+@needs_archive
+def test_reference_rasterizer_route_resolves_to_the_reference_wrapper_and_restores_the_drop_ins():
+    """load(rasterizer="reference"): `diff_gaussian_rasterization` is the REFERENCE's own Python wrapper (unchanged) over a `_C`
+    that binds the reference's own kernels; unload() puts this repo's drop-in packages back under the same names."""
+    import sys
+    import diff_gaussian_rasterization as ours
+    ref = ref_py.load(rasterizer="reference")
+    try:
+        import diff_gaussian_rasterization as theirs
+        assert theirs is not ours and theirs.__file__.startswith(ref.root)
+        want = open(os.path.join(ref.root, ref_py.RAST_WRAPPER), "rb").read()
+        assert open(theirs.__file__, "rb").read() == want
+        assert theirs._C.rasterize_gaussians.__module__ == "oracle.ref_diff_raster_C"
+        assert ref.gaussian_renderer.GaussianRasterizer is theirs.GaussianRasterizer
+        assert ref.gaussian_model.distCUDA2.__module__ == "oracle.ref_diff_raster_C"
+    finally:
+        ref_py.unload()
+    import diff_gaussian_rasterization as again
+    assert again is ours and sys.modules["diff_gaussian_rasterization"] is ours

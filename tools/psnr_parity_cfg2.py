@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""PSNR parity at a BASELINE configuration (north_star: "PSNR within 0.1 dB of the reference").
+
+Two trainings of the SAME scene by the reference's OWN `train.py::scene_reconstruction` (train.py:216-560, unchanged, from
+oracle/_ref/reference_py.tar.gz), same initial state, same view order (shared `random` seed), same targets, same densify / prune
+schedule (the reference's own rules, scene/gaussian_model.py:661-678) and the same torch RNG seed for densify_and_split:
+
+  reference : the WHOLE reference on the MI355X -- its Python, its `diff_gaussian_rasterization` wrapper, its own kernels
+              (forward.cu / backward.cu / rasterizer_impl.cu compiled for gfx950 by oracle/build_ref.sh, bound by
+              oracle/ref_diff_raster_C.py), its plain-PyTorch HexPlane + MLP, torch SSIM, torch.optim.Adam.  No product code.
+  product   : the same train.py on this repo's drop-in packages under `s3gaussian_amd.patch.patch_reference()` (fused sampler + MFMA
+              MLP, two-image rasterizer passes, fused losses, one-launch Adam) -- zero file edits.
+
+Afterwards every training view and every held-out view is rendered by each side's own `render()` and compared with the target.
+Reported: split-mean PSNR difference (bar 0.1 dB), per-view rows, loss curves, point counts across the densify / prune events, and
+the wall time per iteration of both stacks (the first number in this repository for the reference running end to end on this GPU).
+
+    python tools/psnr_parity_cfg2.py                      # cfg2: 600 k Gaussians, 1066x1600, 1000 iterations  -> profiles/psnr_parity_cfg2.json
+    python tools/psnr_parity_cfg2.py --P 60000 --width 480 --height 320 --iters 150      # what the -m gpu suite runs
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _psnr(a, b):
+    return float(10.0 * torch.log10(1.0 / ((a - b) ** 2).mean().clamp_min(1e-12)))
+
+
+def run(P=600_000, W=1600, H=1066, iters=1000, n_frames=6, seed=0, densify_at=None, prune_at=None, grad_threshold=0.0002,
+        opacity_threshold=0.005, verbose=True):
+    from types import SimpleNamespace
+    from oracle import ref_py
+    from s3gaussian_amd import raster_C, synth
+    from s3gaussian_amd.pipeline import GaussianParams, default_hyper, render as product_render
+    dev = torch.device("cuda:0")
+    densify_at = densify_at if densify_at is not None else iters // 2 + 1     # (twice that is past the last iteration: ONE event)
+    prune_at = prune_at if prune_at is not None else (3 * iters) // 4
+    scn = synth.street_scene(P=P, seed=seed, width=W, height=H, n_frames=n_frames)
+    cams = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in c.items()} for c in scn["cameras"]]
+    ids = list(range(len(cams)))
+    test_ids = ids[1::3]                      # one of the three cameras of every frame is held out
+    train_ids = [i for i in ids if i not in test_ids]
+    bg = scn["bg"].to(dev)
+
+    # ---- targets: the scene with perturbed positions / colours, rendered once (synchronous product forward; both sides share them) ----
+    hyper0 = default_hyper()
+    torch.manual_seed(seed)
+    pc = GaussianParams(3, hyper0)
+    gs = scn["gaussians"]
+    pc.init_from_tensors(gs["xyz"], gs["log_scales"], gs["rotations_raw"], gs["opacity_logit"], gs["shs"], dev)
+    pc._deformation.deformation_net.set_aabb(*scn["aabb"])
+    init_state = {k: v.detach().clone() for k, v in pc._deformation.state_dict().items()}
+    pipe0 = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
+    targets = {}
+    prev = raster_C.set_async(False)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(9)
+        pc._xyz.data.add_(0.05 * torch.randn(pc._xyz.shape, generator=g).to(dev))
+        pc._features_dc.data.add_(0.5 * torch.randn(pc._features_dc.shape, generator=g).to(dev))
+        for v in ids:
+            pk = product_render(cams[v], pc, pipe0, bg, stage="fine", render_feat=True)
+            targets[v] = (pk["render"].clamp(0, 1).clone(), pk["depth"].clone(), pk["feat"].clone())
+    raster_C.set_async(prev)
+    del pc
+    torch.cuda.empty_cache()
+
+    out = {}
+    for side in ("reference", "product"):
+        ref = ref_py.load(patch=(side == "product"), rasterizer="reference" if side == "reference" else "dropin")
+        try:
+            args, dataset, hyper, opt, pipe = ref_py.default_arguments(ref)
+            dataset.render_process = False
+            # one densify and one prune event inside the run, by the reference's own schedule arithmetic (train.py:500-509)
+            opt.densify_from_iter, opt.densification_interval = densify_at - 1, densify_at
+            opt.pruning_from_iter, opt.pruning_interval = prune_at - 1, prune_at
+            opt.opacity_reset_interval = 10 ** 9
+            opt.densify_grad_threshold_fine_init = opt.densify_grad_threshold_after = grad_threshold
+            opt.opacity_threshold_fine_init = opt.opacity_threshold_fine_after = opacity_threshold
+            torch.manual_seed(seed)
+            gm = ref_py.make_gaussians(ref, gs, scn["aabb"], hyper)
+            gm._deformation.load_state_dict(init_state)
+            cam_objs = {v: ref_py.make_camera(ref, cams[v], targets[v], uid=v) for v in ids}
+            scene = ref_py.SceneStub([cam_objs[v] for v in train_ids], cameras_extent=50.0)
+            random.seed(seed + 1)
+            torch.manual_seed(seed + 1)
+            timer = ref_py.RecordingTimer(record_locals=True)
+            t0 = time.perf_counter()
+            ref_py.run_scene_reconstruction(ref, gm, scene, dataset, hyper, opt, pipe, iterations=iters, stage="fine", timer=timer)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            rows = {}
+            with torch.no_grad():
+                for v in ids:
+                    img = ref.gaussian_renderer.render(cam_objs[v], gm, pipe, bg, stage="fine")["render"].clamp(0, 1)
+                    rows[v] = _psnr(img, targets[v][0])
+            st = timer.stamps
+            steady = 1000.0 * (st[-1] - st[len(st) // 10]) / max(len(st) - 1 - len(st) // 10, 1)
+            out[side] = dict(psnr=rows, losses=timer.losses, points=timer.points, wall_s=wall, ms_per_iteration=steady,
+                             optimizer=type(gm.optimizer).__module__ + "." + type(gm.optimizer).__name__,
+                             deformation=type(gm._deformation).__module__,
+                             rasterizer=sys.modules["diff_gaussian_rasterization"].__file__.replace(ref.root, "<archive>").replace(ROOT, "<repo>"))
+            if verbose:
+                print(f"[{side}] {iters} iterations in {wall:.1f} s ({steady:.2f} ms/iteration), points {timer.points[0]} -> {timer.points[-1]}, "
+                      f"loss {np.mean(timer.losses[:10]):.4f} -> {np.mean(timer.losses[-10:]):.4f}", file=sys.stderr)
+            del gm, scene, cam_objs
+        finally:
+            ref_py.unload()
+            torch.cuda.empty_cache()
+
+    a, b = out["product"], out["reference"]
+    views = [dict(view=v, split="test" if v in test_ids else "train", psnr_product=a["psnr"][v], psnr_reference=b["psnr"][v],
+                  delta_db=a["psnr"][v] - b["psnr"][v]) for v in ids]
+    mean_delta = {sp: float(np.mean([r["psnr_product"] for r in views if r["split"] == sp]) -
+                            np.mean([r["psnr_reference"] for r in views if r["split"] == sp])) for sp in ("train", "test")}
+    la, lb = np.array(a["losses"]), np.array(b["losses"])
+    gaps = np.abs(la - lb) / np.maximum(np.abs(lb), 1e-12)
+    k = max(iters // 50, 1)
+    rec = dict(
+        what=f"{iters} fine-stage iterations of the reference's own train.py::scene_reconstruction, {P} Gaussians, {H}x{W}, "
+             f"{len(train_ids)} train + {len(test_ids)} held-out views, one densify event (iteration {densify_at}) and one prune event "
+             f"(iteration {prune_at}) by the reference's own rules, shared seeds: product (drop-in packages + patch_reference) vs the "
+             "whole reference on this GPU (its Python + its own kernels built for gfx950 + torch.optim.Adam)",
+        mean_psnr_delta_db=mean_delta, max_abs_delta_db=float(max(abs(r["delta_db"]) for r in views)), views=views,
+        mean_psnr_db={sp: {"product": float(np.mean([r["psnr_product"] for r in views if r["split"] == sp])),
+                           "reference": float(np.mean([r["psnr_reference"] for r in views if r["split"] == sp]))} for sp in ("train", "test")},
+        points={"product": [a["points"][0], a["points"][min(densify_at, iters - 1)], a["points"][-1]],
+                "reference": [b["points"][0], b["points"][min(densify_at, iters - 1)], b["points"][-1]],
+                "at_iterations": [1, densify_at + 1, iters]},
+        max_rel_loss_gap_first20=float(gaps[:20].max()), rel_loss_gap_at={str(i): float(gaps[i]) for i in (0, 1, 5, 20, iters // 4, iters // 2, iters - 1)},
+        loss_first10_mean=float(lb[:10].mean()), loss_last10_mean={"product": float(la[-10:].mean()), "reference": float(lb[-10:].mean())},
+        loss_curve_every=k, loss_curve={"product": [round(float(x), 5) for x in la[::k]], "reference": [round(float(x), 5) for x in lb[::k]]},
+        ms_per_iteration={"product": round(a["ms_per_iteration"], 3), "reference_stack_on_mi355x": round(b["ms_per_iteration"], 3)},
+        stacks={sd: {kk: out[sd][kk] for kk in ("optimizer", "deformation", "rasterizer")} for sd in out})
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--P", type=int, default=600_000)
+    ap.add_argument("--width", type=int, default=1600)
+    ap.add_argument("--height", type=int, default=1066)
+    ap.add_argument("--iters", type=int, default=1000)
+    ap.add_argument("--frames", type=int, default=6)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psnr_parity_cfg2.json"))
+    a = ap.parse_args()
+    rec = run(a.P, a.width, a.height, a.iters, a.frames)
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(rec, open(a.out, "w"), indent=1)
+    print(json.dumps({k: rec[k] for k in ("mean_psnr_delta_db", "max_abs_delta_db", "mean_psnr_db", "points", "ms_per_iteration",
+                                           "max_rel_loss_gap_first20", "loss_last10_mean")}))
+
+
+if __name__ == "__main__":
+    main()
