@@ -50,19 +50,20 @@ int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, co
 
 /* dL_dfeatures [P, levels*32] -> dL_dxyz [P,3] (written) and dL_dplanes[l][i] (same layout as planes; ACCUMULATED,
  * the caller zero-fills them; a NULL entry skips that plane).  `workspace`: device scratch of
- * s3g_hexplane_backward_workspace_bytes(d, P, features != NULL) bytes (sort buffers, per-orientation dL/dxyz partials, the
- * row tables and their gradients when uniform_time; + 128 B per point and level (one row T = dL/dfeature * feature; rounds 1-2: 3 KB per point) on the features == NULL
- * path), uninitialised. */
-int s3g_hexplane_backward_scratch_rows(int levels);   /* 128-byte rows of scratch per point the features == NULL path writes */
+ * s3g_hexplane_backward_workspace_bytes(d, P, features != NULL) bytes (sort buffers, the row tables and their gradients when
+ * uniform_time, + 128 B per point and level: one row T = dL/dfeature * feature; rounds 1-2: 3 KB per point), uninitialised. */
+int s3g_hexplane_backward_scratch_rows(int levels);   /* 128-byte rows of scratch per point the per-point pass writes */
 /* 32-bit words per point of `sort_state` below: 2 x (walk orders) + 1.  Round 4: one walk order per orientation AND level,
  * 6 * levels + 1 words (25 at the reference's four levels); rounds 1-3 kept three orders (7 words). */
 int s3g_hexplane_sort_state_words(int levels);
 size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P, int have_features);
-/* Backward algorithms (s3g_hexplane_backward_algo; s3g_hexplane_backward selects SLAB for features == NULL, WALK otherwise):
- *   S3G_HEX_SLAB      two passes: a per-point pass forms dL/d(sample) by the product rule, finishes dL/dxyz and stores ONE row per
- *                     level, T = dL/dfeature * feature; sorted scatter walks divide T by the sample they re-derive.
- *   S3G_HEX_WALK      no per-point pass (30 B of scratch per point): every walk derives its share of dL/dxyz too.  Needs `features`.
- *   S3G_HEX_SLAB_DIV  (round 4, what s3gaussian_amd.hexplane uses) the two passes of SLAB, but the per-point pass takes
+/* Backward algorithms (s3g_hexplane_backward_algo; s3g_hexplane_backward selects SLAB for features == NULL, SLAB_DIV otherwise):
+ *   S3G_HEX_SLAB      the exact fallback that needs nothing from the forward: a per-point pass forms dL/d(sample) by the product
+ *                     rule, finishes dL/dxyz and stores ONE row per level, T = dL/dfeature * feature; sorted scatter walks divide
+ *                     T by the sample they re-derive.
+ *   S3G_HEX_WALK      (rounds 2-4: no per-point pass, 30 B of scratch per point, 1.4 x slower) REMOVED in ABI 12: the entry point
+ *                     returns S3G_ERR_INVALID_ARG for it.
+ *   S3G_HEX_SLAB_DIV  (the default: what s3gaussian_amd.hexplane uses) the two passes of SLAB, but the per-point pass takes
  *                     T = dL/dfeature * feature from the forward's output (`features`, required) and dL/d(sample_i) = T / sample_i
  *                     plane by plane, instead of keeping six samples live for the product rule: the forward's register count
  *                     and occupancy.  Same exact fallback for samples that cannot be divided by. */
@@ -76,11 +77,10 @@ int s3g_hexplane_backward_algo(const s3g_hexplane_desc* d, int P, const float* x
 int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const float* xyz, const float* time,
                           const float* dL_dfeatures,
                           const float* features /* [P, levels*32]: the OUTPUT of the matching s3g_hexplane_forward (same
-                          planes, xyz, time).  With it dL/d(sample_i) = dL/dfeature * feature / sample_i needs only the one
-                          sample each scatter walk re-derives from its local texels, and the workspace is 30 bytes per point;
-                          NULL selects the two-pass algorithm (the default, faster): a per-point pass stores ONE row per level,
-                          T = dL/dfeature * feature, and finishes dL/dxyz; the scatter walks divide T by the sample they re-derive
-                          (128 B per point and level of scratch; rounds 1-2 stored dL/d(sample) for all 24 plane-levels). */,
+                          planes, xyz, time): selects S3G_HEX_SLAB_DIV (T = dL/dfeature * feature in one multiply, every plane
+                          divides by its own sample).  NULL selects S3G_HEX_SLAB (product rule; needs nothing from the forward).
+                          Either way a per-point pass stores ONE row per level and finishes dL/dxyz, and the scatter walks divide
+                          T by the sample they re-derive (128 B per point and level of scratch). */,
                           float* dL_dxyz, float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6],
                           void* workspace,
                           unsigned int* sort_state /* [s3g_hexplane_sort_state_words(levels) * P] device or NULL.  With

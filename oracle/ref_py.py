@@ -325,9 +325,9 @@ class RecordingTimer:
     """Stands where utils/timer.py::Timer stands.  The iteration body calls pause() then start() once per iteration
     (train.py:469,484): pause() records the host time and, from the caller's frame, the loss / point count of that iteration."""
 
-    def __init__(self, record_locals=True, sync=None):
+    def __init__(self, record_locals=True, sync=None, after_pause=None):
         self.stamps, self.losses, self.points, self.psnrs = [], [], [], []
-        self.record_locals, self.sync = record_locals, sync
+        self.record_locals, self.sync, self.after_pause = record_locals, sync, after_pause
 
     def start(self):
         pass
@@ -342,6 +342,8 @@ class RecordingTimer:
                 self.losses.append(float(f["loss"].item()))
                 self.points.append(int(f["total_point"]))
                 self.psnrs.append(float(f["psnr_"]))
+        if self.after_pause is not None:
+            self.after_pause(len(self.stamps))      # iteration number (1-based) whose body has just called pause()
 
     def get_elapsed_time(self):
         return 0.0

@@ -39,15 +39,10 @@ namespace s3g {
 // 3 KB, 1.5 KB read back instead of 3 KB.  A sample whose magnitude is not safely divisible (|s| <= 1e-18, or not finite) is
 // left out by the walk and scattered EXACTLY (g * prod_{j != i} s_j, direct atomics) by the per-point pass, which has all six
 // samples: both passes evaluate the same predicate on the same bits of s (same taps, same operation order, contraction off).
-#ifndef S3G_HEX_TSLAB
-#define S3G_HEX_TSLAB 1
-#endif
-// Walk orders of the scatter.  0 (rounds 1-3): three orders, the finest level's (major, minor) cells per orientation; every level
-// of an orientation is walked in that order, two levels per walk.  1 (round 4): one order per orientation AND level -- each
-// (orientation, level) walk is monotone in its own cells (see sort_cell below).
-#ifndef S3G_HEX_PER_LEVEL
-#define S3G_HEX_PER_LEVEL 1
-#endif
+// (Rounds 1-2 stored dL/d(sample) for all 24 plane-levels -- 3 KB per point -- and rounds 1-3 walked every level in the finest
+//  level's cell order, two levels per walk: both forms were compile-time switches until round 5 and are gone; DESIGN.md 6 / 10
+//  keep their measurements.)  One walk order per orientation AND level: each (orientation, level) walk is monotone in its own
+// cells (see sort_cell below).
 #define S3G_POINT_PREFETCH 1
 constexpr float TSLAB_SAFE = 1e-18f;
 __device__ __forceinline__ bool tslab_divisible(float s) { return fabsf(s) > TSLAB_SAFE && fabsf(s) < __builtin_huge_valf(); }
@@ -102,12 +97,9 @@ __global__ void __launch_bounds__(256) hexplane_forward_kernel(const HexArgs a) 
   }
 }
 
-// ---- pass A: per point, dL/ds for every plane-level -> G, and dL/dxyz ----
-// G layout (point-major): the 24 rows of a point are contiguous, points in PROCESSING order, so pass A streams its stores:
-// row (orientation o, level l, kind q) of processing position pi = G + ((pi * 3 + o) * levels + l) * 2 + q) * 32; pass B reads
-// the 1 KB of an orientation by the position comp[o][k] of its k-th point.
-__device__ constexpr int ORI_OF[6] = {0, 2, 0, 1, 1, 2};   // plane i -> orientation pass that scatters it
-__device__ constexpr int KIND_OF[6] = {0, 0, 1, 0, 1, 1};  // 0 = spatial plane of the pass, 1 = its time plane
+// ---- pass A: per point, dL/dxyz and the level's row T = dL/dfeature * feature -> G ----
+// G layout (point-major): the `levels` rows of a point are contiguous, points in PROCESSING order, so pass A streams its stores:
+// row l of processing position pi = G + (pi * levels + l) * 32; a scatter walk reads it by the position comp[oi][k] of its k-th point.
 
 
 // Same lane mapping and tap sharing as the forward.  Per plane only the sample s and its two coordinate derivatives are kept:
@@ -261,20 +253,13 @@ __device__ __forceinline__ void finish_level(const HexArgs& a, int p, int l, int
     const V gi = gs * pre[i];  // dL/ds_i
     gs = gs * S.s[i];
     if (store) {
-      if (!S3G_HEX_TSLAB) {
-        // point-major G: row (orientation, level, kind) of this point's block, gbase = processing position * 24 rows
-        V* grow = reinterpret_cast<V*>(G + gbase + (size_t)(((ORI_OF[i] * a.d.levels + l) * 2 + KIND_OF[i]) * HEXC + c0));
-        if (G_NONTEMPORAL) __builtin_nontemporal_store(gi, grow);   // written once, read once by the scatter pass much later
-        else *grow = gi;
-      } else {
 #pragma unroll
-        for (int k = 0; k < vec_of<V>::N; k++) badbits |= tslab_near_unsafe(vget<V>(S.s[i], k)) ? (1u << i) : 0u;
-      }
+      for (int k = 0; k < vec_of<V>::N; k++) badbits |= tslab_near_unsafe(vget<V>(S.s[i], k)) ? (1u << i) : 0u;
       if (PAIR0[i] < 3) du[PAIR0[i]] += S.mx[i] * vdot(S.dX[i], gi);
       if (PAIR1[i] < 3) du[PAIR1[i]] += S.my[i] * vdot(S.dY[i], gi);
     }
   }
-  if (S3G_HEX_TSLAB && store) {   // gs = g * s5 * s4 * ... * s0 = dL/dfeature * feature: the level's ONE row, gbase = position * levels rows
+  if (store) {   // gs = g * s5 * s4 * ... * s0 = dL/dfeature * feature: the level's ONE row, gbase = position * levels rows
     V* trow = reinterpret_cast<V*>(G + gbase + (size_t)(l * HEXC + c0));
     if (G_NONTEMPORAL) __builtin_nontemporal_store(gs, trow);
     else *trow = gs;
@@ -295,7 +280,7 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
     const int pi = p0 + slot;
     const bool live = pi < a.P;
     const int p = live ? (a.proc_order ? (int)a.proc_order[pi] : pi) : 0;
-    const size_t gbase = (size_t)pi * (size_t)((S3G_HEX_TSLAB ? 1 : 6) * L * HEXC);   // point-major layout: the rows of this PROCESSING position
+    const size_t gbase = (size_t)pi * (size_t)(L * HEXC);   // point-major layout: the rows of this PROCESSING position
     float u[4];
     point_coords(a, p, u);
     wave_lds_sync();
@@ -303,7 +288,7 @@ __global__ void __launch_bounds__(256) hexplane_backward_point_kernel(const HexA
     wave_lds_sync();
     const float* grow = a.gfeat + (size_t)p * F + c0;
     float du[3] = {0.f, 0.f, 0.f};
-    if constexpr (S3G_HEX_TSLAB != 0 && S3G_POINT_PREFETCH != 0 && LV == 4) {
+    if constexpr (S3G_POINT_PREFETCH != 0 && LV == 4) {
       // T-slab: with the 24 G rows gone the kernel has registers to spare (188 of 256): the NEXT level's texels are requested
       // before this level's arithmetic, in two alternating register sets (fully unrolled: no set crosses a back-edge)
       LevelIn<V> X0, X1;
@@ -506,7 +491,7 @@ __device__ __forceinline__ int sort_cell(const HexArgs& a, int p, int axis, int 
 // points are close in x, y AND z and all three spatial planes' texels stay in the L2 of the XCD that works on the block.
 // (In an (x, y) order every tap of the (y, z) plane missed: 2.5 GB of 128-byte fetches per pass at 1.2 M points.)
 // Order ids: oi = orientation * levels + level for the 3 * levels walk orders, oi = 3 * levels for the processing order.
-static inline int n_walk_orders(int levels) { return S3G_HEX_PER_LEVEL ? 3 * levels : 3; }
+static inline int n_walk_orders(int levels) { return 3 * levels; }
 static inline int n_orders(int levels) { return n_walk_orders(levels) + 1; }
 __device__ __forceinline__ int block_key(const HexArgs& a, int p, int shift) {
   int key = 0;
@@ -519,9 +504,9 @@ __device__ __forceinline__ int block_key(const HexArgs& a, int p, int shift) {
   return key;
 }
 __device__ __forceinline__ int order_key(const HexArgs& a, int p, int oi, bool major) {
-  const int nw = S3G_HEX_PER_LEVEL ? 3 * a.d.levels : 3;
+  const int nw = 3 * a.d.levels;
   if (oi >= nw) return block_key(a, p, major ? 3 : 0);
-  const int o = S3G_HEX_PER_LEVEL ? oi / a.d.levels : oi, level = S3G_HEX_PER_LEVEL ? oi % a.d.levels : a.d.levels - 1;
+  const int o = oi / a.d.levels, level = oi % a.d.levels;
   return sort_cell(a, p, major ? MAJ[o] : MIN_[o], level);
 }
 __device__ __forceinline__ int major_key(const HexArgs& a, int p, int oi) { return order_key(a, p, oi, true); }
@@ -631,46 +616,20 @@ __global__ void __launch_bounds__(256) hexsort_compose_kernel(int P, const uint3
 // give more half-waves; 256 measured best at 1.2 M points (1.21 vs 1.30 ms), 128 below a million
 static inline int segment_length(int P) { return P >= 1000000 ? 256 : 128; }
 
-// One bilinear footprint being accumulated in registers: key = texel offset of its nw corner (-1 = empty), flags bit0 =
-// ne/se column in range, bit1 = sw/se row in range (the other three corners follow from key, flags and the plane width).
-// A lane owns CPL adjacent channels: T = float (CPL = 1, 32 lanes per walker) or f2v (CPL = 2, 16 lanes per walker: every key
-// compare, select and cache-management instruction then serves two channels and the accumulation is v_pk_fma_f32 -- the walk
-// is bound by VALU issue, 4 cycles per wave64 instruction).
-constexpr bool FOOT_SHIFT = true;
-typedef float f2v __attribute__((ext_vector_type(2)));
-template <typename T> struct lanes_of;
-template <> struct lanes_of<float> {
-  static constexpr int CPL = 1;
-  static __device__ __forceinline__ float first(float v) { return v; }
-  static __device__ __forceinline__ float splat(float v) { return v; }
-};
-template <> struct lanes_of<f2v> {
-  static constexpr int CPL = 2;
-  static __device__ __forceinline__ float first(f2v v) { return v.x; }
-  static __device__ __forceinline__ f2v splat(float v) { return f2v{v, v}; }
-};
-__device__ __forceinline__ float vzero(float) { return 0.f; }
-__device__ __forceinline__ f2v vzero(f2v) { return f2v{0.f, 0.f}; }
-__device__ __forceinline__ float vfma(float g, float w, float acc) { return __builtin_fmaf(g, w, acc); }
-__device__ __forceinline__ f2v vfma(f2v g, float w, f2v acc) { return __builtin_elementwise_fma(g, f2v{w, w}, acc); }
-__device__ __forceinline__ void vatomic(char* base, uint32_t k, float v) { atomicAdd(reinterpret_cast<float*>(base + k), v); }
-__device__ __forceinline__ void vatomic(char* base, uint32_t k, f2v v) {
-  atomicAdd(reinterpret_cast<float*>(base + k), v.x);
-  atomicAdd(reinterpret_cast<float*>(base + (k + 4u)), v.y);
-}
-template <typename T>
-struct FootT {
+// One bilinear footprint being accumulated in registers by a walker lane (= one channel): key = texel offset of its nw corner
+// (-1 = empty), flags bit0 = ne/se column in range, bit1 = sw/se row in range (the other three corners follow from key, flags and
+// the plane width).
+struct Foot {
   int key, flags;
-  T a00, a01, a10, a11;
+  float a00, a01, a10, a11;
 };
-using Foot = FootT<float>;
+__device__ __forceinline__ void vatomic(char* base, uint32_t k, float v) { atomicAdd(reinterpret_cast<float*>(base + k), v); }
 // Offsets are 32-bit BYTE offsets off a uniform base pointer (`base + zext(u32)` selects the scalar-base + VGPR-offset
 // addressing mode: no 64-bit address arithmetic per atomic; a plane is at most 2^24 texels).  The corner tests stay
 // branches on purpose: an unconditional atomic of an exact zero to a clamped address was measured 6x SLOWER for the whole
 // pass -- every empty entry and every out-of-range corner then lands on the same few lines (texel 0 of each plane, the nw
-// texel again), and same-address atomics serialise at ~10 ns each.  c = first channel of the lane.
-template <typename T>
-__device__ __forceinline__ void foot_flush(const FootT<T>& f, float* __restrict__ gp, int W, int c) {
+// texel again), and same-address atomics serialise at ~10 ns each.  c = channel of the lane.
+__device__ __forceinline__ void foot_flush(const Foot& f, float* __restrict__ gp, int W, int c) {
   if (f.key < 0) return;
   const uint32_t k = ((uint32_t)f.key * HEXC + (uint32_t)c) * 4u;
   const uint32_t dy = (uint32_t)W * (HEXC * 4u);
@@ -680,171 +639,24 @@ __device__ __forceinline__ void foot_flush(const FootT<T>& f, float* __restrict_
   if (f.flags & 2) vatomic(base, k + dy, f.a10);
   if ((f.flags & 3) == 3) vatomic(base, k + dy + HEXC * 4u, f.a11);
 }
-// Two-entry footprint cache.  align_corners grids of different levels do not nest, so inside one finest-level cell the
-// points alternate between two (sometimes four) coarse footprints; remembering the previous one as well removes most of
-// those flushes.
 struct PackedTap {  // what the scatter needs of a Tap: 8 floats in LDS
   int key, flags;
   float w00, w01, w10, w11;
 };
-// Entries stay where they are (no MRU swap) and the hit path is BRANCH-FREE: both entries take an fma whose multiplicand is
-// the gradient or 0.  The scatter kernel used to be instruction-bound on this function: the walkers sharing a wave walk
-// different segments, so every data-dependent branch of the old hit-A / hit-B-swap / miss cascade ran both sides under
-// complementary exec masks (~100 instructions per call, 32 calls per group of four points).  Only the miss -- about one
-// call in four -- still branches: it flushes the entry that was NOT used last and installs the new footprint in its place.
-template <typename T>
-struct Foot2T {
-  int key0, key1, fl0, fl1, mru;
-  T a0[4], a1[4];
-  float v0[S3G_HEX_TSLAB ? 4 : 1], v1[S3G_HEX_TSLAB ? 4 : 1];   // T-slab: the footprints' own texel VALUES (loaded when a footprint is installed)
-};
-using Foot2 = Foot2T<float>;
-template <typename T>
-__device__ __forceinline__ void foot2_init(Foot2T<T>& F) {
-  F.key0 = F.key1 = -1;
-  F.fl0 = F.fl1 = F.mru = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) F.a0[k] = F.a1[k] = vzero(T{});
-}
-// ROW = true: the plane is a height-1 row table (uniform time): only the nw / ne corners exist, the sw / se halves of
-// the footprint (weights exactly 0, flag bit 1 clear) are compiled out -- half the fmas, selects and flush atomics.
-template <bool ROW = false, typename T>
-__device__ __forceinline__ void foot2_flush_all(const Foot2T<T>& F, float* __restrict__ gp, int W, int c) {
-  const T z = vzero(T{});
-  foot_flush(FootT<T>{F.key0, ROW ? (F.fl0 & 1) : F.fl0, F.a0[0], F.a0[1], ROW ? z : F.a0[2], ROW ? z : F.a0[3]}, gp, W, c);
-  foot_flush(FootT<T>{F.key1, ROW ? (F.fl1 & 1) : F.fl1, F.a1[0], F.a1[1], ROW ? z : F.a1[2], ROW ? z : F.a1[3]}, gp, W, c);
-}
-// Miss path, one code shape for both cases (a second set of divergent branches cost more scalar registers than the kernel has):
-//   evict  the entry that was NOT used last is flushed (up to 4 atomics) and restarts empty with the new footprint;
-//   shift  the new footprint is one row BELOW / one column RIGHT of the most recent one -- the usual step of a walk along the
-//          minor axis.  Two of its texels are already being summed in that entry: only the row / column left behind is
-//          flushed (2 atomics instead of 4 -- the walk is bound by the rate of atomic line-ops) and the other two sums move up.
-template <bool ROW = false, typename T>
-__device__ __forceinline__ void foot2_add(Foot2T<T>& F, const PackedTap& t, T g, float* __restrict__ gp, int W, int c) {
-  const T z = vzero(T{});
-  bool h0 = t.key == F.key0, h1 = t.key == F.key1;
-  if (!(h0 || h1)) {  // miss (uniform inside the walker's lanes)
-    const bool m1 = F.mru != 0;                       // most recent entry
-    const int mkey = m1 ? F.key1 : F.key0, mfl = m1 ? F.fl1 : F.fl0;
-    const bool down = FOOT_SHIFT && !ROW && mkey >= 0 && t.key == mkey + W;
-    const bool right = FOOT_SHIFT && mkey >= 0 && t.key == mkey + 1 && (mfl & 1);
-    const bool shift = down || right;
-    const bool w1 = shift ? m1 : !m1;                 // entry that is flushed (partly) and rewritten
-    const int K = w1 ? F.key1 : F.key0, FL = w1 ? F.fl1 : F.fl0;
-    const T A0 = w1 ? F.a1[0] : F.a0[0], A1 = w1 ? F.a1[1] : F.a0[1];
-    const T A2 = ROW ? z : (w1 ? F.a1[2] : F.a0[2]), A3 = ROW ? z : (w1 ? F.a1[3] : F.a0[3]);
-    if (K >= 0) {
-      const uint32_t k = ((uint32_t)K * HEXC + (uint32_t)c) * 4u;
-      const uint32_t dy = (uint32_t)W * (HEXC * 4u);
-      char* base = reinterpret_cast<char*>(gp);
-      vatomic(base, k, A0);                                                    // nw leaves in every case
-      if ((FL & 1) && !right) vatomic(base, k + HEXC * 4u, A1);               // ne stays when shifting right
-      if (!ROW && (FL & 2) && !down) vatomic(base, k + dy, A2);               // sw stays when shifting down
-      if (!ROW && (FL & 3) == 3 && !shift) vatomic(base, k + dy + HEXC * 4u, A3);
-    }
-    // new contents: shift down (nw, ne, sw, se) <- (sw, se, 0, 0); shift right <- (ne, 0, se, 0); evict <- 0
-    const T n0 = down ? A2 : (right ? A1 : z), n1 = down ? A3 : z, n2 = right ? A3 : z;
-    F.a1[0] = w1 ? n0 : F.a1[0];  F.a0[0] = w1 ? F.a0[0] : n0;
-    F.a1[1] = w1 ? n1 : F.a1[1];  F.a0[1] = w1 ? F.a0[1] : n1;
-    if (!ROW) {
-      F.a1[2] = w1 ? n2 : F.a1[2];  F.a0[2] = w1 ? F.a0[2] : n2;
-      F.a1[3] = w1 ? z : F.a1[3];   F.a0[3] = w1 ? F.a0[3] : z;
-    }
-    F.key1 = w1 ? t.key : F.key1;  F.key0 = w1 ? F.key0 : t.key;
-    F.fl1 = w1 ? t.flags : F.fl1;  F.fl0 = w1 ? F.fl0 : t.flags;
-    h1 = w1;
-    h0 = !w1;
-  }
-  const T g0 = h0 ? g : z, g1 = h1 ? g : z;
-  F.a0[0] = vfma(g0, t.w00, F.a0[0]); F.a0[1] = vfma(g0, t.w01, F.a0[1]);
-  F.a1[0] = vfma(g1, t.w00, F.a1[0]); F.a1[1] = vfma(g1, t.w01, F.a1[1]);
-  if (!ROW) {
-    F.a0[2] = vfma(g0, t.w10, F.a0[2]); F.a0[3] = vfma(g0, t.w11, F.a0[3]);
-    F.a1[2] = vfma(g1, t.w10, F.a1[2]); F.a1[3] = vfma(g1, t.w11, F.a1[3]);
-  }
-  F.mru = h1 ? 1 : 0;
-}
-
-// T-slab form of foot2_add: `tv` is the point's T = dL/dfeature * feature for this level; the sample the footprint produced in the
-// forward is re-derived from the footprint's texel VALUES -- kept in the cache entry, so a HIT (three calls in four) costs no load
-// at all and a miss loads the four (two) texels of the footprint it installs -- and dL/ds = T / s is what gets accumulated.
+// The walker's ONE remembered footprint (round 4; rounds 1-3 walked every level in the finest level's order and needed a two-entry
+// cache with an MRU bit because foreign cell boundaries made the points alternate between two footprints -- removed in round 5,
+// tools/sim/flush_orders.py still prices both).  A walk that is monotone in its OWN level's cells enters a footprint once.
+//   hit   (three calls in four): no load at all -- the entry keeps the texel VALUES of its corners next to the partial sums; the
+//         sample the footprint produced in the forward is re-derived from them and dL/ds = T / s is accumulated;
+//   miss  (uniform inside the walker's lanes): the four (two) texels of the new footprint are loaded, and
+//         evict  the old entry is flushed (up to 4 atomics) and restarts empty, or
+//         shift  the new footprint is one row BELOW / one column RIGHT of the old one -- the usual step of a walk along the minor
+//                axis: two of its texels are already being summed, only the row / column left behind is flushed (2 atomics
+//                instead of 4 -- the walk is bound by the rate of atomic line-ops) and the other two sums move up.
+// ROW = true: the plane is a height-1 row table (uniform time): only the nw / ne corners exist.
 // An out-of-range corner has weight exactly 0 and takes the nw texel's value, like the per-point pass; a sample that is not safely
 // divisible contributes nothing here (the per-point pass scattered it exactly: same predicate, same bits).
-// key0 / key1 hold (texel index << 2 | corner flags) here -- the flags are a function of the index -- which frees fl0 / fl1.
-// Measured alternatives (cfg3, scatter ms): texels fetched where they are used 2.21; all four points of the group requested up
-// front 1.49 (one level per walk; two levels spill: 7.3); one point ahead in two alternating register sets 2.03 (spills) / 1.60
-// (one level per walk); THIS 1.35, of which 0.33 are the misses' exposed round trips (1.04 with the loads compiled out: the planes
-// do not fit the L2, a new footprint row comes from the Infinity Cache).  Against those 0.33 ms: the tap lanes touching the
-// footprint's four lines a group ahead 1.72 (four more live registers spill); lookup and accumulation as two phases per point so
-// that a point's misses overlap 1.54 (the flags / re-read taps cost more than the overlap gains).
-template <bool ROW = false>
-__device__ __forceinline__ void foot2_add_t(Foot2T<float>& F, const PackedTap& t, float tv, float* __restrict__ gp,
-                                            const float* __restrict__ pl /* plane values + channel */, int W, int c) {
-  const int tkf = (t.key << 2) | (t.flags & 3);
-  bool h0 = tkf == F.key0, h1 = tkf == F.key1;
-  if (!(h0 || h1)) {  // miss (uniform inside the walker's lanes)
-    const float* px = pl + (size_t)t.key * HEXC;
-    const float n0 = px[0], n1 = px[(t.flags & 1) ? HEXC : 0];
-    float n2 = 0.f, n3 = 0.f;
-    if (!ROW) {
-      n2 = px[(t.flags & 2) ? (size_t)W * HEXC : 0];
-      n3 = px[((t.flags & 3) == 3) ? (size_t)W * HEXC + HEXC : 0];
-    }
-    const bool m1 = F.mru != 0;                       // most recent entry
-    const int mkf = m1 ? F.key1 : F.key0;
-    const int mkey = mkf >> 2, mfl = mkf & 3;          // (-1 stays -1)
-    const bool down = FOOT_SHIFT && !ROW && mkf >= 0 && t.key == mkey + W;
-    const bool right = FOOT_SHIFT && mkf >= 0 && t.key == mkey + 1 && (mfl & 1);
-    const bool shift = down || right;
-    const bool w1 = shift ? m1 : !m1;                 // entry that is flushed (partly) and rewritten
-    const int KF = w1 ? F.key1 : F.key0;
-    const int K = KF >> 2, FL = KF & 3;
-    const float A0 = w1 ? F.a1[0] : F.a0[0], A1 = w1 ? F.a1[1] : F.a0[1];
-    const float A2 = ROW ? 0.f : (w1 ? F.a1[2] : F.a0[2]), A3 = ROW ? 0.f : (w1 ? F.a1[3] : F.a0[3]);
-    if (KF >= 0) {
-      const uint32_t k = ((uint32_t)K * HEXC + (uint32_t)c) * 4u;
-      const uint32_t dy = (uint32_t)W * (HEXC * 4u);
-      char* base = reinterpret_cast<char*>(gp);
-      vatomic(base, k, A0);                                                    // nw leaves in every case
-      if ((FL & 1) && !right) vatomic(base, k + HEXC * 4u, A1);               // ne stays when shifting right
-      if (!ROW && (FL & 2) && !down) vatomic(base, k + dy, A2);               // sw stays when shifting down
-      if (!ROW && (FL & 3) == 3 && !shift) vatomic(base, k + dy + HEXC * 4u, A3);
-    }
-    const float m0 = down ? A2 : (right ? A1 : 0.f), mm1 = down ? A3 : 0.f, m2 = right ? A3 : 0.f;
-    F.a1[0] = w1 ? m0 : F.a1[0];   F.a0[0] = w1 ? F.a0[0] : m0;
-    F.a1[1] = w1 ? mm1 : F.a1[1];  F.a0[1] = w1 ? F.a0[1] : mm1;
-    F.v1[0] = w1 ? n0 : F.v1[0];   F.v0[0] = w1 ? F.v0[0] : n0;
-    F.v1[1] = w1 ? n1 : F.v1[1];   F.v0[1] = w1 ? F.v0[1] : n1;
-    if (!ROW) {
-      F.a1[2] = w1 ? m2 : F.a1[2];   F.a0[2] = w1 ? F.a0[2] : m2;
-      F.a1[3] = w1 ? 0.f : F.a1[3];  F.a0[3] = w1 ? F.a0[3] : 0.f;
-      F.v1[2] = w1 ? n2 : F.v1[2];   F.v0[2] = w1 ? F.v0[2] : n2;
-      F.v1[3] = w1 ? n3 : F.v1[3];   F.v0[3] = w1 ? F.v0[3] : n3;
-    }
-    F.key1 = w1 ? tkf : F.key1;  F.key0 = w1 ? F.key0 : tkf;
-    h1 = w1;
-    h0 = !w1;
-  }
-  float sv = (h1 ? F.v1[0] : F.v0[0]) * t.w00;
-  sv = sv + (h1 ? F.v1[1] : F.v0[1]) * t.w01;
-  if (!ROW) {
-    sv = sv + (h1 ? F.v1[2] : F.v0[2]) * t.w10;
-    sv = sv + (h1 ? F.v1[3] : F.v0[3]) * t.w11;
-  }
-  const float g = tslab_divisible(sv) ? tv * __builtin_amdgcn_rcpf(sv) : 0.f;
-  const float g0 = h0 ? g : 0.f, g1 = h1 ? g : 0.f;
-  F.a0[0] = vfma(g0, t.w00, F.a0[0]); F.a0[1] = vfma(g0, t.w01, F.a0[1]);
-  F.a1[0] = vfma(g1, t.w00, F.a1[0]); F.a1[1] = vfma(g1, t.w01, F.a1[1]);
-  if (!ROW) {
-    F.a0[2] = vfma(g0, t.w10, F.a0[2]); F.a0[3] = vfma(g0, t.w11, F.a0[3]);
-    F.a1[2] = vfma(g1, t.w10, F.a1[2]); F.a1[3] = vfma(g1, t.w11, F.a1[3]);
-  }
-  F.mru = h1 ? 1 : 0;
-}
-// Single-entry form for the per-level walk orders (S3G_HEX_PER_LEVEL): a walk that is monotone in its OWN level's cells never
-// alternates between footprints, so the second entry buys nothing (tools/sim/flush_orders.py: 2.42 M line-atomics with one entry,
-// 2.42 M with two) and costs nine registers and a select per accumulator and call.  Same miss path (evict / shift down / shift
-// right relative to the one entry), same arithmetic, same division-safety predicate as foot2_add_t.
+constexpr bool FOOT_SHIFT = true;
 struct Foot1 {
   int key;          // (texel index << 2 | corner flags), -1 = empty
   float a[4], v[4]; // partial sums and texel values of the footprint's corners (nw, ne, sw, se)
@@ -880,6 +692,7 @@ __device__ __forceinline__ void foot1_add_t(Foot1& F, const PackedTap& t, float 
       if (!ROW && (FL & 2) && !down) vatomic(base, k + dy, A2);               // sw stays when shifting down
       if (!ROW && (FL & 3) == 3 && !shift) vatomic(base, k + dy + HEXC * 4u, A3);
     }
+    // new contents: shift down (nw, ne, sw, se) <- (sw, se, 0, 0); shift right <- (ne, 0, se, 0); evict <- 0
     F.a[0] = down ? A2 : (right ? A1 : 0.f);
     F.a[1] = down ? A3 : 0.f;
     F.v[0] = n0; F.v[1] = n1;
@@ -897,489 +710,131 @@ __device__ __forceinline__ void foot1_add_t(Foot1& F, const PackedTap& t, float 
     sv = sv + F.v[3] * t.w11;
   }
   const float g = tslab_divisible(sv) ? tv * __builtin_amdgcn_rcpf(sv) : 0.f;
-  F.a[0] = vfma(g, t.w00, F.a[0]); F.a[1] = vfma(g, t.w01, F.a[1]);
+  F.a[0] = __builtin_fmaf(g, t.w00, F.a[0]); F.a[1] = __builtin_fmaf(g, t.w01, F.a[1]);
   if (!ROW) {
-    F.a[2] = vfma(g, t.w10, F.a[2]); F.a[3] = vfma(g, t.w11, F.a[3]);
+    F.a[2] = __builtin_fmaf(g, t.w10, F.a[2]); F.a[3] = __builtin_fmaf(g, t.w11, F.a[3]);
   }
 }
 template <bool ROW = false>
 __device__ __forceinline__ void foot1_flush_all(const Foot1& F, float* __restrict__ gp, int W, int c) {
   if (F.key < 0) return;
-  foot_flush(FootT<float>{F.key >> 2, ROW ? (F.key & 1) : (F.key & 3), F.a[0], F.a[1], ROW ? 0.f : F.a[2], ROW ? 0.f : F.a[3]}, gp, W, c);
-}
-// end of a walk: back to the (key, flags) form foot2_flush_all expects
-__device__ __forceinline__ void foot2_unpack_t(Foot2T<float>& F) {
-  F.fl0 = F.key0 & 3; F.fl1 = F.key1 & 3;
-  F.key0 >>= 2; F.key1 >>= 2;
+  foot_flush(Foot{F.key >> 2, ROW ? (F.key & 1) : (F.key & 3), F.a[0], F.a[1], ROW ? 0.f : F.a[2], ROW ? 0.f : F.a[3]}, gp, W, c);
 }
 
-// A WALKER = 32 / CPL lanes (each owning CPL adjacent channels) walks seg_len consecutive points of the sorted order.  The
-// kernel used to be VALU-bound on make_tap, which every lane repeated for each (level, plane) tap of a point; now the walker's
-// lanes compute the taps of FOUR points at once (lane = point q x tap j), park them in LDS, and every lane reads them back
-// with broadcast loads while it accumulates its channels.
-constexpr int SCATTER_LG = S3G_HEX_PER_LEVEL ? 1 : 2;          // levels handled per walk of a segment (per-level orders: one)
-#ifndef S3G_HEX_FOOT_ENTRIES
-#define S3G_HEX_FOOT_ENTRIES (S3G_HEX_PER_LEVEL ? 1 : 2)
-#endif
-constexpr int SCATTER_CPL = 1;         // channels per lane (2 = v_pk_fma accumulation, but twice the flush atomics: 2.07 vs 1.14 ms -- the walk is bound by atomic line-ops)
-constexpr bool SCATTER_ONE_ENTRY = S3G_HEX_FOOT_ENTRIES == 1 && S3G_HEX_TSLAB != 0 && SCATTER_CPL == 1;
+// A WALKER = 32 lanes (one per channel: a half-wave) walks seg_len consecutive points of ONE (orientation, level) order:
+// blockIdx.y = orientation * levels + level.  The kernel used to be VALU-bound on make_tap, which every lane repeated for each
+// tap of a point; the walker's lanes compute the taps of FOUR points at once (lane = point q x tap j), park them in LDS, and
+// every lane reads them back with broadcast loads while it accumulates its channel.  (Removed in round 5, measured slower in
+// rounds 2-4: two levels per walk, two channels per lane with v_pk_fma -- twice the flush atomics, 2.07 vs 1.14 ms --, the
+// two-entry footprint cache, 512- and 1024-point segments: DESIGN.md section 10.)
 #ifndef S3G_HEX_SCATTER_WAVES
 #define S3G_HEX_SCATTER_WAVES 6
 #endif
-constexpr int SCATTER_WG_PER_CU = SCATTER_CPL == 2 ? 3 : S3G_HEX_SCATTER_WAVES;   // waves per SIMD the register budget is set for (two levels per walk: 5 = 96 VGPRs, the shift path spills, 1.57 vs 1.00 ms)
+constexpr int SCATTER_WG_PER_CU = S3G_HEX_SCATTER_WAVES;   // waves per SIMD the register budget is set for
 constexpr int TAPF = 8;  // floats per packed tap in LDS (6 used; 32-byte slots keep the 16-byte reads aligned)
-template <typename T> __device__ __forceinline__ T load_g(const float* p);
-template <> __device__ __forceinline__ float load_g<float>(const float* p) { return G_NONTEMPORAL_LOAD ? __builtin_nontemporal_load(p) : *p; }
-template <> __device__ __forceinline__ f2v load_g<f2v>(const float* p) {
-  const f2v* q = reinterpret_cast<const f2v*>(p);
-  return G_NONTEMPORAL_LOAD ? __builtin_nontemporal_load(q) : *q;
-}
-template <bool UT, typename T>   // UT: uniform time -- the (axis, t) planes are height-1 row tables
+__device__ __forceinline__ float load_g(const float* p) { return G_NONTEMPORAL_LOAD ? __builtin_nontemporal_load(p) : *p; }
+template <bool UT>   // UT: uniform time -- the (axis, t) planes are height-1 row tables
 __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_CU - 1) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
                                                                const uint32_t* __restrict__ order_all, const uint32_t* __restrict__ comp_all) {
-  constexpr int CPL = lanes_of<T>::CPL, LANES = HEXC / CPL, WALKERS = 256 / LANES;
-  constexpr int LG = SCATTER_LG;      // levels handled together: LG levels x 2 planes x 2 footprints live in registers
-  constexpr int NTAP = 2 * LG;        // taps per point and walk
+  constexpr int LANES = HEXC, WALKERS = 256 / LANES;
+  constexpr int NTAP = 2;             // taps per point and walk: the orientation's spatial plane and its (major, t) plane
   static_assert(LANES >= 4 * NTAP, "tap phase: one lane per (point of the group of four, tap)");
   __shared__ __attribute__((aligned(16))) float tapbuf[WALKERS][2][4][NTAP][TAPF];  // [walker][double buffer][point][tap]
-  // per-level orders: blockIdx.y = orientation * levels + level and the walk handles that one level in ITS order
   const int oi = blockIdx.y;
-  const int o = S3G_HEX_PER_LEVEL ? oi / a.d.levels : oi;
-  const int lbeg = S3G_HEX_PER_LEVEL ? oi % a.d.levels : 0, lend = S3G_HEX_PER_LEVEL ? lbeg + 1 : a.d.levels;
-  const int ln = threadIdx.x & (LANES - 1), hw = threadIdx.x / LANES;
-  const int c = ln * CPL;             // first channel of this lane
-  const int q = (ln / NTAP) & 3, j = ln % NTAP;  // tap-phase role: point q of the group of four, tap j = (level j >> 1, kind j & 1)
-  const bool tap_lane = ln < 4 * NTAP;
+  const int o = oi / a.d.levels, lv = oi % a.d.levels;
+  const int c = threadIdx.x & (LANES - 1), hw = threadIdx.x / LANES;   // channel of this lane, walker of this half-wave
+  const int q = (c / NTAP) & 3, j = c % NTAP;  // tap-phase role: point q of the group of four, tap j (0 spatial, 1 time plane)
+  const bool tap_lane = c < 4 * NTAP;
   const int seg = blockIdx.x * WALKERS + hw;
   const int k0 = seg * a.seg_len, k1 = min(a.P, k0 + a.seg_len);
   if (k0 >= a.P) return;  // whole walkers drop out; the LDS traffic below is private to a walker (wave-ordered)
   const uint32_t* order = order_all + (size_t)oi * a.P;
   const uint32_t* comp = comp_all + (size_t)oi * a.P;
-  const size_t GP = (size_t)((S3G_HEX_TSLAB ? 1 : 6) * a.d.levels * HEXC);   // point-major layout: floats per point
+  const size_t GP = (size_t)(a.d.levels * HEXC);   // point-major T rows: floats per point
   const int i0 = PLA[o], i1 = PLT[o];
-  const int ip = (j & 1) ? i1 : i0;                   // the plane of this lane's tap
+  const int ip = j ? i1 : i0;                         // the plane of this lane's tap
   const int axw = PAIR0[ip], axh = PAIR1[ip];
-  for (int l0 = lbeg; l0 < lend; l0 += LG) {
-    Foot2T<T> ft[SCATTER_ONE_ENTRY ? 1 : LG][SCATTER_ONE_ENTRY ? 1 : 2];
-    Foot1 f1[SCATTER_ONE_ENTRY ? LG : 1][2];
-    if constexpr (SCATTER_ONE_ENTRY) {
-#pragma unroll
-      for (int l = 0; l < LG; l++)
-#pragma unroll
-        for (int m = 0; m < 2; m++) foot1_init(f1[l][m]);
-    } else {
-#pragma unroll
-      for (int l = 0; l < LG; l++)
-#pragma unroll
-        for (int m = 0; m < 2; m++) foot2_init(ft[l][m]);
-    }
-    const int lt = l0 + (j >> 1);                     // level of this lane's tap
-    const bool tap_on = lt < a.d.levels;
-    const int Wt = tap_on ? a.d.res[lt][axw] : 2, Ht = tap_on ? a.d.res[lt][axh] : 2;
-    // Three-stage software pipeline per lane role (point q of a group, tap j): the sorted index of group g+2, the
-    // coordinates of group g+1 and the taps of group g+1 are produced while group g is accumulated, so neither the
-    // index -> position load chain nor the tap arithmetic sits between a group's G loads and their use.
-    auto load_index = [&](int kb) { return (int)order[min(kb + q, k1 - 1)]; };
-    auto load_coords = [&](int p, float* u) { point_coords(a, p, u); };
-    auto store_taps = [&](const float* u, int buf) {
-      const Tap t = make_tap(u[axw], u[axh], Wt, Ht);
-      float4 lo;
-      lo.x = __int_as_float(t.o00);
-      lo.y = __int_as_float((t.o01 >= 0 ? 1 : 0) | (t.o10 >= 0 ? 2 : 0));
-      lo.z = t.w00;
-      lo.w = t.w01;
-      if (tap_lane) {
-        float* dst = &tapbuf[hw][buf][q][j][0];
-        *reinterpret_cast<float4*>(dst) = lo;
-        *reinterpret_cast<float2*>(dst + 4) = make_float2(t.w10, t.w11);
-      }
-    };
-    float un[4];                       // coordinates of the NEXT group's point
-    {
-      float u0[4];
-      load_coords(load_index(k0), u0);
-      store_taps(u0, 0);
-    }
-    load_coords(load_index(k0 + 4), un);
-    int pnn = load_index(k0 + 8);      // index of the group after next
-    // point-major G: processing positions of this group's four points, fetched a group ahead (G's addresses depend on them)
-    uint32_t cpos[4], cpos_n[4];
-#pragma unroll
-    for (int qq = 0; qq < 4; qq++) cpos[qq] = comp[min(k0 + qq, k1 - 1)];
-    int buf = 0;
-    for (int kb = k0; kb < k1; kb += 4, buf ^= 1) {
-#pragma unroll
-      for (int qq = 0; qq < 4; qq++) cpos_n[qq] = comp[min(kb + 4 + qq, k1 - 1)];
-      // 1. this group's G rows: 4 points x 2 LG rows requested at once
-      T g[4][LG][2];
-#pragma unroll
-      for (int qq = 0; qq < 4; qq++) {
-#pragma unroll
-        for (int l = 0; l < LG; l++) {
-          // unconditional (level clamped; rows exist for every plane): a load behind a uniform branch costs two branch
-          // instructions and splits the basic block the scheduler could have filled
-          const int lv = min(l0 + l, a.d.levels - 1);
-          if (S3G_HEX_TSLAB) {   // ONE row per level: T = dL/dfeature * feature; both planes of the walk divide it by their sample (step 3)
-            g[qq][l][0] = load_g<T>(G + (size_t)cpos[qq] * GP + (size_t)(lv * HEXC + c));
-          } else {
-            const float* row = G + (size_t)cpos[qq] * GP + (size_t)(((o * a.d.levels + lv) * 2) * HEXC + c);
-            g[qq][l][0] = load_g<T>(row);
-            g[qq][l][1] = load_g<T>(row + HEXC);
-          }
-        }
-      }
-#pragma unroll
-      for (int qq = 0; qq < 4; qq++) cpos[qq] = cpos_n[qq];
-      // 2. the NEXT group's taps from coordinates loaded one iteration ago; then advance the two prefetch stages
-      store_taps(un, buf ^ 1);
-      load_coords(pnn, un);
-      pnn = load_index(kb + 12);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // 3. accumulate
-      const int nq = min(4, k1 - kb);
-#pragma unroll
-      for (int qq = 0; qq < 4; qq++) {
-        if (qq >= nq) break;
-#pragma unroll
-        for (int l = 0; l < LG; l++) {
-          if (l0 + l >= a.d.levels) break;
-#pragma unroll
-          for (int m = 0; m < 2; m++) {
-            float* gp = a.gplanes[l0 + l][m ? i1 : i0];
-            if (gp == nullptr) continue;
-            const float* src = &tapbuf[hw][buf][qq][l * 2 + m][0];
-            const float4 lo = *reinterpret_cast<const float4*>(src);
-            const float2 hi = *reinterpret_cast<const float2*>(src + 4);
-            PackedTap t;
-            t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
-            t.w00 = lo.z; t.w01 = lo.w; t.w10 = hi.x; t.w11 = hi.y;
-            if constexpr (S3G_HEX_TSLAB != 0) {
-              static_assert(S3G_HEX_TSLAB == 0 || CPL == 1, "the T-slab walk is written for one channel per lane");
-              const float* pl = a.d.planes[l0 + l][m ? i1 : i0] + c;
-              const int Wm = a.d.res[l0 + l][PAIR0[m ? i1 : i0]];
-              if constexpr (SCATTER_ONE_ENTRY) {
-                if (UT && m == 1) foot1_add_t<true>(f1[l][m], t, lanes_of<T>::first(g[qq][l][0]), gp, pl, Wm, c);
-                else foot1_add_t<false>(f1[l][m], t, lanes_of<T>::first(g[qq][l][0]), gp, pl, Wm, c);
-              } else {
-                if (UT && m == 1) foot2_add_t<true>(ft[l][m], t, lanes_of<T>::first(g[qq][l][0]), gp, pl, Wm, c);
-                else foot2_add_t<false>(ft[l][m], t, lanes_of<T>::first(g[qq][l][0]), gp, pl, Wm, c);
-              }
-            } else {
-              if (UT && m == 1) foot2_add<true>(ft[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[i1]], c);
-              else foot2_add<false>(ft[l][m], t, g[qq][l][m], gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
-            }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int l = 0; l < LG; l++) {
-      if (l0 + l >= a.d.levels) break;
-#pragma unroll
-      for (int m = 0; m < 2; m++) {
-        float* gp = a.gplanes[l0 + l][m ? i1 : i0];
-        if (gp == nullptr) continue;
-        const int W = a.d.res[l0 + l][PAIR0[m ? i1 : i0]];
-        if constexpr (SCATTER_ONE_ENTRY) {
-          if (UT && m == 1) foot1_flush_all<true>(f1[l][m], gp, W, c);
-          else foot1_flush_all<false>(f1[l][m], gp, W, c);
-        } else {
-          if constexpr (S3G_HEX_TSLAB != 0 && CPL == 1) foot2_unpack_t(ft[l][m]);
-          if (UT && m == 1) foot2_flush_all<true>(ft[l][m], gp, W, c);
-          else foot2_flush_all<false>(ft[l][m], gp, W, c);
-        }
-      }
-    }
-  }
-}
-
-// =========================================================================================================================
-// Backward WITHOUT the per-plane gradient slab ("walk" kernel).
-//
-// dL/ds_i = g * prod_{j != i} s_j.  The product over ALL six samples is the forward's output feature f = prod_j s_j, which
-// is still in memory (it is the MLP's saved input), so with R = g * f
-//                                   dL/ds_i = R / s_i
-// needs only the ONE sample the pass is about to scatter anyway -- and in the sorted order of orientation o the texels of its
-// spatial plane and of its time table are exactly the footprint the walk is accumulating (L1-resident).  The same texels give
-// ds/d(ix), ds/d(iy), hence this orientation's share of dL/dxyz.  So each of the three orientation walks reads, per point and
-// level, two 128-byte rows by index (g, f) and six local texels, and the per-point pass that wrote 3 KB of dL/ds per point
-// (and this pass reading them back: 7.4 GB per iteration) is gone, together with its 72 non-local texel gathers per point.
-//
-// Division safety: R / s_i is exact to ~2 ulp when |s_i| is a normal number of ordinary size.  If ANY channel of a point's
-// sample is tiny, zero or not finite (|s| <= 1e-18 -- a plane region that is exactly zero, say) the walk contributes NOTHING
-// for that (point, level, plane) and sets a bit in a per-(orientation, point) mask; hexplane_backward_fixup_kernel then forms
-// the product of the OTHER five samples from their texels for exactly those entries (20 non-local gathers and direct atomics
-// each -- slow but exact), so the result is defined for every input the reference accepts.  With no bit set the fix-up pass
-// reads 6 bytes per point and returns.
-// =========================================================================================================================
-constexpr int WALK_LG = 2;          // levels per walk of a segment
-constexpr int WALK_WG_PER_CU = 3;   // waves per SIMD the register budget is set for
-constexpr float WALK_SAFE = 1e-18f;
-
-struct WalkTap {  // 6 floats in LDS: nw texel offset, flags (bit0 ne/se column in range, bit1 sw/se row in range, bit2 d(ix)/du
-  int key, flags;  // != 0, bit3 d(iy)/du != 0), 1-D weights x1-ix, ix-x0, y1-iy, iy-y0
-  float wx0, wx1, wy0, wy1;
-};
-__device__ __forceinline__ WalkTap walk_tap_read(const float* src) {
-  const float4 lo = *reinterpret_cast<const float4*>(src);
-  const float2 hi = *reinterpret_cast<const float2*>(src + 4);
-  WalkTap t;
-  t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
-  t.wx0 = lo.z; t.wx1 = lo.w; t.wy0 = hi.x; t.wy1 = hi.y;
-  return t;
-}
-__global__ void __launch_bounds__(256, WALK_WG_PER_CU)
-hexplane_backward_walk_kernel(const HexArgs a, const float* __restrict__ feat, const uint32_t* __restrict__ order_all,
-                              float* __restrict__ dup /* [3][P][2] partial dL/du per orientation */,
-                              uint16_t* __restrict__ badmask /* [3][P], zero-filled: bit 2*level + kind */,
-                              int order_stride, int order_offset /* order of orientation o = order_all[o * stride + offset] */) {
-  constexpr int LG = WALK_LG;
-  __shared__ __attribute__((aligned(16))) float tapbuf[8][2][4][8][TAPF];  // [half-wave][double buffer][point][tap]
-  // g / f rows of a group of four points, DMA-copied global -> LDS one group ahead (no registers held across the wait):
-  // [wave][double buffer][point][level][g | f][64 lanes = the two half-waves' rows side by side]
-  __shared__ __attribute__((aligned(16))) float rowbuf[4][2][4][LG][2][64];
-  const int o = blockIdx.y;
-  const int c = threadIdx.x & 31, hw = threadIdx.x >> 5, wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
-  const int half_base = threadIdx.x & 32;  // first lane of this half-wave inside its wave
-  const int q = c >> 3, j = c & 7;  // tap-phase role: point q of the group of four, tap j = (level j >> 1, kind j & 1)
-  const int seg = blockIdx.x * 8 + hw;
-  const int k0 = seg * a.seg_len, k1 = min(a.P, k0 + a.seg_len);
-  if (k0 >= a.P) return;  // whole half-waves drop out; LDS traffic and shuffles below stay inside a half-wave
-  const uint32_t* order = order_all + (size_t)(o * order_stride + order_offset) * a.P;
-  const int F = a.d.levels * HEXC;
-  const int i0 = PLA[o], i1 = PLT[o];
-  const int ip = (j & 1) ? i1 : i0;                   // the plane of this lane's tap
-  const int axw = PAIR0[ip], axh = PAIR1[ip];
-  // dL/du slots of this orientation: slot 0 = axis PAIR0[i0], slot 1 = axis PAIR1[i0]; the time table's spatial axis
-  // (PAIR0[i1] = the major axis o) is one of the two
-  const bool table_in_slot0 = PAIR0[i1] == PAIR0[i0];
-  for (int l0 = 0; l0 < a.d.levels; l0 += LG) {
-    Foot2 ft[LG][2];
-#pragma unroll
-    for (int l = 0; l < LG; l++)
-#pragma unroll
-      for (int m = 0; m < 2; m++) foot2_init(ft[l][m]);
-    const int lt = l0 + (j >> 1);                     // level of this lane's tap
-    const bool tap_on = (j >> 1) < LG && lt < a.d.levels;
-    const int Wt = tap_on ? a.d.res[lt][axw] : 2, Ht = tap_on ? a.d.res[lt][axh] : 2;
-    auto load_index = [&](int kb) { return (int)order[min(kb + q, k1 - 1)]; };
-    auto store_taps = [&](const float* u, int buf) {
-      const Tap t = make_tap(u[axw], u[axh], Wt, Ht);
-      float4 lo;
-      lo.x = __int_as_float(t.o00);
-      lo.y = __int_as_float((t.o01 >= 0 ? 1 : 0) | (t.o10 >= 0 ? 2 : 0) | (t.mx != 0.f ? 4 : 0) | (t.my != 0.f ? 8 : 0));
-      lo.z = t.x1f - t.ix;
-      lo.w = t.ix - t.x0f;
+  Foot1 f1[2];
+  foot1_init(f1[0]);
+  foot1_init(f1[1]);
+  const int Wt = a.d.res[lv][axw], Ht = a.d.res[lv][axh];
+  // Three-stage software pipeline per lane role (point q of a group, tap j): the sorted index of group g+2, the
+  // coordinates of group g+1 and the taps of group g+1 are produced while group g is accumulated, so neither the
+  // index -> position load chain nor the tap arithmetic sits between a group's T loads and their use.
+  auto load_index = [&](int kb) { return (int)order[min(kb + q, k1 - 1)]; };
+  auto load_coords = [&](int p, float* u) { point_coords(a, p, u); };
+  auto store_taps = [&](const float* u, int buf) {
+    const Tap t = make_tap(u[axw], u[axh], Wt, Ht);
+    float4 lo;
+    lo.x = __int_as_float(t.o00);
+    lo.y = __int_as_float((t.o01 >= 0 ? 1 : 0) | (t.o10 >= 0 ? 2 : 0));
+    lo.z = t.w00;
+    lo.w = t.w01;
+    if (tap_lane) {
       float* dst = &tapbuf[hw][buf][q][j][0];
       *reinterpret_cast<float4*>(dst) = lo;
-      *reinterpret_cast<float2*>(dst + 4) = make_float2(t.y1f - t.iy, t.iy - t.y0f);
-    };
-    // rows of the group whose role lanes hold `pidx`: 4 points x LG levels x {g, f}, one 4-byte DMA per lane and row
-    auto dma_rows = [&](int pidx, int buf) {
-#pragma unroll
-      for (int qq = 0; qq < 4; qq++) {
-        const size_t prow = (size_t)__shfl(pidx, half_base + 8 * qq) * F + c;
-#pragma unroll
-        for (int l = 0; l < LG; l++) {
-          const size_t off = prow + min(l0 + l, a.d.levels - 1) * HEXC;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.gfeat + off),
-                                           (__attribute__((address_space(3))) void*)&rowbuf[wave][buf][qq][l][0][0], 4, 0, 0);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(feat + off),
-                                           (__attribute__((address_space(3))) void*)&rowbuf[wave][buf][qq][l][1][0], 4, 0, 0);
-        }
-      }
-    };
-    // the eight texels (plane a: nw ne sw se, table t: nw ne sw se) of point qq for every level of the group; corners out of
-    // range have weight 0 (the clip puts ix on the last column / row), their offsets are clamped to the nw texel
-    auto load_texels = [&](int buf, int qq, float (&v)[LG][8]) {
-#pragma unroll
-      for (int l = 0; l < LG; l++) {
-        const int lv = min(l0 + l, a.d.levels - 1);
-        const float2 ka = *reinterpret_cast<const float2*>(&tapbuf[hw][buf][qq][l * 2 + 0][0]);
-        const float2 kt = *reinterpret_cast<const float2*>(&tapbuf[hw][buf][qq][l * 2 + 1][0]);
-        const int keya = __float_as_int(ka.x), fla = __float_as_int(ka.y), keyt = __float_as_int(kt.x), flt = __float_as_int(kt.y);
-        // uniform base pointer + 32-bit BYTE offset per lane (scalar-base addressing, no 64-bit address arithmetic)
-        const char* pa = reinterpret_cast<const char*>(a.d.planes[lv][i0]);
-        const char* pt = reinterpret_cast<const char*>(a.d.planes[lv][i1]);
-        const uint32_t Wa = (uint32_t)a.d.res[lv][PAIR0[i0]], Wtt = (uint32_t)a.d.res[lv][PAIR0[i1]];
-        const uint32_t ka0 = ((uint32_t)keya * HEXC + (uint32_t)c) * 4u, kt0 = ((uint32_t)keyt * HEXC + (uint32_t)c) * 4u;
-        const uint32_t ax1 = (fla & 1) ? HEXC * 4u : 0u, ay1 = (fla & 2) ? Wa * (HEXC * 4u) : 0u;
-        const uint32_t tx1 = (flt & 1) ? HEXC * 4u : 0u, ty1 = (flt & 2) ? Wtt * (HEXC * 4u) : 0u;
-        auto ld = [](const char* b, uint32_t off) { return *reinterpret_cast<const float*>(b + off); };
-        v[l][0] = ld(pa, ka0); v[l][1] = ld(pa, ka0 + ax1); v[l][2] = ld(pa, ka0 + ay1); v[l][3] = ld(pa, ka0 + ax1 + ay1);
-        v[l][4] = ld(pt, kt0); v[l][5] = ld(pt, kt0 + tx1); v[l][6] = ld(pt, kt0 + ty1); v[l][7] = ld(pt, kt0 + tx1 + ty1);
-      }
-    };
-    // three-stage pipeline per lane role: index of group g+2; coordinates, taps and g / f rows of group g+1; accumulation of g
-    int pc = load_index(k0), pn, pnn;
-    float un[4];
-    {
-      float u0[4];
-      point_coords(a, pc, u0);
-      store_taps(u0, 0);
+      *reinterpret_cast<float2*>(dst + 4) = make_float2(t.w10, t.w11);
     }
-    dma_rows(pc, 0);
-    pn = load_index(k0 + 4);
-    point_coords(a, pn, un);
-    pnn = load_index(k0 + 8);
-    int buf = 0;
-    for (int kb = k0; kb < k1; kb += 4, buf ^= 1) {
-      // 0. the rows of THIS group (requested one iteration ago) have landed once every outstanding memory operation has
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // 1. next group: rows by DMA, taps from the coordinates loaded one iteration ago; advance the prefetch stages
-      dma_rows(pn, buf ^ 1);
-      store_taps(un, buf ^ 1);
-      const int pc_next = pn;
-      pn = pnn;
-      point_coords(a, pn, un);
-      pnn = load_index(kb + 12);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // 2. point by point (a rolled loop: one copy of the body); the texels of the next point are in flight while the
-      //    current one is worked on
-      const int nq = min(4, k1 - kb);
-      float vc[LG][8], vn[LG][8];
-      load_texels(buf, 0, vc);
-#pragma unroll 1
-      for (int qq = 0; qq < nq; qq++) {
-        load_texels(buf, min(qq + 1, 3), vn);
-        const int pthis = __shfl(pc, half_base + 8 * qq);
-        float du0 = 0.f, du1 = 0.f;
-        uint32_t badbits = 0;
+  };
+  float un[4];                       // coordinates of the NEXT group's point
+  {
+    float u0[4];
+    load_coords(load_index(k0), u0);
+    store_taps(u0, 0);
+  }
+  load_coords(load_index(k0 + 4), un);
+  int pnn = load_index(k0 + 8);      // index of the group after next
+  // processing positions of this group's four points, fetched a group ahead (the T rows' addresses depend on them)
+  uint32_t cpos[4], cpos_n[4];
 #pragma unroll
-        for (int l = 0; l < LG; l++) {
-          if (l0 + l >= a.d.levels) break;
-          const int lv = l0 + l;
-          const WalkTap ta = walk_tap_read(&tapbuf[hw][buf][qq][l * 2 + 0][0]);
-          const WalkTap tt = walk_tap_read(&tapbuf[hw][buf][qq][l * 2 + 1][0]);
-          const int Wa = a.d.res[lv][PAIR0[i0]], Wtt = a.d.res[lv][PAIR0[i1]];
-          const float a00 = vc[l][0], a01 = vc[l][1], a10 = vc[l][2], a11 = vc[l][3];
-          const float t00 = vc[l][4], t01 = vc[l][5], t10 = vc[l][6], t11 = vc[l][7];
-          PackedTap fa, fb;
-          fa.key = ta.key; fa.flags = ta.flags & 3;
-          fa.w00 = ta.wx0 * ta.wy0; fa.w01 = ta.wx1 * ta.wy0; fa.w10 = ta.wx0 * ta.wy1; fa.w11 = ta.wx1 * ta.wy1;
-          fb.key = tt.key; fb.flags = tt.flags & 3;
-          fb.w00 = tt.wx0 * tt.wy0; fb.w01 = tt.wx1 * tt.wy0; fb.w10 = tt.wx0 * tt.wy1; fb.w11 = tt.wx1 * tt.wy1;
-          float sa = a00 * fa.w00; sa = sa + a01 * fa.w01; sa = sa + a10 * fa.w10; sa = sa + a11 * fa.w11;
-          float st = t00 * fb.w00; st = st + t01 * fb.w01; st = st + t10 * fb.w10; st = st + t11 * fb.w11;
-          const float g = rowbuf[wave][buf][qq][l][0][lane64], R = g * rowbuf[wave][buf][qq][l][1][lane64];
-          float ga = R * __builtin_amdgcn_rcpf(sa), gt = R * __builtin_amdgcn_rcpf(st);
-          const bool bad_a = !(fabsf(sa) > WALK_SAFE) || !(fabsf(sa) < 1e18f);
-          const bool bad_t = !(fabsf(st) > WALK_SAFE) || !(fabsf(st) < 1e18f);
-          if ((__ballot(bad_a || bad_t) >> half_base) & 0xffffffffull) {   // any channel of THIS half-wave: leave it to the fix-up
-            if ((__ballot(bad_a) >> half_base) & 0xffffffffull) { ga = 0.f; badbits |= 1u << (2 * lv); }
-            if ((__ballot(bad_t) >> half_base) & 0xffffffffull) { gt = 0.f; badbits |= 2u << (2 * lv); }
-          }
-          // this orientation's share of dL/du: ds/dix = (ne - nw)(y1 - iy) + (se - sw)(iy - y0), ds/diy likewise
-          const float dXa = (a01 - a00) * ta.wy0 + (a11 - a10) * ta.wy1;
-          const float dYa = (a10 - a00) * ta.wx0 + (a11 - a01) * ta.wx1;
-          const float dXt = (t01 - t00) * tt.wy0 + (t11 - t10) * tt.wy1;
-          const float mxa = (ta.flags & 4) ? (float)(Wa - 1) / 2.f : 0.f;
-          const float mya = (ta.flags & 8) ? (float)(a.d.res[lv][PAIR1[i0]] - 1) / 2.f : 0.f;
-          const float mxt = (tt.flags & 4) ? (float)(Wtt - 1) / 2.f : 0.f;
-          const float tterm = mxt * (dXt * gt);
-          du0 += mxa * (dXa * ga) + (table_in_slot0 ? tterm : 0.f);
-          du1 += mya * (dYa * ga) + (table_in_slot0 ? 0.f : tterm);
-          float* gpa = a.gplanes[lv][i0];
-          float* gpt = a.gplanes[lv][i1];
-          if (gpa != nullptr) foot2_add(ft[l][0], fa, ga, gpa, Wa, c);
-          if (gpt != nullptr) foot2_add(ft[l][1], fb, gt, gpt, Wtt, c);
-        }
-        // dL/du: sum over the 32 channels; lanes 0 and 1 add slots 0 and 1 to this orientation's partials
-        for (int off = 16; off >= 1; off >>= 1) {
-          du0 += __shfl_xor(du0, off);
-          du1 += __shfl_xor(du1, off);
-        }
-        if (c < 2) {
-          float* dst = dup + ((size_t)o * a.P + pthis) * 2 + c;
-          *dst = (l0 == 0 ? 0.f : *dst) + (c == 0 ? du0 : du1);   // the same half-wave revisits the point in the next level group
-        }
-        if (badbits != 0 && c == 0) badmask[(size_t)o * a.P + pthis] |= (uint16_t)badbits;
+  for (int qq = 0; qq < 4; qq++) cpos[qq] = comp[min(k0 + qq, k1 - 1)];
+  int buf = 0;
+  for (int kb = k0; kb < k1; kb += 4, buf ^= 1) {
 #pragma unroll
-        for (int l = 0; l < LG; l++)
+    for (int qq = 0; qq < 4; qq++) cpos_n[qq] = comp[min(kb + 4 + qq, k1 - 1)];
+    // 1. this group's T rows (ONE row per point and level: T = dL/dfeature * feature; both planes of the walk divide it by their sample)
+    float g[4];
 #pragma unroll
-          for (int k = 0; k < 8; k++) vc[l][k] = vn[l][k];
-      }
-      pc = pc_next;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (clamped) prefetch must not land in a buffer the next level group reuses
+    for (int qq = 0; qq < 4; qq++) g[qq] = load_g(G + (size_t)cpos[qq] * GP + (size_t)(lv * HEXC + c));
 #pragma unroll
-    for (int l = 0; l < LG; l++) {
-      if (l0 + l >= a.d.levels) break;
+    for (int qq = 0; qq < 4; qq++) cpos[qq] = cpos_n[qq];
+    // 2. the NEXT group's taps from coordinates loaded one iteration ago; then advance the two prefetch stages
+    store_taps(un, buf ^ 1);
+    load_coords(pnn, un);
+    pnn = load_index(kb + 12);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // 3. accumulate
+    const int nq = min(4, k1 - kb);
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) {
+      if (qq >= nq) break;
 #pragma unroll
       for (int m = 0; m < 2; m++) {
-        float* gp = a.gplanes[l0 + l][m ? i1 : i0];
+        float* gp = a.gplanes[lv][m ? i1 : i0];
         if (gp == nullptr) continue;
-        foot2_flush_all(ft[l][m], gp, a.d.res[l0 + l][PAIR0[m ? i1 : i0]], c);
+        const float* src = &tapbuf[hw][buf][qq][m][0];
+        const float4 lo = *reinterpret_cast<const float4*>(src);
+        const float2 hi = *reinterpret_cast<const float2*>(src + 4);
+        PackedTap t;
+        t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
+        t.w00 = lo.z; t.w01 = lo.w; t.w10 = hi.x; t.w11 = hi.y;
+        const float* pl = a.d.planes[lv][m ? i1 : i0] + c;
+        const int Wm = a.d.res[lv][PAIR0[m ? i1 : i0]];
+        if (UT && m == 1) foot1_add_t<true>(f1[m], t, g[qq], gp, pl, Wm, c);
+        else foot1_add_t<false>(f1[m], t, g[qq], gp, pl, Wm, c);
       }
     }
   }
-}
-
-// Exact contributions of the (orientation, point, level, plane) entries the walk skipped.  One half-wave per flagged
-// (orientation, point); lanes = channels; direct atomics (the entries are rare by construction).
-__global__ void __launch_bounds__(256) hexplane_backward_fixup_kernel(const HexArgs a, const uint16_t* __restrict__ badmask,
-                                                                      float* __restrict__ dup) {
-  const int o = blockIdx.y, c = threadIdx.x & 31;
-  const int F = a.d.levels * HEXC;
-  const bool table_in_slot0 = PAIR0[PLT[o]] == PAIR0[PLA[o]];
-  for (int p = blockIdx.x * 8 + (threadIdx.x >> 5); p < a.P; p += gridDim.x * 8) {
-    const uint32_t bits = badmask[(size_t)o * a.P + p];
-    if (bits == 0) continue;   // uniform inside the half-wave
-    float u[4];
-    point_coords(a, p, u);
-    float du0 = 0.f, du1 = 0.f;
-    for (int l = 0; l < a.d.levels; l++)
-      for (int m = 0; m < 2; m++) {
-        if (!((bits >> (2 * l + m)) & 1u)) continue;
-        const int i = m ? PLT[o] : PLA[o];
-        // g * prod_{j != i} s_j in autograd's order: prefix product left to right, suffix factors from the right
-        float pre = 1.f, suf = a.gfeat[(size_t)p * F + l * HEXC + c];
-        for (int k = 5; k > i; k--) suf = suf * walk_sample(a, l, k, u, c);
-        for (int k = 0; k < i; k++) pre = pre * walk_sample(a, l, k, u, c);
-        const float gi = suf * pre;
-        const int W = a.d.res[l][PAIR0[i]], H = a.d.res[l][PAIR1[i]];
-        const Tap t = make_tap(u[PAIR0[i]], u[PAIR1[i]], W, H);
-        const float* pl = a.d.planes[l][i];
-        const float v00 = fetch(pl, t.o00, c), v01 = fetch(pl, t.o01, c), v10 = fetch(pl, t.o10, c), v11 = fetch(pl, t.o11, c);
-        const float dX = (v01 - v00) * (t.y1f - t.iy) + (v11 - v10) * (t.iy - t.y0f);
-        const float dY = (v10 - v00) * (t.x1f - t.ix) + (v11 - v01) * (t.ix - t.x0f);
-        if (m == 0) {
-          du0 += t.mx * (dX * gi);
-          du1 += t.my * (dY * gi);
-        } else {
-          (table_in_slot0 ? du0 : du1) += t.mx * (dX * gi);
-        }
-        float* gp = a.gplanes[l][i];
-        if (gp != nullptr) {
-          atomicAdd(&gp[(size_t)t.o00 * HEXC + c], gi * t.w00);
-          if (t.o01 >= 0) atomicAdd(&gp[(size_t)t.o01 * HEXC + c], gi * t.w01);
-          if (t.o10 >= 0) atomicAdd(&gp[(size_t)t.o10 * HEXC + c], gi * t.w10);
-          if (t.o11 >= 0) atomicAdd(&gp[(size_t)t.o11 * HEXC + c], gi * t.w11);
-        }
-      }
-    for (int off = 16; off >= 1; off >>= 1) {
-      du0 += __shfl_xor(du0, off);
-      du1 += __shfl_xor(du1, off);
-    }
-    if (c < 2) dup[((size_t)o * a.P + p) * 2 + c] += c == 0 ? du0 : du1;
-  }
-}
-
-// dL/dxyz = (sum of the orientations' shares) * d(u)/d(xyz): axis 0 <- (o0, slot0) + (o2, slot0), axis 1 <- (o0, slot1) +
-// (o1, slot0), axis 2 <- (o1, slot1) + (o2, slot1)
-__global__ void __launch_bounds__(256) hexplane_dxyz_kernel(const HexArgs a, const float* __restrict__ dup) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= a.P) return;
-  const size_t P = (size_t)a.P;
-  const float2 d0 = reinterpret_cast<const float2*>(dup)[p], d1 = reinterpret_cast<const float2*>(dup)[P + p];
-  const float2 d2 = reinterpret_cast<const float2*>(dup)[2 * P + p];
-  const float du[3] = {d0.x + d2.x, d0.y + d1.x, d1.y + d2.y};
 #pragma unroll
-  for (int k = 0; k < 3; k++) a.gxyz[3 * (size_t)p + k] = du[k] * (2.0f / (a.d.aabb_min[k] - a.d.aabb_max[k]));
+  for (int m = 0; m < 2; m++) {
+    float* gp = a.gplanes[lv][m ? i1 : i0];
+    if (gp == nullptr) continue;
+    const int W = a.d.res[lv][PAIR0[m ? i1 : i0]];
+    if (UT && m == 1) foot1_flush_all<true>(f1[m], gp, W, c);
+    else foot1_flush_all<false>(f1[m], gp, W, c);
+  }
 }
 
 }  // namespace s3g
@@ -1414,10 +869,9 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
   return S3G_OK;
 }
 
-static void carve_backward(Carver& c, const s3g_hexplane_desc* d, int P, bool walk, float** G, float** tables, SortWork* w,
-                           float** dup, uint16_t** badmask) {
+static void carve_backward(Carver& c, const s3g_hexplane_desc* d, int P, float** G, float** tables, SortWork* w) {
   const size_t n = (size_t)P;
-  float* g = walk ? nullptr : c.take<float>((size_t)d->levels * (S3G_HEX_TSLAB ? 1 : 6) * n * HEXC);   // slab path: T rows (r3) / per-plane gradient rows
+  float* g = c.take<float>((size_t)d->levels * n * HEXC);   // the T rows: one 128-byte row per point and level
   float* tb = d->uniform_time ? c.take<float>(2 * time_table_floats(d)) : nullptr;
   SortWork s;
   const size_t NO = (size_t)n_orders(d->levels), NW = (size_t)n_walk_orders(d->levels);
@@ -1428,17 +882,13 @@ static void carve_backward(Carver& c, const s3g_hexplane_desc* d, int P, bool wa
   s.order = c.take<uint32_t>(NW * n);
   s.comp = c.take<uint32_t>(NW * n);
   s.proc = c.take<uint32_t>(n);
-  float* du = walk ? c.take<float>(6 * n) : nullptr;
-  uint16_t* bm = walk ? c.take<uint16_t>(3 * n) : nullptr;
   if (G) *G = g;
   if (tables) *tables = tb;
   if (w) *w = s;
-  if (dup) *dup = du;
-  if (badmask) *badmask = bm;
 }
 
 // 128-byte rows of scratch the default (slab) backward writes per point and level set: bench.py prices the implementation bytes
-extern "C" int s3g_hexplane_backward_scratch_rows(int levels) { return (S3G_HEX_TSLAB ? 1 : 6) * levels; }
+extern "C" int s3g_hexplane_backward_scratch_rows(int levels) { return levels; }
 
 // 32-bit words per point of the caller-kept `sort_state`: the walk orders, their compositions with the processing order, and the
 // processing order itself (round 4: one walk order per orientation AND level, 6 * levels + 1; rounds 1-3: 7)
@@ -1447,7 +897,8 @@ extern "C" int s3g_hexplane_sort_state_words(int levels) { return 2 * n_walk_ord
 extern "C" size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc* d, int P, int have_features) {
   if (!d || d->levels < 1 || d->levels > S3G_HEX_MAX_LEVELS || P < 0) return 0;
   Carver c(nullptr);
-  carve_backward(c, d, P, have_features != 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+  (void)have_features;   // (until round 5 the slab-free "walk" algorithm had a different, smaller layout)
+  carve_backward(c, d, P, nullptr, nullptr, nullptr);
   return c.bytes();
 }
 
@@ -1460,7 +911,7 @@ extern "C" int s3g_hexplane_backward(const s3g_hexplane_desc* d, int P, const fl
                                      const float* dL_dfeatures, const float* features, float* dL_dxyz,
                                      float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* workspace,
                                      uint32_t* sort_state, int sort_reuse, void* stream_) {
-  return hexplane_backward_impl(d, P, xyz, time, dL_dfeatures, features, features ? S3G_HEX_WALK : S3G_HEX_SLAB, dL_dxyz,
+  return hexplane_backward_impl(d, P, xyz, time, dL_dfeatures, features, features ? S3G_HEX_SLAB_DIV : S3G_HEX_SLAB, dL_dxyz,
                                 dL_dplanes, workspace, sort_state, sort_reuse, stream_);
 }
 
@@ -1468,7 +919,11 @@ extern "C" int s3g_hexplane_backward_algo(const s3g_hexplane_desc* d, int P, con
                                           const float* dL_dfeatures, const float* features, int algorithm, float* dL_dxyz,
                                           float* const dL_dplanes[S3G_HEX_MAX_LEVELS][6], void* workspace,
                                           uint32_t* sort_state, int sort_reuse, void* stream_) {
-  if (algorithm != S3G_HEX_SLAB && algorithm != S3G_HEX_WALK && algorithm != S3G_HEX_SLAB_DIV) {
+  if (algorithm == S3G_HEX_WALK) {
+    set_error("s3g_hexplane_backward_algo: the slab-free walk (algorithm %d) was removed in ABI 12; use S3G_HEX_SLAB_DIV or S3G_HEX_SLAB", algorithm);
+    return S3G_ERR_INVALID_ARG;
+  }
+  if (algorithm != S3G_HEX_SLAB && algorithm != S3G_HEX_SLAB_DIV) {
     set_error("s3g_hexplane_backward_algo: unknown algorithm %d", algorithm);
     return S3G_ERR_INVALID_ARG;
   }
@@ -1492,17 +947,15 @@ static int hexplane_backward_impl(const s3g_hexplane_desc* d, int P, const float
   }
   if (P == 0) return S3G_OK;
   hipStream_t stream = (hipStream_t)stream_;
-  const bool walk = algorithm == S3G_HEX_WALK;
   HexArgs a;
   memset(&a, 0, sizeof a);
   a.d = *d; a.P = P; a.xyz = xyz; a.time = time; a.gfeat = dL_dfeatures; a.gxyz = dL_dxyz;
   for (int l = 0; l < d->levels; l++)
     for (int i = 0; i < 6; i++) a.gplanes[l][i] = dL_dplanes[l][i];
   Carver c(workspace);
-  float *G, *tables, *dup;
-  uint16_t* badmask;
+  float *G, *tables;
   SortWork w;
-  carve_backward(c, d, P, walk, &G, &tables, &w, &dup, &badmask);
+  carve_backward(c, d, P, &G, &tables, &w);
   const int NO = n_orders(d->levels), NW = n_walk_orders(d->levels);
   if (sort_state) {  // caller-owned, persistent: s3g_hexplane_sort_state_words(levels) * P words
     w.order = sort_state;
@@ -1531,24 +984,14 @@ static int hexplane_backward_impl(const s3g_hexplane_desc* d, int P, const float
   }
   a.seg_len = segment_length(P);
   const int nseg = (P + a.seg_len - 1) / a.seg_len;
-  if (walk) {
-    // 2. one walk per orientation over the sorted points: dL/ds = g f / s from local texels (no per-plane gradient slab),
-    //    then the rare exact fix-ups and the assembly of dL/dxyz
-    S3G_HIP_CHECK(hipMemsetAsync(badmask, 0, (size_t)3 * P * sizeof(uint16_t), stream));
-    profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
-    hipLaunchKernelGGL(hexplane_backward_walk_kernel, dim3((nseg + 7) / 8, 3), dim3(256), 0, stream, a, features, w.order, dup,
-                       badmask, S3G_HEX_PER_LEVEL ? d->levels : 1, S3G_HEX_PER_LEVEL ? d->levels - 1 : 0);
-    profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
-    hipLaunchKernelGGL(hexplane_backward_fixup_kernel, dim3(min((P + 7) / 8, 2048), 3), dim3(256), 0, stream, a, badmask, dup);
-    hipLaunchKernelGGL(hexplane_dxyz_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a, dup);
-  } else {
-    // 2'. legacy: per-point pass writing dL/ds of all 24 plane-levels to G, then the scatter walk reading it back
+  {
+    // 2. per-point pass (dL/dxyz; ONE row T = dL/dfeature * feature per point and level -> G), then the scatter walks reading it back
     a.proc_order = w.proc;
     profile_begin(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream);
     constexpr int ppw = 256 / (HEXC / vec_of<PointV>::N);   // points per workgroup
     const int pblocks = (P + ppw - 1) / ppw;
     const size_t lds = (size_t)ppw * tap_stride(d->levels) * sizeof(float4);
-    if (algorithm == S3G_HEX_SLAB_DIV && S3G_HEX_TSLAB) {
+    if (algorithm == S3G_HEX_SLAB_DIV) {
       const int dblocks = (P + 31) / 32;
       const size_t dlds = (size_t)32 * tap_stride(d->levels) * sizeof(float4);
       if (d->uniform_time) hipLaunchKernelGGL(hexplane_backward_pointdiv_kernel<true>, dim3(dblocks), dim3(256), dlds, stream, a, features, G);
@@ -1559,12 +1002,11 @@ static int hexplane_backward_impl(const s3g_hexplane_desc* d, int P, const float
     profile_end(S3G_PROFILE_HEXPLANE_BACKWARD_POINT, stream, (double)P, (double)d->levels);
     S3G_HIP_CHECK(hipGetLastError());
     profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
-    using ScatterT = std::conditional<SCATTER_CPL == 2, f2v, float>::type;
-    constexpr int walkers = 256 / (HEXC / SCATTER_CPL);
+    constexpr int walkers = 256 / HEXC;
     if (d->uniform_time)
-      hipLaunchKernelGGL((hexplane_scatter_kernel<true, ScatterT>), dim3((nseg + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, G, w.order, w.comp);
+      hipLaunchKernelGGL((hexplane_scatter_kernel<true>), dim3((nseg + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, G, w.order, w.comp);
     else
-      hipLaunchKernelGGL((hexplane_scatter_kernel<false, ScatterT>), dim3((nseg + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, G, w.order, w.comp);
+      hipLaunchKernelGGL((hexplane_scatter_kernel<false>), dim3((nseg + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, G, w.order, w.comp);
     profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
   }
   if (d->uniform_time) {

@@ -967,17 +967,13 @@ __device__ __forceinline__ void row_load(float (&v)[RowSplit<W>::VEC], const flo
 // the full memory latency once per tile that way: ~9 us per tile for 1.7 us of MFMA work).  The one ragged tile at the end
 // of the array is handled separately with masked loads.
 constexpr int WG_WAVES = 8;  // waves per wgrad workgroup (one persistent workgroup per CU)
-#ifndef S3G_WGRAD_STREAM
-#define S3G_WGRAD_STREAM 0   // streaming loads for the planes a launch reads once: measured SLOWER (0.955 -> 1.01 ms, r3), kept as an A/B switch
-#endif
 #ifndef S3G_WGRAD_PAIRED
-#define S3G_WGRAD_PAIRED 2   // 2: all nine GEMMs in ONE launch; 1: five launches (GEMMs sharing an operand paired); 0: the nine launches of round 2
+#define S3G_WGRAD_PAIRED 2   // 2: all nine GEMMs in ONE launch (default); 0: the nine launches of round 2 (fallback)
 #endif
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
-// streaming operand loads in the single-GEMM launches: r2 measured them slower (1.19 -> 1.27 ms) while `hidden` was re-read by three
-// of those launches; since the paired launches (below) only D2 / P2 / S2 remain here and every plane they read is read once
-constexpr bool WGRAD_NONTEMPORAL = S3G_WGRAD_PAIRED && S3G_WGRAD_STREAM;
+// (streaming / non-temporal operand loads were measured slower in rounds 2 and 3 -- 1.19 -> 1.27 ms, 0.955 -> 1.01 ms -- and are gone)
+constexpr bool WGRAD_NONTEMPORAL = false;
 
 // raw (select-free) operand loads of a FULL tile: columns are clamped statically so lanes beyond the row's width re-read
 // valid data (their MFMA rows are discarded at the flush)
@@ -1138,14 +1134,12 @@ __global__ void __launch_bounds__(WG_WAVES * 64) mlp_wgrad_kernel(const WgradArg
   if (a.db != nullptr && threadIdx.x < GW) atomicAdd(&a.db[threadIdx.x], red[32 * GV * AW + threadIdx.x]);
 }
 
-// ---- weight gradients of GEMMs that SHARE an operand, in one launch ---------------------------------------------------------
+// ---- one GEMM of the weight-gradient set ("job") ------------------------------------------------------------------------------
 // D0 / P1 / S1 all multiply by `hidden` (P1 and S1 through a ReLU), the two K halves of feature_out share `ghid`; as nine separate
-// launches every shared plane came from HBM once per launch (4.87 GB per iteration for 0.61 GB of algorithmic input).  Here the
-// waves of a persistent workgroup are split by GEMM ("job") and the waves with the same index inside their jobs walk the SAME
-// tile sequence, so the rows of a shared plane are requested by two to three waves of one CU within the same few microseconds and
-// all but the first request hit in the L2 of that XCD (or are merged in the L1).  One code path for every job of the launch -- the
-// shapes (64 x 64, row strides, ReLU on the activation) are runtime values -- because a workgroup whose waves run eight differently
-// unrolled code paths thrashes the instruction cache (all nine GEMMs in one launch, 1.55 -> 1.93 ms).
+// launches (mlp_wgrad_kernel above, kept as the compile-time fallback S3G_WGRAD_PAIRED=0) every shared plane comes from HBM once per
+// launch: 4.87 GB per iteration for 0.61 GB of algorithmic input.  mlp_wgrad_all_kernel below runs them all in ONE launch.  (Round
+// 3's five-launch form -- GEMMs sharing an operand paired, mlp_wgrad_multi_kernel -- measured 0.97 vs 0.92 ms and was removed in
+// round 5.)
 struct WJob {
   const float* G;   // [P][64]
   const float* A;   // [P][astride], 64 columns used
@@ -1154,146 +1148,7 @@ struct WJob {
   int astride;
   float relu_lo;    // 0 = ReLU on A, -inf = none: one v_max either way
 };
-struct WMultiArgs {
-  WJob job[4];
-  int wpj;          // waves per job (workgroup = njobs * wpj waves)
-  int P;
-};
 constexpr int WM_RED = 32 * 2 * 64 + 32 * 2;   // floats of LDS per job: its 64 x 64 block + the bias sums
-
-// NT: streaming load for a plane this launch reads exactly once (evict-first in L2, so the SHARED plane's rows survive until the
-// sibling waves have asked for them)
-template <bool NT>
-__device__ __forceinline__ void wide_row(float (&v)[2], const float* __restrict__ g, int p, int stride, int i) {
-  const float* src = g + (size_t)p * stride + 2 * i;
-  if (NT && S3G_WGRAD_STREAM) {
-    const f2v x = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(src));
-    v[0] = x.x; v[1] = x.y;
-  } else {
-    const float2 x = *reinterpret_cast<const float2*>(src);
-    v[0] = x.x; v[1] = x.y;
-  }
-}
-
-template <bool G_NT, bool A_NT>
-__global__ void __launch_bounds__(WG_WAVES * 64) mlp_wgrad_multi_kernel(const WMultiArgs a) {
-  constexpr int STEPS = MT / 2;
-  extern __shared__ __attribute__((aligned(16))) float red_all[];
-  const int nw = blockDim.x >> 6;
-  for (int e = threadIdx.x; e < (nw / a.wpj) * WM_RED; e += blockDim.x) red_all[e] = 0.f;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int jidx = wave / a.wpj, wj = wave % a.wpj;
-  const WJob jb = a.job[jidx];
-  float* red = red_all + jidx * WM_RED;
-  const int i = lane & 31, k = lane >> 5;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int m = 0; m < 2; m++)
-#pragma unroll
-    for (int n = 0; n < 2; n++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
-  float bsum[2] = {0.f, 0.f};
-  const int nfull = a.P / MT;
-  const int stride = gridDim.x * a.wpj;
-  struct Set {
-    float g[STEPS][2];
-    float v[STEPS][2];
-  };
-  auto issue = [&](Set& S, int tile) {  // requires tile < nfull
-    const int p0 = tile * MT;
-#pragma unroll
-    for (int s = 0; s < STEPS; s++) {
-      wide_row<G_NT>(S.g[s], jb.G, p0 + 2 * s + k, HID, i);
-      wide_row<A_NT>(S.v[s], jb.A, p0 + 2 * s + k, jb.astride, i);
-    }
-  };
-  auto consume = [&](const Set& S) {
-#pragma unroll
-    for (int s = 0; s < STEPS; s++) {
-      const float b0 = fmaxf(S.v[s][0], jb.relu_lo), b1 = fmaxf(S.v[s][1], jb.relu_lo);
-#pragma unroll
-      for (int m = 0; m < 2; m++) {
-        bsum[m] += S.g[s][m];
-        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(S.g[s][m], b0, acc[m][0], 0, 0, 0);
-        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(S.g[s][m], b1, acc[m][1], 0, 0, 0);
-      }
-    }
-  };
-  {
-    Set A, B;   // two alternating register sets, unconditional clamped prefetch: see mlp_wgrad_kernel
-    const int t0 = blockIdx.x * a.wpj + wj;
-    const int cnt = t0 < nfull ? (nfull - t0 + stride - 1) / stride : 0;
-    const int last = nfull - 1;
-    if (cnt > 0) {
-      issue(A, t0);
-      for (int it = 0; it < cnt; it += 2) {
-        issue(B, min(t0 + (it + 1) * stride, last));
-        __builtin_amdgcn_sched_barrier(0);
-        consume(A);
-        __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 >= cnt) break;
-        issue(A, min(t0 + (it + 2) * stride, last));
-        __builtin_amdgcn_sched_barrier(0);
-        consume(B);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  if (a.P % MT != 0 && (nfull % stride) == blockIdx.x * a.wpj + wj) {   // the ragged last tile, masked loads
-    const int p0 = nfull * MT;
-#pragma unroll
-    for (int s = 0; s < STEPS; s++) {
-      const int p = p0 + 2 * s + k;
-      float ga[2] = {0.f, 0.f}, ba[2] = {0.f, 0.f};
-      if (p < a.P) {
-        wide_row<false>(ga, jb.G, p, HID, i);
-        wide_row<false>(ba, jb.A, p, jb.astride, i);
-        ba[0] = fmaxf(ba[0], jb.relu_lo); ba[1] = fmaxf(ba[1], jb.relu_lo);
-      }
-#pragma unroll
-      for (int m = 0; m < 2; m++) {
-        bsum[m] += ga[m];
-#pragma unroll
-        for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[m], ba[n], acc[m][n], 0, 0, 0);
-      }
-    }
-  }
-  // the waves of a job add their blocks into the job's LDS block one after the other (plain read-modify-writes, fixed order)
-  for (int w = 0; w < a.wpj; w++) {
-    if (wj == w) {
-#pragma unroll
-      for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) red[(2 * acc_row(r, lane) + m) * 64 + 2 * (lane & 31) + n] += acc[m][n][r];
-#pragma unroll
-      for (int m = 0; m < 2; m++) {
-        const float tot = bsum[m] + __shfl_xor(bsum[m], 32);
-        if (k == 0) red[32 * 2 * 64 + 2 * i + m] += tot;
-      }
-    }
-    __syncthreads();
-  }
-  for (int e = wj * 64 + lane; e < 64 * 64; e += a.wpj * 64)
-    atomicAdd(&jb.dW[(size_t)(e >> 6) * jb.astride + (e & 63)], red[e]);
-  if (jb.db != nullptr && wj == 0) atomicAdd(&jb.db[lane], red[32 * 2 * 64 + lane]);
-}
-
-template <bool G_NT, bool A_NT>
-static int launch_wgrad_multi(const WJob* jobs, int njobs, int P, hipStream_t stream) {
-  WMultiArgs a;
-  for (int j = 0; j < 4; j++) a.job[j] = jobs[j < njobs ? j : 0];
-  a.wpj = WG_WAVES / njobs;
-  a.P = P;
-  const int ntiles = (P + MT - 1) / MT;
-  const int blocks = min((ntiles + a.wpj - 1) / a.wpj, 256);
-  hipLaunchKernelGGL((mlp_wgrad_multi_kernel<G_NT, A_NT>), dim3(blocks), dim3(njobs * a.wpj * 64), (size_t)njobs * WM_RED * sizeof(float), stream, a);
-  S3G_HIP_CHECK(hipGetLastError());
-  return S3G_OK;
-}
 
 // ---- ALL weight gradients in one launch --------------------------------------------------------------------------------------
 // One persistent workgroup per CU, one wave per GEMM ("job"), every wave of a workgroup on the SAME tile sequence: each of the ten
@@ -1569,8 +1424,6 @@ static int mlp_set_attrs() {
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_backward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
-    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_multi_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WM_RED * 4));
-    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_multi_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WM_RED * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WM_RED * 4));
     device_setup_done(done);
   }
@@ -1628,7 +1481,7 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   profile_begin(S3G_PROFILE_MLP_WGRAD, stream);
   const size_t PS = (size_t)P * HID;
   const float NONE = -__builtin_huge_valf(), RELU = 0.f;
-  // GEMMs that share an operand run in ONE launch each (see mlp_wgrad_multi_kernel): feature_out's two K halves share ghid ...
+  // the jobs: feature_out's two K halves share ghid ...
   const WJob w0a{workspace + 4 * PS, features, gw->W0, gw->b0, FEAT, NONE}, w0b{workspace + 4 * PS, features + 64, gw->W0 + 64, nullptr, FEAT, NONE};
   // ... and D0 / P1 / S1 share `hidden` (stash plane 0); D1 fills the fourth wave pair of the workgroup
   const WJob d0{workspace + 1 * PS, stash + 0 * PS, gw->D0, gw->db0, HID, NONE}, d1{workspace + 0 * PS, stash + 3 * PS, gw->D1, gw->db1, HID, NONE};
@@ -1645,18 +1498,6 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
       const WJobX jobs[6] = {wide(w0a), wide(w0b), wide(p1), wide(s1), s2, head};
       if (int e = launch_wgrad_all(jobs, 6, P, stream)) return e;
     }
-  } else if (S3G_WGRAD_PAIRED) {
-    { const WJob jobs[2] = {w0a, w0b}; if (int e = (launch_wgrad_multi<false, true>(jobs, 2, P, stream))) return e; }   // ghid shared, feature halves read once
-    if (g_feat != nullptr) {  // NULL: the dino head received no gradient; its six parameter gradients are left untouched
-      const WJob jobs[4] = {d0, p1, s1, d1};
-      if (int e = (launch_wgrad_multi<true, false>(jobs, 4, P, stream))) return e;   // every G plane read once, `hidden` shared
-      if (int e = launch_wgrad<3, 64, false>(g_feat, stash + 4 * PS, gw->D2, gw->db2, P, stream)) return e;
-    } else {
-      const WJob jobs[2] = {p1, s1};
-      if (int e = (launch_wgrad_multi<true, false>(jobs, 2, P, stream))) return e;
-    }
-    if (int e = launch_wgrad<3, 64, false>(g_dx, stash + 1 * PS, gw->P2, gw->pb2, P, stream)) return e;
-    if (int e = launch_wgrad<48, 64, false>(g_dshs, stash + 2 * PS, gw->S2, gw->sb2, P, stream)) return e;
   } else {
   if (g_feat != nullptr) {
     if (int e = launch_wgrad<3, 64, false>(g_feat, stash + 4 * PS, gw->D2, gw->db2, P, stream)) return e;

@@ -32,16 +32,13 @@ def sort_state_words(levels: int) -> int:
     return int(L.s3g_hexplane_sort_state_words(int(levels)))
 
 
-# Backward algorithm (include/s3g_hexplane.h): "slab" (default) = the per-point pass finishes dL/dxyz and writes ONE row per point
-# and level, T = dL/dfeature * feature (512 B per point since round 3; rounds 1-2 wrote dL/d(sample) of all 24 plane-levels, 3 KB);
-# three sorted scatter walks read it back and divide by the sample they re-derive from the footprint they are accumulating
-# (2.37 ms at 1.2 M points).  "walk" = no slab and no per-point pass at all: each scatter walk forms dL/d(sample) =
-# dL/dfeature * feature / sample from the forward's output and also derives its share of dL/dxyz (30 B of scratch per point; 3.36 ms).
-# Round 4: "slab" takes T = dL/dfeature * feature from the forward's saved output and dL/d(sample_i) = T / sample_i plane by plane in
-# the per-point pass too (S3G_HEX_SLAB_DIV: the forward's register count and occupancy instead of 252 VGPRs for the product rule);
-# "slab_product" = round 3's per-point pass (S3G_HEX_SLAB).
+# Backward algorithm (include/s3g_hexplane.h): "slab" (default, S3G_HEX_SLAB_DIV) = the per-point pass takes T = dL/dfeature *
+# feature from the forward's saved output in one multiply, divides plane by plane, finishes dL/dxyz and writes ONE row per point and
+# level; twelve sorted scatter walks read it back and divide by the sample they re-derive from the footprint they are accumulating.
+# "slab_product" (S3G_HEX_SLAB) = the exact fallback that needs nothing from the forward: the same two passes with the per-point
+# pass forming dL/d(sample) by the product rule.  (The slab-free "walk" of rounds 2-4 was removed in round 5.)
 BACKWARD_MODE = os.environ.get("S3G_HEX_BACKWARD", "slab")
-_ALGORITHM = {"slab_product": 0, "walk": 1, "slab": 2}     # S3G_HEX_SLAB, S3G_HEX_WALK, S3G_HEX_SLAB_DIV (include/s3g_hexplane.h)
+_ALGORITHM = {"slab_product": 0, "slab": 2}     # S3G_HEX_SLAB, S3G_HEX_SLAB_DIV (include/s3g_hexplane.h)
 
 
 class _HexDesc(C.Structure):
@@ -179,7 +176,7 @@ class _HexPlaneSample(torch.autograd.Function):
         if BACKWARD_MODE not in _ALGORITHM:
             raise RuntimeError(f"S3G_HEX_BACKWARD must be one of {sorted(_ALGORITHM)}, got {BACKWARD_MODE!r}")
         algorithm = _ALGORITHM[BACKWARD_MODE]
-        work = torch.empty(L.s3g_hexplane_backward_workspace_bytes(C.byref(d), P, 1 if algorithm == 1 else 0), dtype=torch.uint8,
+        work = torch.empty(L.s3g_hexplane_backward_workspace_bytes(C.byref(d), P, 0), dtype=torch.uint8,
                            device=xyz_c.device)
         # the spatial walk orders live in the field's cache and are refreshed every SORT_REFRESH backward passes (or when
         # P changes): they steer the walk, not the result, and the points move slowly between iterations

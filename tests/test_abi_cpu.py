@@ -182,3 +182,14 @@ def test_mlp_arithmetic_switch_round_trips_without_a_gpu():
         mlp.set_mlp_arithmetic("f32")
     with pytest.raises(ValueError):          # the inference kernel's switch is validated before anything touches a device
         mlp.deform_infer(None, None, None, None, None, None, None, arithmetic="fp16")
+
+
+def test_removed_hexplane_algorithm_is_refused_not_remapped():
+    """ABI 12 removed the slab-free "walk" backward (S3G_HEX_WALK = 1): the entry point must say so instead of silently running
+    something else under that id (argument validation only: nothing is launched, no GPU needed)."""
+    import ctypes as C
+    from s3gaussian_amd import _lib
+    L = _lib.lib()
+    L.s3g_hexplane_backward_algo.restype = C.c_int
+    rc = L.s3g_hexplane_backward_algo(None, C.c_int(0), None, None, None, None, C.c_int(1), None, None, None, None, C.c_int(0), None)
+    assert rc == 1 and b"removed in ABI 12" in L.s3g_last_error()

@@ -1,18 +1,18 @@
-"""The two-entry footprint cache of hexplane.hip::foot2_add (hit path, evict, shift down / right), modelled statement by
+"""The walker's remembered footprint of hexplane.hip::foot1_add_t (hit path, evict, shift down / right), modelled statement by
 statement in Python: whatever sequence of bilinear taps a walker sees, the flushed sums plus the final flush must equal the
 direct scatter.  Integer-valued gradients and weights make every order of summation exact.  Test infrastructure only
-(documents why the miss path conserves every contribution; the compiled kernel is checked by tests/test_hexplane_gpu.py)."""
+(documents why the miss path conserves every contribution; the compiled kernel is checked by tests/test_hexplane_gpu.py).
+(Rounds 1-4 carried a two-entry cache with an MRU bit, foot2_add; it went with the finest-level walk orders in round 5.  The model
+below takes the gradient already divided by the sample: the division is a per-call scalar and does not touch the bookkeeping.)"""
 import numpy as np
 import pytest
 
 
-class Foot2:
+class Foot1:
     def __init__(self, W, H, row):
         self.W, self.H, self.row = W, H, row
-        self.key = [-1, -1]
-        self.fl = [0, 0]
-        self.a = [[0.0] * 4, [0.0] * 4]
-        self.mru = 0
+        self.key = -1                  # (texel index << 2 | corner flags), -1 = empty
+        self.a = [0.0] * 4
         self.out = np.zeros(W * H)
         self.atomics = 0
 
@@ -21,21 +21,19 @@ class Foot2:
         self.atomics += 1
 
     def add(self, key, flags, w, g):
-        """foot2_add<ROW>: key = nw texel, flags bit0 = ne column in range, bit1 = sw row in range, w = (w00, w01, w10, w11)."""
+        """foot1_add_t<ROW>: key = nw texel, flags bit0 = ne column in range, bit1 = sw row in range, w = (w00, w01, w10, w11)."""
         W, row = self.W, self.row
-        h = [key == self.key[0], key == self.key[1]]
-        if not (h[0] or h[1]):
-            m1 = self.mru != 0
-            mkey, mfl = self.key[m1], self.fl[m1]
-            down = (not row) and mkey >= 0 and key == mkey + W
-            right = mkey >= 0 and key == mkey + 1 and bool(mfl & 1)
+        tkf = (key << 2) | (flags & 3)
+        if tkf != self.key:
+            KF = self.key
+            K, FL = KF >> 2, KF & 3
+            down = (not row) and KF >= 0 and key == K + W
+            right = KF >= 0 and key == K + 1 and bool(FL & 1)
             shift = down or right
-            w1 = m1 if shift else (not m1)
-            K, FL = self.key[w1], self.fl[w1]
-            A = list(self.a[w1])
+            A = list(self.a)
             if row:
                 A[2] = A[3] = 0.0
-            if K >= 0:
+            if KF >= 0:
                 self._atomic(K, A[0])
                 if (FL & 1) and not right:
                     self._atomic(K + 1, A[1])
@@ -43,30 +41,26 @@ class Foot2:
                     self._atomic(K + W, A[2])
                 if (not row) and (FL & 3) == 3 and not shift:
                     self._atomic(K + W + 1, A[3])
-            n0 = A[2] if down else (A[1] if right else 0.0)
-            n1 = A[3] if down else 0.0
-            n2 = A[3] if right else 0.0
-            self.a[w1] = [n0, n1, n2 if not row else self.a[w1][2], 0.0 if not row else self.a[w1][3]]
-            self.key[w1], self.fl[w1] = key, flags
-            h = [not w1, bool(w1)]
-        for e in (0, 1):
-            ge = g if h[e] else 0.0
-            for k in range(2 if row else 4):
-                self.a[e][k] += ge * w[k]
-        self.mru = 1 if h[1] else 0
+            self.a[0] = A[2] if down else (A[1] if right else 0.0)
+            self.a[1] = A[3] if down else 0.0
+            if not row:
+                self.a[2] = A[3] if right else 0.0
+                self.a[3] = 0.0
+            self.key = tkf
+        for k in range(2 if row else 4):
+            self.a[k] += g * w[k]
 
     def flush_all(self):
-        for e in (0, 1):
-            K, FL, A = self.key[e], self.fl[e] & (1 if self.row else 3), self.a[e]
-            if K < 0:
-                continue
-            self._atomic(K, A[0])
-            if FL & 1:
-                self._atomic(K + 1, A[1])
-            if FL & 2:
-                self._atomic(K + self.W, A[2])
-            if (FL & 3) == 3:
-                self._atomic(K + self.W + 1, A[3])
+        if self.key < 0:
+            return
+        K, FL, A = self.key >> 2, (self.key & 1) if self.row else (self.key & 3), self.a
+        self._atomic(K, A[0])
+        if FL & 1:
+            self._atomic(K + 1, A[1])
+        if FL & 2:
+            self._atomic(K + self.W, A[2])
+        if (FL & 3) == 3:
+            self._atomic(K + self.W + 1, A[3])
 
 
 def walk(rng, W, H, n, mode):
@@ -92,7 +86,7 @@ def test_cache_conserves_every_contribution(mode, row):
     W, H = 9, (1 if row else 7)
     n = 40
     x0, y0 = walk(rng, W, H, n, mode)
-    cache = Foot2(W, H, row)
+    cache = Foot1(W, H, row)
     want = np.zeros(W * H)
     for i in range(n):
         key = int(y0[i]) * W + int(x0[i])
@@ -116,12 +110,23 @@ def test_cache_conserves_every_contribution(mode, row):
 
 
 def test_shift_halves_the_atomics_of_a_walk_down_a_column():
-    rng = np.random.default_rng(5)
     W, H, n = 9, 40, 120
-    cache = Foot2(W, H, False)
+    cache = Foot1(W, H, False)
     for i in range(n):
         y = min(i // 3, H - 2)
         cache.add(y * W + 4, 3, (1.0, 1.0, 1.0, 1.0), 1.0)
     cache.flush_all()
     steps = min((n - 1) // 3, H - 2)
     assert cache.atomics == 2 * steps + 4          # two per step instead of four, plus the final footprint
+
+
+def test_alternating_footprints_cost_an_eviction_each():
+    """What the second entry of rounds 1-4 was for: a walk in a FOREIGN level's order alternates between two footprints and a
+    single entry then flushes on every step.  Per-level walk orders (one order per orientation and level) never do that, which is
+    why one entry suffices -- this pins the cost the sort orders must keep avoiding."""
+    W, H, n = 9, 8, 40
+    cache = Foot1(W, H, False)
+    for i in range(n):
+        cache.add((3 + 2 * (i % 2)) * W + 2, 3, (1.0, 1.0, 1.0, 1.0), 1.0)      # two footprints two rows apart: no shift reuse
+    cache.flush_all()
+    assert cache.atomics == 4 * n

@@ -213,14 +213,14 @@ def test_non_default_deformation_switches_match_reference_golden(gpu_device, var
     assert rel_l2(xyz.grad.cpu().numpy(), z[f"{variant}::grad_xyz"]) < 1e-4
 
 
-@pytest.mark.parametrize("mode", ["walk", "slab", "slab_product"])
+@pytest.mark.parametrize("mode", ["slab", "slab_product"])
 @pytest.mark.parametrize("tmode", ["per_point", 0.37])
 def test_exact_zero_samples_take_the_exact_fallback(gpu_device, tmode, mode, monkeypatch):
     """The backward forms dL/d(sample_i) as dL/dfeature * feature / sample_i.  Samples that are exactly zero (a zeroed plane
     region, a whole zero plane, a zero time plane) or tiny cannot be divided by: those (point, level, plane) entries must
     come out of the exact fix-up pass with the same gradients as autograd gives the reference.  "slab" is the default (round 4: the
-    per-point pass divides too -- its dL/dxyz of such samples comes from exact_du --), "slab_product" round 3's product-rule pass,
-    "walk" the slab-free algorithm, all on the same data."""
+    per-point pass divides too -- its dL/dxyz of such samples comes from exact_du --), "slab_product" the product-rule pass that
+    stays as the exact fallback needing nothing from the forward (the slab-free "walk" of rounds 2-4 was removed in round 5)."""
     from oracle import hexplane_ref as hr
     from s3gaussian_amd.hexplane import HexPlaneField
     from s3gaussian_amd import hexplane as hx
@@ -256,9 +256,10 @@ def test_exact_zero_samples_take_the_exact_fallback(gpu_device, tmode, mode, mon
 
 
 @pytest.mark.parametrize("tmode", ["per_point", 0.37, 1.0])
-def test_walk_backward_matches_the_slab_backward(gpu_device, tmode, monkeypatch):
-    """The two backward algorithms (include/s3g_hexplane.h: `features` given or NULL) on the default-resolution field:
-    same dL/dxyz and plane gradients to fp32 round-off (1e-5 relative; the walk divides by one re-derived sample)."""
+def test_product_rule_fallback_matches_the_default_backward(gpu_device, tmode, monkeypatch):
+    """The two backward algorithms (include/s3g_hexplane.h: `features` given = S3G_HEX_SLAB_DIV, NULL = S3G_HEX_SLAB) on the
+    default-resolution field: same dL/dxyz and plane gradients to fp32 round-off (1e-5 relative); and the removed algorithm id is
+    refused with an error, not silently mapped."""
     from s3gaussian_amd import hexplane as hx
     torch.manual_seed(5)
     cfg = dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32, resolution=[64, 64, 64, 25])
@@ -273,14 +274,14 @@ def test_walk_backward_matches_the_slab_backward(gpu_device, tmode, monkeypatch)
     time = (torch.rand(P, 1) if tmode == "per_point" else torch.full((P, 1), float(tmode))).to(gpu_device)
     w = torch.randn(P, 128).to(gpu_device)
     res = {}
-    for mode in ("slab", "walk", "slab_product"):
+    for mode in ("slab", "slab_product"):
         monkeypatch.setattr(hx, "BACKWARD_MODE", mode)
         for p in f.parameters():
             p.grad = None
         x = xyz.clone().requires_grad_(True)
         (f(x, time) * w).sum().backward()
         res[mode] = (x.grad.clone(), [p.grad.clone() for p in f.parameters() if p.requires_grad])
-    for other in ("walk", "slab_product"):
+    for other in ("slab_product",):
         assert rel_l2(res[other][0].cpu().numpy(), res["slab"][0].cpu().numpy()) < 1e-5, other
         for a, b in zip(res[other][1], res["slab"][1]):
             assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, other

@@ -38,7 +38,11 @@ def _psnr(a, b):
 
 
 def run(P=600_000, W=1600, H=1066, iters=1000, n_frames=6, seed=0, densify_at=None, prune_at=None, grad_threshold=0.0002,
-        opacity_threshold=0.005, verbose=True):
+        opacity_threshold=0.005, verbose=True, reference_twice=False, eval_at=()):
+    """reference_twice: train the reference stack a second time from the same state and seeds -- its backward sums with float atomics
+    (backward.cu:550-587), so two runs of the REFERENCE ITSELF are a chaotic pair too; their distance is the yardstick the
+    product-vs-reference distance has to be read against.  eval_at: iterations at which every view is also rendered and scored
+    inside the run (from the loop's own `timer.pause()` call, under its no_grad block; rendering draws no random numbers)."""
     from types import SimpleNamespace
     from oracle import ref_py
     from s3gaussian_amd import raster_C, synth
@@ -76,8 +80,8 @@ def run(P=600_000, W=1600, H=1066, iters=1000, n_frames=6, seed=0, densify_at=No
     torch.cuda.empty_cache()
 
     out = {}
-    for side in ("reference", "product"):
-        ref = ref_py.load(patch=(side == "product"), rasterizer="reference" if side == "reference" else "dropin")
+    for side in (("reference", "reference_again", "product") if reference_twice else ("reference", "product")):
+        ref = ref_py.load(patch=(side == "product"), rasterizer="dropin" if side == "product" else "reference")
         try:
             args, dataset, hyper, opt, pipe = ref_py.default_arguments(ref)
             dataset.render_process = False
@@ -95,18 +99,27 @@ def run(P=600_000, W=1600, H=1066, iters=1000, n_frames=6, seed=0, densify_at=No
             random.seed(seed + 1)
             torch.manual_seed(seed + 1)
             timer = ref_py.RecordingTimer(record_locals=True)
+            checkpoints = {}
+
+            def score(gm=gm, ref=ref, cam_objs=cam_objs, pipe=pipe):
+                with torch.no_grad():
+                    return {v: _psnr(ref.gaussian_renderer.render(cam_objs[v], gm, pipe, bg, stage="fine")["render"].clamp(0, 1),
+                                     targets[v][0]) for v in ids}
+
+            if eval_at:
+                def at_iteration(it):
+                    if it in eval_at:
+                        checkpoints[it] = score()
+
+                timer.after_pause = at_iteration
             t0 = time.perf_counter()
             ref_py.run_scene_reconstruction(ref, gm, scene, dataset, hyper, opt, pipe, iterations=iters, stage="fine", timer=timer)
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
-            rows = {}
-            with torch.no_grad():
-                for v in ids:
-                    img = ref.gaussian_renderer.render(cam_objs[v], gm, pipe, bg, stage="fine")["render"].clamp(0, 1)
-                    rows[v] = _psnr(img, targets[v][0])
+            rows = score()
             st = timer.stamps
             steady = 1000.0 * (st[-1] - st[len(st) // 10]) / max(len(st) - 1 - len(st) // 10, 1)
-            out[side] = dict(psnr=rows, losses=timer.losses, points=timer.points, wall_s=wall, ms_per_iteration=steady,
+            out[side] = dict(psnr=rows, checkpoints=checkpoints, losses=timer.losses, points=timer.points, wall_s=wall, ms_per_iteration=steady,
                              optimizer=type(gm.optimizer).__module__ + "." + type(gm.optimizer).__name__,
                              deformation=type(gm._deformation).__module__,
                              rasterizer=sys.modules["diff_gaussian_rasterization"].__file__.replace(ref.root, "<archive>").replace(ROOT, "<repo>"))
@@ -142,6 +155,28 @@ def run(P=600_000, W=1600, H=1066, iters=1000, n_frames=6, seed=0, densify_at=No
         loss_curve_every=k, loss_curve={"product": [round(float(x), 5) for x in la[::k]], "reference": [round(float(x), 5) for x in lb[::k]]},
         ms_per_iteration={"product": round(a["ms_per_iteration"], 3), "reference_stack_on_mi355x": round(b["ms_per_iteration"], 3)},
         stacks={sd: {kk: out[sd][kk] for kk in ("optimizer", "deformation", "rasterizer")} for sd in out})
+
+    def split_means(rows):
+        return {sp: float(np.mean([rows[v] for v in ids if (v in test_ids) == (sp == "test")])) for sp in ("train", "test")}
+
+    if eval_at:     # where along the run do the two trainings separate?
+        rec["mean_psnr_delta_db_at_iteration"] = {
+            str(it): {sp: split_means(a["checkpoints"][it])[sp] - split_means(b["checkpoints"][it])[sp] for sp in ("train", "test")}
+            for it in sorted(a["checkpoints"]) if it in b["checkpoints"]}
+    if reference_twice:
+        c = out["reference_again"]
+        lc = np.array(c["losses"])
+        rec["reference_vs_reference_again"] = dict(
+            what="the reference stack trained twice from the same state and seeds (its float-atomic backward is not reproducible): the "
+                 "distance between two runs of the REFERENCE ITSELF, same measures as above",
+            mean_psnr_delta_db={sp: split_means(c["psnr"])[sp] - split_means(b["psnr"])[sp] for sp in ("train", "test")},
+            max_abs_delta_db=float(max(abs(c["psnr"][v] - b["psnr"][v]) for v in ids)),
+            per_view_delta_db=[round(c["psnr"][v] - b["psnr"][v], 4) for v in ids],
+            points=[c["points"][0], c["points"][min(densify_at, iters - 1)], c["points"][-1]],
+            rel_loss_gap_at={str(i): float(abs(lc[i] - lb[i]) / max(abs(lb[i]), 1e-12)) for i in (0, 1, 5, 20, iters // 4, iters // 2, iters - 1)},
+            mean_psnr_delta_db_at_iteration={
+                str(it): {sp: split_means(c["checkpoints"][it])[sp] - split_means(b["checkpoints"][it])[sp] for sp in ("train", "test")}
+                for it in sorted(c["checkpoints"]) if it in b["checkpoints"]})
     return rec
 
 
@@ -153,12 +188,15 @@ def main():
     ap.add_argument("--iters", type=int, default=1000)
     ap.add_argument("--frames", type=int, default=6)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psnr_parity_cfg2.json"))
+    ap.add_argument("--reference-twice", action="store_true", help="also train the reference stack a second time: its own run-to-run spread")
+    ap.add_argument("--eval-at", type=int, nargs="*", default=[], help="iterations at which every view is scored inside the run")
     a = ap.parse_args()
-    rec = run(a.P, a.width, a.height, a.iters, a.frames)
+    rec = run(a.P, a.width, a.height, a.iters, a.frames, reference_twice=a.reference_twice, eval_at=tuple(a.eval_at))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(rec, open(a.out, "w"), indent=1)
     print(json.dumps({k: rec[k] for k in ("mean_psnr_delta_db", "max_abs_delta_db", "mean_psnr_db", "points", "ms_per_iteration",
-                                           "max_rel_loss_gap_first20", "loss_last10_mean")}))
+                                           "max_rel_loss_gap_first20", "loss_last10_mean", "mean_psnr_delta_db_at_iteration",
+                                           "reference_vs_reference_again") if k in rec}))
 
 
 if __name__ == "__main__":
