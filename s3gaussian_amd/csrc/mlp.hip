@@ -69,6 +69,43 @@ __device__ __forceinline__ void gemm_reg_t(const float* wl, int ld, const f32x16
     }
 }
 
+// The two 3-row heads (pos_deform / dino_head output layers, 64 -> 3) on v_mfma_f32_4x4x1_16B_f32 (round 5).  A 32x32x2 MFMA spends
+// a full 32-row block (64 cycles per K step) on three live rows: 2 x 32 of the forward's 512 MFMA slots per tile.  The 4x4x1
+// instruction is sixteen independent 4x4 outer products (8 cycles): block b = lanes 4b .. 4b+3; lane 4b+j supplies B[j] and receives
+// column j of the block in four registers, lane 4b+i supplies A[i].  It fits the register-resident scheme without moving anything:
+//   B = the lane's OWN activation register in[mbi][r] -- feature f = 32 mbi + rrow(r) + 4 (lane >> 5) of point lane & 31; the four
+//       lanes of a block share f (blocks do not straddle lane 32) and hold four different points;
+//   A = W[lane & 3][f] from the [in][out + 1] weight image (rows 3 .. 31 of a head slab are zero, so i = 3 contributes nothing);
+//   D = in lane l, registers 0 .. 2: rows 0 .. 2 of the output for point l & 31, summed over the features of the lane's half.
+// The two halves (lanes l and l + 32 hold the K steps of features 4h .. 4h + 3 mod 8) meet in one cross-half add.  Summation
+// order differs from the 32x32x2 chain (two half-K chains per mbi, added at the end): the training forward and the inference kernel
+// use THIS function both, so they stay bit-identical to each other (tests/test_infer_gpu.py).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void head3_fw(const float* wl /* [64 in][33] head slab */, const float* bias /* LDS, >= 3 floats */,
+                                         const f32x16 (&in)[2], float (&o)[3], int lane) {
+  const int h = lane >> 5;
+  const float* base = wl + 4 * h * 33 + (lane & 3);
+  f32x4 c0, c1;
+  c0[0] = h == 0 ? bias[0] : 0.f; c0[1] = h == 0 ? bias[1] : 0.f; c0[2] = h == 0 ? bias[2] : 0.f; c0[3] = 0.f;
+  c1[0] = c1[1] = c1[2] = c1[3] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {      // two independent accumulation chains (mbi = 0 / 1): no MFMA waits for its predecessor's result
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(base[rrow(r) * 33], in[0][r], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(base[(32 + rrow(r)) * 33], in[1][r], c1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float v = c0[i] + c1[i];
+    o[i] = v + __shfl_xor(v, 32);   // both halves end up with the total; the stores below use lanes 0 .. 31
+  }
+}
+__device__ __forceinline__ void store3(const float (&o)[3], float* __restrict__ g, int p0, int npts, int lane) {
+  if (lane < npts) {   // [P][3] rows, not 16-byte aligned
+    float* row = g + (size_t)(p0 + lane) * 3;
+    row[0] = o[0]; row[1] = o[1]; row[2] = o[2];
+  }
+}
+
 template <int MB>
 __device__ __forceinline__ void acc_zero(f32x16 (&acc)[MB]) {
 #pragma unroll
@@ -398,9 +435,15 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_forward_kernel(const MlpFwdArg
     relu_inplace<2>(act);
     if (a.stash) act_store<HID, 2, false>(act, a.stash + 1 * PS, 0, p0, npts, ln);
     if (mw) mw[1 * 64] = pack_positive<2>(act);
-    acc_bias<1>(o, BIAS(3), ln);
-    gemm_fw<SPLIT, 1, 2, false>(WSLAB(4), 33, act, o, ln);
-    act_store3(o, a.dx, p0, npts, ln);
+    if constexpr (SPLIT) {
+      acc_bias<1>(o, BIAS(3), ln);
+      gemm_fw<SPLIT, 1, 2, false>(WSLAB(4), 33, act, o, ln);
+      act_store3(o, a.dx, p0, npts, ln);
+    } else {
+      float o3[3];
+      head3_fw(WSLAB(4), BIAS(3), act, o3, ln);
+      store3(o3, a.dx, p0, npts, ln);
+    }
     // shs head: dshs = S2 relu(S1 relu(hidden) + sb1) + sb2
     acc_bias<2>(act, BIAS(2), ln);
     gemm_fw<SPLIT, 2, 2, true>(WSLAB(3), 65, hid, act, ln);
@@ -422,9 +465,15 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_forward_kernel(const MlpFwdArg
     relu_inplace<2>(acc);
     if (a.stash) act_store<HID, 2, false>(acc, a.stash + 4 * PS, 0, p0, npts, ln);
     if (mw) mw[4 * 64] = pack_positive<2>(acc);
-    acc_bias<1>(o, BIAS(7), ln);
-    gemm_fw<SPLIT, 1, 2, false>(WSLAB(8), 33, acc, o, ln);
-    act_store3(o, a.feat, p0, npts, ln);
+    if constexpr (SPLIT) {
+      acc_bias<1>(o, BIAS(7), ln);
+      gemm_fw<SPLIT, 1, 2, false>(WSLAB(8), 33, acc, o, ln);
+      act_store3(o, a.feat, p0, npts, ln);
+    } else {
+      float o3[3];
+      head3_fw(WSLAB(8), BIAS(7), acc, o3, ln);
+      store3(o3, a.feat, p0, npts, ln);
+    }
     }
     __builtin_amdgcn_sched_barrier(0);
     cur = nxt;   // copies at the very end: the prefetch has had the whole tile to land
@@ -888,11 +937,13 @@ __global__ void __launch_bounds__(NWAVE * 64) deform_infer_kernel(const InferArg
     acc_bias<2>(act, bias(1), lane);
     if (S3G_INFER_EXPERIMENT != 1) gemm_reg<2, 2, true>(wslab(2), 65, hid, act, lane);
     relu_inplace<2>(act);
-    acc_bias<1>(o, bias(3), lane);
-    if (S3G_INFER_EXPERIMENT != 1) gemm_reg<1, 2, false>(wslab(4), 33, act, o, lane);
-    if (livem && hh == 0) {
-      float* row = a.dx + pm * 3;
-      row[0] = o[0][0]; row[1] = o[0][1]; row[2] = o[0][2];
+    {
+      float o3[3] = {0.f, 0.f, 0.f};
+      if (S3G_INFER_EXPERIMENT != 1) head3_fw(wslab(4), bias(3), act, o3, lane);
+      if (livem && hh == 0) {
+        float* row = a.dx + pm * 3;
+        row[0] = o3[0]; row[1] = o3[1]; row[2] = o3[2];
+      }
     }
     // shs head
     acc_bias<2>(act, bias(2), lane);

@@ -9,7 +9,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --no-cpu-baseline --no-alt-paths"
+B="python $ROOT/bench.py --no-cpu-baseline --no-alt-paths --sustain-steps 0"
 SQ1="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES"
 SQ2="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM"
 TCC="TCC_ATOMIC TCC_REQ TCC_HIT TCC_MISS"
@@ -48,4 +48,7 @@ cd "$ROOT"
 S3G_DIST_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 3 --warmup 1 --P 300000 > "$OUT/${TAG}_two_ranks_gloo.json" 2> "$OUT/${TAG}_two_ranks_gloo.err"
 timeout 120 python bench.py --gpus 2 --steps 2 --warmup 1 --P 100000 > "$OUT/${TAG}_two_ranks_refused.json" 2> "$OUT/${TAG}_two_ranks_refused.err"
 echo "exit code of the plain --gpus 2 command on a 1-GPU box without the gloo override: $?" >> "$OUT/${TAG}_two_ranks_refused.err"
+# 7. RCCL itself, as a process group of ONE rank (S3G_FORCE_DIST=1, dp.force_dist): the `comm` block of an executed nccl backend
+S3G_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29671 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python bench.py --gpus 1 --steps 10 --warmup 3 --sustain-steps 0 \
+  > "$OUT/${TAG}_rccl_one_rank_line.json" 2> "$OUT/${TAG}_rccl_one_rank_line.err"
 echo done

@@ -38,11 +38,14 @@ def _psnr(a, b):
 
 
 def run(P=600_000, W=1600, H=1066, iters=1000, n_frames=6, seed=0, densify_at=None, prune_at=None, grad_threshold=0.0002,
-        opacity_threshold=0.005, verbose=True, reference_twice=False, eval_at=()):
+        opacity_threshold=0.005, verbose=True, reference_twice=False, eval_at=(), product_runs=1, reference=True):
     """reference_twice: train the reference stack a second time from the same state and seeds -- its backward sums with float atomics
     (backward.cu:550-587), so two runs of the REFERENCE ITSELF are a chaotic pair too; their distance is the yardstick the
     product-vs-reference distance has to be read against.  eval_at: iterations at which every view is also rendered and scored
-    inside the run (from the loop's own `timer.pause()` call, under its no_grad block; rendering draws no random numbers)."""
+    inside the run (from the loop's own `timer.pause()` call, under its no_grad block; rendering draws no random numbers).
+    product_runs > 1: the product is trained that many times from the same state and seeds (its HexPlane scatter and weight-gradient
+    flush sum with float atomics, so it is not bit-reproducible either): the spread of ITS split-mean PSNR.  reference=False: skip
+    the reference stack (200 ms per iteration) and return only the product runs (-> {"product_runs": [...]})."""
     from types import SimpleNamespace
     from oracle import ref_py
     from s3gaussian_amd import raster_C, synth
@@ -80,8 +83,11 @@ def run(P=600_000, W=1600, H=1066, iters=1000, n_frames=6, seed=0, densify_at=No
     torch.cuda.empty_cache()
 
     out = {}
-    for side in (("reference", "reference_again", "product") if reference_twice else ("reference", "product")):
-        ref = ref_py.load(patch=(side == "product"), rasterizer="dropin" if side == "product" else "reference")
+    sides = (("reference", "reference_again") if reference_twice else ("reference",)) if reference else ()
+    sides = sides + ("product",) + tuple(f"product_{k}" for k in range(2, product_runs + 1))
+    for side in sides:
+        is_product = side.startswith("product")
+        ref = ref_py.load(patch=is_product, rasterizer="dropin" if is_product else "reference")
         try:
             args, dataset, hyper, opt, pipe = ref_py.default_arguments(ref)
             dataset.render_process = False
@@ -131,6 +137,15 @@ def run(P=600_000, W=1600, H=1066, iters=1000, n_frames=6, seed=0, densify_at=No
             ref_py.unload()
             torch.cuda.empty_cache()
 
+    def split_means(rows):
+        return {sp: float(np.mean([rows[v] for v in ids if (v in test_ids) == (sp == "test")])) for sp in ("train", "test")}
+
+    runs = [dict(run=sd, mean_psnr_db=split_means(out[sd]["psnr"]), points_final=out[sd]["points"][-1],
+                 loss_last10_mean=float(np.mean(out[sd]["losses"][-10:])), ms_per_iteration=round(out[sd]["ms_per_iteration"], 3))
+            for sd in out if sd.startswith("product")]
+    if not reference:
+        return dict(what=f"the product trained {product_runs} times from the same state and seeds: {iters} iterations, {P} Gaussians, {H}x{W}",
+                    product_runs=runs)
     a, b = out["product"], out["reference"]
     views = [dict(view=v, split="test" if v in test_ids else "train", psnr_product=a["psnr"][v], psnr_reference=b["psnr"][v],
                   delta_db=a["psnr"][v] - b["psnr"][v]) for v in ids]
@@ -156,9 +171,8 @@ def run(P=600_000, W=1600, H=1066, iters=1000, n_frames=6, seed=0, densify_at=No
         ms_per_iteration={"product": round(a["ms_per_iteration"], 3), "reference_stack_on_mi355x": round(b["ms_per_iteration"], 3)},
         stacks={sd: {kk: out[sd][kk] for kk in ("optimizer", "deformation", "rasterizer")} for sd in out})
 
-    def split_means(rows):
-        return {sp: float(np.mean([rows[v] for v in ids if (v in test_ids) == (sp == "test")])) for sp in ("train", "test")}
-
+    if product_runs > 1:
+        rec["product_runs"] = runs
     if eval_at:     # where along the run do the two trainings separate?
         rec["mean_psnr_delta_db_at_iteration"] = {
             str(it): {sp: split_means(a["checkpoints"][it])[sp] - split_means(b["checkpoints"][it])[sp] for sp in ("train", "test")}
@@ -190,13 +204,16 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psnr_parity_cfg2.json"))
     ap.add_argument("--reference-twice", action="store_true", help="also train the reference stack a second time: its own run-to-run spread")
     ap.add_argument("--eval-at", type=int, nargs="*", default=[], help="iterations at which every view is scored inside the run")
+    ap.add_argument("--product-runs", type=int, default=1, help="train the product this many times (its own run-to-run spread)")
+    ap.add_argument("--no-reference", action="store_true", help="product runs only (the reference stack costs 200 ms per iteration)")
     a = ap.parse_args()
-    rec = run(a.P, a.width, a.height, a.iters, a.frames, reference_twice=a.reference_twice, eval_at=tuple(a.eval_at))
+    rec = run(a.P, a.width, a.height, a.iters, a.frames, reference_twice=a.reference_twice, eval_at=tuple(a.eval_at),
+              product_runs=a.product_runs, reference=not a.no_reference)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(rec, open(a.out, "w"), indent=1)
     print(json.dumps({k: rec[k] for k in ("mean_psnr_delta_db", "max_abs_delta_db", "mean_psnr_db", "points", "ms_per_iteration",
                                            "max_rel_loss_gap_first20", "loss_last10_mean", "mean_psnr_delta_db_at_iteration",
-                                           "reference_vs_reference_again") if k in rec}))
+                                           "reference_vs_reference_again", "product_runs") if k in rec}))
 
 
 if __name__ == "__main__":
