@@ -1033,6 +1033,18 @@ def main(argv=None):
                 out["config"]["psnr_parity_source"] = "profiles/psnr_parity.json: " + pj.get("what", "")
             except Exception:
                 pass
+        cfg2_file = os.path.join(ROOT, "profiles", "psnr_parity_cfg2.json")
+        if os.path.exists(cfg2_file):   # round 5: against the WHOLE reference on this GPU at BASELINE cfg2 size (tools/psnr_parity_cfg2.py)
+            try:
+                pj = json.load(open(cfg2_file))
+                out["config"]["psnr_cfg2_mean_delta_vs_reference_stack_db"] = pj["summary"]["delta_of_means_db"]
+                out["config"]["psnr_cfg2_runs"] = {"reference": pj["summary"]["train"]["reference"]["n"], "product": pj["summary"]["train"]["product"]["n"]}
+                out["config"]["psnr_cfg2_single_run_std_db"] = {"reference": round(pj["summary"]["train"]["reference"]["std"], 4),
+                                                                "product": round(pj["summary"]["train"]["product"]["std"], 4)}
+                out["config"]["psnr_cfg2_source"] = "profiles/psnr_parity_cfg2.json (NOT collected in this run)"
+                out["config"]["reference_stack_on_this_gpu_ms_per_iteration_cfg2"] = pj["ms_per_iteration"]["reference_stack_on_mi355x"]
+            except Exception:
+                pass
         if world == 1 and not dist_on and not a.no_cpu_baseline:
             try:
                 import contextlib
