@@ -61,7 +61,7 @@ int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* feature
  *                   exact for 2^-110 <= |x| < 3.39e38 (smaller numbers keep an absolute error below 2^-133; larger ones
  *                   become infinite like any bf16 conversion): tests/test_split_arith_cpu.py.
  * The weight-gradient GEMMs (K = points) are the exact fp32 chain in both modes.  Returns S3G_ERR_INVALID_ARG for another mode. */
-enum { S3G_MLP_F32 = 0, S3G_MLP_BF16X3 = 1 };
+enum { S3G_MLP_F32 = 0, S3G_MLP_BF16X3 = 1, S3G_MLP_BF16X3_ONTHEFLY = 2 };
 int s3g_deform_mlp_set_arithmetic(int mode);
 int s3g_deform_mlp_get_arithmetic(void);
 

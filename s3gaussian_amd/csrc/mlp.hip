@@ -661,6 +661,200 @@ __device__ __forceinline__ void gemm_split(const uint32_t* frag, int KS, int ks0
     }
 }
 
+// ---- training forward on the bf16 matrix pipe with the weights split ONCE (round 5; S3G_MLP_BF16X3) ------------------------------
+// mlp_forward_kernel<true> splits every weight fragment on the fly, in every wave, for every 32-point tile: 44 VALU instructions per
+// fragment, 64 fragments per tile -- the kernel is VALU-bound and gains 15 % where the instruction rates promise 2.7 x.
+// Here the A operands of all layers but P1 are pre-split by mlp_pack_presplit_fwd_kernel into fragment order (three pieces x 64 lanes
+// x 16 bytes: one conflict-free ds_read_b128 per piece and lane) and stay in LDS; P1 stays fp32 and is split by the lanes that read
+// it (everything pre-split would need 168 KB; this image is 159 KiB of the 160).  Same pieces, same MFMA order as the on-the-fly
+// kernel: outputs, stash and mask words are BIT-IDENTICAL to mlp_forward_kernel<true> (tests/test_mlp_gpu.py), which stays in the
+// tree as the checker of this one (S3G_MLP_BF16X3_ONTHEFLY).
+namespace tpw {   // 32-bit words
+constexpr int FRAG = 256;
+constexpr int W0 = 0;                                 // [mbo 2][ks 8][piece 3][FRAG]
+constexpr int S1 = W0 + 2 * 8 * 3 * FRAG;             // [mbo 2][ks 4][piece 3][FRAG]
+constexpr int D0 = S1 + 2 * 4 * 3 * FRAG;
+constexpr int D1 = D0 + 2 * 4 * 3 * FRAG;
+constexpr int S2A = D1 + 2 * 4 * 3 * FRAG;            // [ks 4][piece 3][FRAG]        rows 0..31
+constexpr int S2B = S2A + 4 * 3 * FRAG;               // [ks 4][piece 3][FRAG / 2]    rows 32..47: slot = 16 * h + (row & 15)
+constexpr int P2 = S2B + 4 * 3 * (FRAG / 2);          // [ks 4][piece 3][h 2][row 3][4 words]
+constexpr int D2 = P2 + 4 * 3 * 2 * 3 * 4;
+constexpr int P1LD = 68;
+constexpr int P1 = D2 + 4 * 3 * 2 * 3 * 4;            // fp32 [row 64][64 inputs + 4]
+constexpr int BIAS = P1 + 64 * P1LD;
+constexpr int B_B0 = 0, B_PB1 = 64, B_SB1 = 128, B_SB2 = 192, B_DB0 = 256, B_DB1 = 320, B_PB2 = 384, B_DB2 = 416, NBIAS = 448;   // the two 3-row biases zero padded to 32
+constexpr int WORDS = BIAS + NBIAS;
+static_assert(WORDS % 256 == 0 && WORDS * 4 <= 160 * 1024, "whole 1 KiB DMA rows, inside the CU's LDS");
+static_assert(P2 % 4 == 0 && D2 % 4 == 0 && P1 % 4 == 0 && BIAS % 4 == 0, "16-byte aligned regions");
+}  // namespace tpw
+
+namespace tbw { constexpr int WORDS = 0; }   // pre-split BACKWARD image: not built yet (the backward splits on the fly)
+constexpr int PACK_TOTAL = PACK_FLOATS + tpw::WORDS + tbw::WORDS;   // floats in front of the activation stash
+
+__global__ void __launch_bounds__(256) mlp_pack_presplit_fwd_kernel(const s3g_mlp_params w, uint32_t* __restrict__ img) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= tpw::WORDS) return;
+  uint32_t out = 0;
+  if (x < tpw::S2B) {   // full fragments
+    const float* W; int KS, ld, rows, y;
+    if (x < tpw::S1) { W = w.W0; KS = 8; ld = FEAT; rows = 64; y = x - tpw::W0; }
+    else if (x < tpw::D0) { W = w.S1; KS = 4; ld = HID; rows = 64; y = x - tpw::S1; }
+    else if (x < tpw::D1) { W = w.D0; KS = 4; ld = HID; rows = 64; y = x - tpw::D0; }
+    else if (x < tpw::S2A) { W = w.D1; KS = 4; ld = HID; rows = 64; y = x - tpw::D1; }
+    else { W = w.S2; KS = 4; ld = HID; rows = 48; y = x - tpw::S2A; }
+    const int t = y & 3, lane = (y >> 2) & 63, piece = (y >> 8) % 3, fr = (y >> 8) / 3, ks = fr % KS, mbo = fr / KS;
+    out = split_word(W, rows, ld, 32 * mbo + (lane & 31), split_feature(ks, lane >> 5, 2 * t), split_feature(ks, lane >> 5, 2 * t + 1), piece);
+  } else if (x < tpw::P2) {   // S2 rows 32..47
+    const int y = x - tpw::S2B, t = y & 3, slot = (y >> 2) & 31, piece = (y >> 7) % 3, ks = (y >> 7) / 3;
+    out = split_word(w.S2, 48, HID, 32 + (slot & 15), split_feature(ks, slot >> 4, 2 * t), split_feature(ks, slot >> 4, 2 * t + 1), piece);
+  } else if (x < tpw::P1) {   // the two 3-row heads
+    const bool dino = x >= tpw::D2;
+    const int y = x - (dino ? tpw::D2 : tpw::P2), t = y & 3, q = y >> 2, row = q % 3, h = (q / 3) & 1, piece = (q / 6) % 3, ks = q / 18;
+    out = split_word(dino ? w.D2 : w.P2, 3, HID, row, split_feature(ks, h, 2 * t), split_feature(ks, h, 2 * t + 1), piece);
+  } else if (x < tpw::BIAS) {   // P1 as it is, rows padded
+    const int y = x - tpw::P1, row = y / tpw::P1LD, f = y % tpw::P1LD;
+    out = f < HID ? __float_as_uint(w.P1[row * HID + f]) : 0u;
+  } else {
+    const int y = x - tpw::BIAS;
+    float v = 0.f;
+    if (y < 64) v = w.b0[y];
+    else if (y < 128) v = w.pb1[y - 64];
+    else if (y < 192) v = w.sb1[y - 128];
+    else if (y < 256) v = y - 192 < 48 ? w.sb2[y - 192] : 0.f;
+    else if (y < 320) v = w.db0[y - 256];
+    else if (y < 384) v = w.db1[y - 320];
+    else if (y < 416) v = y - 384 < 3 ? w.pb2[y - 384] : 0.f;
+    else v = y - 416 < 3 ? w.db2[y - 416] : 0.f;
+    out = __float_as_uint(v);
+  }
+  img[x] = out;
+}
+
+__global__ void __launch_bounds__(NWAVE * 64) mlp_forward_presplit_kernel(const MlpFwdArgs a) {   // a.packed = the tpw image
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const uint32_t* wsplit = reinterpret_cast<const uint32_t*>(lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = wave; c < tpw::WORDS / 256; c += NWAVE)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.packed + c * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(lds + c * 256), 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  auto bias = [&](int off) { return lds + tpw::BIAS + off; };
+  const int ntiles = (a.P + MT - 1) / MT;
+  const size_t PS = (size_t)a.P * HID;
+  struct XIn { float4 v[16]; };
+  const int jj = lane & 31, hh = lane >> 5;
+  auto issue = [&](XIn& X, int tile) {
+    const float* row = a.x + (size_t)min(tile * MT + jj, a.P - 1) * FEAT + 4 * hh;
+#pragma unroll
+    for (int c = 0; c < 16; c++) X.v[c] = *reinterpret_cast<const float4*>(row + 8 * c);
+  };
+  auto unpack = [&](f32x16 (&x)[2], const XIn& X, int half) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const float4 v = X.v[8 * half + c];
+      x[c >> 2][4 * (c & 3) + 0] = v.x; x[c >> 2][4 * (c & 3) + 1] = v.y;
+      x[c >> 2][4 * (c & 3) + 2] = v.z; x[c >> 2][4 * (c & 3) + 3] = v.w;
+    }
+  };
+  // the two 3-row heads: rows 0..2 are stored; the other lanes read row 0 (their accumulator rows are never written out)
+  auto head3 = [&](int region, const ActSplit<2>& B, f32x16 (&o)[1], int ln) {
+    const int j3 = (ln & 31) < 3 ? (ln & 31) : 0, h3 = ln >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      Split8 w;
+#pragma unroll
+      for (int pc = 0; pc < 3; pc++)
+        w.p[pc] = *reinterpret_cast<const u32x4*>(wsplit + region + ((((ks * 3 + pc) * 2 + h3) * 3 + j3) << 2));
+      o[0] = mfma_split(o[0], w, B.b[ks >> 1][ks & 1]);
+    }
+  };
+  const int stride = gridDim.x * NWAVE, t0 = blockIdx.x * NWAVE + wave;
+  XIn cur, nxt;
+  if (t0 < ntiles) issue(cur, t0);
+  for (int tile = t0; tile < ntiles; tile += stride) {
+    issue(nxt, min(tile + stride, ntiles - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    const int p0 = tile * MT, npts = min(MT, a.P - p0);
+    f32x16 hid[2], act[2], acc[2], o[1];
+    int ln = lane;   // per-tile copy: LDS / output addresses are re-derived instead of being carried (and spilled) across the loop
+    asm volatile("" : "+v"(ln));
+    ActSplit<2> hs, as;
+    {  // hidden = W0 x + b0, K = 128 in two halves
+      f32x16 x[2];
+      acc_bias<2>(hid, bias(tpw::B_B0), ln);
+      unpack(x, cur, 0);
+      act_split<2, false>(as, x);
+      gemm_split<2, 2>(wsplit + tpw::W0, 8, 0, as, hid, ln);
+      unpack(x, cur, 1);
+      act_split<2, false>(as, x);
+      gemm_split<2, 2>(wsplit + tpw::W0, 8, 4, as, hid, ln);
+    }
+    uint32_t* mw = a.maskbits ? a.maskbits + (size_t)tile * 5 * 64 + ln : nullptr;
+    if (a.stash) act_store<HID, 2, false>(hid, a.stash + 0 * PS, 0, p0, npts, ln);
+    if (mw) mw[0 * 64] = pack_positive<2>(hid);
+    act_split<2, true>(hs, hid);   // relu(hidden): the input of the position and SH heads
+    // pos head: dx = P2 relu(P1 relu(hidden) + pb1) + pb2.  P1 is fp32 in LDS: a lane's eight weights of a fragment are two 16-byte chunks of its row
+    acc_bias<2>(act, bias(tpw::B_PB1), ln);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+      for (int mbo = 0; mbo < 2; mbo++) {
+        const float* wr = lds + tpw::P1 + (32 * mbo + (ln & 31)) * tpw::P1LD + 4 * (ln >> 5) + 16 * ks;   // inputs 16 ks + 4 h + {0..3, 8..11}
+        const float4 lo = *reinterpret_cast<const float4*>(wr);
+        const float4 hi = *reinterpret_cast<const float4*>(wr + 8);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        act[mbo] = mfma_split(act[mbo], split8(v), hs.b[ks >> 1][ks & 1]);
+      }
+    relu_inplace<2>(act);
+    if (a.stash) act_store<HID, 2, false>(act, a.stash + 1 * PS, 0, p0, npts, ln);
+    if (mw) mw[1 * 64] = pack_positive<2>(act);
+    act_split<2, false>(as, act);
+    acc_bias<1>(o, bias(tpw::B_PB2), ln);
+    head3(tpw::P2, as, o, ln);
+    act_store3(o, a.dx, p0, npts, ln);
+    // shs head: dshs = S2 relu(S1 relu(hidden) + sb1) + sb2
+    acc_bias<2>(act, bias(tpw::B_SB1), ln);
+    gemm_split<2, 2>(wsplit + tpw::S1, 4, 0, hs, act, ln);
+    relu_inplace<2>(act);
+    if (a.stash) act_store<HID, 2, false>(act, a.stash + 2 * PS, 0, p0, npts, ln);
+    if (mw) mw[2 * 64] = pack_positive<2>(act);
+    act_split<2, false>(as, act);
+    acc_bias<2>(acc, bias(tpw::B_SB2), ln);
+    gemm_split<1, 2>(wsplit + tpw::S2A, 4, 0, as, *reinterpret_cast<f32x16(*)[1]>(&acc[0]), ln);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {   // rows 32..47: lanes of rows 48..63 read rows 32..47 again (never written out)
+      Split8 w;
+#pragma unroll
+      for (int pc = 0; pc < 3; pc++)
+        w.p[pc] = *reinterpret_cast<const u32x4*>(wsplit + tpw::S2B + (ks * 3 + pc) * (tpw::FRAG / 2) + ((16 * (ln >> 5) + (ln & 15)) << 2));
+      acc[1] = mfma_split(acc[1], w, as.b[ks >> 1][ks & 1]);
+    }
+    act_store<48, 2, false, 48>(acc, a.dshs, 0, p0, npts, ln);
+    if (a.feat != nullptr) {
+      // dino head: feat = D2 relu(D1 relu(D0 hidden + db0) + db1) + db2   (input is the RAW hidden, deformation.py:126)
+      act_split<2, false>(hs, hid);
+      acc_bias<2>(act, bias(tpw::B_DB0), ln);
+      gemm_split<2, 2>(wsplit + tpw::D0, 4, 0, hs, act, ln);
+      relu_inplace<2>(act);
+      if (a.stash) act_store<HID, 2, false>(act, a.stash + 3 * PS, 0, p0, npts, ln);
+      if (mw) mw[3 * 64] = pack_positive<2>(act);
+      act_split<2, false>(as, act);
+      acc_bias<2>(acc, bias(tpw::B_DB1), ln);
+      gemm_split<2, 2>(wsplit + tpw::D1, 4, 0, as, acc, ln);
+      relu_inplace<2>(acc);
+      if (a.stash) act_store<HID, 2, false>(acc, a.stash + 4 * PS, 0, p0, npts, ln);
+      if (mw) mw[4 * 64] = pack_positive<2>(acc);
+      act_split<2, false>(as, acc);
+      acc_bias<1>(o, bias(tpw::B_DB2), ln);
+      head3(tpw::D2, as, o, ln);
+      act_store3(o, a.feat, p0, npts, ln);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+  }
+}
+
 // ---- inference: HexPlane sampler (+) MLP heads in ONE kernel (render(): gaussian_renderer/__init__.py:82-97) --------
 // Under no_grad nothing is stashed and the feature (dino) head is not needed, so the weight image shrinks to the first six slabs
 // (W0 | W0 | P1 | S1 | P2 | S2 = 104 KB) and 46 KB of LDS are left: each wave gets a 32-point x 32-channel staging tile and one
@@ -1448,19 +1642,20 @@ static int launch_wgrad(const float* G, const float* A, float* dW, float* db, in
 
 using namespace s3g;
 
-// stash = [packed weight slabs + biases (PACK_FLOATS)] [5 x P x 64 activations] [tiles x 5 x 64 ReLU mask words]
+// stash = [packed weight slabs + biases (PACK_FLOATS)] [pre-split forward image (tpw::WORDS)] [pre-split backward image (tbw::WORDS)]
+//         [5 x P x 64 activations] [tiles x 5 x 64 ReLU mask words]
 static size_t mask_words(int P) { return (size_t)((P > 0 ? P : 0) + MT - 1) / MT * 5 * 64; }
 extern "C" size_t s3g_deform_mlp_stash_bytes(int P) {
-  return ((size_t)PACK_FLOATS + (size_t)5 * (size_t)(P > 0 ? P : 0) * HID + mask_words(P)) * sizeof(float);
+  return ((size_t)PACK_TOTAL + (size_t)5 * (size_t)(P > 0 ? P : 0) * HID + mask_words(P)) * sizeof(float);
 }
-extern "C" size_t s3g_deform_mlp_pack_bytes(void) { return (size_t)PACK_FLOATS * sizeof(float); }
+extern "C" size_t s3g_deform_mlp_pack_bytes(void) { return (size_t)PACK_TOTAL * sizeof(float); }
 
 // arithmetic of the per-point GEMM chains of s3g_deform_mlp_forward / _backward (process-wide; the weight-gradient GEMMs, whose K
 // dimension is the points, are always the exact fp32 chain)
 static std::atomic<int> g_mlp_arithmetic{S3G_MLP_F32};
 extern "C" int s3g_deform_mlp_set_arithmetic(int mode) {
-  if (mode != S3G_MLP_F32 && mode != S3G_MLP_BF16X3) {
-    set_error("s3g_deform_mlp_set_arithmetic: mode must be S3G_MLP_F32 or S3G_MLP_BF16X3");
+  if (mode != S3G_MLP_F32 && mode != S3G_MLP_BF16X3 && mode != S3G_MLP_BF16X3_ONTHEFLY) {
+    set_error("s3g_deform_mlp_set_arithmetic: mode must be S3G_MLP_F32, S3G_MLP_BF16X3 or S3G_MLP_BF16X3_ONTHEFLY");
     return S3G_ERR_INVALID_ARG;
   }
   g_mlp_arithmetic.store(mode, std::memory_order_relaxed);
@@ -1476,6 +1671,7 @@ static int mlp_set_attrs() {
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WM_RED * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_presplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tpw::WORDS * 4));
     device_setup_done(done);
   }
   return S3G_OK;
@@ -1493,12 +1689,20 @@ extern "C" int s3g_deform_mlp_forward(const s3g_mlp_params* w, int P, const floa
   hipLaunchKernelGGL(mlp_pack_kernel, dim3(NSLAB + 1), dim3(256), 0, stream, *w, stash);
   MlpFwdArgs a;
   a.P = P; a.x = features; a.packed = stash; a.dx = dx; a.dshs = dshs; a.feat = feat;
-  a.stash = save_activations ? stash + PACK_FLOATS : nullptr;
-  a.maskbits = save_activations ? reinterpret_cast<uint32_t*>(stash + PACK_FLOATS + (size_t)5 * P * HID) : nullptr;
+  a.stash = save_activations ? stash + PACK_TOTAL : nullptr;
+  a.maskbits = save_activations ? reinterpret_cast<uint32_t*>(stash + PACK_TOTAL + (size_t)5 * P * HID) : nullptr;
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
+  const int arith = g_mlp_arithmetic.load(std::memory_order_relaxed);
+  if (arith == S3G_MLP_BF16X3)   // the forward's pre-split image, behind the fp32 one (which the backward still reads)
+    hipLaunchKernelGGL(mlp_pack_presplit_fwd_kernel, dim3((tpw::WORDS + 255) / 256), dim3(256), 0, stream, *w,
+                       reinterpret_cast<uint32_t*>(stash + PACK_FLOATS));
   profile_begin(S3G_PROFILE_MLP_FORWARD, stream);
-  if (g_mlp_arithmetic.load(std::memory_order_relaxed) == S3G_MLP_BF16X3)
+  if (arith == S3G_MLP_BF16X3) {
+    MlpFwdArgs s = a;
+    s.packed = stash + PACK_FLOATS;
+    hipLaunchKernelGGL(mlp_forward_presplit_kernel, dim3(blocks), dim3(NWAVE * 64), tpw::WORDS * 4, stream, s);
+  } else if (arith == S3G_MLP_BF16X3_ONTHEFLY)
     hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, a);
   else
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, a);
@@ -1517,13 +1721,13 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   if (P == 0) return S3G_OK;
   if (int e = mlp_set_attrs()) return e;
   hipStream_t stream = (hipStream_t)stream_;
-  const float* stash = stash_ + PACK_FLOATS;  // activations; the packed weight slabs of the forward sit in front
+  const float* stash = stash_ + PACK_TOTAL;  // activations; the packed weight images of the forward sit in front
   MlpBwdArgs b;
   b.P = P; b.packed = stash_; b.maskbits = reinterpret_cast<const uint32_t*>(stash + (size_t)5 * P * HID); b.g_dx = g_dx; b.g_dshs = g_dshs; b.g_feat = g_feat; b.g_x = g_features; b.ws = workspace;
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
   profile_begin(S3G_PROFILE_MLP_BACKWARD, stream);
-  if (g_mlp_arithmetic.load(std::memory_order_relaxed) == S3G_MLP_BF16X3)
+  if (g_mlp_arithmetic.load(std::memory_order_relaxed) != S3G_MLP_F32)
     hipLaunchKernelGGL(mlp_backward_kernel<true>, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, b);
   else
     hipLaunchKernelGGL(mlp_backward_kernel<false>, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, b);

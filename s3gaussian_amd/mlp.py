@@ -50,7 +50,7 @@ def _bind():
     return L
 
 
-_ARITHMETIC = {"f32": 0, "bf16x3": 1}     # S3G_MLP_F32, S3G_MLP_BF16X3 (include/s3g_mlp.h)
+_ARITHMETIC = {"f32": 0, "bf16x3": 1, "bf16x3_onthefly": 2}     # S3G_MLP_F32, S3G_MLP_BF16X3, S3G_MLP_BF16X3_ONTHEFLY (include/s3g_mlp.h)
 
 
 def set_mlp_arithmetic(mode: str) -> None:
