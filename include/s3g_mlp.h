@@ -60,7 +60,14 @@ int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* feature
  *                   is dropped is <= 2^-23 of each product (fp32 accuracy; not bit-identical to S3G_MLP_F32).  The split is
  *                   exact for 2^-110 <= |x| < 3.39e38 (smaller numbers keep an absolute error below 2^-133; larger ones
  *                   become infinite like any bf16 conversion): tests/test_split_arith_cpu.py.
- * The weight-gradient GEMMs (K = points) are the exact fp32 chain in both modes.  Returns S3G_ERR_INVALID_ARG for another mode. */
+ *                   Round 5: the weight fragments of both chain kernels are split ONCE per call into 159 KiB LDS images
+ *                   (mlp_forward_presplit_kernel / mlp_backward_presplit_kernel; P1 alone is split by the lanes that read it, the
+ *                   3-row heads of the backward run on the exact fp32 MFMA): forward 0.71 -> 0.55 ms, backward 0.76 -> 0.63 ms at
+ *                   1.2 M points on one box.  (The backward writes its transposed image into the slot the stash reserves for it;
+ *                   forward and backward may run in different modes.)
+ *   S3G_MLP_BF16X3_ONTHEFLY  the same arithmetic with every fragment split by the wave that uses it (rounds 3-4; bit-identical
+ *                   results, 15-20 % slower): kept as the checker of the pre-split kernels.
+ * The weight-gradient GEMMs (K = points) are the exact fp32 chain in every mode.  Returns S3G_ERR_INVALID_ARG for another mode. */
 enum { S3G_MLP_F32 = 0, S3G_MLP_BF16X3 = 1, S3G_MLP_BF16X3_ONTHEFLY = 2 };
 int s3g_deform_mlp_set_arithmetic(int mode);
 int s3g_deform_mlp_get_arithmetic(void);

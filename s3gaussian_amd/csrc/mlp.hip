@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_backward_kernel(const MlpBwdAr
     if (dino) {
       head3(g3, cur.gf);
       acc_zero<2>(acc);
-      gemm_bw<SPLIT, 2, 1, 3>(WSLAB(8), 33, g3, acc, lane);           // D2^T g_feat (3 live K steps)
+      gemm_reg_t<2, 1, 3>(WSLAB(8), 33, g3, acc, lane);              // D2^T g_feat (3 live K steps: exact fp32 MFMAs in both arithmetics)
       masked_bits<2, false>(g, acc, cur.bits[4]);                  // gradient wrt dino2 pre-activation
       act_store<HID, 2, false>(g, a.ws + 0 * PS, 0, p0, npts, lane);
       acc_zero<2>(acc);
@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_backward_kernel(const MlpBwdAr
     // ---- pos head ----
     head3(g3, cur.gd);
     acc_zero<2>(acc);
-    gemm_bw<SPLIT, 2, 1, 3>(WSLAB(4), 33, g3, acc, lane);             // P2^T g_dx
+    gemm_reg_t<2, 1, 3>(WSLAB(4), 33, g3, acc, lane);                // P2^T g_dx (exact fp32 MFMAs in both arithmetics)
     masked_bits<2, false>(g, acc, cur.bits[1]);
     act_store<HID, 2, false>(g, a.ws + 2 * PS, 0, p0, npts, lane);
     acc_zero<2>(acc);
@@ -688,7 +688,26 @@ static_assert(WORDS % 256 == 0 && WORDS * 4 <= 160 * 1024, "whole 1 KiB DMA rows
 static_assert(P2 % 4 == 0 && D2 % 4 == 0 && P1 % 4 == 0 && BIAS % 4 == 0, "16-byte aligned regions");
 }  // namespace tpw
 
-namespace tbw { constexpr int WORDS = 0; }   // pre-split BACKWARD image: not built yet (the backward splits on the fly)
+// The backward's image: the TRANSPOSED layers in fragment order -- A[row = input feature][k = output feature] -- for W0 (four
+// 32-row blocks: the 128 inputs), D1, D0, S1 and S2 (K = 48: three K steps); P1^T stays fp32 [64 in][64 out + 4] and is split by the
+// lanes that read it; the two 3-row heads (K = 3) run on the exact fp32 MFMA from a compact fp32 [64 in][8] image (columns 0..2 = the
+// three output rows, 3..7 zero: what the h = 1 lanes read).  159 KiB like the forward's.
+namespace tbw {   // 32-bit words
+constexpr int FRAG = 256;
+constexpr int W0T = 0;                                // [mbo 4][ks 4][piece 3][FRAG]
+constexpr int D1T = W0T + 4 * 4 * 3 * FRAG;           // [mbo 2][ks 4][piece 3][FRAG]
+constexpr int D0T = D1T + 2 * 4 * 3 * FRAG;
+constexpr int S1T = D0T + 2 * 4 * 3 * FRAG;
+constexpr int S2T = S1T + 2 * 4 * 3 * FRAG;           // [mbo 2][ks 3][piece 3][FRAG]   (48 output features = 3 K steps)
+constexpr int P1LD = 68;
+constexpr int P1T = S2T + 2 * 3 * 3 * FRAG;           // fp32 [in 64][64 outputs + 4]
+constexpr int H3LD = 8;
+constexpr int P2T = P1T + 64 * P1LD;                  // fp32 [in 64][8]
+constexpr int D2T = P2T + 64 * H3LD;
+constexpr int WORDS = D2T + 64 * H3LD;
+static_assert(WORDS % 256 == 0 && WORDS * 4 <= 160 * 1024, "whole 1 KiB DMA rows, inside the CU's LDS");
+static_assert(P1T % 4 == 0 && P2T % 4 == 0, "16-byte aligned regions");
+}  // namespace tbw
 constexpr int PACK_TOTAL = PACK_FLOATS + tpw::WORDS + tbw::WORDS;   // floats in front of the activation stash
 
 __global__ void __launch_bounds__(256) mlp_pack_presplit_fwd_kernel(const s3g_mlp_params w, uint32_t* __restrict__ img) {
@@ -728,6 +747,157 @@ __global__ void __launch_bounds__(256) mlp_pack_presplit_fwd_kernel(const s3g_ml
     out = __float_as_uint(v);
   }
   img[x] = out;
+}
+
+// word t of piece `piece` of the transposed pair (W[o0][in], W[o1][in]); output features >= outs are zero
+__device__ __forceinline__ uint32_t split_word_t(const float* __restrict__ W, int outs, int ld, int in, int o0, int o1, int piece) {
+  uint32_t p[3];
+  const float a = o0 < outs ? W[(size_t)o0 * ld + in] : 0.f, b = o1 < outs ? W[(size_t)o1 * ld + in] : 0.f;
+  split_pair(a, b, p[0], p[1], p[2]);
+  return piece == 0 ? p[0] : (piece == 1 ? p[1] : p[2]);
+}
+__global__ void __launch_bounds__(256) mlp_pack_presplit_bwd_kernel(const s3g_mlp_params w, uint32_t* __restrict__ img) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= tbw::WORDS) return;
+  uint32_t out = 0;
+  if (x < tbw::P1T) {   // full fragments of W^T: row = input feature, k = output feature
+    const float* W; int KS, ld, outs, y;
+    if (x < tbw::D1T) { W = w.W0; KS = 4; ld = FEAT; outs = 64; y = x - tbw::W0T; }
+    else if (x < tbw::D0T) { W = w.D1; KS = 4; ld = HID; outs = 64; y = x - tbw::D1T; }
+    else if (x < tbw::S1T) { W = w.D0; KS = 4; ld = HID; outs = 64; y = x - tbw::D0T; }
+    else if (x < tbw::S2T) { W = w.S1; KS = 4; ld = HID; outs = 64; y = x - tbw::S1T; }
+    else { W = w.S2; KS = 3; ld = HID; outs = 48; y = x - tbw::S2T; }
+    const int t = y & 3, lane = (y >> 2) & 63, piece = (y >> 8) % 3, fr = (y >> 8) / 3, ks = fr % KS, mbo = fr / KS;
+    out = split_word_t(W, outs, ld, 32 * mbo + (lane & 31), split_feature(ks, lane >> 5, 2 * t), split_feature(ks, lane >> 5, 2 * t + 1), piece);
+  } else if (x < tbw::P2T) {   // P1^T as fp32 rows
+    const int y = x - tbw::P1T, in = y / tbw::P1LD, o = y % tbw::P1LD;
+    out = o < HID ? __float_as_uint(w.P1[o * HID + in]) : 0u;
+  } else {   // the 3-row heads, transposed: [in][8]
+    const bool dino = x >= tbw::D2T;
+    const int y = x - (dino ? tbw::D2T : tbw::P2T), in = y / tbw::H3LD, o = y % tbw::H3LD;
+    out = o < 3 ? __float_as_uint((dino ? w.D2 : w.P2)[o * HID + in]) : 0u;
+  }
+  img[x] = out;
+}
+
+// Per-point backward chain on the pre-split image: mlp_backward_kernel<true> with every fragment split ONCE (bit-identical to it).
+__global__ void __launch_bounds__(NWAVE * 64) mlp_backward_presplit_kernel(const MlpBwdArgs a) {   // a.packed = the tbw image
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const uint32_t* wsplit = reinterpret_cast<const uint32_t*>(lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = wave; c < tbw::WORDS / 256; c += NWAVE)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.packed + c * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(lds + c * 256), 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int ntiles = (a.P + MT - 1) / MT;
+  const size_t PS = (size_t)a.P * HID;
+  const int j = lane & 31, h = lane >> 5;
+  const bool dino = a.g_feat != nullptr;
+  auto issue = [&](BwdIn& I, int tile) {
+    const size_t p = (size_t)min(tile * MT + j, a.P - 1);
+    const uint32_t* mw = a.maskbits + (size_t)tile * 5 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 5; k++) I.bits[k] = mw[k * 64];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      I.gd[k] = a.g_dx[p * 3 + k];
+      I.gf[k] = dino ? a.g_feat[p * 3 + k] : 0.f;
+    }
+    const float* row = a.g_dshs + p * 48 + 4 * h;
+#pragma unroll
+    for (int c = 0; c < 6; c++) I.gs[c] = *reinterpret_cast<const float4*>(row + 8 * c);
+  };
+  auto head3 = [&](f32x16 (&g3)[1], const float (&v)[3]) {
+    acc_zero<1>(g3);
+#pragma unroll
+    for (int k = 0; k < 3; k++) g3[0][k] = h == 0 ? v[k] : 0.f;
+  };
+  const int stride = gridDim.x * NWAVE, t0 = blockIdx.x * NWAVE + wave;
+  BwdIn cur, nxt;
+  if (t0 < ntiles) issue(cur, t0);
+  for (int tile = t0; tile < ntiles; tile += stride) {
+    issue(nxt, min(tile + stride, ntiles - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    const int p0 = tile * MT, npts = min(MT, a.P - p0);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    f32x16 ghid[2], g[2], acc[2], g3[1];
+    ActSplit<2> gsp;
+    acc_zero<2>(ghid);
+    if (dino) {
+      head3(g3, cur.gf);
+      acc_zero<2>(acc);
+      gemm_reg_t<2, 1, 3>(lds + tbw::D2T, tbw::H3LD, g3, acc, ln);          // D2^T g_feat: exact fp32 MFMAs (3 live K steps)
+      masked_bits<2, false>(g, acc, cur.bits[4]);
+      act_store<HID, 2, false>(g, a.ws + 0 * PS, 0, p0, npts, ln);
+      acc_zero<2>(acc);
+      act_split<2, false>(gsp, g);
+      gemm_split<2, 2>(wsplit + tbw::D1T, 4, 0, gsp, acc, ln);              // D1^T
+      masked_bits<2, false>(g, acc, cur.bits[3]);
+      act_store<HID, 2, false>(g, a.ws + 1 * PS, 0, p0, npts, ln);
+      act_split<2, false>(gsp, g);
+      gemm_split<2, 2>(wsplit + tbw::D0T, 4, 0, gsp, ghid, ln);             // ghid = D0^T (dino input is the raw hidden: no mask)
+    }
+    // ---- pos head ----
+    head3(g3, cur.gd);
+    acc_zero<2>(acc);
+    gemm_reg_t<2, 1, 3>(lds + tbw::P2T, tbw::H3LD, g3, acc, ln);            // P2^T g_dx
+    masked_bits<2, false>(g, acc, cur.bits[1]);
+    act_store<HID, 2, false>(g, a.ws + 2 * PS, 0, p0, npts, ln);
+    acc_zero<2>(acc);
+    act_split<2, false>(gsp, g);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)      // P1^T: fp32 rows in LDS, split by the lanes that read them (same element order as gemm_reg_t_split)
+#pragma unroll
+      for (int mbo = 0; mbo < 2; mbo++) {
+        const float* wr = lds + tbw::P1T + (32 * mbo + (ln & 31)) * tbw::P1LD + 4 * (ln >> 5) + 16 * ks;
+        const float4 lo = *reinterpret_cast<const float4*>(wr);
+        const float4 hi = *reinterpret_cast<const float4*>(wr + 8);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        acc[mbo] = mfma_split(acc[mbo], split8(v), gsp.b[ks >> 1][ks & 1]);
+      }
+    // ---- shs head ----
+    {
+      f32x16 gs[2], t[2];
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const float4 v = c < 6 ? cur.gs[c < 6 ? c : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        gs[c >> 2][4 * (c & 3) + 0] = v.x; gs[c >> 2][4 * (c & 3) + 1] = v.y;
+        gs[c >> 2][4 * (c & 3) + 2] = v.z; gs[c >> 2][4 * (c & 3) + 3] = v.w;
+      }
+      acc_zero<2>(t);
+      ActSplit<2> ssp;
+      act_split<2, false>(ssp, gs);
+#pragma unroll
+      for (int ks = 0; ks < 3; ks++) {    // S2^T g_dshs: K = 48 (the on-the-fly kernel's fourth K step multiplies zeros by zeros)
+        Split8 aw[2];
+#pragma unroll
+        for (int mbo = 0; mbo < 2; mbo++)
+#pragma unroll
+          for (int pc = 0; pc < 3; pc++)
+            aw[mbo].p[pc] = *reinterpret_cast<const u32x4*>(wsplit + tbw::S2T + ((mbo * 3 + ks) * 3 + pc) * tbw::FRAG + ln * 4);
+#pragma unroll
+        for (int mbo = 0; mbo < 2; mbo++) t[mbo] = mfma_split(t[mbo], aw[mbo], ssp.b[ks >> 1][ks & 1]);
+      }
+      masked_bits<2, false>(g, t, cur.bits[2]);
+    }
+    act_store<HID, 2, false>(g, a.ws + 3 * PS, 0, p0, npts, ln);
+    act_split<2, false>(gsp, g);
+    gemm_split<2, 2>(wsplit + tbw::S1T, 4, 0, gsp, acc, ln);                // + S1^T  (same relu(hidden) mask as P1^T)
+    masked_bits<2, true>(ghid, acc, cur.bits[0]);
+    act_store<HID, 2, false>(ghid, a.ws + 4 * PS, 0, p0, npts, ln);
+    // ---- feature_out: g_x[:, half] = W0[:, half]^T ghid ----
+    act_split<2, false>(gsp, ghid);
+    acc_zero<2>(acc);
+    gemm_split<2, 2>(wsplit + tbw::W0T, 4, 0, gsp, acc, ln);
+    act_store<FEAT, 2, false>(acc, a.g_x, 0, p0, npts, ln);
+    acc_zero<2>(acc);
+    gemm_split<2, 2>(wsplit + tbw::W0T + 2 * 4 * 3 * tbw::FRAG, 4, 0, gsp, acc, ln);
+    act_store<FEAT, 2, false>(acc, a.g_x, 64, p0, npts, ln);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+  }
 }
 
 __global__ void __launch_bounds__(NWAVE * 64) mlp_forward_presplit_kernel(const MlpFwdArgs a) {   // a.packed = the tpw image
@@ -1672,6 +1842,7 @@ static int mlp_set_attrs() {
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_FLOATS * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_wgrad_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WM_RED * 4));
     S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_forward_presplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tpw::WORDS * 4));
+    S3G_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_backward_presplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tbw::WORDS * 4));
     device_setup_done(done);
   }
   return S3G_OK;
@@ -1694,7 +1865,7 @@ extern "C" int s3g_deform_mlp_forward(const s3g_mlp_params* w, int P, const floa
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
   const int arith = g_mlp_arithmetic.load(std::memory_order_relaxed);
-  if (arith == S3G_MLP_BF16X3)   // the forward's pre-split image, behind the fp32 one (which the backward still reads)
+  if (arith == S3G_MLP_BF16X3)   // the forward's pre-split image, behind the fp32 one (the backward packs its own: it may run in another mode)
     hipLaunchKernelGGL(mlp_pack_presplit_fwd_kernel, dim3((tpw::WORDS + 255) / 256), dim3(256), 0, stream, *w,
                        reinterpret_cast<uint32_t*>(stash + PACK_FLOATS));
   profile_begin(S3G_PROFILE_MLP_FORWARD, stream);
@@ -1726,8 +1897,17 @@ extern "C" int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const flo
   b.P = P; b.packed = stash_; b.maskbits = reinterpret_cast<const uint32_t*>(stash + (size_t)5 * P * HID); b.g_dx = g_dx; b.g_dshs = g_dshs; b.g_feat = g_feat; b.g_x = g_features; b.ws = workspace;
   const int ntiles = (P + MT - 1) / MT;
   const int blocks = min((ntiles + NWAVE - 1) / NWAVE, 256);
+  const int arith = g_mlp_arithmetic.load(std::memory_order_relaxed);
+  // S3G_MLP_BF16X3: the transposed pre-split image goes into the slot the stash reserves for it (the caller's buffer: only this region is written)
+  float* img = const_cast<float*>(stash_) + PACK_FLOATS + tpw::WORDS;
+  if (arith == S3G_MLP_BF16X3)
+    hipLaunchKernelGGL(mlp_pack_presplit_bwd_kernel, dim3((tbw::WORDS + 255) / 256), dim3(256), 0, stream, *w, reinterpret_cast<uint32_t*>(img));
   profile_begin(S3G_PROFILE_MLP_BACKWARD, stream);
-  if (g_mlp_arithmetic.load(std::memory_order_relaxed) != S3G_MLP_F32)
+  if (arith == S3G_MLP_BF16X3) {
+    MlpBwdArgs sb = b;
+    sb.packed = img;
+    hipLaunchKernelGGL(mlp_backward_presplit_kernel, dim3(blocks), dim3(NWAVE * 64), tbw::WORDS * 4, stream, sb);
+  } else if (arith != S3G_MLP_F32)
     hipLaunchKernelGGL(mlp_backward_kernel<true>, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, b);
   else
     hipLaunchKernelGGL(mlp_backward_kernel<false>, dim3(blocks), dim3(NWAVE * 64), MLP_LDS_FLOATS * 4, stream, b);

@@ -208,3 +208,86 @@ def test_split_arithmetic_at_baseline_size(gpu_device):
     assert max(st["dx"], st["dshs"], st["feat"]) < 1e-6, st
     assert st["g_features_rows_off_by_1e-3"] < 2e-3, st
     assert max(st["gW0"], st["gS1"]) < 5e-3, st
+
+
+@pytest.mark.parametrize("P", [1, 31, 32, 33, 4097, 70_001, 1_200_013])
+def test_presplit_bf16x3_kernels_are_bit_identical_to_the_on_the_fly_split(gpu_device, P):
+    """Round 5: S3G_MLP_BF16X3 runs mlp_forward_presplit_kernel / mlp_backward_presplit_kernel -- the weight fragments split ONCE into a
+    159 KiB LDS image instead of by every wave for every tile.  Same pieces, same MFMA order as the on-the-fly kernels
+    (S3G_MLP_BF16X3_ONTHEFLY, kept as the checker): outputs, activation stash, ReLU mask words, g_features and the five gradient-signal
+    planes must agree BIT FOR BIT, ragged last tiles included; the weight gradients (exact fp32 chain, atomic flush) to round-off."""
+    import ctypes as C
+    from s3gaussian_amd import _lib, mlp
+    dev = gpu_device
+    L = mlp._bind()
+    g = torch.Generator().manual_seed(P)
+    x = (torch.rand(P, 128, generator=g) * 0.5).to(dev)
+    params = [(torch.randn(*s, generator=g) * (0.2 if len(s) == 2 else 0.05)).to(dev) for s in mlp._SHAPES]
+    g_dx, g_dshs, g_feat = (torch.randn(P, n, generator=g).to(dev) for n in (3, 48, 3))
+    pk = L.s3g_deform_mlp_pack_bytes() // 4
+    bits = lambda t: t.contiguous().view(torch.int32)
+    out = {}
+    try:
+        for mode in ("bf16x3_onthefly", "bf16x3"):
+            mlp.set_mlp_arithmetic(mode)
+            for with_feat in (True, False):
+                dx, dshs, feat = (torch.empty(P, n, device=dev) for n in (3, 48, 3))
+                stash = torch.zeros(L.s3g_deform_mlp_stash_bytes(P) // 4, device=dev)
+                grads = [torch.zeros_like(p) for p in params]
+                w, gw = mlp._pack(params), mlp._pack(grads)
+                gx, ws = torch.empty_like(x), torch.zeros(5, P, 64, device=dev)
+                stream = torch.cuda.current_stream().cuda_stream
+                _lib.check(L.s3g_deform_mlp_forward(C.byref(w), P, x.data_ptr(), dx.data_ptr(), dshs.data_ptr(), feat.data_ptr(), stash.data_ptr(), 1, stream))
+                _lib.check(L.s3g_deform_mlp_backward(C.byref(w), P, x.data_ptr(), stash.data_ptr(), g_dx.data_ptr(), g_dshs.data_ptr(),
+                                                     g_feat.data_ptr() if with_feat else None, gx.data_ptr(), C.byref(gw), ws.data_ptr(), stream))
+                torch.cuda.synchronize()
+                out[(mode, with_feat)] = dict(dx=dx, dshs=dshs, feat=feat, stash=stash[pk:].clone(), gx=gx, ws=ws if with_feat else ws[2:].clone(), grads=grads)
+    finally:
+        mlp.set_mlp_arithmetic("f32")
+    for with_feat in (True, False):
+        a, b = out[("bf16x3_onthefly", with_feat)], out[("bf16x3", with_feat)]
+        for k in ("dx", "dshs", "feat", "stash", "gx", "ws"):
+            assert torch.equal(bits(a[k]), bits(b[k])), (k, with_feat)
+        for n, ga, gb in zip(mlp._NAMES, a["grads"], b["grads"]):
+            if not with_feat and n.startswith(("D", "db")):
+                assert float(gb.abs().max()) == 0.0        # the dino head's gradients are left untouched
+                continue
+            assert float((ga - gb).abs().max()) <= 2e-6 * float(ga.abs().max()) + 1e-30, n
+
+
+def test_presplit_bf16x3_kernels_are_bit_reproducible_over_200_launches(gpu_device):
+    """The bf16 matrix pipe beside packed VALU work has bitten before (the inference kernel's staging stores).  The
+    training kernels park nothing in LDS, but the stress form is cheap: 200 forward + backward launches at 1.2 M points, every one
+    compared on the device with the first."""
+    import ctypes as C
+    from s3gaussian_amd import _lib, mlp
+    dev = gpu_device
+    L = mlp._bind()
+    P = 1_200_013
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(P, 128, generator=g) * 0.5).to(dev)
+    params = [(torch.randn(*s, generator=g) * (0.2 if len(s) == 2 else 0.05)).to(dev) for s in mlp._SHAPES]
+    g_dx, g_dshs, g_feat = (torch.randn(P, n, generator=g).to(dev) for n in (3, 48, 3))
+    dx, dshs, feat = (torch.empty(P, n, device=dev) for n in (3, 48, 3))
+    stash = torch.zeros(L.s3g_deform_mlp_stash_bytes(P) // 4, device=dev)
+    grads = [torch.zeros_like(p) for p in params]
+    w, gw = mlp._pack(params), mlp._pack(grads)
+    gx, ws = torch.empty_like(x), torch.empty(5, P, 64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    first = None
+    try:
+        mlp.set_mlp_arithmetic("bf16x3")
+        for it in range(200):
+            _lib.check(L.s3g_deform_mlp_forward(C.byref(w), P, x.data_ptr(), dx.data_ptr(), dshs.data_ptr(), feat.data_ptr(), stash.data_ptr(), 1, stream))
+            _lib.check(L.s3g_deform_mlp_backward(C.byref(w), P, x.data_ptr(), stash.data_ptr(), g_dx.data_ptr(), g_dshs.data_ptr(), g_feat.data_ptr(),
+                                                 gx.data_ptr(), C.byref(gw), ws.data_ptr(), stream))
+            cur = [t.view(torch.int32) for t in (dx, dshs, feat, gx, ws)]
+            if first is None:
+                first = [t.clone() for t in cur]
+            else:
+                for a, b in zip(first, cur):
+                    bad += (a != b).sum()
+    finally:
+        mlp.set_mlp_arithmetic("f32")
+    assert int(bad.item()) == 0

@@ -55,12 +55,31 @@ def run(mode):
     return dict(dx=dx, dshs=dshs, feat=feat, stash=stash[pack_floats:].clone(), gx=gx, ws=ws, grads=grads), times
 
 
+def forward_only(mode, save):
+    """the forward alone, with / without the activation stash (save = 0: what an inference render that draws the feature image runs)"""
+    mlp.set_mlp_arithmetic(mode)
+    dx, dshs, feat = (torch.empty(P, n, device=dev) for n in (3, 48, 3))
+    stash = torch.zeros(L.s3g_deform_mlp_stash_bytes(P) // 4, device=dev)
+    w = mlp._pack(params)
+    stream = torch.cuda.current_stream().cuda_stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 2)]
+    for r in range(reps + 1):
+        ev[r].record()
+        _lib.check(L.s3g_deform_mlp_forward(C.byref(w), P, x.data_ptr(), dx.data_ptr(), dshs.data_ptr(), feat.data_ptr(), stash.data_ptr(), save, stream))
+    ev[reps + 1].record()
+    torch.cuda.synchronize()
+    return round(ev[1].elapsed_time(ev[reps + 1]) / reps, 4)     # (includes the pack kernels: ~10 us)
+
+
 res, times = {}, {}
 for mode in ("f32", "bf16x3_onthefly", "bf16x3"):
     res[mode], times[mode] = run(mode)
+    times[mode]["forward_call_ms_with_stash"] = forward_only(mode, 1)
+    times[mode]["forward_call_ms_no_stash"] = forward_only(mode, 0)
 mlp.set_mlp_arithmetic("f32")
 a, b = res["bf16x3_onthefly"], res["bf16x3"]
-same = {k: bool(torch.equal(a[k], b[k])) for k in ("dx", "dshs", "feat", "stash", "gx", "ws")}
+bits = lambda t: t.contiguous().view(torch.int32)       # (mask words reinterpreted as floats may be NaN patterns: compare the bits)
+same = {k: bool(torch.equal(bits(a[k]), bits(b[k]))) for k in ("dx", "dshs", "feat", "stash", "gx", "ws")}
 same["weight_grads_max_rel"] = max(float((ga - gb).abs().max() / ga.abs().max().clamp_min(1e-30)) for ga, gb in zip(a["grads"], b["grads"]))
 f = res["f32"]
 dist = {k: float((b[k] - f[k]).norm() / f[k].norm()) for k in ("dx", "dshs", "feat", "gx")}
