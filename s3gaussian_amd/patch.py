@@ -60,11 +60,9 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
            return_decomposition=False, return_dx=False, render_feat=False):
     """Signature of gaussian_renderer/__init__.py:23; `pc` is the reference's GaussianModel (same attribute names as
     pipeline.GaussianParams), `viewpoint_camera` its Camera."""
-    if getattr(pipe, "compute_cov3D_python", False) and "render" in _REFERENCE:
-        # a switch the fused route does not special-case: hand the call back to the reference's own render() (saved by
-        # patch_reference), whatever it does with it, on the drop-in rasterizer
-        return _REFERENCE["render"](viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, stage,
-                                    return_decomposition, return_dx, render_feat)
+    # (pipe.compute_cov3D_python is honoured by pipeline.render itself -- covariance built in Python, handed over as cov3D_precomp --;
+    #  until round 5 this function handed that switch back to the reference's own render(), which raises TypeError on it:
+    #  torch.exp(None), gaussian_renderer/__init__.py:76-101.  One implementation for both entry points now, ADVICE r4.)
     out = _pipeline.render(_cam_dict(viewpoint_camera), pc, pipe, bg_color, scaling_modifier, override_color, stage,
                            return_decomposition, return_dx, render_feat)
     reg = out.get("plane_reg") if isinstance(out, dict) else None

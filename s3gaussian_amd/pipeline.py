@@ -513,8 +513,10 @@ def render(viewpoint_camera: Dict, pc: GaussianParams, pipe: SimpleNamespace, bg
             img, rad, dep = rasterizer(means3D=means3D_final[m], means2D=means2D[m],
                                        shs=shs_final[m] if shs_final is not None else None,
                                        colors_precomp=colors_precomp[m] if colors_precomp is not None else None,
-                                       opacities=opacity[m], scales=scales_final[m], rotations=rotations_final[m],
-                                       cov3D_precomp=None)
+                                       opacities=opacity[m],
+                                       scales=scales_final[m] if scales_final is not None else None,
+                                       rotations=rotations_final[m] if rotations_final is not None else None,
+                                       cov3D_precomp=cov3D_precomp[m] if cov3D_precomp is not None else None)
             out.update({f"render_{tag}": img, f"depth_{tag}": dep, f"visibility_filter_{tag}": rad > 0})
     if return_dx and "fine" in stage:
         out.update({"dx": dx, "dshs": dshs})

@@ -127,6 +127,7 @@ class _AsyncState:
         self.overflows = []        # seq numbers of the calls that rendered nothing because THEY overflowed
         self.frozen = []           # seq numbers of the calls that rendered nothing because an EARLIER call had (replay mode)
         self.sticky_dev = torch.zeros(1, dtype=torch.int32, device=device)   # the sticky word of replay mode
+        self.fit_key = None        # (P, W, H, capacities) last checked against the free device memory
         self.replay_from = None    # seq of the earliest overflowed call the host has not acknowledged yet
         self.ack_seq = 0           # calls issued before the last acknowledgement are covered by that rewind
         self.sum_instances = 0     # over the drained calls (workload statistics)
@@ -269,11 +270,37 @@ def async_reset_statistics(device=None) -> None:
         st.sum_instances, st.drained, st.overflows, st.frozen = 0, 0, [], []
 
 
+def _fits_device_memory(st: _AsyncState, L, dev, P, W, H, caps) -> bool:
+    """the speculative arenas (and the backward records sized from the same capacity: 56 B per instance) must not be what
+    exhausts the device.  Checked once per (P, image size, capacity) -- hipMemGetInfo is a driver call --: the arenas of a forward +
+    its backward may take at most half of what is free (driver-free + cached by torch's allocator)."""
+    fit_key = (P, W, H, caps[0], caps[1])
+    if st.fit_key == fit_key:
+        return True
+    nb = (C.c_size_t(), C.c_size_t(), C.c_size_t())
+    _lib.check(L.s3g_raster_arena_bytes(P, W, H, caps[0], caps[1], C.byref(nb[0]), C.byref(nb[1]), C.byref(nb[2])))
+    need = sum(int(n.value) for n in nb) + 56 * int(caps[0])
+    free, _total = torch.cuda.mem_get_info(dev)
+    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    if need > free // 2:
+        return False
+    st.fit_key = fit_key
+    return True
+
+
 def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_depth, out_color2, radii, forward_only=False):
-    """One s3g_raster_forward_async call (or several while the capacity is being learnt).  -> (R capacity, geom, binning, img)"""
+    """One s3g_raster_forward_async call (or several while the capacity is being learnt).  -> (R capacity, geom, binning, img), or
+    None when not even twice the largest counts seen fits half of the free device memory: the caller then takes the synchronous
+    forward, whose arenas are sized for the true counts."""
     key = (W, H)
     st.drain()
     caps = st.caps(key)
+    if caps is not None and not _fits_device_memory(st, L, dev, P, W, H, caps):
+        h = st.hist[key]          # 2 x instead of 4 x headroom, no floor: dense scenes / 8K images on a crowded device
+        tight = (min(_quantise(2 * h[0] + 1), 0x7fffffff), min(max(_quantise(2 * h[1] + 1), _quantise(2 * h[0] + 1)), 0xffffffff), caps[2], caps[3])
+        if not _fits_device_memory(st, L, dev, P, W, H, tight):
+            return None
+        caps = tight
     learn = caps is None                    # first call for this image size: generous capacity, wait once, remember the counts
     if learn:
         caps = (_quantise(_ASYNC_MIN_INSTANCES), _quantise(2 * _ASYNC_MIN_INSTANCES), 4096, 1)
@@ -398,9 +425,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         col2_ = _f32(colors2, "colors2") if colors2 is not None else None
         if col2_ is not None and col2_.shape != (P, NUM_CHANNELS):
             raise RuntimeError("colors2 must have shape (num_points, 3)")
+        res = None
         if allow_async and ASYNC and not debug and not prefiltered:   # a `prefiltered` violation must raise from THIS call
-            R_cap, geom_t, binning_t, img_t = _forward_async(L, _async_state(dev), inp, col2_, P, W, H, dev, out_color, out_depth,
-                                                             out_color2, radii, forward_only)
+            res = _forward_async(L, _async_state(dev), inp, col2_, P, W, H, dev, out_color, out_depth, out_color2, radii, forward_only)
+            if res is None:      # synchronous fallback: no overflow word belongs to this forward (the guarded steps must not read an old one)
+                _async_state(dev).last_slot = None
+        if res is not None:
+            R_cap, geom_t, binning_t, img_t = res
             if key is not None:
                 _geom_cache = (key, geo_tensors, (R_cap, radii, geom_t, binning_t, img_t))
                 _geom_cache_forward_only = forward_only

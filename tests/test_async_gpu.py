@@ -222,3 +222,45 @@ def test_forward_only_render_is_bit_identical_and_never_feeds_a_backward(gpu_dev
         with torch.no_grad():
             rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=col, scales=sc, rotations=rot)
         assert raster_C._geom_cache_hits == hits + 1
+
+
+def test_speculative_arenas_yield_to_a_crowded_device(gpu_device, monkeypatch):
+    """the asynchronous forward sizes its arenas (and through them the backward's records) for 4 x the largest count seen,
+    at least 16 M instances -- about 1.2 GB per render / backward pair.  When that does not fit half of the free device memory it
+    tries 2 x without a floor, and when that does not fit either the call takes the SYNCHRONOUS forward (arenas sized for the true
+    counts): same image, same gradients, no asynchronous call issued, and no stale overflow word left for the guarded optimizer."""
+    from s3gaussian_amd import raster_C
+    dev = gpu_device
+    s = tiny_scene(P=20_000, W=320, H=208, seed=6)
+    prev = raster_C.set_async(True)
+    try:
+        raster_C._async_states.pop(dev.index or 0, None)
+        raster_C.invalidate_geometry_cache()
+        ref_out, ref_grads = _render_and_grads(s, dev, pair=True)          # learns the counts; asynchronous from the second call on
+        st = raster_C._async_state(dev)
+        st.drain(block=True)
+        calls = raster_C.async_status(dev, block=True)["calls"]
+        real = torch.cuda.mem_get_info
+        # (1) room for the tight capacity only: still asynchronous, smaller arenas
+        need4 = 56 * st.caps((320, 208))[0]
+        monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (need4 // 4, real(d)[1]))
+        monkeypatch.setattr(torch.cuda, "memory_reserved", lambda d=None: 0)
+        monkeypatch.setattr(torch.cuda, "memory_allocated", lambda d=None: 0)
+        st.fit_key = None
+        raster_C.invalidate_geometry_cache()
+        out, grads = _render_and_grads(s, dev, pair=True)
+        for a, b in zip(ref_out + ref_grads, out + grads):
+            assert torch.equal(a, b)
+        assert raster_C.async_status(dev, block=True)["calls"] == calls + 1
+        # (2) no room at all: the synchronous forward
+        monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (1 << 20, real(d)[1]))
+        st.fit_key = None
+        raster_C.invalidate_geometry_cache()
+        out, grads = _render_and_grads(s, dev, pair=True)
+        for a, b in zip(ref_out + ref_grads, out + grads):
+            assert torch.equal(a, b)
+        assert raster_C.async_status(dev, block=True)["calls"] == calls + 1 and raster_C.async_skip_flag(dev) is None
+    finally:
+        raster_C.set_async(prev)
+        raster_C._async_states.pop(dev.index or 0, None)
+        raster_C.invalidate_geometry_cache()

@@ -166,3 +166,28 @@ def test_compute_cov3d_python_switch_renders_the_same_image(gpu_device):
     # the in-kernel path differentiates w.r.t. the quaternion AS GIVEN (backward.cu:340); the Python expression normalises it first,
     # so only the component orthogonal to q is comparable -- which is the whole gradient for unit quaternions (these are)
     assert rel_l2(outs[True][3].cpu().numpy(), outs[False][3].cpu().numpy()) < 5e-2
+
+
+def test_decomposition_fallback_with_python_covariance(gpu_device):
+    """return_decomposition through the per-mask fallback (grad enabled, or pipe.fused_decomposition = False) together with
+    pipe.compute_cov3D_python used to index scales_final = None.  Both switches together: the masked renders take cov3D_precomp[mask],
+    and agree with the in-kernel covariance; patch.render and pipeline.render are the same implementation."""
+    from s3gaussian_amd import patch, synth
+    from s3gaussian_amd.pipeline import GaussianParams, default_hyper, default_opt, render
+    dev = gpu_device
+    scn = synth.street_scene(P=6_000, seed=4, width=160, height=112, n_frames=2)
+    pc = GaussianParams(3, default_hyper())
+    gs = scn["gaussians"]
+    pc.init_from_tensors(gs["xyz"], gs["log_scales"], gs["rotations_raw"], gs["opacity_logit"], gs["shs"], dev)
+    pc._deformation.deformation_net.set_aabb(*scn["aabb"])
+    pc.training_setup(default_opt())
+    cam = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scn["cameras"][0].items()}
+    outs = {}
+    for flag in (False, True):
+        pipe = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=flag, debug=False, fused_decomposition=False)
+        pkg = render(cam, pc, pipe, scn["bg"].to(dev), stage="fine", return_decomposition=True)     # grad enabled: the fallback
+        outs[flag] = (pkg["render_d"].detach(), pkg["render_s"].detach())
+        pkg2 = patch.render(cam, pc, pipe, scn["bg"].to(dev), stage="fine", return_decomposition=True)
+        assert torch.equal(pkg2["render_d"], pkg["render_d"]) and torch.equal(pkg2["render_s"], pkg["render_s"])
+    for a, b in zip(outs[True], outs[False]):
+        assert float((a - b).abs().max()) < 2e-4
