@@ -940,11 +940,12 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_forward_presplit_kernel(const 
     }
   };
   const int stride = gridDim.x * NWAVE, t0 = blockIdx.x * NWAVE + wave;
-  XIn cur, nxt;
+  // ONE input buffer: the 128 features of a tile are consumed by the first GEMM (split into `as`), after which their registers are free
+  // again -- the NEXT tile's rows are requested right there and have the remaining three quarters of the tile's work to arrive
+  // (the exact kernel keeps two buffers across the whole tile: 64 more live registers, which this kernel does not have)
+  XIn cur;
   if (t0 < ntiles) issue(cur, t0);
   for (int tile = t0; tile < ntiles; tile += stride) {
-    issue(nxt, min(tile + stride, ntiles - 1));
-    __builtin_amdgcn_sched_barrier(0);
     const int p0 = tile * MT, npts = min(MT, a.P - p0);
     f32x16 hid[2], act[2], acc[2], o[1];
     int ln = lane;   // per-tile copy: LDS / output addresses are re-derived instead of being carried (and spilled) across the loop
@@ -958,6 +959,9 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_forward_presplit_kernel(const 
       gemm_split<2, 2>(wsplit + tpw::W0, 8, 0, as, hid, ln);
       unpack(x, cur, 1);
       act_split<2, false>(as, x);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(cur, min(tile + stride, ntiles - 1));   // unconditional (clamped): see mlp_wgrad_kernel
+      __builtin_amdgcn_sched_barrier(0);
       gemm_split<2, 2>(wsplit + tpw::W0, 8, 4, as, hid, ln);
     }
     uint32_t* mw = a.maskbits ? a.maskbits + (size_t)tile * 5 * 64 + ln : nullptr;
@@ -1021,7 +1025,6 @@ __global__ void __launch_bounds__(NWAVE * 64) mlp_forward_presplit_kernel(const 
       act_store3(o, a.feat, p0, npts, ln);
     }
     __builtin_amdgcn_sched_barrier(0);
-    cur = nxt;
   }
 }
 
