@@ -742,6 +742,30 @@ def main(argv=None):
                      "gc_gen2_passes": GC_PASSES[-1], "arena_overflows": s_over}
         comm.update(elems=0, events=[], sparse_rows=0)
 
+    # ---- 1c. the opt-in arithmetic of the MLP kernels (bf16 matrix pipe on exactly split operands, weight fragments split once, fp32
+    #          accuracy), A/B at the SAME point of the process: the fp32 step again, then the bf16x3 step, same views.  (Up to round 5's
+    #          first lines this leg ran last and was read against the headline: but every loop after the first ~2 s of load runs
+    #          ~0.2 ms/step slower than the opening 20-step burst on these boxes, so the faster arithmetic looked slower.)
+    mlp_ab = None
+    if world == 1 and not dist_on and not a.no_alt_paths:
+        from s3gaussian_amd import mlp as _mlp
+        try:
+            ab_idx = [i % n_needed for i in range(a.steps)]
+            dt_a, _, ps_a = timed_loop(step, ab_idx, 1, device)
+            _mlp.set_mlp_arithmetic("bf16x3")
+            for i in range(3):
+                step(i % n_needed)
+            dt_b, _, ps_b = timed_loop(step, ab_idx, 1, device)
+            ms_b = 1000.0 * dt_b / a.steps
+            mlp_ab = {"ms_per_step": round(ms_b, 3), "iters_per_s": round(1000.0 / ms_b, 2), "steps": a.steps,
+                      "f32_back_to_back_ms_per_step": round(1000.0 * dt_a / a.steps, 3),
+                      "gpu_ms_per_step": round(sum(ps_b) / len(ps_b), 3), "f32_back_to_back_gpu_ms_per_step": round(sum(ps_a) / len(ps_a), 3)}
+        except Exception as ex:   # never take the headline down
+            mlp_ab = {"ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"}
+        finally:
+            _mlp.set_mlp_arithmetic("f32")
+        comm.update(elems=0, events=[], sparse_rows=0)
+
     # ---- 2. roofline leg: the SAME steps again with the nine hot kernels bracketed by hipEvent pairs inside libs3g.so -------
     clear_profile_slots()
     L.s3g_profile_enable(1)
@@ -1009,18 +1033,8 @@ def main(argv=None):
                 out["config"]["paths"].update(time_alt_paths(pc, cams, views, targets, tkeys, hyper, opt, bg))
                 out["config"]["paths_note"] = ("oracle/_ref/reference_py.tar.gz absent: `patched` / `import_swap` / `zero_diff` are RESTATEMENTS of "
                                                "train.py's iteration body inside bench.py")
-            try:   # the fused step again with the MLP kernels' per-point GEMM chains on the bf16 matrix pipe (opt-in, fp32 accuracy)
-                from s3gaussian_amd import mlp as _mlp
-                _mlp.set_mlp_arithmetic("bf16x3")
-                for i in range(3):
-                    step(i % len(views))
-                dt2, _, _ = timed_loop(step, [i % len(views) for i in range(a.steps)], 1, device)
-                ms2 = 1000.0 * dt2 / a.steps
-                out["config"]["paths"]["fused_mlp_bf16x3"] = {"ms_per_step": round(ms2, 3), "iters_per_s": round(1000.0 / ms2, 2), "steps": a.steps}
-            except Exception as ex:   # never take the headline down
-                out["config"]["paths"]["fused_mlp_bf16x3"] = {"ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"}
-            finally:
-                _mlp.set_mlp_arithmetic("f32")
+            if mlp_ab is not None:
+                out["config"]["paths"]["fused_mlp_bf16x3"] = mlp_ab
         psnr_file = os.path.join(ROOT, "profiles", "psnr_parity.json")
         if os.path.exists(psnr_file):   # the third part of BASELINE's metric: written by tools/psnr_parity.py on the GPU box
             try:
