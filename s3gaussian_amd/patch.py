@@ -22,6 +22,10 @@ PyTorch launches per iteration (2.9 it/s at BASELINE cfg3).  `patch_reference()`
            cat_tensors_to_optimizer / prune_optimizer keep working)
   GaussianModel.add_densification_stats   (scene/gaussian_model.py:693-695)   -> one pass, no boolean-index host syncs
 
+  render_pkg["dshs"]   -> a tensor that answers `torch.mean(torch.abs(.))` (train.py:407-410) with the sum the render glue already formed
+           in its own pass (and folds the gradient into the glue's backward kernel): -0.5 ms of five passes over 230 MB; any other use
+           sees the plain tensor
+
 What train.py does inline (loss assembly one `loss +=` at a time, `loss.item()`, psnr, the max_radii2D update with boolean masks)
 stays as it is; `bench.py` times exactly that iteration body as `config.paths.patched`.  Every replacement is value-checked against
 the formulation it replaces (tests/test_patch_gpu.py) and the call sites it binds to are pinned against the reference's sources
@@ -74,7 +78,73 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         planes = pc._deformation.deformation_net.grid._planes()
         pc._s3g_plane_reg = ((float(hy.time_smoothness_weight), float(hy.l1_time_planes), float(hy.plane_tv_weight)),
                              tuple(p._version for p in planes), reg)
+    if isinstance(out, dict) and out.get("dshs_l1") is not None and torch.is_tensor(out.get("dshs")) and FUSE_DSHS_L1:
+        out["dshs"] = _L1Ready.wrap(out["dshs"], out["dshs_l1"])      # train.py:408-409 asks for mean|dshs| as abs -> mean
     return out
+
+
+# ---- `torch.mean(torch.abs(render_pkg["dshs"]))` (train.py:407-410) without its five passes over the 230 MB of dshs ------------------
+# train.py writes the regulariser out as abs -> mean on the [P,16,3] tensor: |x| materialised (read + write), reduced (read), and in
+# backward a broadcast, a sign, a product and the accumulation into the gradient the renderer sends -- 0.5 ms of an 8.8-ms iteration at
+# 1.2 M Gaussians (profiles/r05_patched_iteration_trace.txt), for a number the render glue has ALREADY summed in its own pass over dshs
+# (glue.activations_and_colors(with_dshs_l1=True): differentiable, its gradient folded into the glue's backward kernel).  render() below
+# hands dshs out as a tensor that recognises exactly that expression and answers it with the fused value; ANY other use -- another
+# reduction, indexing, arithmetic, printing -- sees the ordinary tensor (|x| is computed the moment something else asks for it).
+_SAFE_GETTERS = {"shape", "dtype", "device", "ndim", "requires_grad", "is_cuda", "layout", "is_sparse", "is_quantized", "is_meta", "names"}
+
+
+def _standing_for(t):
+    """The plain tensor an _L1Ready / _LazyAbs stands for (|x| is computed here, once, if it has not been asked for before)."""
+    if isinstance(t, _LazyAbs):
+        v = t.__dict__.get("_s3g_value")
+        if v is None:
+            v = t.__dict__["_s3g_value"] = torch.abs(t.__dict__["_s3g_src"])
+        return v
+    if isinstance(t, _L1Ready):
+        return t.__dict__["_s3g_src"]
+    return t
+
+
+def _run_plain(func, args, kwargs):
+    from torch.utils._pytree import tree_map
+    with torch._C.DisableTorchFunctionSubclass():
+        return func(*tree_map(_standing_for, tuple(args)), **tree_map(_standing_for, dict(kwargs or {})))
+
+
+class _LazyAbs(torch.Tensor):
+    """torch.abs(x) of an _L1Ready x, not computed yet.  `.mean()` / `torch.mean(.)` over everything -> the fused mean|x|."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        me = args[0] if args and isinstance(args[0], _LazyAbs) else None
+        if me is not None and len(args) == 1 and not kwargs:
+            if func in (torch.mean, torch.Tensor.mean):
+                return me.__dict__["_s3g_l1"]
+            getter = getattr(getattr(func, "__self__", None), "__name__", None)
+            if getattr(func, "__name__", "") == "__get__" and getter in _SAFE_GETTERS:      # same for |x| as for x: no pass over the data
+                with torch._C.DisableTorchFunctionSubclass():
+                    return func(me.__dict__["_s3g_src"])
+        return _run_plain(func, args, kwargs)
+
+
+class _L1Ready(torch.Tensor):
+    """x with mean|x| known (a differentiable scalar of the same graph).  `torch.abs(x)` / `x.abs()` -> _LazyAbs; all else: plain x."""
+
+    @staticmethod
+    def wrap(x: torch.Tensor, l1: torch.Tensor):
+        t = x.as_subclass(_L1Ready)
+        t.__dict__["_s3g_src"], t.__dict__["_s3g_l1"] = x, l1
+        return t
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if func in (torch.abs, torch.Tensor.abs) and len(args) == 1 and not kwargs and isinstance(args[0], _L1Ready):
+            src, l1 = args[0].__dict__["_s3g_src"], args[0].__dict__["_s3g_l1"]
+            with torch._C.DisableTorchFunctionSubclass():
+                lazy = src.as_subclass(_LazyAbs)
+            lazy.__dict__["_s3g_src"], lazy.__dict__["_s3g_l1"] = src, l1
+            return lazy
+        return _run_plain(func, args, kwargs)
 
 
 def _as_image(t: torch.Tensor, channels: int):
@@ -156,6 +226,7 @@ def fused_optimizer_from(optimizer: torch.optim.Optimizer):
     return Adam(groups, lr=d.get("lr", 0.0), betas=d.get("betas", (0.9, 0.999)), eps=d.get("eps", 1e-15))
 
 
+FUSE_DSHS_L1 = True        # render(): hand dshs out as _L1Ready (False: the plain tensor, the expression runs as train.py spells it)
 _REFERENCE: Dict = {}     # the reference's own callables, kept for the cases a replacement hands back
 _PATCHED = False
 

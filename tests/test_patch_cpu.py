@@ -172,3 +172,30 @@ def test_patch_reference_rebinds_a_package_tree_with_the_reference_layout(tmp_pa
     monkeypatch.setattr(patch, "_PATCHED", False)
     for m in [k for k in sys.modules if k.split(".")[0] in ("scene", "utils", "gaussian_renderer")]:
         monkeypatch.delitem(sys.modules, m)
+
+
+def test_the_dshs_stand_in_answers_only_abs_then_mean_and_is_an_ordinary_tensor_otherwise():
+    """patch._L1Ready / _LazyAbs (the tensor render() hands out as render_pkg['dshs']): `torch.mean(torch.abs(x))` and `x.abs().mean()`
+    return the fused scalar it was built with; everything else -- other reductions, arithmetic, indexing, in-place use, autograd --
+    behaves like the plain tensor, with |x| computed the moment it is needed."""
+    import torch
+    from s3gaussian_amd.patch import _L1Ready, _LazyAbs
+    x = torch.randn(40, 16, 3, requires_grad=True)
+    y = x * 1.0
+    fused = y.abs().mean() + 0.0          # stands for the glue's differentiable mean|dshs|
+    t = _L1Ready.wrap(y, fused)
+    assert isinstance(t, torch.Tensor) and t.shape == y.shape and t.dtype == y.dtype and t.requires_grad
+    assert torch.mean(torch.abs(t)) is fused and t.abs().mean() is fused
+    a = torch.abs(t)
+    assert type(a) is _LazyAbs and a.shape == y.shape and a.device == y.device and "_s3g_value" not in a.__dict__     # nothing computed yet
+    assert torch.equal(a.mean(dim=0), y.abs().mean(dim=0)) and "_s3g_value" in a.__dict__                               # now it is
+    assert torch.equal(a.sum(), y.abs().sum()) and torch.equal(a[3], y.abs()[3]) and torch.equal(a.data, y.abs().data)
+    assert torch.equal(torch.mean(a, dim=1), y.abs().mean(dim=1)) and torch.equal(a.mean(0, keepdim=True), y.abs().mean(0, keepdim=True))
+    assert type(a + 1) is torch.Tensor and type(t * 2) is torch.Tensor and torch.equal(t * 2, y * 2) and torch.equal(t[1], y[1])
+    assert torch.equal(t.detach(), y.detach()) and torch.equal(torch.cat([t, t]), torch.cat([y, y])) and torch.equal(t.abs().max(), y.abs().max())
+    assert "nan" not in repr(a) and float(a.min()) >= 0.0
+    (t.abs().mean() * 0.01 + (t * 2).sum() + torch.abs(t).sum()).backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = x2 * 1.0
+    (y2.abs().mean() * 0.01 + (y2 * 2).sum() + y2.abs().sum()).backward()
+    assert torch.allclose(x.grad, x2.grad, rtol=1e-6, atol=1e-7)

@@ -191,3 +191,56 @@ def test_decomposition_fallback_with_python_covariance(gpu_device):
         assert torch.equal(pkg2["render_d"], pkg["render_d"]) and torch.equal(pkg2["render_s"], pkg["render_s"])
     for a, b in zip(outs[True], outs[False]):
         assert float((a - b).abs().max()) < 2e-4
+
+
+def test_dshs_regulariser_of_train_py_is_answered_by_the_glue_pass(gpu_device, monkeypatch):
+    """train.py:407-410 spells the SH-offset regulariser `torch.mean(torch.abs(render_pkg['dshs']))`: five passes over [P,16,3].  The
+    patched render() hands dshs out as a tensor that answers exactly that expression with the sum the render glue formed in its own
+    pass; value and every parameter gradient must equal the spelled-out expression, and any other use must see the plain tensor."""
+    from s3gaussian_amd import patch, synth
+    from s3gaussian_amd.pipeline import GaussianParams, default_hyper, default_opt
+    dev = gpu_device
+    scn = synth.street_scene(P=20_000, seed=7, width=160, height=112, n_frames=2)
+    hyper, opt = default_hyper(), default_opt()
+    cam = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scn["cameras"][0].items()}
+    pipe = SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False, debug=False)
+
+    def model():
+        torch.manual_seed(0)
+        pc = GaussianParams(3, hyper)
+        gs = scn["gaussians"]
+        pc.init_from_tensors(gs["xyz"], gs["log_scales"], gs["rotations_raw"], gs["opacity_logit"], gs["shs"], dev)
+        pc._deformation.deformation_net.set_aabb(*scn["aabb"])
+        with torch.no_grad():      # the SH head starts at zero output: give it something to regularise
+            for p in pc._deformation.deformation_net.shs_deform.parameters():
+                p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(3)).to(dev))
+        pc.training_setup(opt)
+        return pc
+
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(patch, "FUSE_DSHS_L1", fused)
+        pc = model()
+        pkg = patch.render(cam, pc, pipe, scn["bg"].to(dev), stage="fine", return_dx=True, render_feat=True)
+        d = pkg["dshs"]
+        assert isinstance(d, torch.Tensor) and d.shape == (20_000, 16, 3) and (type(d) is patch._L1Ready) == fused
+        dshs_abs = torch.abs(d)                                    # train.py:408
+        assert (type(dshs_abs) is patch._LazyAbs) == fused
+        reg = torch.mean(dshs_abs) * 0.5                            # train.py:409
+        assert (reg.grad_fn is not None) and type(reg) is torch.Tensor
+        loss = pkg["render"].mean() + reg
+        loss.backward()
+        out[fused] = (float(reg), {n: p.grad.detach().clone() for n, p in pc.named_parameters() if p.grad is not None},
+                      d.detach().clone() if not fused else torch.Tensor.detach(d.__dict__["_s3g_src"]).clone(), dshs_abs)
+    assert out[True][0] > 0
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-6)
+    assert out[True][1].keys() == out[False][1].keys()
+    for n, g in out[True][1].items():
+        if "grid" in n or n == "_xyz":      # float atomics in the sampler's backward: compared against their scale
+            assert rel_l2(g.cpu().numpy(), out[False][1][n].cpu().numpy()) < 1e-5, n
+        else:
+            assert rel_l2(g.cpu().numpy(), out[False][1][n].cpu().numpy()) < 2e-6, n
+    # every other use of the two stand-ins sees ordinary tensors with the ordinary values
+    lazy, plain = out[True][3], out[True][2]
+    assert torch.equal(lazy.sum(), plain.abs().sum()) and torch.equal(lazy[5], plain[5].abs()) and torch.equal(lazy.mean(dim=0), plain.abs().mean(dim=0))
+    assert torch.equal(lazy.detach(), plain.abs()) and float(lazy.min()) >= 0.0 and lazy.cpu().shape == plain.shape

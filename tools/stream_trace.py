@@ -11,6 +11,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursi
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
 rows.sort()
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+ALL = "all" in sys.argv[3:]      # every dispatch, the small launches of the main queue included (the zero-edit route's iteration: K past the fused loops)
 marks = [i for i, r in enumerate(rows) if "mlp_forward_kernel" in r[2] or "mlp_forward_presplit_kernel" in r[2]]
 pairs = [(x, y) for x, y in zip(marks, marks[1:]) if any("mlp_backward" in r[2] for r in rows[x:y])]     # training iterations only
 a, b = pairs[K]
@@ -29,10 +30,15 @@ for s, e, n, q in step:
 union += cur_e - cur_s
 for s, e, n, q in step:
     shared = sum(max(0, min(e, e2) - max(s, s2)) for s2, e2, _, q2 in step if q2 != q)
-    if e - s < 20_000 and q == main and not shared:
+    if e - s < 20_000 and q == main and not shared and not ALL:
         continue        # the small launches of the main queue are in tools/step_trace.py
     n = re.sub(r"\(.*", "", n).replace("void ", "")[:70]
     print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:8.1f}  queue {q:>3}{'' if q == main else '*'}  beside another queue {shared / 1e3:8.1f}  {n}")
 span = rows[b][0] - t0
+prev_end, idle = step[0][1], 0
+for s_, e_, _, _ in step[1:]:
+    idle += max(0, s_ - prev_end)
+    prev_end = max(prev_end, e_)
+print(f"idle between kernels {idle / 1e3:.1f} us, launches {len(step)}")
 print(f"span {span / 1e3:.1f} us (mlp_forward to mlp_forward), union of kernel time {union / 1e3:.1f} us, sum of kernel time "
       f"{sum(e - s for s, e, _, _ in step) / 1e3:.1f} us, queues {queues} (main {main})")
