@@ -34,6 +34,7 @@ with `ast` (tests/test_patch_cpu.py).
 from __future__ import annotations
 
 import math
+import os
 import sys
 from typing import Dict
 
@@ -226,7 +227,8 @@ def fused_optimizer_from(optimizer: torch.optim.Optimizer):
     return Adam(groups, lr=d.get("lr", 0.0), betas=d.get("betas", (0.9, 0.999)), eps=d.get("eps", 1e-15))
 
 
-FUSE_DSHS_L1 = True        # render(): hand dshs out as _L1Ready (False: the plain tensor, the expression runs as train.py spells it)
+# S3G_PATCH_FUSE_DSHS_L1=0 switches the stand-in off for a whole run (the expression then runs as train.py spells it)
+FUSE_DSHS_L1 = os.environ.get("S3G_PATCH_FUSE_DSHS_L1", "1") != "0"     # render(): hand dshs out as _L1Ready
 _REFERENCE: Dict = {}     # the reference's own callables, kept for the cases a replacement hands back
 _PATCHED = False
 
