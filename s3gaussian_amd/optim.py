@@ -4,6 +4,7 @@ scene/gaussian_model.py:177-189 and what its densification code edits: `state[p]
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import torch
 
@@ -31,6 +32,8 @@ class Adam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
         self.grad_scale = 1.0   # every gradient is multiplied by this inside the kernel; the data-parallel wrapper sets
                                 # 1 / world_size after a SUM all-reduce instead of spending a pass on the average
+        self._entries = {}      # id(param) -> _Entry (launch record + what was checked once), see step()
+        self._lib = None
 
     @torch.no_grad()
     def rewind(self, iterations: int) -> None:
@@ -44,50 +47,75 @@ class Adam(torch.optim.Adam):
                 if float(st["step"]) < 0:
                     st["step"].zero_()
 
+    def _entry(self, group, p):
+        """Everything about one parameter that does not change from step to step, checked once: the launch record with the
+        parameter's own fields filled in, its state dict, its layout."""
+        if not p.is_cuda:
+            raise RuntimeError("s3gaussian_amd.optim.Adam: parameters must live on the GPU (no CPU fallback)")
+        if p.dtype != torch.float32 or not _dense(p):
+            raise RuntimeError("s3gaussian_amd.optim.Adam handles dense float32 parameters only")
+        e = _Entry()
+        e.p, e.stride, e.device = p, p.stride(), p.device
+        e.rec = _AdamTensor(p.data_ptr(), None, None, None, p.numel(), 0.0, 0.0, 0.0, 1.0)
+        e.p_ptr, e.m, e.v = p.data_ptr(), None, None
+        return e
+
     @torch.no_grad()
     def step(self, closure=None):
+        """Host side: ~4 us per parameter before the launch (the launch records are kept from step to step; only the gradient pointer and
+        the step-dependent scalars are written) -- on the zero-edit route the GPU sits idle behind train.py's `loss.item()` until this
+        launch is out, so every microsecond in front of it is a microsecond of the iteration (profiles/r05_patched_iteration_trace.txt)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        L = _lib.lib()
-        L.s3g_adam_step_guarded.restype = C.c_int
-        L.s3g_adam_step_guarded.argtypes = [C.c_int, C.POINTER(_AdamTensor), C.c_double, C.c_double, C.c_void_p, C.c_void_p]
-        # 1. validate everything before touching any state: an exception must not leave some parameters with an advanced
-        #    step count and others without
-        todo = []
+        L = self._lib
+        if L is None:
+            L = self._lib = _lib.lib()
+            L.s3g_adam_step_guarded.restype = C.c_int
+            L.s3g_adam_step_guarded.argtypes = [C.c_int, C.POINTER(_AdamTensor), C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        entries, f32, gs = self._entries, torch.float32, float(self.grad_scale)
+        # 1. validate everything and fill the launch records; no state is touched before the launches are out: an exception must not
+        #    leave some parameters with an advanced step count and others without
+        by_betas, keep, todo = {}, [], []
         for group in self.param_groups:
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if not p.is_cuda:
-                    raise RuntimeError("s3gaussian_amd.optim.Adam: parameters must live on the GPU (no CPU fallback)")
-                if p.dtype != torch.float32 or p.grad.is_sparse or not _dense(p):
-                    raise RuntimeError("s3gaussian_amd.optim.Adam handles dense float32 parameters only")
-                todo.append((group, p))
-        # 2. lazy state, step counters, launch records
-        by_betas = {}
-        keep = []   # tensors created here must outlive the launch call
-        for group, p in todo:
+            lr, eps = group["lr"], group["eps"]
             beta1, beta2 = group["betas"]
-            st = self.state[p]
-            if len(st) == 0:   # same lazy initialisation as torch/optim/adam.py::_init_group
-                st["step"] = torch.tensor(0.0)
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["step"] += 1
-            step = float(st["step"])
-            g = p.grad
-            if g.dtype != torch.float32 or g.stride() != p.stride():
-                g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
-                keep.append(g)
-            for name in ("exp_avg", "exp_avg_sq"):   # densification code may have replaced them with other layouts
-                if st[name].stride() != p.stride():
-                    st[name] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[name])
-            bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
-            by_betas.setdefault((p.device, float(beta1), float(beta2)), []).append(
-                _AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
-                            group["lr"] / bc1, 1.0 / (bc2 ** 0.5), group["eps"], float(self.grad_scale)))
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                e = entries.get(id(p))
+                if e is None or e.p is not p or e.p_ptr != p.data_ptr():
+                    e = entries[id(p)] = self._entry(group, p)
+                if g.is_sparse:
+                    raise RuntimeError("s3gaussian_amd.optim.Adam handles dense float32 parameters only")
+                if g.dtype != f32 or g.stride() != e.stride:
+                    g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
+                    keep.append(g)            # must outlive the launch call
+                st = self.state[p]
+                if len(st) == 0:   # same lazy initialisation as torch/optim/adam.py::_init_group
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                m, v = st["exp_avg"], st["exp_avg_sq"]
+                if m is not e.m or v is not e.v:          # first step, or densification / load_state_dict replaced the moments
+                    for name in ("exp_avg", "exp_avg_sq"):
+                        if st[name].stride() != e.stride:     # ... possibly with another layout
+                            st[name] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[name])
+                    m, v = e.m, e.v = st["exp_avg"], st["exp_avg_sq"]
+                    e.rec.exp_avg, e.rec.exp_avg_sq = m.data_ptr(), v.data_ptr()
+                step = float(st["step"]) + 1.0
+                rec = e.rec
+                rec.grad, rec.step_size, rec.inv_sqrt_bc2 = g.data_ptr(), lr / (1.0 - beta1 ** step), 1.0 / math.sqrt(1.0 - beta2 ** step)
+                rec.eps, rec.grad_scale = eps, gs
+                by_betas.setdefault((e.device, float(beta1), float(beta2)), []).append(rec)
+                todo.append((e, st))
+        if len(entries) > 4 * max(len(todo), 16):     # parameters come and go with densification: do not keep the dead ones' records
+            live = {id(p) for group in self.param_groups for p in group["params"]}
+            for k in [k for k in entries if k not in live]:
+                del entries[k]
+        # 2. launch
         from . import raster_C
         for (dev, beta1, beta2), items in by_betas.items():
             # host-asynchronous rasterizer (raster_C.ASYNC): if the last forward on this device overflowed its speculative
@@ -104,17 +132,23 @@ class Adam(torch.optim.Adam):
                     arr = (_AdamTensor * len(chunk))(*chunk)
                     _lib.check(L.s3g_adam_step_guarded(len(chunk), arr, beta1, beta2,
                                                        flag.data_ptr() if flag is not None else None, stream))
-        # 3. the kernel wrote the parameters (and moments) through raw pointers: tell PyTorch.  Version counters are what
-        #    autograd's saved-tensor checks and the rasterizer's geometry cache (raster_C._geom_key) look at; without the
-        #    bump a render of the SAME parameter tensors after this step could be served the previous step's binning.
-        for _, p in todo:
-            torch.autograd.graph.increment_version(p)
-            st = self.state[p]
-            torch.autograd.graph.increment_version(st["exp_avg"])
-            torch.autograd.graph.increment_version(st["exp_avg_sq"])
+        # 3. the kernel is out: advance the step counts, and tell PyTorch that parameters and moments were written through raw
+        #    pointers.  Version counters are what autograd's saved-tensor checks and the rasterizer's geometry cache
+        #    (raster_C._geom_key) look at; without the bump a render of the SAME parameter tensors after this step could be served
+        #    the previous step's binning.
+        bump = torch.autograd.graph.increment_version
+        for e, st in todo:
+            st["step"] += 1
+            bump(e.p)
+            bump(e.m)
+            bump(e.v)
         if todo:
             raster_C.invalidate_geometry_cache()
         return loss
+
+
+class _Entry:
+    __slots__ = ("p", "stride", "device", "rec", "p_ptr", "m", "v")
 
 
 @torch.no_grad()
