@@ -166,7 +166,12 @@ def densify_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_rad
     g = viewspace_grad if (viewspace_grad.dtype == torch.float32 and viewspace_grad.stride(-1) == 1 and viewspace_grad.dim() == 2) \
         else viewspace_grad.float().contiguous()
     r = radii if radii.dtype == torch.int32 and radii.is_contiguous() else radii.to(torch.int32).contiguous()
-    v = None if visible is None else visible.to(torch.uint8).contiguous()
+    if visible is None:
+        v = None
+    elif visible.dtype == torch.bool and visible.is_contiguous():
+        v = visible.view(torch.uint8)            # one byte per element, 0 / 1: the same storage, no conversion pass
+    else:
+        v = visible.to(torch.uint8).contiguous()
     from . import raster_C
     flag = raster_C.async_skip_flag(radii.device)     # the view's asynchronous forward overflowed -> no statistics
     with torch.cuda.device(radii.device):
