@@ -99,7 +99,11 @@ def _standing_for(t):
     if isinstance(t, _LazyAbs):
         v = t.__dict__.get("_s3g_value")
         if v is None:
-            v = t.__dict__["_s3g_value"] = torch.abs(t.__dict__["_s3g_src"])
+            src = t.__dict__["_s3g_src"]
+            if src._version != t.__dict__["_s3g_version"]:      # loud, not wrong: abs() was taken BEFORE x changed in place
+                raise RuntimeError("s3gaussian_amd.patch: render_pkg['dshs'] was modified in place between torch.abs(.) and the use of its "
+                                   "result; set S3G_PATCH_FUSE_DSHS_L1=0 for this program")
+            v = t.__dict__["_s3g_value"] = torch.abs(src)
         return v
     if isinstance(t, _L1Ready):
         return t.__dict__["_s3g_src"]
@@ -143,7 +147,7 @@ class _L1Ready(torch.Tensor):
             src, l1 = args[0].__dict__["_s3g_src"], args[0].__dict__["_s3g_l1"]
             with torch._C.DisableTorchFunctionSubclass():
                 lazy = src.as_subclass(_LazyAbs)
-            lazy.__dict__["_s3g_src"], lazy.__dict__["_s3g_l1"] = src, l1
+            lazy.__dict__["_s3g_src"], lazy.__dict__["_s3g_l1"], lazy.__dict__["_s3g_version"] = src, l1, src._version
             return lazy
         return _run_plain(func, args, kwargs)
 

@@ -199,3 +199,9 @@ def test_the_dshs_stand_in_answers_only_abs_then_mean_and_is_an_ordinary_tensor_
     y2 = x2 * 1.0
     (y2.abs().mean() * 0.01 + (y2 * 2).sum() + y2.abs().sum()).backward()
     assert torch.allclose(x.grad, x2.grad, rtol=1e-6, atol=1e-7)
+    # |x| taken, x changed in place, |x| used: the lazy form cannot give the old values any more -- it must say so, not return new ones
+    z = torch.randn(5, 16, 3)
+    held = torch.abs(_L1Ready.wrap(z, z.abs().mean()))
+    z.mul_(2.0)
+    with pytest.raises(RuntimeError, match="S3G_PATCH_FUSE_DSHS_L1"):
+        held.sum()
