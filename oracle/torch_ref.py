@@ -15,7 +15,6 @@ that autograd reproduces the reference's convention:
 """
 from __future__ import annotations
 
-import math
 
 import torch
 

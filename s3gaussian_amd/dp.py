@@ -22,7 +22,7 @@ Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests (tests/test_dp_c
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Optional, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist

@@ -1,7 +1,5 @@
 """Checkpoint / point-cloud I/O compatibility with the reference's formats (scene/gaussian_model.py:71-111 capture /
 restore, :258-275 save_ply, :355-395 load_ply).  CPU only."""
-import io
-import os
 
 import numpy as np
 import torch
