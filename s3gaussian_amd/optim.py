@@ -136,13 +136,12 @@ class Adam(torch.optim.Adam):
         #    pointers.  Version counters are what autograd's saved-tensor checks and the rasterizer's geometry cache
         #    (raster_C._geom_key) look at; without the bump a render of the SAME parameter tensors after this step could be served
         #    the previous step's binning.
-        bump = torch.autograd.graph.increment_version
+        written = []
         for e, st in todo:
             st["step"] += 1
-            bump(e.p)
-            bump(e.m)
-            bump(e.v)
+            written += (e.p, e.m, e.v)
         if todo:
+            torch.autograd.graph.increment_version(written)     # one call for all of them: 6 us instead of 60
             raster_C.invalidate_geometry_cache()
         return loss
 
