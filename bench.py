@@ -548,6 +548,11 @@ def launch_ranks(a, argv):
 
 
 GC_PASSES = []     # generation-2 collections that ran inside each timed_loop call, in call order
+GC1_PASSES = []    # generation-1 collections, same order (diagnostics: one run in 25 of round 5 had a 42-ms step in its 20-step headline with no
+                   # generation-2 pass inside -- 109 instead of 137 it/s, profiles/r05_bench_line_host_stall.json; the container may not raise its
+                   # scheduling priority (os.setpriority is refused), so a host thread that loses its core in the first ~7 steps, while the host
+                   # is less than 35 ms ahead of the device, shows up 1 : 1; `sustained` is the number that does not depend on it)
+HOST_STALLS = []   # per timed_loop call: the longest host-side gap between two consecutive step() calls' returns, in ms
 
 
 def timed_loop(step, indices, world, device, after_step=None, collect=True):
@@ -561,23 +566,29 @@ def timed_loop(step, indices, world, device, after_step=None, collect=True):
     if collect:
         gc.collect()
     gen2_before = gc.get_stats()[2]["collections"]
+    gen1_before = gc.get_stats()[1]["collections"]
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     evs[0].record()
+    t_prev, longest = t0, 0.0
     for k, i in enumerate(indices):
         out = step(i)
         evs[k + 1].record()
         if after_step is not None:
             after_step(out)
+        t_now = time.perf_counter()
+        longest, t_prev = max(longest, t_now - t_prev), t_now
     t_enq = time.perf_counter() - t0
+    HOST_STALLS.append(round(1000.0 * longest, 3))
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     per_step = [evs[k].elapsed_time(evs[k + 1]) for k in range(len(indices))]
     GC_PASSES.append(gc.get_stats()[2]["collections"] - gen2_before)
+    GC1_PASSES.append(gc.get_stats()[1]["collections"] - gen1_before)
     return dt, t_enq, per_step
 
 
@@ -700,6 +711,8 @@ def main(argv=None):
         vis_masks.clear()
         losses.clear()
         GC_PASSES.clear()
+        GC1_PASSES.clear()
+        HOST_STALLS.clear()
         comm.update(elems=0, events=[], sparse_rows=0)
         raster_C.async_reset_statistics(device)
         dt, t_enq, per_step = timed_loop(step, headline_idx, world, device, after_step=keep)
@@ -973,6 +986,8 @@ def main(argv=None):
             "host_enqueue_ms_per_step": round(1000.0 * t_enq / a.steps, 3),
             "instrumented_loop_ms_per_step": round(sum(per_step_instrumented) / len(per_step_instrumented), 3),
             "gc_gen2_passes_in_timed_loop": GC_PASSES[0] if GC_PASSES else None,
+            "gc_gen1_passes_in_timed_loop": GC1_PASSES[0] if GC1_PASSES else None,
+            "longest_host_enqueue_of_one_step_ms": HOST_STALLS[0] if HOST_STALLS else None,
             "sustained_iters_per_s": sustained["iters_per_s"] if sustained else None,
             "step_ms_p99": sustained["step_ms_p99"] if sustained else None,
             "sustained": sustained,
