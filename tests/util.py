@@ -85,6 +85,8 @@ def validate_bench_line(d, default_workload=True, n_gpus=1, round3_accounting=Fa
         assert 0 < d["step_ms_min"] <= d["step_ms_median"] <= d["step_ms_max"]
         assert d["host_enqueue_ms_per_step"] > 0 and d["gpu_ms_per_step"] > 0
         assert d["gpu_ms_per_step"] <= 1.05 * d["ms_per_step"] + 0.05    # stream time between step boundaries cannot exceed the wall
+    if d.get("longest_host_enqueue_of_one_step_ms") is not None:     # round 5: what a host stall inside the 0.15-s region looks like
+        assert d["longest_host_enqueue_of_one_step_ms"] > 0 and d["gc_gen1_passes_in_timed_loop"] >= 0
     c = d["config"]
     if n_gpus == 1:
         assert ("BASELINE cfg3" in c["workload"]) == default_workload, c["workload"]     # the label is derived from the arguments
