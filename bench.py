@@ -22,8 +22,9 @@ section 4's one-line import swap only (fused HexPlane + MLP, the rest as zero_di
 `roofline`: hipEvent times are measured live in this run; `algorithmic_bytes_per_launch` is the STRICT model of SURVEY 8(d)
 (inputs and outputs the math needs -- scratch this implementation chose to write, e.g. the HexPlane backward's G slab or the
 MLP's activation stash, is `implementation_bytes_per_launch`, never algorithmic); `frac` is priced on the strict figure.
-`traffic` is NOT collected in this run: it is read from profiles/kernel_traffic.json (separate rocprofv3 --pmc passes of the
-same command, see `traffic_source`).
+`traffic` / the VALU instruction counts: collected BY THIS RUN when `rocprofv3` is on the box (round 6) -- three extra passes of a
+3-step child (`--pmc-child`) under `rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU --kernel-trace` after the timed loops --
+else read from profiles/kernel_traffic.json (an earlier collection of the same passes); `traffic_source` says which.
 """
 import argparse
 import gc
@@ -77,6 +78,7 @@ def make_targets(pc, cam, bg, hyper, seed):
     pc._xyz.data.add_(0.01 * torch.randn(xyz0.shape, generator=g).to(xyz0.device))
     pkg = render(cam, pc, pipe, bg, stage="fine", render_feat=True)
     pc._xyz.data.copy_(xyz0)
+    raster_C.invalidate_geometry_cache()     # writes through .data bump no version counter (geometry + inference-deformation caches)
     raster_C.set_async(prev_async)
     return pkg["render"].clamp(0, 1).clone(), pkg["depth"].clone(), pkg["feat"].clone()
 
@@ -225,8 +227,6 @@ def cpu_baseline(P_full, width, height, seed=0):
       "tile_rasterizer_port": the oracle path proper (same PyTorch front end, C/OpenMP restatement of the tile rasterizer
           fwd+bwd x2) sampled at THREE sizes of P up to P_full/4 at the full image, least-squares t = a + b*P with the residuals."""
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)     # intra-op parallelism of these element-wise / gather ops stops paying beyond ~64 threads on this host
-    torch.set_num_threads(threads)
     ref = None
     try:
         from oracle import ref_py
@@ -234,8 +234,18 @@ def cpu_baseline(P_full, width, height, seed=0):
             ref = ref_py.load(patch=False)
     except Exception:
         ref = None
+    # BASELINE.md section 4 plans "all host cores"; whether torch's intra-op pools pay beyond ~64 threads for these element-wise /
+    # gather ops is a property of the box, so it is MEASURED here: the same P/40 iteration at every candidate
+    # thread count, the full-size iteration at the fastest; all timings go into the line
+    probe_P, probe = max(2000, P_full // 40), {}
     try:
-        _time_iteration(max(2000, P_full // 40), width, height, seed, True, repeats=1, warm=False, ref=ref)
+        torch.set_num_threads(cores)
+        _time_iteration(probe_P, width, height, seed, True, repeats=1, warm=False, ref=ref)       # allocator, lazy inits
+        for n in sorted({cores, min(cores, 128), min(cores, 64), min(cores, 32)}, reverse=True):
+            torch.set_num_threads(n)
+            probe[n] = _time_iteration(probe_P, width, height, seed, True, repeats=1, warm=True, ref=ref)
+        threads = min(probe, key=probe.get)
+        torch.set_num_threads(threads)
         t_full = _time_iteration(P_full, width, height, seed, True, repeats=1, warm=False, ref=ref)
     finally:
         if ref is not None:
@@ -247,7 +257,9 @@ def cpu_baseline(P_full, width, height, seed=0):
            "kind": "reference" if ref is not None else "port", "what": "point_splat",
            "sample": f"measured, not extrapolated: ONE full iteration of the workload itself ({P_full} Gaussians, {width}x{height}) in "
                      f"{t_full:.2f} s -- {front}, rasterizer stubbed to a nearest-pixel "
-                     f"point splat (torch threads {threads} of {cores} cores)"}
+                     f"point splat (torch threads {threads} of {cores} cores: the fastest of {sorted(probe)} on a {probe_P}-Gaussian "
+                     f"iteration, s/iter {[round(probe[k], 2) for k in sorted(probe)]})",
+           "thread_probe_s_per_iter": {str(k): round(v, 3) for k, v in sorted(probe.items())}}
     try:
         sizes = (max(2000, P_full // 120), max(6000, P_full // 40), max(20000, P_full // 4))
         est, model = _fit(P_full, width, height, seed, False, sizes)
@@ -481,6 +493,57 @@ def time_reference_paths(pc, cams, targets, bg, aabb):
     return out
 
 
+def collect_counters_in_run(a, per_pass_timeout_s=170):
+    """HBM-side traffic (FETCH_SIZE, WRITE_SIZE: they cannot share a pass) and wave-level VALU instruction counts (SQ_INSTS_VALU) of
+    every kernel of a training step, collected BY THIS RUN: three passes of `rocprofv3 --pmc <counter> --kernel-trace` (counters in
+    their own runs with the kernel trace only, MI355X_MICROARCH.md / the pool's rule) over a child of this script that builds the same
+    scene and issues 2 + 3 training steps (`--pmc-child`); attributed to the training iterations by dispatch order
+    (tools/pmc_traffic.py::collect, the code that wrote profiles/kernel_traffic.json in earlier rounds).
+    -> (dict like profiles/kernel_traffic.json | None, note)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found on this box"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_traffic
+    except Exception as ex:
+        return None, f"tools/pmc_traffic.py not importable: {ex}"
+    base = tempfile.mkdtemp(prefix="s3g_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "3", "--warmup", "2", "--P", str(a.P), "--width", str(a.width),
+             "--height", str(a.height), "--frames", str(a.frames), "--scale-mult", str(a.scale_mult)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    got, t0 = {}, time.perf_counter()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+            d = os.path.join(base, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=per_pass_timeout_s)
+            if r.returncode != 0:
+                return None, f"{counter} pass: rocprofv3 exited with {r.returncode}: {r.stderr.decode('utf-8', 'replace')[-300:]}"
+            got[counter] = pmc_traffic.collect(d, counter)
+            if not got[counter]:
+                return None, f"{counter} pass produced no counter rows"
+    except subprocess.TimeoutExpired:
+        return None, f"a counter pass exceeded {per_pass_timeout_s} s"
+    except Exception as ex:
+        return None, f"{type(ex).__name__}: {ex}"
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    fetch, write = got["FETCH_SIZE"], got["WRITE_SIZE"]
+    traffic = {k: int(round((2.0 * fetch.get(k, (0, 0.0))[1] + write.get(k, (0, 0.0))[1]) * 1024.0)) for k in set(fetch) | set(write)}
+    return ({"hbm_bytes_per_launch": traffic, "launches_per_bracket": {},
+             "fetch_bytes_per_launch_uncorrected": {k: int(round(v[1] * 1024.0)) for k, v in fetch.items()},
+             "write_bytes_per_launch": {k: int(round(v[1] * 1024.0)) for k, v in write.items()},
+             "valu_wave_instructions_per_launch": {k: int(round(v[1])) for k, v in got["SQ_INSTS_VALU"].items()},
+             "seconds": round(time.perf_counter() - t0, 1)},
+            "collected IN THIS RUN: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU --kernel-trace (three passes) -- python bench.py "
+            "--pmc-child --steps 3 --warmup 2; hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 (the guide's gfx950 correction for 16 B/lane "
+            "streaming reads; profiles/r06_fetch_calib.txt holds the factor measured for the 4 B/lane and 8 x 16 B row gathers of the HexPlane kernels)")
+
+
 def workload_label(a, world=None):
     """Name of the workload, derived from the arguments: a BASELINE.json config name only when the run IS that config."""
     world = a.gpus if world is None else world
@@ -519,6 +582,12 @@ def parse_args(argv=None):
                     help="after the K timed steps: this many more in one untended loop -> sustained_iters_per_s, step_ms_p99 (0: skip)")
     ap.add_argument("--sync-raster", action="store_true",
                     help="rasterizer forward with the reference's one host wait per call (default: host-asynchronous, raster_C.ASYNC)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect HBM traffic / VALU counters with rocprofv3 after the timed loops")
+    ap.add_argument("--pmc-child", action="store_true",
+                    help="(internal) the 3-step run the counter passes profile: scene, warm-up, K steps, nothing else, no JSON line")
+    ap.add_argument("--no-heavy-raster", action="store_true", help="skip the rasterizer-heavy leg (config.paths.heavy_raster)")
+    ap.add_argument("--heavy-scale-mult", type=float, default=3.5)
+    ap.add_argument("--heavy-steps", type=int, default=60)
     return ap.parse_args(argv)
 
 
@@ -613,6 +682,10 @@ def main(argv=None):
     torch.cuda.set_device(device)
     if a.sync_raster:
         raster_C.set_async(False)
+    # the loops of this script check for arena overflows AFTER each timed region and repeat it if there was one (and `sustained`
+    # reports its count): they run the speculative form of the asynchronous forward (nothing waits for a verdict).  The drop-in
+    # boundary's default is "verified" (raster_C.POLICY); the reference's own train.py legs below run under that default.
+    raster_C.set_async_policy("speculative")
     import ctypes as C
     L = _lib.lib()
     L.s3g_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -678,6 +751,14 @@ def main(argv=None):
         loss, pkg = training_step(pc, cams[v], gt_img, gt_depth, gt_feat, hyper, opt, bg, stage="fine", grad_hook=hook,
                                   densify_stats=(not dist_on), optimizer_step=optimizer_step if dist_on else None)
         return loss, pkg
+
+    if a.pmc_child:
+        # the run the counter passes profile (collect_counters_in_run): warm-up + K training steps of the workload, nothing else
+        L.s3g_profile_enable(0)
+        for i in range(a.warmup + a.steps):
+            step(i)
+        torch.cuda.synchronize()
+        return
 
     # everything built so far (scene, targets, modules, the torch / ctypes machinery) is long-lived: take it out of the collector's
     # working set, so that a generation-2 pass during the loops below walks this step's garbage, not the whole heap
@@ -779,6 +860,53 @@ def main(argv=None):
             _mlp.set_mlp_arithmetic("f32")
         comm.update(elems=0, events=[], sparse_rows=0)
 
+    # ---- 1d. a rasterizer-HEAVY workload in the driver-visible line (VERDICT r5 missing #4): the same 1.2 M Gaussians with every scale
+    #          multiplied (default 3.5: R ~ 11 M instances per view, SURVEY 8a-a11's estimate for a trained cfg3 scene is 5-12 M, the
+    #          headline scene has 1.46 M), own model, own targets, 60 timed steps --------------------------------------------------
+    heavy = None
+    if world == 1 and not dist_on and not a.no_alt_paths and not a.no_heavy_raster:
+        pc_h = None
+        try:
+            pc_h, cams_h, hyper_h, opt_h, bg_h = build_scene(a.P, a.width, a.height, a.frames, device, scale_mult=a.scale_mult * a.heavy_scale_mult)
+            hv = [my_views[i % len(my_views)] for i in range(6)]
+            tg_h = {v: make_targets(pc_h, cams_h[v], bg_h, hyper_h, seed=2000 + v) for v in sorted(set(hv))}
+            hvis = []
+
+            def step_h(i):
+                v = hv[i % len(hv)]
+                return training_step(pc_h, cams_h[v], *tg_h[v], hyper_h, opt_h, bg_h, stage="fine", densify_stats=True)
+
+            for i in range(6):
+                step_h(i)
+            torch.cuda.synchronize()
+            for attempt in range(2):          # an overflowed step did no work: the capacity has grown by now, time again
+                hvis.clear()
+                raster_C.async_reset_statistics(device)
+                dt_h, enq_h, ps_h = timed_loop(step_h, list(range(a.heavy_steps)), 1, device, after_step=lambda o: hvis.append(o[1]["visibility_filter"]))
+                st_h = raster_C.async_status(device, block=True)
+                if not st_h["overflows"]:
+                    break
+            ms_h = 1000.0 * dt_h / a.heavy_steps
+            srt_h = sorted(ps_h)
+            R_h = st_h["mean_instances"] or 0.0
+            heavy = {"ms_per_step": round(ms_h, 3), "iters_per_s": round(1000.0 / ms_h, 2), "steps": a.heavy_steps,
+                     "scale_mult": a.scale_mult * a.heavy_scale_mult, "gaussians": a.P, "instances_R_per_view": round(R_h),
+                     "visible_V_per_view": round(float(sum(int(m.sum()) for m in hvis)) / max(len(hvis), 1)),
+                     "mean_tile_list_length": round(R_h / (((a.width + 15) // 16) * ((a.height + 15) // 16)), 1),
+                     "gpu_ms_per_step": round(sum(ps_h) / len(ps_h), 3), "step_ms_median": round(srt_h[len(srt_h) // 2], 3),
+                     "step_ms_max": round(srt_h[-1], 3), "host_enqueue_ms_per_step": round(1000.0 * enq_h / a.heavy_steps, 3),
+                     "arena_overflows": len(st_h["overflows"]),
+                     "what": "the fused step on the same scene with every Gaussian's scale multiplied: the blend / sort / binning kernels "
+                             "carry ~8 x the instances of the headline scene"}
+        except Exception as ex:   # never take the headline down
+            heavy = {"ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"}
+        finally:
+            del pc_h
+            gc.collect()
+            torch.cuda.empty_cache()
+            raster_C.invalidate_geometry_cache()
+        comm.update(elems=0, events=[], sparse_rows=0)
+
     # ---- 2. roofline leg: the SAME steps again with the nine hot kernels bracketed by hipEvent pairs inside libs3g.so -------
     clear_profile_slots()
     L.s3g_profile_enable(1)
@@ -818,8 +946,40 @@ def main(argv=None):
             render_outliers.append({"frame": raw.index(per[-1]), "ms": round(per[-1], 3), "median_ms": round(per[n_frames // 2], 3)})
         return wall, per[n_frames // 2]
 
+    import s3gaussian_amd.deformation as _deformation
+
+    def render_loop_by_timestamp():
+        """The evaluation loops of the reference visit the cameras in dataset order -- the 3 Waymo cameras of one frame back to back
+        (utils/video_utils.py:116-349) -- and the deformation depends on (xyz, t) only: under no_grad its outputs are reused for the 2nd
+        and 3rd camera of a timestamp (deformation.INFER_CACHE).  -> median stream ms of a frame that OPENS a timestamp (evaluates the
+        field), of a frame that shares its predecessor's timestamp, and the mean over the video order (3 cameras per timestamp)."""
+        order = [3 * k + c for k in range(min(a.frames, 8)) for c in range(3) if 3 * k + c < len(cams)]
+        if len(order) < 6:
+            return None
+        for v in order[:6]:
+            render_fn(cams[v], pc, pipe, bg, stage="fine")
+        hits0 = _deformation.infer_cache_hits
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(order) + 1)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        evs[0].record()
+        for k, v in enumerate(order):
+            render_fn(cams[v], pc, pipe, bg, stage="fine")
+            evs[k + 1].record()
+        torch.cuda.synchronize()
+        wall = 1000.0 * (time.perf_counter() - t1) / len(order)
+        raw = [evs[k].elapsed_time(evs[k + 1]) for k in range(len(order))]
+        fresh = sorted(raw[k] for k in range(len(order)) if k % 3 == 0)
+        shared = sorted(raw[k] for k in range(len(order)) if k % 3 != 0)
+        return {"fresh_timestamp_ms": round(fresh[len(fresh) // 2], 3), "same_timestamp_ms": round(shared[len(shared) // 2], 3),
+                "video_order_ms_per_frame": round(wall, 3), "frames": len(order), "deformation_reused_for": _deformation.infer_cache_hits - hits0}
+
     with torch.no_grad():
         render_ms, render_median_ms = render_loop()
+        try:
+            render_by_timestamp = render_loop_by_timestamp()
+        except Exception as ex:
+            render_by_timestamp = {"error": f"{type(ex).__name__}: {ex}"}
         clear_profile_slots()
         L.s3g_profile_enable(1)          # a separate, instrumented pass for the inference kernel's own time
         for i in range(8):
@@ -832,13 +992,19 @@ def main(argv=None):
         clear_profile_slots()
         # the same frames with the inference kernel's GEMM layers on the bf16 matrix pipe (exactly split operands: fp32 accuracy,
         # include/s3g_mlp.h::s3g_deform_infer_split) -- reported beside the default, which stays the exact fp32 chain
-        import s3gaussian_amd.deformation as _deformation
         _arith = _deformation.INFER_ARITHMETIC
         _deformation.INFER_ARITHMETIC = "bf16x3"
         try:
             render_split_ms, render_split_median_ms = render_loop()
         finally:
             _deformation.INFER_ARITHMETIC = _arith
+
+    # ---- 4. counters of this very run (rank 0 of a one-GPU run; the timed loops above are over) --------------------------------
+    pmc_in_run, pmc_in_run_note = None, "not attempted (--no-pmc, N > 1 or --no-alt-paths)"
+    if world == 1 and not dist_on and not a.no_pmc and not a.no_alt_paths:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        pmc_in_run, pmc_in_run_note = collect_counters_in_run(a)
 
     dev_ids = None
     if dist_on:     # collectives are called by EVERY rank, never inside the rank-0 block below
@@ -897,8 +1063,15 @@ def main(argv=None):
         }
         traffic_db, traffic_launches, traffic_source, valu_db = {}, {}, None, {}
         default_workload = (a.P, a.width, a.height, a.frames, a.scale_mult) == (1_200_000, 1600, 1066, 50, 1.0)
+        pmc_note = None
+        if pmc_in_run is not None:     # counters of THIS run on THIS box (collect_counters_in_run)
+            traffic_db = pmc_in_run.get("hbm_bytes_per_launch", {})
+            valu_db = pmc_in_run.get("valu_wave_instructions_per_launch", {})
+            traffic_source = pmc_in_run_note
+        else:
+            pmc_note = pmc_in_run_note
         pmc = os.path.join(ROOT, "profiles", "kernel_traffic.json")
-        if os.path.exists(pmc) and default_workload:   # the PMC passes were collected on the default workload only
+        if not traffic_db and os.path.exists(pmc) and default_workload:   # earlier collection of the same passes, default workload only
             try:
                 db = json.load(open(pmc))
                 traffic_db = db.get("hbm_bytes_per_launch", {})
@@ -930,19 +1103,22 @@ def main(argv=None):
                 if tf / PEAK_MFMA_F32_TFLOPS > frac:   # the roof this kernel sits closer to
                     bound, frac = "mfma", tf / PEAK_MFMA_F32_TFLOPS
             base = name.split(" ")[0]
-            if i in (0, 1):
-                # the blend passes are VALU / v_exp-bound in dense tiles (~80 FLOP/B >> the 25 FLOP/B machine
-                # balance).  VALU roof: a wave64 instruction holds its 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs at
-                # VALU_CLOCK_GHZ.  Instruction counts are PMC data (SQ_INSTS_VALU), like `traffic` not collected in this run.
-                ent["bound"] = "valu"
-                if base in valu_db:
-                    busy_ms = valu_db[base] * 4.0 / (1024.0 * VALU_CLOCK_GHZ * 1e9) * 1e3
-                    ent.update({"valu_wave_instructions_per_launch": valu_db[base], "valu_issue_ms": round(busy_ms, 4),
-                                "valu_frac": round(busy_ms / avg_ms, 4)})
+            # The third roof: VALU issue.  A wave64 VALU instruction holds its SIMD for 4 cycles; 256 CUs x 4 SIMDs at
+            # VALU_CLOCK_GHZ = 614.4 G wave-instructions/s.  Priced for EVERY kernel that has a SQ_INSTS_VALU count (VERDICT r5 weak #2:
+            # rounds 4-5 applied it to the two blend kernels only and labelled the HexPlane backward kernels "hbm 0.016" when the same
+            # counters put them at 0.83 / 0.73 of the VALU issue roof); `bound` = the roof the kernel sits closest to.  SURVEY 8(d)
+            # predicted it for the blend passes (~80 FLOP/B >> the 25 FLOP/B machine balance).  fp32 MFMA shares the vector datapath
+            # (MI355X_MICROARCH.md: 64 FLOP/clk/SIMD = the FP32 vector rate), so for the MLP kernels the two figures are read together.
+            if base in valu_db and valu_db[base] > 0:
+                busy_ms = valu_db[base] * 4.0 / (1024.0 * VALU_CLOCK_GHZ * 1e9) * 1e3
+                ent.update({"valu_wave_instructions_per_launch": valu_db[base], "valu_issue_ms": round(busy_ms, 4),
+                            "valu_frac": round(busy_ms / avg_ms, 4)})
+                if busy_ms / avg_ms > frac:
                     bound, frac = "valu", busy_ms / avg_ms
-                else:
-                    ent["valu_frac"] = None   # no SQ_INSTS_VALU pass for this workload: the HBM figure below is NOT this kernel's roof
-            ent["bound"] = bound if i not in (0, 1) else "valu"
+            elif i in (0, 1):
+                bound = "valu"               # no SQ_INSTS_VALU count for this workload: still not an HBM kernel
+                ent["valu_frac"] = None      # ... and the HBM figure is NOT its roof
+            ent["bound"] = bound
             ent["frac"] = round(frac, 4)
             ent["ms_per_step"] = round(avg_ms * n / a.steps, 4)
             if base in traffic_db:   # PMC bytes per launch (the wgrad bracket may cover several launches)
@@ -954,9 +1130,20 @@ def main(argv=None):
             if dom["bound"] == "mfma":
                 roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["mfma_TFLOPs"], "peak": PEAK_MFMA_F32_TFLOPS,
                         "unit": "TFLOP/s", "frac": dom["mfma_frac"], "traffic": dom.get("traffic")}
+            elif dom["bound"] == "valu" and dom.get("valu_frac"):
+                peak_gi = 1024.0 * VALU_CLOCK_GHZ / 4.0        # G wave-instructions/s the chip can issue
+                ach = dom["valu_wave_instructions_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9
+                roof = {"kernel": dom["kernel"], "bound": "valu", "achieved": round(ach, 1), "peak": round(peak_gi, 1),
+                        "unit": "G wave-instructions/s", "frac": round(ach / peak_gi, 4), "traffic": dom.get("traffic"),
+                        # the contract's own roofs for the same kernel, for a reader who prices everything against HBM
+                        "hbm": {"achieved": dom["hbm_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": dom["hbm_frac"]}}
             else:
                 roof = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["hbm_GBps"], "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": dom["hbm_frac"], "traffic": dom.get("traffic")}
+            if pmc_note:
+                roof["counters_in_this_run"] = pmc_note
+            elif pmc_in_run is not None:
+                roof["counters_in_this_run"] = {"seconds": pmc_in_run.get("seconds"), "kernels": len(traffic_db)}
             roof.update({"avg_launch_ms": dom["avg_launch_ms"], "launches_per_step": dom["launches_per_step"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                          "implementation_bytes_per_launch": dom["implementation_bytes_per_launch"],
@@ -999,14 +1186,16 @@ def main(argv=None):
                        "scale_mult": a.scale_mult, "gaussians_in_morton_order": bool(a.reorder), "instances_R_per_view": round(R_mean), "visible_V_per_view": round(V),
                        "mean_tile_list_length": round(R_mean / (((a.width + 15) // 16) * ((a.height + 15) // 16)), 1),
                        "densify_bookkeeping_in_step": True,
-                       "rasterizer_forward": ("host-asynchronous (speculative arena capacity, s3g_raster_forward_async)" if astat.get("enabled")
+                       "rasterizer_forward": ("host-asynchronous, policy 'speculative' (arena sized for a speculative capacity, overflows checked after "
+                                              "each timed loop: s3g_raster_forward_async; the drop-in default 'verified' reads every forward's verdict)" if astat.get("enabled")
                                               else "synchronous (one host wait per forward, like the reference)"),
-                       "raster_async": {k: astat.get(k) for k in ("enabled", "calls", "drained", "overflows", "overflows_in_discarded_first_attempt")
+                       "raster_async": {k: astat.get(k) for k in ("enabled", "policy", "calls", "drained", "overflows", "overflows_in_discarded_first_attempt")
                                         if k in astat},
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
                        "blend_forward_avg_ms": fwd["avg_launch_ms"] if fwd else None,
                        "render_ms_per_frame": round(render_ms, 3), "render_ms_per_frame_median": round(render_median_ms, 3),
                        "render_deform_infer_kernel_ms": round(infer_kernel_ms, 4) if infer_kernel_ms else None,
+                       "render_by_timestamp": render_by_timestamp,
                        "render_ms_per_frame_bf16x3": round(render_split_ms, 3),
                        "render_ms_per_frame_bf16x3_median": round(render_split_median_ms, 3),
                        "render_loop_outliers": render_outliers},
@@ -1050,6 +1239,8 @@ def main(argv=None):
                                                "train.py's iteration body inside bench.py")
             if mlp_ab is not None:
                 out["config"]["paths"]["fused_mlp_bf16x3"] = mlp_ab
+            if heavy is not None:
+                out["config"]["paths"]["heavy_raster"] = heavy
         psnr_file = os.path.join(ROOT, "profiles", "psnr_parity.json")
         if os.path.exists(psnr_file):   # the third part of BASELINE's metric: written by tools/psnr_parity.py on the GPU box
             try:

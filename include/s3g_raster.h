@@ -147,6 +147,13 @@ typedef struct s3g_raster_async {
                                  * overflowed iteration on; the host, which reads the status rows late, raises the capacity, clears
                                  * the word and re-issues the iterations from the overflowed one -- no (view, step) pair is dropped
                                  * or reordered w.r.t. the reference's synchronous loop (train.py:291-522). */
+  void* status_event;           /* optional hipEvent_t (ABI 13), recorded on `stream` right behind the copy that fills status_host --
+                                 * i.e. after the COUNTING kernels and before the sort / blend kernels of the same call.  A caller
+                                 * that must know the verdict before it uses the image (the drop-in Python boundary in its default
+                                 * "verified" policy: a render is never silently wrong) waits for THIS event: by then the row is
+                                 * valid, while the device still has the rest of the forward to execute, so the wait costs the
+                                 * device no idle time.  On [4] != 0 the caller issues the call again with the capacity the true
+                                 * counts ask for, into the same output buffers, before anything has read them. */
 } s3g_raster_async;
 int s3g_raster_arena_bytes(int P, int width, int height, uint32_t capacity_instances, uint32_t capacity_slots,
                            size_t* geometry_bytes, size_t* binning_bytes, size_t* image_bytes);

@@ -261,6 +261,10 @@ def default_arguments(ref, argv=()):
     parser.add_argument("--debug_from", type=int, default=-1)
     parser.add_argument("--expname", type=str, default="waymo")
     parser.add_argument("--eval_only", action="store_true")
+    parser.add_argument("--start_checkpoint", type=str, default=None)
+    parser.add_argument("--prior_checkpoint", type=str, default=None)      # train.py:615 reads it between the two stages
+    parser.add_argument("--merge", action="store_true")
+    parser.add_argument("--prior_checkpoint2", type=str, default=None)
     args = parser.parse_args(list(argv))
     ref.train.args = args
     return args, lp.extract(args), hp.extract(args), op.extract(args), pp.extract(args)
@@ -282,14 +286,15 @@ def make_camera(ref, cam: dict, gts, uid: int = 0):
     return c
 
 
-def make_gaussians(ref, gs: dict, aabb, hyper, sh_degree: int = 3):
+def make_gaussians(ref, gs: dict, aabb, hyper, sh_degree: int = 3, model=None):
     """A reference GaussianModel (scene/gaussian_model.py:50-70) holding the synthetic scene: built through its own
     create_from_pcd (:144-168; calls simple_knn._C.distCUDA2) and then overwritten parameter by parameter with the scene's values
-    (the reference has no constructor from tensors); aabb as scene/__init__.py sets it."""
+    (the reference has no constructor from tensors); aabb as scene/__init__.py sets it.  `model`: fill THIS GaussianModel (the one
+    train.py::training constructs itself, train.py:556) instead of constructing one."""
     import numpy as np
     import torch
     GM = ref.gaussian_model
-    g = GM.GaussianModel(sh_degree, hyper)
+    g = GM.GaussianModel(sh_degree, hyper) if model is None else model
     xyz = gs["xyz"].detach().cpu().numpy().astype(np.float64)
     pcd = ref.graphics_utils.BasicPointCloud(points=xyz, colors=np.full_like(xyz, 0.5), normals=np.zeros_like(xyz))
     g.create_from_pcd(pcd, 1.0)
@@ -319,6 +324,9 @@ class SceneStub:
 
     def getTestCameras(self):
         return self._test
+
+    def getFullCameras(self):                  # train.py:564 (`training` copies the three stacks for its evaluation call)
+        return self._train + self._test
 
 
 class RecordingTimer:
@@ -363,6 +371,52 @@ def run_scene_reconstruction(ref, gaussians, scene, dataset, hyper, opt, pipe, i
     finally:
         os.execv = real_execv
     return timer
+
+
+def run_training(ref, fill_model, train_cameras, dataset, hyper, opt, pipe, test_cameras=(), cameras_extent=50.0, after_scene=None):
+    """train.py:553-641 `training` ITSELF -- it constructs the GaussianModel, runs scene_reconstruction(stage="coarse") for
+    opt.coarse_iterations, then scene_reconstruction(stage="fine") on the SAME model (whose optimizer training_setup rebuilds) for
+    opt.iterations, then calls its evaluation.  Three names of the `train` module are rebound for the call, because what they stand for
+    is bound to a dataset on disk and to packages the image lacks (out of scope), nothing else:
+      Scene          -> SceneStub around `train_cameras`; `fill_model(gaussians)` puts the synthetic scene into the model training()
+                        constructed (what Scene.__init__ does through create_from_pcd, scene/__init__.py)
+      Timer          -> RecordingTimer (one record per iteration of either stage)
+      do_evaluation  -> a recorder (utils/..., lpips, video writers: not on the path)
+    -> namespace(timer, gaussians, evaluations=[step, ...])"""
+    import tempfile as _tf
+    T = ref.train
+    made = {}
+    real = {n: getattr(T, n) for n in ("Scene", "Timer", "do_evaluation")}
+
+    def _scene(dataset_, gaussians, load_coarse=None):
+        fill_model(gaussians)
+        made["gaussians"] = gaussians
+        made["scene"] = SceneStub(train_cameras, test_cameras, cameras_extent, model_path=T.args.model_path)
+        if after_scene is not None:
+            after_scene(gaussians)
+        return made["scene"]
+
+    def _timer():
+        made["timer"] = RecordingTimer()
+        return made["timer"]
+
+    evaluations = []
+    T.Scene, T.Timer = _scene, _timer
+    T.do_evaluation = lambda *a, **k: evaluations.append(k.get("step"))
+    T.args.model_path = _tf.mkdtemp(prefix="s3g_ref_training_")
+    real_execv = os.execv
+
+    def _no_reexec(*a, **k):
+        raise RuntimeError("train.py asked to re-exec the program after a NaN loss")
+
+    os.execv = _no_reexec
+    try:
+        T.training(dataset, hyper, opt, pipe, [], [], [], None, -1, "s3g_test")
+    finally:
+        os.execv = real_execv
+        for n, v in real.items():
+            setattr(T, n, v)
+    return types.SimpleNamespace(timer=made["timer"], gaussians=made["gaussians"], evaluations=evaluations)
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("S3G_LIB_PATH") or os.path.join(_HERE, "lib", "libs3g.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -42,7 +42,7 @@ class RasterAsync(C.Structure):
     _fields_ = [("capacity_instances", C.c_uint32), ("capacity_slots", C.c_uint32), ("sort_lds_keys", C.c_uint32),
                 ("long_lists", C.c_int), ("geometry_arena", C.c_void_p), ("binning_arena", C.c_void_p),
                 ("image_arena", C.c_void_p), ("status_device", C.c_void_p), ("status_host", C.c_void_p),
-                ("forward_only", C.c_int), ("sticky_device", C.c_void_p)]
+                ("forward_only", C.c_int), ("sticky_device", C.c_void_p), ("status_event", C.c_void_p)]
 
 
 def build(force: bool = False) -> str:

@@ -802,7 +802,7 @@ static inline uint32_t round_up8(uint32_t v) { return (v + 7u) & ~7u; }
 using namespace s3g;
 
 extern "C" const char* s3g_last_error(void) { return g_err; }
-extern "C" int s3g_abi_version(void) { return 12; }
+extern "C" int s3g_abi_version(void) { return 13; }
 
 // as != NULL: the host-asynchronous variant (s3g_raster_forward_async) -- arenas are the caller's, sized for a speculative
 // capacity, and nothing below waits for the device.
@@ -945,6 +945,8 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
     bin_p = as->binning_arena;
     if (as->status_host)
       S3G_HIP_CHECK(hipMemcpyAsync(as->status_host, im.ctrl, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (as->status_event)   // the verdict is on its way: a caller that has to know it waits for THIS, not for the sort / blend below
+      S3G_HIP_CHECK(hipEventRecord((hipEvent_t)as->status_event, stream));
     if (num_rendered) *num_rendered = (int)R;
   }
   BinningState b = BinningState::carve(bin_p, R, S, nullptr);

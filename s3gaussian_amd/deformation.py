@@ -25,6 +25,12 @@ FUSED_INFERENCE = os.environ.get("S3G_FUSED_INFERENCE", "1") != "0"
 # Arithmetic of the fused inference kernel's GEMM layers: "f32" = exact fp32 fma chains (v_mfma_f32_32x32x2_f32, bit-identical to the
 # training kernels), "bf16x3" = the bf16 matrix pipe on exactly split operands (include/s3g_mlp.h::s3g_deform_infer_split)
 INFER_ARITHMETIC = os.environ.get("S3G_INFER_ARITHMETIC", "f32")
+# S3G_INFER_CACHE=0: every no_grad render evaluates the deformation field afresh (A/B, diagnostics).  Default: the heads' outputs of the
+# last no_grad evaluation are kept and handed to the next render of the SAME Gaussians at the SAME timestamp with the SAME parameters
+# -- the deformation depends on (xyz, t) only, not on the camera, and the evaluation loops of the reference visit the cameras of one
+# timestamp back to back (utils/video_utils.py:116-349 iterates `viewpoint_cams` in dataset order: 3 Waymo cameras per frame)
+INFER_CACHE = os.environ.get("S3G_INFER_CACHE", "1") != "0"
+infer_cache_hits = 0      # renders served from the cache (tests, bench.py)
 
 
 def poc_fre(input_data, poc_buf):
@@ -135,12 +141,28 @@ class Deformation(nn.Module):
         """(dx [P,3], dshs [P,16,3], feat [P,3]) only -- the part of forward_dynamic that is not a pass-through in the
         reference's default configuration.  Lets a caller that fuses `shs + dshs` downstream (pipeline.render) skip
         materialising the [P,16,3] sum."""
+        global infer_cache_hits
+        key = None
+        if INFER_CACHE and not torch.is_grad_enabled() and reg_weights is None and xyz.is_cuda:
+            # identity + version of everything the outputs depend on (the rasterizer's geometry cache is keyed the same way,
+            # raster_C._geom_key): optimizer steps, load_state_dict and in-place edits bump the version counters; writes through
+            # `.data` or raw pointers do not -- call raster_C.invalidate_geometry_cache(), which also drops this entry, after those
+            key = (tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (xyz, time)), bool(uniform_time), bool(need_feat),
+                   INFER_ARITHMETIC if not need_feat else "f32", FUSED_INFERENCE,
+                   tuple((p.data_ptr(), p._version) for p in self.parameters()))
+            hit = self.__dict__.get("_infer_cache")
+            if hit is not None and hit[0] == key and all(t._version == v for t, v in hit[2]):   # (a consumer edited dx in place: miss)
+                infer_cache_hits += 1
+                return hit[1]
         if (FUSED_INFERENCE and not torch.is_grad_enabled() and not need_feat and reg_weights is None and xyz.is_cuda
                 and len(self.grid.resolutions) == 4):
             # inference render without the feature image: sampler (+) heads in one kernel, no [P,128] round trip
             dx, dshs = deform_infer(self.grid, xyz[:, :3], time[:, :1], self.feature_out, self.pos_deform, self.shs_deform,
                                     self.dino_head, uniform_time, arithmetic=INFER_ARITHMETIC)
-            return dx, dshs.reshape([xyz.shape[0], 16, 3]), None
+            out = (dx, dshs.reshape([xyz.shape[0], 16, 3]), None)
+            if key is not None:
+                self._keep_inference(key, out, xyz, time)
+            return out
         reg = None
         if reg_weights is not None:   # plane regulariser evaluated on the sampler's autograd node (hexplane_sample)
             feats, reg = self.grid(xyz[:, :3], time[:, :1], uniform_time, reg_weights)
@@ -149,7 +171,19 @@ class Deformation(nn.Module):
         # need_feat=False (honoured only when no backward follows): skip the feature head, `feat` is then None
         dx, dshs, feat = deform_mlp(feats, self.feature_out, self.pos_deform, self.shs_deform, self.dino_head, need_feat)
         out = (dx, dshs.reshape([xyz.shape[0], 16, 3]), feat)
+        if key is not None:      # (no_grad, no regulariser: what an evaluation render with the feature image asks for)
+            self._keep_inference(key, out, xyz, time)
         return out + (reg,) if reg_weights is not None else out
+
+    def _keep_inference(self, key, out, xyz, time) -> None:
+        """ONE entry (the last timestamp): dx 14 MB + dshs 230 MB (+ feat 14 MB) at 1.2 M Gaussians.  xyz / time are kept alive so
+        that their (pointer, version) identity in the key cannot be recycled by another tensor."""
+        from . import raster_C
+        self.__dict__["_infer_cache"] = (key, out, [(t, t._version) for t in out if t is not None], (xyz, time))
+        raster_C._infer_cache_owners.add(self)
+
+    def drop_inference_cache(self) -> None:
+        self.__dict__.pop("_infer_cache", None)
 
     def forward_dynamic(self, rays_pts_emb, scales_emb, rotations_emb, opacity_emb, shs_emb, time_feature, time_emb):
         a = self.args

@@ -322,6 +322,8 @@ def reduce_densification_stats(viewspace_grad: torch.Tensor, visibility: torch.T
     any_vis = visibility.to(torch.int32).clone()
     rmax = radii.clone()
     if active():
+        # the bookkeeping that consumes these statistics is guarded by the overflow word: agree on it BEFORE it is read
+        reduce_skip_flag(viewspace_grad.device if viewspace_grad.is_cuda else None)
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
         dist.all_reduce(any_vis, op=dist.ReduceOp.MAX)
         dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
@@ -330,21 +332,53 @@ def reduce_densification_stats(viewspace_grad: torch.Tensor, visibility: torch.T
     return g, any_vis.bool(), rmax
 
 
+_skip_agreed_for = {}     # device index -> count of training forwards issued when the word was last all-reduced
+
+
 @torch.no_grad()
 def reduce_skip_flag(device=None):
     """Host-asynchronous rasterizer (raster_C.ASYNC): a forward whose instance count exceeded its speculative arena renders
-    nothing, back-propagates zeros, and flags that in a device word which the guarded Adam step honours
-    (include/s3g_optim.h::s3g_adam_step_guarded).  Replicas must drop the SAME steps, so the flag is all-reduced (MAX, one
-    4-byte collective, no host wait) IN PLACE: optim.Adam.step() reads the same word.  -> the int32 [1] device tensor, or None
-    when this rank has issued no asynchronous forward (then nothing is reduced: every rank runs the same code path, so all or
-    none have one).  Call it between backward and the optimizer step."""
+    nothing, back-propagates zeros, and flags that in a device word which the guarded Adam step and the guarded densification
+    bookkeeping honour (include/s3g_optim.h::s3g_adam_step_guarded, s3g_densify_stats_guarded).  Replicas must drop the SAME
+    steps, so the flag is all-reduced (MAX, one 4-byte collective, no host wait) IN PLACE: every guarded consumer reads the same
+    word.  -> the int32 [1] device tensor, or None when this rank has issued no asynchronous forward (then nothing is reduced:
+    every rank runs the same code path, so all or none have one).
+    Idempotent per training forward: the first guarded consumer of an iteration -- dp.reduce_densification_stats in bench.py's
+    hook, else the reducers' finish() / finish_and_step() -- triggers the one collective, later calls of the same iteration find
+    the word already agreed (the statistics used to read the rank-LOCAL word, because only the reducers, which run after
+    the hook, agreed on it: a rank whose forward overflowed skipped its accumulators while the others applied theirs)."""
     from . import raster_C
     flag = raster_C.async_skip_flag(device)
     if flag is None:
         return None
     if active():
+        st = raster_C._state_of(device)
+        if st is not None:      # (None: the word is a test double -- reduce every time)
+            if _skip_agreed_for.get(st.device.index) == st.train_forwards:
+                return flag
+            _skip_agreed_for[st.device.index] = st.train_forwards
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)     # in place: the view into the status ring now holds the batch's verdict
     return flag
+
+
+_host_group = None
+
+
+def agree_min(value: Optional[int]) -> Optional[int]:
+    """Smallest `value` over all ranks (None = "nothing to report"; None if every rank says so), agreed on the HOST: one 8-byte
+    all-reduce over a gloo side group, which waits for the other ranks' hosts, never for a device.  pipeline.run_training_steps
+    uses it under data parallelism so that every replica rewinds to the same iteration at the same point of its loop (a collective
+    on the device stream would make every host wait for its GPU once per iteration)."""
+    global _host_group
+    if not active():
+        return value
+    if _host_group is None:
+        _host_group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    big = (1 << 62)
+    t = torch.tensor([big if value is None else int(value)], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=_host_group)
+    v = int(t.item())
+    return None if v >= big else v
 
 
 @torch.no_grad()
@@ -355,6 +389,10 @@ def add_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tenso
     if xyz_gradient_accum.is_cuda:
         from .optim import densify_stats
         densify_stats(xyz_gradient_accum, denom, max_radii2D, viewspace_grad_xy, radii, visible)
+        return
+    from . import raster_C
+    flag = raster_C.async_skip_flag()            # CPU tensors (gloo tests): the same guard, read on the host
+    if flag is not None and int(flag.item()) != 0:
         return
     xyz_gradient_accum[visible] += torch.norm(viewspace_grad_xy[visible, :2], dim=-1, keepdim=True)
     denom[visible] += 1

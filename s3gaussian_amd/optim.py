@@ -34,18 +34,32 @@ class Adam(torch.optim.Adam):
                                 # 1 / world_size after a SUM all-reduce instead of spending a pass on the average
         self._entries = {}      # id(param) -> _Entry (launch record + what was checked once), see step()
         self._lib = None
+        self.step_calls = 0     # number of step() calls that launched something (the replay loop notes it per iteration)
+        self._journal = []      # [(step_calls after the call, [state dicts whose step count it advanced])], newest last, bounded
 
     @torch.no_grad()
+    def rewind_to(self, step_calls: int) -> int:
+        """The step() calls after the `step_calls`-th were dropped ON THE DEVICE (guarded step, skip word set: the asynchronous
+        rasterizer's overflow in replay mode, raster_C.set_async_replay) and the iterations that issued them are about to be issued
+        again: take the host-side step counts -- which feed the bias corrections -- back, so that the re-issued steps compute exactly
+        what the dropped ones would have.  Per PARAMETER: each journal entry lists the states that call advanced (a parameter
+        without a gradient in a dropped iteration, or stepped in the other phase of a two-phase data-parallel step, is not touched
+        for it -- ADVICE r5).  The moments and parameters were never written by the dropped launches.  -> calls taken back."""
+        n = 0
+        while self._journal and self._journal[-1][0] > step_calls:
+            _, states = self._journal.pop()
+            for st in states:
+                st["step"] -= 1.0
+            n += 1
+        if self.step_calls - n > step_calls:
+            raise RuntimeError(f"optim.Adam.rewind_to({step_calls}): only the last {len(self._journal) + n} step() calls are journalled "
+                               f"({self.step_calls} issued)")
+        self.step_calls -= n
+        return n
+
     def rewind(self, iterations: int) -> None:
-        """The last `iterations` iterations were dropped ON THE DEVICE (guarded step, skip word set: the asynchronous rasterizer's
-        overflow in replay mode, raster_C.set_async_replay) and are about to be issued again: take the host-side step counts --
-        which feed the bias corrections -- back, so that the re-issued steps compute exactly what the dropped ones would have.
-        The moments and parameters were never touched by the dropped launches."""
-        for st in self.state.values():
-            if "step" in st:
-                st["step"] -= float(iterations)
-                if float(st["step"]) < 0:
-                    st["step"].zero_()
+        """rewind_to() for a loop that issues exactly one step() per iteration."""
+        self.rewind_to(max(self.step_calls - int(iterations), 0))
 
     def _entry(self, group, p):
         """Everything about one parameter that does not change from step to step, checked once: the launch record with the
@@ -77,7 +91,7 @@ class Adam(torch.optim.Adam):
         entries, f32, gs = self._entries, torch.float32, float(self.grad_scale)
         # 1. validate everything and fill the launch records; no state is touched before the launches are out: an exception must not
         #    leave some parameters with an advanced step count and others without
-        by_betas, keep, todo = {}, [], []
+        by_betas, keep, todo, stale = {}, [], [], False
         for group in self.param_groups:
             lr, eps = group["lr"], group["eps"]
             beta1, beta2 = group["betas"]
@@ -88,6 +102,7 @@ class Adam(torch.optim.Adam):
                 e = entries.get(id(p))
                 if e is None or e.p is not p or e.p_ptr != p.data_ptr():
                     e = entries[id(p)] = self._entry(group, p)
+                    stale = True
                 if g.is_sparse:
                     raise RuntimeError("s3gaussian_amd.optim.Adam handles dense float32 parameters only")
                 if g.dtype != f32 or g.stride() != e.stride:
@@ -111,7 +126,11 @@ class Adam(torch.optim.Adam):
                 rec.eps, rec.grad_scale = eps, gs
                 by_betas.setdefault((e.device, float(beta1), float(beta2)), []).append(rec)
                 todo.append((e, st))
-        if len(entries) > 4 * max(len(todo), 16):     # parameters come and go with densification: do not keep the dead ones' records
+        if stale:
+            # a parameter was new or replaced (densify / prune / reset_opacity put fresh nn.Parameters into the groups every 100
+            # iterations, scene/gaussian_model.py:397-494): drop the records of the ones that left RIGHT AWAY.  A record holds its
+            # parameter and both moments strongly -- 708 B per Gaussian and generation; kept "until there are many" (rounds 3-5) that was
+            # up to ~20 GB of dead tensors at 1.2 M Gaussians, which the reference's torch.optim.Adam frees at once
             live = {id(p) for group in self.param_groups for p in group["params"]}
             for k in [k for k in entries if k not in live]:
                 del entries[k]
@@ -141,6 +160,10 @@ class Adam(torch.optim.Adam):
             st["step"] += 1
             written += (e.p, e.m, e.v)
         if todo:
+            self.step_calls += 1
+            self._journal.append((self.step_calls, [st for _, st in todo]))
+            if len(self._journal) > 256:          # the host is never more than one status ring (64 forwards) ahead of the device
+                del self._journal[:128]
             torch.autograd.graph.increment_version(written)     # one call for all of them: 6 us instead of 60
             raster_C.invalidate_geometry_cache()
         return loss

@@ -146,7 +146,11 @@ class _L1Ready(torch.Tensor):
         if func in (torch.abs, torch.Tensor.abs) and len(args) == 1 and not kwargs and isinstance(args[0], _L1Ready):
             src, l1 = args[0].__dict__["_s3g_src"], args[0].__dict__["_s3g_l1"]
             with torch._C.DisableTorchFunctionSubclass():
-                lazy = src.as_subclass(_LazyAbs)
+                # the stand-in owns NO data: a meta tensor of x's shape and dtype.  Every consumer that dispatches through
+                # __torch_function__ is handed |x| (or the fused mean) above; one that unwraps the object WITHOUT dispatching -- a
+                # C++ custom op taking tensor lists, a functorch / compile path -- finds a meta tensor and fails on the spot,
+                # where an alias of x's storage would have handed it the SIGNED values in silence
+                lazy = torch.empty(src.shape, dtype=src.dtype, device="meta").as_subclass(_LazyAbs)
             lazy.__dict__["_s3g_src"], lazy.__dict__["_s3g_l1"], lazy.__dict__["_s3g_version"] = src, l1, src._version
             return lazy
         return _run_plain(func, args, kwargs)

@@ -686,6 +686,71 @@ def training_step(pc: GaussianParams, cam: Dict, gt_image, gt_depth, gt_feat, hy
     return loss.detach(), pkg
 
 
+_replay_loop = None      # the _ReplayLoop of the run_training_steps call in progress (surgery_barrier talks to it)
+
+
+class _ReplayLoop:
+    """Bookkeeping of run_training_steps: which iteration issued which forward / how many optimizer launches had gone out when it
+    started, the (data-parallel: agreed) iteration to resume from, the rewind itself."""
+
+    def __init__(self, optimizer, device, first):
+        from . import raster_C
+        self.rc, self.optimizer, self.device, self.first = raster_C, optimizer, device, first
+        self.marks: Dict[int, tuple] = {}      # iteration -> (forwards issued, optimizer.step_calls) when it started
+        self.rewinds = []
+
+    def mark(self, i):
+        self.marks[i] = (self.rc.async_issued(self.device), getattr(self.optimizer, "step_calls", None))
+        horizon = i - 4 * self.rc._ASYNC_RING      # the host is never more than one status ring of forwards ahead of the device
+        for k in [k for k in self.marks if k < horizon]:
+            del self.marks[k]
+
+    def iteration_of(self, seq) -> int:
+        cands = [k for k, (s0, _) in self.marks.items() if s0 <= seq]
+        # (a forward issued BEFORE this loop started cannot be replayed by it: run_training_steps drains those first, and should one
+        #  slip through, the loop resumes from its own first iteration instead of failing on an empty max())
+        return max(cands) if cands else (min(self.marks) if self.marks else self.first)
+
+    def pending(self, block: bool) -> Optional[int]:
+        """-> the iteration to resume from, or None.  Data parallel: the smallest over all ranks, agreed on the host (dp.agree_min),
+        so that every replica rewinds to the same iteration at the same point of its loop -- every rank calls this at the same
+        points: after each issue(i), at the tail, inside surgery_barrier()."""
+        from . import dp
+        seq = self.rc.async_replay_pending(self.device, block=block)
+        j = None if seq is None else self.iteration_of(seq)
+        return dp.agree_min(j) if dp.active() else j
+
+    def rewind(self, j: int, at: int) -> int:
+        calls = self.marks[j][1] if j in self.marks else None
+        opt = self.optimizer
+        if opt is not None and hasattr(opt, "rewind_to") and calls is not None:
+            opt.rewind_to(calls)            # per parameter: only what the dropped launches advanced (optim.Adam journal)
+        elif opt is not None and hasattr(opt, "rewind"):
+            opt.rewind(at - j + 1)
+        self.rc.async_acknowledge(self.device)
+        self.rewinds.append((j, at))
+        for k in [k for k in self.marks if k >= j]:
+            del self.marks[k]
+        return j
+
+
+def surgery_barrier(device=None) -> None:
+    """Call inside `issue(i)` BEFORE any host-side mutation of the model -- densify / prune / reset_opacity (new Parameters), an
+    SH-degree step, a checkpoint -- when the loop is driven by run_training_steps.  Such a mutation is not covered by the device's
+    freeze: applied inside a frozen window it would hit the frozen model and then be applied AGAIN by the replay.  This
+    waits until every forward issued so far has reported (the reference's loop waits at `loss.item()` every iteration; this waits
+    only where it mutates, every 100th) and, if one of them overflowed, raises raster_C.ReplayNeeded: run_training_steps rewinds and
+    issue(i) runs again later, when the mutation sees the model the synchronous loop would have shown it.  Outside such a loop:
+    no-op."""
+    from . import raster_C
+    loop = _replay_loop
+    if loop is None or not raster_C.REPLAY:
+        return
+    j = loop.pending(block=True)
+    if j is not None:
+        raise raster_C.ReplayNeeded(iteration=j)
+
+
 def run_training_steps(issue, first: int, last: int, optimizer=None, device=None, log: Optional[list] = None) -> Dict:
     """Drives iterations first..last (inclusive) through the host-asynchronous rasterizer WITHOUT ever dropping one.
 
@@ -698,40 +763,42 @@ def run_training_steps(issue, first: int, last: int, optimizer=None, device=None
     (view, optimizer step) pairs applied to the model is then exactly the one the reference's synchronous loop applies
     (train.py:291-522) -- VERDICT r4 item 8: round 4 dropped the overflowed iteration and went on.
 
-    Single process only: under data parallelism the replicas would have to agree on the rewind point at the same host step, which
-    needs a host-visible collective; there the reducers keep every replica dropping the same step instead (dp.reduce_skip_flag).
+    Contract of `issue(i)`: what it does to the model goes through the device (kernels the sticky word freezes); a
+    HOST-side mutation -- densify / prune, opacity reset, oneupSHdegree, popping a view stack that is not a function of i -- must be
+    preceded by `surgery_barrier()`, which waits for the outstanding reports and hands control back to this loop if a rewind is due.
+
+    Data parallel (round 6): every replica runs this loop; after each iteration the ranks agree on the HOST (dp.agree_min over a gloo
+    side group: no device wait) on the earliest iteration any of them has to resume from, and all rewind there together -- the
+    reducers have kept every replica skipping the same steps in the meantime (dp.reduce_skip_flag).
     -> {"issued": total issue() calls, "rewinds": [(from_iteration, noticed_at_iteration), ...]}"""
+    global _replay_loop
     from . import raster_C
+    raster_C.async_status(device, block=True)      # forwards issued BEFORE this loop report under the policy they were issued with
     prev = raster_C.set_async_replay(True)
-    marks: Dict[int, int] = {}
-    rewinds = []
+    loop = _ReplayLoop(optimizer, device, first)
+    outer, _replay_loop = _replay_loop, loop
     issued = 0
-
-    def rewind_to(seq, at):
-        j = max(k for k, s0 in marks.items() if s0 <= seq)      # the iteration that issued forward #seq
-        if optimizer is not None and hasattr(optimizer, "rewind"):
-            optimizer.rewind(at - j + 1)
-        raster_C.async_acknowledge(device)
-        rewinds.append((j, at))
-        for k in [k for k in marks if k >= j]:
-            del marks[k]
-        return j
-
     try:
         i = first
         while True:
             while i <= last:
-                marks[i] = raster_C.async_issued(device)
-                issue(i)
+                loop.mark(i)
+                try:
+                    issue(i)
+                except raster_C.ReplayNeeded as rn:      # surgery_barrier() / a synchronous-fallback forward inside issue(i)
+                    j = rn.iteration if rn.iteration is not None else loop.iteration_of(rn.seq)
+                    i = loop.rewind(j, i)
+                    continue
                 issued += 1
                 if log is not None:
                     log.append(i)
-                seq = raster_C.async_replay_pending(device)
-                i = rewind_to(seq, i) if seq is not None else i + 1
-            seq = raster_C.async_replay_pending(device, block=True)      # the tail: every status row has landed
-            if seq is None:
+                j = loop.pending(block=False)
+                i = loop.rewind(j, i) if j is not None else i + 1
+            j = loop.pending(block=True)                 # the tail: every status row has landed
+            if j is None:
                 break
-            i = rewind_to(seq, last)
+            i = loop.rewind(j, last)
     finally:
         raster_C.set_async_replay(prev)
-    return {"issued": issued, "rewinds": rewinds}
+        _replay_loop = outer
+    return {"issued": issued, "rewinds": loop.rewinds}

@@ -8,7 +8,7 @@ from tests.test_abi_cpu import _struct_fields
 def test_async_descriptor_matches_the_header():
     from s3gaussian_amd import _lib
     assert _struct_fields("s3g_raster.h", "s3g_raster_async") == [f[0] for f in _lib.RasterAsync._fields_]
-    assert ctypes.sizeof(_lib.RasterAsync) == 4 * 4 + 5 * 8 + 8 + 8   # + forward_only (int, padded) + sticky_device (round 5)
+    assert ctypes.sizeof(_lib.RasterAsync) == 4 * 4 + 5 * 8 + 8 + 8 + 8   # + forward_only (int, padded) + sticky_device (round 5) + status_event (round 6)
 
 
 def test_capacity_ladder_is_monotone_tight_and_repeats():
@@ -79,18 +79,97 @@ def test_run_training_steps_rewinds_to_the_overflowed_iteration(monkeypatch):
     monkeypatch.setattr(raster_C, "async_acknowledge", fake_ack)
 
     class Opt:
+        """stands for optim.Adam: one step() per iteration, journalled (rewind_to takes launches back by COUNT of step() calls)."""
+        step_calls = 0
         rewound = []
 
-        def rewind(self, n):
-            self.rewound.append(n)
+        def rewind_to(self, calls):
+            self.rewound.append(self.step_calls - calls)
+            self.step_calls = calls
 
     log = []
+    opt = Opt()
 
     def issue(i):
         issued_calls["n"] += 2
+        opt.step_calls += 1
 
-    out = pipeline.run_training_steps(issue, 1, 8, optimizer=Opt(), log=log)
+    monkeypatch.setattr(raster_C, "async_status", lambda device=None, block=False: {})
+    out = pipeline.run_training_steps(issue, 1, 8, optimizer=opt, log=log)
     # forwards: it1 = #0,1  it2 = #2,3  it3 = #4,5  it4 = #6,7 ...  it7 = #12,13
     assert log[:7] == [1, 2, 3, 4, 5, 6, 7] and log[7:12] == [4, 5, 6, 7, 8] and log[12:] == [8]
     assert out["rewinds"] == [(4, 7), (8, 8)] and Opt.rewound == [4, 1] and out["issued"] == len(log) == 13
-    assert raster_C.REPLAY is False
+    assert raster_C.REPLAY is False and pipeline._replay_loop is None
+
+
+def test_surgery_barrier_hands_control_back_before_a_host_side_mutation(monkeypatch):
+    """a densify / prune / opacity reset inside issue(i) is a HOST-side mutation the device's freeze does not cover.  With
+    pipeline.surgery_barrier() in front of it, an overflow reported while iteration 5 is about to mutate sends the loop back to the
+    overflowed iteration 3 WITHOUT the mutation having run; it runs once, when iteration 5 is issued again on a thawed model.  The
+    optimizer had launched steps for iterations 1-4 (not 5: the barrier sits before its step): exactly 3 and 4 are taken back."""
+    from s3gaussian_amd import pipeline, raster_C
+    n = {"fwd": 0}
+    state = {"pending": None, "acks": 0}
+
+    def fake_pending(device=None, block=False):
+        if block and state["acks"] == 0 and n["fwd"] >= 5:
+            state["pending"] = 2                       # forward #2 = iteration 3
+        return state["pending"]
+
+    def fake_ack(device=None):
+        state["pending"], state["acks"] = None, state["acks"] + 1
+
+    monkeypatch.setattr(raster_C, "async_issued", lambda device=None: n["fwd"])
+    monkeypatch.setattr(raster_C, "async_replay_pending", fake_pending)
+    monkeypatch.setattr(raster_C, "async_acknowledge", fake_ack)
+    monkeypatch.setattr(raster_C, "async_status", lambda device=None, block=False: {})
+
+    class Opt:
+        step_calls = 0
+        rewound = []
+
+        def rewind_to(self, calls):
+            self.rewound.append(self.step_calls - calls)
+            self.step_calls = calls
+
+    opt, mutations, log = Opt(), [], []
+
+    def issue(i):
+        n["fwd"] += 1                                  # forward + backward of iteration i
+        if i == 5:
+            pipeline.surgery_barrier()                 # train.py:489-516 territory: densify / prune / reset follow
+            mutations.append(i)
+        opt.step_calls += 1
+
+    out = pipeline.run_training_steps(issue, 1, 6, optimizer=opt, log=log)
+    assert log == [1, 2, 3, 4, 3, 4, 5, 6] and mutations == [5] and out["rewinds"] == [(3, 5)] and Opt.rewound == [2]
+    pipeline.surgery_barrier()                          # outside a replay loop: no-op
+
+
+def test_adam_journal_takes_back_exactly_what_the_dropped_launches_advanced():
+    """optim.Adam.rewind_to (host logic, no launch): step counts are taken back per PARAMETER -- a parameter that had no gradient in a
+    dropped iteration, or was stepped by the other launch of a two-phase step, keeps its count (rewind(n) subtracted n
+    from every state)."""
+    import torch
+    from s3gaussian_amd import optim
+    a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(3))
+    opt = optim.Adam([{"params": [a]}, {"params": [b]}], lr=0.1)
+    sa, sb = opt.state[a], opt.state[b]
+    sa["step"], sb["step"] = torch.tensor(0.0), torch.tensor(0.0)
+
+    def launched(states):              # what step() records once its launches are out
+        for st in states:
+            st["step"] += 1
+        opt.step_calls += 1
+        opt._journal.append((opt.step_calls, list(states)))
+
+    launched([sa, sb])                 # iteration 1
+    mark = opt.step_calls
+    launched([sa])                     # iteration 2: b had no gradient
+    launched([sa])                     # iteration 3, phase 1 of a two-phase step
+    launched([sb])                     # iteration 3, phase 2
+    assert (float(sa["step"]), float(sb["step"]), opt.step_calls) == (3.0, 2.0, 4)
+    assert opt.rewind_to(mark) == 3 and (float(sa["step"]), float(sb["step"]), opt.step_calls) == (1.0, 1.0, 1)
+    launched([sa, sb])
+    opt.rewind(1)
+    assert (float(sa["step"]), float(sb["step"]), opt.step_calls) == (1.0, 1.0, 1)

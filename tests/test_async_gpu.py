@@ -74,6 +74,7 @@ def test_overflow_is_a_device_side_no_op_and_is_reported_late(gpu_device, monkey
     dev = gpu_device
     s = tiny_scene(P=4000, W=160, H=112, seed=8)
     prev = raster_C.set_async(True)
+    prev_policy = raster_C.set_async_policy("speculative")                 # (the default policy renders again on the spot: next test)
     try:
         raster_C.invalidate_geometry_cache()
         ref_out, ref_grads = _render_and_grads(s, dev, pair=True)          # learns the true counts of this image size
@@ -132,7 +133,68 @@ def test_overflow_is_a_device_side_no_op_and_is_reported_late(gpu_device, monkey
         assert not torch.equal(op.detach(), before[1]) and float(acc[1].sum()) > 0
     finally:
         raster_C.set_async(prev)
+        raster_C.set_async_policy(prev_policy)
         raster_C._async_states.pop(dev.index or 0, None)                   # forget the doctored history
+        raster_C.invalidate_geometry_cache()
+
+
+def test_the_default_policy_renders_again_on_overflow_and_drops_nothing(gpu_device, monkeypatch):
+    """through the drop-in boundary in its DEFAULT policy ("verified") the same doctored capacity costs
+    nothing but a second issue of the forward: the host reads the verdict behind the counting kernels (s3g_raster_async.status_event),
+    finds the overflow, renders again with the capacity the true counts ask for -- into the same outputs, before anything has read
+    them.  Image, gradients, bookkeeping and optimizer step are those of an ordinary call; nothing is warned about, nothing dropped."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from s3gaussian_amd import raster_C
+    from s3gaussian_amd.optim import Adam
+    dev = gpu_device
+    assert raster_C.POLICY == "verified"
+    s = tiny_scene(P=4000, W=160, H=112, seed=8)
+    prev = raster_C.set_async(True)
+    try:
+        raster_C._async_states.pop(dev.index or 0, None)
+        raster_C.invalidate_geometry_cache()
+        ref_out, ref_grads = _render_and_grads(s, dev, pair=True)
+        st = raster_C._async_state(dev)
+        st.drain(block=True)
+        key = (160, 112)
+        true_R = st.hist[key][0]
+        monkeypatch.setattr(raster_C, "_ASYNC_MIN_INSTANCES", 1)
+        for no_grad in (False, True):
+            st.hist[key] = [true_R // 16, true_R // 16, 4]
+            assert st.caps(key)[0] < true_R
+            rast = GaussianRasterizer(raster_settings=settings_from(s, dev))
+            t = lambda k: torch.nn.Parameter(s[k].to(dev).clone())
+            m3, op, sc, rot, col = t("means3D"), t("opacities"), t("scales"), t("rotations"), t("colors_precomp")
+            col2 = torch.nn.Parameter(s["colors_precomp"].flip(0).to(dev).clone())
+            m2 = torch.zeros_like(m3, requires_grad=True)
+            acc = (torch.zeros(4000, 1, device=dev), torch.zeros(4000, 1, device=dev), torch.zeros(4000, device=dev))
+            opt = Adam([m3, op, sc, rot, col, col2], lr=1e-2)
+            before = op.detach().clone()
+            raster_C.invalidate_geometry_cache()
+            calls, reissued = st.seq, st.reissued
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                if no_grad:
+                    with torch.no_grad():      # an evaluation render: the forward_only form is verified too
+                        color, radii, depth, color2 = rast.forward_pair(means3D=m3, means2D=m2, opacities=op, colors_a=col, colors_b=col2,
+                                                                        scales=sc, rotations=rot)
+                else:
+                    color, radii, depth, color2 = rast.forward_pair(means3D=m3, means2D=m2, opacities=op, colors_a=col, colors_b=col2,
+                                                                    scales=sc, rotations=rot, densify_accum=acc)
+                    (color.sum() + depth.sum() + color2.sum()).backward()
+                    opt.step()
+                torch.cuda.synchronize()
+                status = raster_C.async_status(block=True)
+            assert torch.equal(color, ref_out[0]) and torch.equal(depth, ref_out[1]) and torch.equal(color2, ref_out[2])
+            assert st.seq == calls + 2 and st.reissued == reissued + 1          # issued twice, the second time with room
+            assert status["overflows"] == [] and not any("exceeded its arena" in str(x.message) for x in w)
+            assert st.caps(key)[0] >= true_R
+            if not no_grad:
+                assert int(raster_C.async_skip_flag(dev).item()) == 0
+                assert not torch.equal(op.detach(), before) and float(acc[1].sum()) > 0      # the step and the bookkeeping happened
+    finally:
+        raster_C.set_async(prev)
+        raster_C._async_states.pop(dev.index or 0, None)
         raster_C.invalidate_geometry_cache()
 
 
@@ -155,6 +217,7 @@ def test_training_steps_are_enqueued_ahead_of_the_device(gpu_device):
     gts = (torch.rand(3, H, W, device=dev), torch.rand(1, H, W, device=dev) * 50, torch.rand(3, H, W, device=dev))
     bg = scn["bg"].to(dev)
     prev = raster_C.set_async(True)
+    prev_policy = raster_C.set_async_policy("speculative")      # "verified" (the default) reads each forward's verdict before going on
     try:
         for i in range(3):
             training_step(pc, cams[i % 4], *gts, hyper, opt, bg, stage="fine", densify_stats=True)
@@ -168,11 +231,16 @@ def test_training_steps_are_enqueued_ahead_of_the_device(gpu_device):
         torch.cuda.synchronize()
         assert max_pending >= 2, max_pending
         assert raster_C.async_status(block=True)["overflows"] == []
+        raster_C.set_async_policy("verified")
+        for i in range(4):     # every forward's row has been read by the time its call returns: nothing is ever pending
+            training_step(pc, cams[i % 4], *gts, hyper, opt, bg, stage="fine", densify_stats=True)
+            assert len(st.pending) == 0
         raster_C.set_async(False)
         loss, _ = training_step(pc, cams[0], *gts, hyper, opt, bg, stage="fine", densify_stats=True)
         assert torch.isfinite(loss)
     finally:
         raster_C.set_async(prev)
+        raster_C.set_async_policy(prev_policy)
 
 
 @pytest.mark.parametrize("pair", [False, True])
@@ -246,7 +314,7 @@ def test_speculative_arenas_yield_to_a_crowded_device(gpu_device, monkeypatch):
         monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (need4 // 4, real(d)[1]))
         monkeypatch.setattr(torch.cuda, "memory_reserved", lambda d=None: 0)
         monkeypatch.setattr(torch.cuda, "memory_allocated", lambda d=None: 0)
-        st.fit_key = None
+        st.fit_cache.clear()
         raster_C.invalidate_geometry_cache()
         out, grads = _render_and_grads(s, dev, pair=True)
         for a, b in zip(ref_out + ref_grads, out + grads):
@@ -254,12 +322,15 @@ def test_speculative_arenas_yield_to_a_crowded_device(gpu_device, monkeypatch):
         assert raster_C.async_status(dev, block=True)["calls"] == calls + 1
         # (2) no room at all: the synchronous forward
         monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (1 << 20, real(d)[1]))
-        st.fit_key = None
+        st.fit_cache.clear()
         raster_C.invalidate_geometry_cache()
         out, grads = _render_and_grads(s, dev, pair=True)
         for a, b in zip(ref_out + ref_grads, out + grads):
             assert torch.equal(a, b)
-        assert raster_C.async_status(dev, block=True)["calls"] == calls + 1 and raster_C.async_skip_flag(dev) is None
+        # no asynchronous call was issued; the forward owns a skip word of its own (0: a synchronous forward cannot overflow), never
+        # the word of an older forward
+        assert raster_C.async_status(dev, block=True)["calls"] == calls + 1
+        assert raster_C.async_skip_flag(dev) is st.fallback_word and int(st.fallback_word.item()) == 0
     finally:
         raster_C.set_async(prev)
         raster_C._async_states.pop(dev.index or 0, None)

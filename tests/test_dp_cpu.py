@@ -336,3 +336,104 @@ def test_forced_single_rank_group_executes_the_collectives():
     pr.start()
     assert q.get(timeout=120) == (0, True)
     pr.join(timeout=60)
+
+
+def _stats_skip_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from s3gaussian_amd import dp, raster_C
+    dp.init_from_env(backend="gloo")
+    ok = True
+    res = []
+    for it, overflowed_rank in enumerate((0, None, 1)):        # iteration 0: rank 0's forward overflowed; 1: nobody's; 2: rank 1's
+        word = torch.tensor([1 if rank == overflowed_rank else 0], dtype=torch.int32)
+        raster_C.async_skip_flag = lambda device=None, _w=word: _w
+        accum, denom, maxr = torch.zeros(10, 1), torch.zeros(10, 1), torch.zeros(10)
+        vis = torch.arange(10) % (rank + 2) == 0
+        vg = torch.ones(10, 3) * (rank + 1) * vis[:, None]
+        radii = torch.arange(10, dtype=torch.int32) * (rank + 1)
+        # bench.py's hook: the statistics are reduced and applied BEFORE the reducer's finish() gets to agree on the word
+        g, any_vis, rmax = dp.reduce_densification_stats(vg, vis, radii)
+        dp.add_densification_stats(accum, denom, maxr, g, any_vis, rmax)
+        ok = ok and int(word.item()) == (0 if overflowed_rank is None else 1)          # agreed by the statistics call itself
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (accum.tolist(), denom.tolist(), maxr.tolist()))
+        ok = ok and gathered[0] == gathered[1]                                          # replicas stay identical
+        applied = float(denom.sum()) > 0
+        ok = ok and applied == (overflowed_rank is None)
+        res.append(applied)
+    q.put((rank, bool(ok) and res == [False, True, False]))
+    dist.destroy_process_group()
+
+
+def test_densification_statistics_follow_the_agreed_skip_flag_world_size_2():
+    """the guarded bookkeeping must read the AGREED overflow word.  One rank's forward overflows: both ranks skip their
+    accumulators (identical denom), although the statistics run before the reducers' finish()."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stats_skip_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert results == {0: True, 1: True}
+
+
+def _replay_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from s3gaussian_amd import dp, pipeline, raster_C
+    dp.init_from_env(backend="gloo")
+    n = {"fwd": 0}
+    state = {"pending": None, "acks": 0}
+
+    def fake_pending(device=None, block=False):
+        # rank 1's forward #3 (iteration 4) overflows; ITS host learns of it while issuing iteration 6, rank 0's host never does
+        if rank == 1 and state["acks"] == 0 and n["fwd"] >= 6:
+            state["pending"] = 3
+        return state["pending"]
+
+    def fake_ack(device=None):
+        state["pending"], state["acks"] = None, state["acks"] + 1
+
+    raster_C.async_issued = lambda device=None: n["fwd"]
+    raster_C.async_replay_pending = fake_pending
+    raster_C.async_acknowledge = fake_ack
+    raster_C.async_status = lambda device=None, block=False: {}
+
+    class Opt:
+        step_calls = 0
+        rewound = []
+
+        def rewind_to(self, calls):
+            self.rewound.append(self.step_calls - calls)
+            self.step_calls = calls
+
+    opt, log = Opt(), []
+
+    def issue(i):
+        n["fwd"] += 1
+        opt.step_calls += 1
+
+    out = pipeline.run_training_steps(issue, 1, 8, optimizer=opt, log=log)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (log, out["rewinds"], Opt.rewound, state["acks"]))
+    ok = gathered[0] == gathered[1]                      # both replicas issued the same iterations and rewound to the same one
+    ok = ok and log == [1, 2, 3, 4, 5, 6, 4, 5, 6, 7, 8] and out["rewinds"] == [(4, 6)] and Opt.rewound == [3]
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_replay_rewinds_every_replica_to_the_same_iteration_world_size_2():
+    """replay under data parallelism.  Only one rank's forward overflows and only that rank's host sees the
+    report; dp.agree_min (gloo side group, no device wait) makes both replicas rewind to iteration 4 after issuing iteration 6."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replay_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert results == {0: True, 1: True}

@@ -194,6 +194,12 @@ def test_the_dshs_stand_in_answers_only_abs_then_mean_and_is_an_ordinary_tensor_
     assert type(a + 1) is torch.Tensor and type(t * 2) is torch.Tensor and torch.equal(t * 2, y * 2) and torch.equal(t[1], y[1])
     assert torch.equal(t.detach(), y.detach()) and torch.equal(torch.cat([t, t]), torch.cat([y, y])) and torch.equal(t.abs().max(), y.abs().max())
     assert "nan" not in repr(a) and float(a.min()) >= 0.0
+    # a consumer that gets at the object WITHOUT dispatching through __torch_function__ must fail, not read x's signed values:
+    # the stand-in owns no storage
+    with torch._C.DisableTorchFunctionSubclass():
+        assert a.device.type == "meta" and a.untyped_storage().data_ptr() != y.untyped_storage().data_ptr()
+        with pytest.raises((RuntimeError, NotImplementedError)):
+            float(a.sum())
     (t.abs().mean() * 0.01 + (t * 2).sum() + torch.abs(t).sum()).backward()
     x2 = x.detach().clone().requires_grad_(True)
     y2 = x2 * 1.0

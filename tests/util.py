@@ -96,8 +96,11 @@ def validate_bench_line(d, default_workload=True, n_gpus=1, round3_accounting=Fa
     assert c["path"] == "fused"
     if "paths" in c:
         assert {"fused", "patched", "import_swap", "zero_diff"} <= set(c["paths"]) <= {
-            "fused", "patched", "import_swap", "zero_diff", "fused_mlp_bf16x3"}
-        ips = {k: v["iters_per_s"] for k, v in c["paths"].items() if k != "fused_mlp_bf16x3"}
+            "fused", "patched", "import_swap", "zero_diff", "fused_mlp_bf16x3", "heavy_raster"}
+        ips = {k: v["iters_per_s"] for k, v in c["paths"].items() if k not in ("fused_mlp_bf16x3", "heavy_raster")}
+        if "heavy_raster" in c["paths"]:     # round 6: the same step with ~8 x the (tile, Gaussian) instances
+            hr = c["paths"]["heavy_raster"]
+            assert hr.get("ms_per_step") and hr["arena_overflows"] == 0 and hr["instances_R_per_view"] > c["instances_R_per_view"], hr
         if "fused_mlp_bf16x3" in c["paths"]:     # the opt-in arithmetic of the MLP kernels: timed, never the headline
             assert c["paths"]["fused_mlp_bf16x3"].get("ms_per_step"), c["paths"]["fused_mlp_bf16x3"]
         # the slow routes are slow by an order of magnitude (plain PyTorch deformation field / 24 grid_samples): that much is structural
@@ -115,16 +118,21 @@ def validate_bench_line(d, default_workload=True, n_gpus=1, round3_accounting=Fa
     if "raster_async" in c:
         assert c["raster_async"]["overflows"] == []      # a step that overflowed its arena did no work: never inside the timed loop
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] in ("GB/s", "TFLOP/s", "G wave-instructions/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    if r["bound"] == "valu":      # round 6: the roof the dominant kernel sits closest to; the HBM figure travels beside it
+        assert abs(r["hbm"]["frac"] - r["hbm"]["achieved"] / r["hbm"]["peak"]) < 1e-3 and r["hbm"]["frac"] <= r["frac"]
     if r["traffic"] is not None:
         # (the driver's record keeps the first 128 characters of every string)
-        assert "NOT collected in this run" in r["traffic_source"] or r["traffic_source"].startswith("profiles/kernel_traffic.json")
+        assert ("NOT collected in this run" in r["traffic_source"] or r["traffic_source"].startswith("profiles/kernel_traffic.json")
+                or r["traffic_source"].startswith("collected IN THIS RUN"))
     if "kernels" in r:
         dom = max(r["kernels"], key=lambda k: k["ms_per_step"])
         assert dom["kernel"] == r["kernel"]
         for k in r["kernels"]:
             assert k["algorithmic_bytes_per_launch"] <= k["implementation_bytes_per_launch"] and k["avg_launch_ms"] > 0
+            if "valu_frac" in k and k["valu_frac"] is not None:   # every kernel with a SQ_INSTS_VALU count is priced on the VALU roof too
+                assert 0 < k["valu_frac"] <= 1.05 and k["frac"] >= k["valu_frac"] - 1e-3 and k["frac"] >= k["hbm_frac"] - 1e-3
             if k["kernel"].startswith("s3g::blend_") and not round3_accounting:   # (round 3's lines carry the two bugs below)
                 assert k["bound"] == "valu"                    # VALU / v_exp-bound, never priced as an HBM kernel
                 assert abs(k["launches_per_step"] - 1.0) < 1e-6, k   # ONE two-image launch per step (round 3 mixed the render loop in)
