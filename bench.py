@@ -39,7 +39,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
-PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32), the dtype the MLP computes in
+PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32): the exact chain and the weight-gradient GEMMs
+PEAK_MFMA_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA; the bf16x3 chains issue SIX bf16 piece products per fp32 product
 VALU_CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md: peak engine clock; 256 CUs x 4 SIMDs, a wave64 VALU instruction occupies a SIMD for 4 cycles
 
 
@@ -836,28 +837,31 @@ def main(argv=None):
                      "gc_gen2_passes": GC_PASSES[-1], "arena_overflows": s_over}
         comm.update(elems=0, events=[], sparse_rows=0)
 
-    # ---- 1c. the opt-in arithmetic of the MLP kernels (bf16 matrix pipe on exactly split operands, weight fragments split once, fp32
-    #          accuracy), A/B at the SAME point of the process: the fp32 step again, then the bf16x3 step, same views.  (Up to round 5's
-    #          first lines this leg ran last and was read against the headline: but every loop after the first ~2 s of load runs
-    #          ~0.2 ms/step slower than the opening 20-step burst on these boxes, so the faster arithmetic looked slower.)
+    # ---- 1c. the OTHER arithmetic of the MLP kernels, A/B at the SAME point of the process: the default step again, then the other one,
+    #          same views.  Since round 6 the default is "bf16x3" (the bf16 matrix pipe on operands split exactly into three bf16 pieces,
+    #          weight fragments split once per call, fp32 accumulation: fp32 results) and the leg times the EXACT fp32 fma chains --
+    #          rounds 3-5 had it the other way round.  (Every loop after the first ~2 s of load runs ~0.2 ms/step slower than the opening
+    #          20-step burst on these boxes: read the pair against each other, not against the headline.)
     mlp_ab = None
+    from s3gaussian_amd import mlp as _mlp
+    mlp_default = _mlp.get_mlp_arithmetic()
+    mlp_other = "f32" if mlp_default != "f32" else "bf16x3"
     if world == 1 and not dist_on and not a.no_alt_paths:
-        from s3gaussian_amd import mlp as _mlp
         try:
             ab_idx = [i % n_needed for i in range(a.steps)]
             dt_a, _, ps_a = timed_loop(step, ab_idx, 1, device)
-            _mlp.set_mlp_arithmetic("bf16x3")
+            _mlp.set_mlp_arithmetic(mlp_other)
             for i in range(3):
                 step(i % n_needed)
             dt_b, _, ps_b = timed_loop(step, ab_idx, 1, device)
             ms_b = 1000.0 * dt_b / a.steps
-            mlp_ab = {"ms_per_step": round(ms_b, 3), "iters_per_s": round(1000.0 / ms_b, 2), "steps": a.steps,
-                      "f32_back_to_back_ms_per_step": round(1000.0 * dt_a / a.steps, 3),
-                      "gpu_ms_per_step": round(sum(ps_b) / len(ps_b), 3), "f32_back_to_back_gpu_ms_per_step": round(sum(ps_a) / len(ps_a), 3)}
+            mlp_ab = {"arithmetic": mlp_other, "ms_per_step": round(ms_b, 3), "iters_per_s": round(1000.0 / ms_b, 2), "steps": a.steps,
+                      "default_arithmetic": mlp_default, "default_back_to_back_ms_per_step": round(1000.0 * dt_a / a.steps, 3),
+                      "gpu_ms_per_step": round(sum(ps_b) / len(ps_b), 3), "default_back_to_back_gpu_ms_per_step": round(sum(ps_a) / len(ps_a), 3)}
         except Exception as ex:   # never take the headline down
-            mlp_ab = {"ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"}
+            mlp_ab = {"arithmetic": mlp_other, "ms_per_step": None, "error": f"{type(ex).__name__}: {ex}"}
         finally:
-            _mlp.set_mlp_arithmetic("f32")
+            _mlp.set_mlp_arithmetic(mlp_default)
         comm.update(elems=0, events=[], sparse_rows=0)
 
     # ---- 1d. a rasterizer-HEAVY workload in the driver-visible line (VERDICT r5 missing #4): the same 1.2 M Gaussians with every scale
@@ -990,12 +994,13 @@ def main(argv=None):
         _n = L.s3g_profile_read(9, C.byref(_ms), None, None)
         infer_kernel_ms = (_ms.value / _n) if _n else None   # s3g::deform_infer_kernel (HexPlane (+) MLP heads), per frame
         clear_profile_slots()
-        # the same frames with the inference kernel's GEMM layers on the bf16 matrix pipe (exactly split operands: fp32 accuracy,
-        # include/s3g_mlp.h::s3g_deform_infer_split) -- reported beside the default, which stays the exact fp32 chain
+        # the same frames with the inference kernel in the OTHER arithmetic (default since round 6: the GEMM layers on the bf16 matrix
+        # pipe, exactly split operands, include/s3g_mlp.h::s3g_deform_infer_split; other: the exact fp32 chain) -- reported beside it
         _arith = _deformation.INFER_ARITHMETIC
-        _deformation.INFER_ARITHMETIC = "bf16x3"
+        infer_other = "f32" if _arith != "f32" else "bf16x3"
+        _deformation.INFER_ARITHMETIC = infer_other
         try:
-            render_split_ms, render_split_median_ms = render_loop()
+            render_other_ms, render_other_median_ms = render_loop()
         finally:
             _deformation.INFER_ARITHMETIC = _arith
 
@@ -1035,6 +1040,7 @@ def main(argv=None):
         from s3gaussian_amd import hexplane as _hx
         POINT_KERNEL = ("s3g::hexplane_backward_pointdiv_kernel" if _hx.BACKWARD_MODE == "slab" else "s3g::hexplane_backward_point_kernel")
         RB = lambda R_, N_: (56.0 if pair else 44.0) * R_mean + (36.0 if pair else 24.0) * N_
+        split_chains = mlp_default == "bf16x3"     # the two chain kernels run on the bf16 pipe (6 piece products per product)
         models = {
             # two-image pass (RGB+depth and feature image from one geometry): + colors2 per instance, + one image per pixel
             0: ("s3g::blend_forward_kernel", RB, None, None),
@@ -1051,11 +1057,11 @@ def main(argv=None):
                 lambda n, l: n * (3.0 * l * 20.0 + (3.0 if G_ROWS < 24 else 1.0) * G_ROWS * 128.0) + plane_bytes, None),
             # features in, three heads out; the 5 stashed activations are implementation
             # implementation: + 5 stashed activation planes (for the weight gradients) + 5 ReLU mask words per lane (40 B/point)
-            5: ("s3g::mlp_forward_kernel", lambda n, _: n * (512.0 + 216.0), lambda n, _: n * (512.0 + 5 * 256.0 + 40.0 + 216.0),
-                lambda n: n * MLP_FLOP),
+            5: ("s3g::mlp_forward_presplit_kernel" if split_chains else "s3g::mlp_forward_kernel",
+                lambda n, _: n * (512.0 + 216.0), lambda n, _: n * (512.0 + 5 * 256.0 + 40.0 + 216.0), lambda n: n * MLP_FLOP),
             # implementation: mask words in, 5 gradient-signal planes out (read back by the weight-gradient launches)
-            6: ("s3g::mlp_backward_kernel", lambda n, _: n * (216.0 + 512.0), lambda n, _: n * (40.0 + 216.0 + 5 * 256.0 + 512.0),
-                lambda n: n * MLP_FLOP),
+            6: ("s3g::mlp_backward_presplit_kernel" if split_chains else "s3g::mlp_backward_kernel",
+                lambda n, _: n * (216.0 + 512.0), lambda n, _: n * (40.0 + 216.0 + 5 * 256.0 + 512.0), lambda n: n * MLP_FLOP),
             # ONE launch for all nine GEMMs (mlp_wgrad_all_kernel): every stash / signal plane and the feature rows read once:
             # 5 x 256 (stash) + 5 x 256 (signals) + 512 (features) + 12 + 12 + 192 (head gradients) = 3288 B per point
             7: ("s3g::mlp_wgrad_all_kernel", lambda n, _: n * 512.0, lambda n, _: n * 3288.0, lambda n: n * MLP_FLOP),
@@ -1098,10 +1104,18 @@ def main(argv=None):
             bound, frac = "hbm", gbs / PEAK_HBM_GBS
             if fflops is not None:
                 tf = fflops(x) / t / 1e12
-                ent.update({"flops_per_launch": round(fflops(x)), "mfma_TFLOPs": round(tf, 2),
-                            "mfma_frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4)})
-                if tf / PEAK_MFMA_F32_TFLOPS > frac:   # the roof this kernel sits closer to
-                    bound, frac = "mfma", tf / PEAK_MFMA_F32_TFLOPS
+                if split_chains and i in (5, 6):
+                    # algorithmic fp32 FLOPs stay the unit of `mfma_TFLOPs`; the pipe executes six bf16 piece products for each
+                    mf = 6.0 * tf / PEAK_MFMA_BF16_TFLOPS
+                    ent.update({"mfma_pipe": "bf16 (6 piece products per fp32 product)", "mfma_pipe_TFLOPs": round(6.0 * tf, 1),
+                                "mfma_peak_TFLOPs": PEAK_MFMA_BF16_TFLOPS})
+                else:
+                    mf = tf / PEAK_MFMA_F32_TFLOPS
+                ent.update({"flops_per_launch": round(fflops(x)), "mfma_TFLOPs": round(tf, 2), "mfma_frac": round(mf, 4)})
+                # the chain kernels also stream their stash / signal planes: implementation bytes, priced for information
+                ent["implementation_hbm_frac"] = round((fimpl or fbytes)(x, y) / t / 1e9 / PEAK_HBM_GBS, 4)
+                if mf > frac:   # the roof this kernel sits closer to
+                    bound, frac = "mfma", mf
             base = name.split(" ")[0]
             # The third roof: VALU issue.  A wave64 VALU instruction holds its SIMD for 4 cycles; 256 CUs x 4 SIMDs at
             # VALU_CLOCK_GHZ = 614.4 G wave-instructions/s.  Priced for EVERY kernel that has a SQ_INSTS_VALU count (VERDICT r5 weak #2:
@@ -1128,8 +1142,9 @@ def main(argv=None):
         if kernels:
             dom = max(kernels, key=lambda e: e["ms_per_step"])   # the kernel the step spends most time in
             if dom["bound"] == "mfma":
-                roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["mfma_TFLOPs"], "peak": PEAK_MFMA_F32_TFLOPS,
-                        "unit": "TFLOP/s", "frac": dom["mfma_frac"], "traffic": dom.get("traffic")}
+                roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom.get("mfma_pipe_TFLOPs", dom["mfma_TFLOPs"]),
+                        "peak": dom.get("mfma_peak_TFLOPs", PEAK_MFMA_F32_TFLOPS), "unit": "TFLOP/s", "frac": dom["mfma_frac"],
+                        "traffic": dom.get("traffic")}
             elif dom["bound"] == "valu" and dom.get("valu_frac"):
                 peak_gi = 1024.0 * VALU_CLOCK_GHZ / 4.0        # G wave-instructions/s the chip can issue
                 ach = dom["valu_wave_instructions_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9
@@ -1196,8 +1211,12 @@ def main(argv=None):
                        "render_ms_per_frame": round(render_ms, 3), "render_ms_per_frame_median": round(render_median_ms, 3),
                        "render_deform_infer_kernel_ms": round(infer_kernel_ms, 4) if infer_kernel_ms else None,
                        "render_by_timestamp": render_by_timestamp,
-                       "render_ms_per_frame_bf16x3": round(render_split_ms, 3),
-                       "render_ms_per_frame_bf16x3_median": round(render_split_median_ms, 3),
+                       "render_arithmetic": _arith,
+                       f"render_ms_per_frame_{infer_other}": round(render_other_ms, 3),
+                       f"render_ms_per_frame_{infer_other}_median": round(render_other_median_ms, 3),
+                       "mlp_arithmetic": (mlp_default + (": per-point GEMM chains on the bf16 matrix pipe, every fp32 operand split exactly into three "
+                                          "bf16 pieces, fp32 accumulation -- fp32 results (DESIGN 4.3); weight-gradient GEMMs exact fp32 MFMA"
+                                          if mlp_default == "bf16x3" else ": exact fp32 fma chains (v_mfma_f32_32x32x2_f32)")),
                        "render_loop_outliers": render_outliers},
             "roofline": roof,
         }
@@ -1238,7 +1257,7 @@ def main(argv=None):
                 out["config"]["paths_note"] = ("oracle/_ref/reference_py.tar.gz absent: `patched` / `import_swap` / `zero_diff` are RESTATEMENTS of "
                                                "train.py's iteration body inside bench.py")
             if mlp_ab is not None:
-                out["config"]["paths"]["fused_mlp_bf16x3"] = mlp_ab
+                out["config"]["paths"]["fused_mlp_" + mlp_other] = mlp_ab
             if heavy is not None:
                 out["config"]["paths"]["heavy_raster"] = heavy
         psnr_file = os.path.join(ROOT, "profiles", "psnr_parity.json")

@@ -24,7 +24,8 @@ from .mlp import deform_infer, deform_mlp
 FUSED_INFERENCE = os.environ.get("S3G_FUSED_INFERENCE", "1") != "0"
 # Arithmetic of the fused inference kernel's GEMM layers: "f32" = exact fp32 fma chains (v_mfma_f32_32x32x2_f32, bit-identical to the
 # training kernels), "bf16x3" = the bf16 matrix pipe on exactly split operands (include/s3g_mlp.h::s3g_deform_infer_split)
-INFER_ARITHMETIC = os.environ.get("S3G_INFER_ARITHMETIC", "f32")
+# (round 6: the default follows the training kernels' default -- the split arithmetic; "f32" = the exact chain)
+INFER_ARITHMETIC = os.environ.get("S3G_INFER_ARITHMETIC", "bf16x3")
 # S3G_INFER_CACHE=0: every no_grad render evaluates the deformation field afresh (A/B, diagnostics).  Default: the heads' outputs of the
 # last no_grad evaluation are kept and handed to the next render of the SAME Gaussians at the SAME timestamp with the SAME parameters
 # -- the deformation depends on (xyz, t) only, not on the camera, and the evaluation loops of the reference visit the cameras of one

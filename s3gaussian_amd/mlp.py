@@ -44,19 +44,24 @@ def _bind():
         L.s3g_deform_mlp_set_arithmetic.argtypes = [C.c_int]
         L.s3g_deform_mlp_get_arithmetic.restype = C.c_int
         _bound = True
-        env = os.environ.get("S3G_MLP_ARITHMETIC")
-        if env:
-            set_mlp_arithmetic(env)
+        set_mlp_arithmetic(os.environ.get("S3G_MLP_ARITHMETIC") or DEFAULT_ARITHMETIC)
     return L
 
 
 _ARITHMETIC = {"f32": 0, "bf16x3": 1, "bf16x3_onthefly": 2}     # S3G_MLP_F32, S3G_MLP_BF16X3, S3G_MLP_BF16X3_ONTHEFLY (include/s3g_mlp.h)
+# Round 6: the per-point GEMM chains run on the bf16 matrix pipe with every fp32 operand split EXACTLY into three bf16 pieces and fp32
+# accumulation ("bf16x3", weight fragments split once per call) unless S3G_MLP_ARITHMETIC=f32 asks for the exact fp32 fma chains.  The
+# three conditions round 4's review set for this default were met in round 5: BASELINE-size parity on the exact chain's
+# bars in both arithmetics, PSNR at cfg2 size +0.03 / +0.007 dB against the reference's mean, the split kernels bit-reproducible over
+# 200 / 1000 launches with the staging-store guard asserted on the built ISA.  The results are fp32 results (distance from fp64 no larger
+# than the exact chain's); they are NOT bit-identical to the exact chain.  The C library's own default stays S3G_MLP_F32.
+DEFAULT_ARITHMETIC = "bf16x3"
 
 
 def set_mlp_arithmetic(mode: str) -> None:
     """Arithmetic of the per-point GEMM chains of deform_mlp's forward and backward kernels (process-wide; environment:
-    S3G_MLP_ARITHMETIC): "f32" = exact fp32 fma chains (default), "bf16x3" = the bf16 matrix pipe on operands split exactly into three
-    bf16 pieces (fp32 accuracy, not bit-identical).  The weight-gradient GEMMs are the exact chain in both modes."""
+    S3G_MLP_ARITHMETIC): "f32" = exact fp32 fma chains, "bf16x3" (DEFAULT_ARITHMETIC since round 6) = the bf16 matrix pipe on operands
+    split exactly into three bf16 pieces (fp32 accuracy, not bit-identical to the exact chain).  The weight-gradient GEMMs are the exact chain in both modes."""
     if mode not in _ARITHMETIC:
         raise ValueError(f"set_mlp_arithmetic: mode must be one of {sorted(_ARITHMETIC)}, got {mode!r}")
     _lib.check(_bind().s3g_deform_mlp_set_arithmetic(_ARITHMETIC[mode]))

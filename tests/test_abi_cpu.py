@@ -170,8 +170,12 @@ def test_mlp_arithmetic_switch_round_trips_without_a_gpu():
     from s3gaussian_amd import _lib, mlp
     L = _lib.lib()
     L.s3g_last_error.restype = __import__("ctypes").c_char_p
-    assert mlp.get_mlp_arithmetic() == "f32" and L.s3g_deform_mlp_get_arithmetic() == 0
+    # (the Python binding selects mlp.DEFAULT_ARITHMETIC -- "bf16x3" since round 6 -- when it first binds the library, whose own
+    #  default is the exact chain)
+    assert mlp.get_mlp_arithmetic() == mlp.DEFAULT_ARITHMETIC == "bf16x3" and L.s3g_deform_mlp_get_arithmetic() == 1
     try:
+        mlp.set_mlp_arithmetic("f32")
+        assert mlp.get_mlp_arithmetic() == "f32" and L.s3g_deform_mlp_get_arithmetic() == 0
         mlp.set_mlp_arithmetic("bf16x3")
         assert mlp.get_mlp_arithmetic() == "bf16x3" and L.s3g_deform_mlp_get_arithmetic() == 1
         assert L.s3g_deform_mlp_set_arithmetic(7) != 0 and b"arithmetic" in L.s3g_last_error()
@@ -179,7 +183,7 @@ def test_mlp_arithmetic_switch_round_trips_without_a_gpu():
         with pytest.raises(ValueError):
             mlp.set_mlp_arithmetic("bf16")
     finally:
-        mlp.set_mlp_arithmetic("f32")
+        mlp.set_mlp_arithmetic(mlp.DEFAULT_ARITHMETIC)
     with pytest.raises(ValueError):          # the inference kernel's switch is validated before anything touches a device
         mlp.deform_infer(None, None, None, None, None, None, None, arithmetic="fp16")
 

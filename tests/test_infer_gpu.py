@@ -8,6 +8,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def exact_chain(monkeypatch):
+    """The bit-identity claims below are claims about the EXACT fp32 chain (training kernels and inference kernel share one
+    arithmetic there); since round 6 both default to the split arithmetic (mlp.DEFAULT_ARITHMETIC, deformation.INFER_ARITHMETIC)."""
+    import s3gaussian_amd.deformation as dm
+    from s3gaussian_amd import mlp
+    mlp.set_mlp_arithmetic("f32")
+    monkeypatch.setattr(dm, "INFER_ARITHMETIC", "f32")
+    yield
+    mlp.set_mlp_arithmetic(mlp.DEFAULT_ARITHMETIC)
+
+
 def _net(dev, aabb, seed=0):
     from s3gaussian_amd.deformation import deform_network
     from s3gaussian_amd.pipeline import default_hyper
@@ -26,7 +38,7 @@ def _net(dev, aabb, seed=0):
 
 @pytest.mark.parametrize("tmode", ["uniform", "per_point"])
 @pytest.mark.parametrize("P", [1, 7, 31, 32, 33, 255, 257, 5000, 70_001, 1_200_000])
-def test_fused_inference_is_bit_identical_to_the_two_kernels(gpu_device, P, tmode):
+def test_fused_inference_is_bit_identical_to_the_two_kernels(gpu_device, P, tmode, exact_chain):
     from s3gaussian_amd import synth
     from s3gaussian_amd.mlp import deform_infer, deform_mlp
     dev = gpu_device
@@ -138,7 +150,7 @@ def test_split_inference_is_bit_reproducible_1000_launches(gpu_device, tmode, la
     assert float((first - exact).abs().max() / exact.abs().max()) < 5e-6
 
 
-def test_render_uses_the_fused_inference_path_and_is_unchanged(gpu_device, monkeypatch):
+def test_render_uses_the_fused_inference_path_and_is_unchanged(gpu_device, monkeypatch, exact_chain):
     from types import SimpleNamespace
     import s3gaussian_amd.deformation as dm
     from s3gaussian_amd import synth
@@ -173,7 +185,7 @@ def test_render_uses_the_fused_inference_path_and_is_unchanged(gpu_device, monke
     assert len(calls) == 1
 
 
-def test_render_with_split_arithmetic_is_the_same_picture(gpu_device, monkeypatch):
+def test_render_with_split_arithmetic_is_the_same_picture(gpu_device, monkeypatch, exact_chain):
     """pipeline.render() with deformation.INFER_ARITHMETIC = "bf16x3": the deformation differs from the exact kernel's by fp32
     rounding noise, so the picture may differ only where a splat sits on a discrete threshold (radius rounding, alpha < 1/255)."""
     from types import SimpleNamespace
@@ -252,8 +264,8 @@ def test_the_cameras_of_one_timestamp_share_one_evaluation_of_the_deformation_fi
     d0 = frames([3], return_decomposition=True)[0]
     d1 = frames([4], return_decomposition=True)[0]
     assert len(calls) == 2 and torch.equal(d0["render"], out[3]["render"]) and torch.equal(d1["render_d"], frames([4], return_decomposition=True)[0]["render_d"])
-    f0, f1 = frames([0, 1], render_feat=True)
-    assert len(calls) == 2 and torch.equal(f0["dx"], ref[0]["dx"]) and torch.equal(f1["render"], ref[1]["render"]) and f1["feat"] is not None
+    f0, f1 = frames([0, 1], render_feat=True)       # (two-kernel path: the training kernels' arithmetic, fp32-close to the fused kernel's)
+    assert len(calls) == 2 and torch.allclose(f0["dx"], ref[0]["dx"], rtol=1e-5, atol=1e-6) and f1["feat"] is not None and f1["dx"] is f0["dx"]
     # what must miss
     n = len(calls)
     frames([0])

@@ -48,7 +48,7 @@ def arithmetic(request):
     from s3gaussian_amd import mlp
     mlp.set_mlp_arithmetic(request.param)
     yield request.param
-    mlp.set_mlp_arithmetic("f32")
+    mlp.set_mlp_arithmetic(mlp.DEFAULT_ARITHMETIC)
 
 
 # "bf16x3": the bf16 matrix pipe on operands split exactly into three bf16 pieces -- held to the SAME tolerances as the exact chain
@@ -189,11 +189,12 @@ def test_split_arithmetic_at_baseline_size(gpu_device):
         return [o.detach() for o in outs] + [xg.grad, d.feature_out[0].weight.grad.clone(), d.shs_deform[1].weight.grad.clone()]
 
     try:
+        M.set_mlp_arithmetic("f32")
         exact = run()
         M.set_mlp_arithmetic("bf16x3")
         split = [run() for _ in range(3)]
     finally:
-        M.set_mlp_arithmetic("f32")
+        M.set_mlp_arithmetic(M.DEFAULT_ARITHMETIC)
     for r in split[1:]:
         for a, b in zip(r[:4], split[0][:4]):
             assert torch.equal(a, b)                       # deterministic (the weight gradients are atomic sums: not compared bitwise)
@@ -243,7 +244,7 @@ def test_presplit_bf16x3_kernels_are_bit_identical_to_the_on_the_fly_split(gpu_d
                 torch.cuda.synchronize()
                 out[(mode, with_feat)] = dict(dx=dx, dshs=dshs, feat=feat, stash=stash[pk:].clone(), gx=gx, ws=ws if with_feat else ws[2:].clone(), grads=grads)
     finally:
-        mlp.set_mlp_arithmetic("f32")
+        mlp.set_mlp_arithmetic(mlp.DEFAULT_ARITHMETIC)
     for with_feat in (True, False):
         a, b = out[("bf16x3_onthefly", with_feat)], out[("bf16x3", with_feat)]
         for k in ("dx", "dshs", "feat", "stash", "gx", "ws"):
@@ -289,5 +290,5 @@ def test_presplit_bf16x3_kernels_are_bit_reproducible_over_200_launches(gpu_devi
                 for a, b in zip(first, cur):
                     bad += (a != b).sum()
     finally:
-        mlp.set_mlp_arithmetic("f32")
+        mlp.set_mlp_arithmetic(mlp.DEFAULT_ARITHMETIC)
     assert int(bad.item()) == 0

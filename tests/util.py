@@ -96,8 +96,10 @@ def validate_bench_line(d, default_workload=True, n_gpus=1, round3_accounting=Fa
     assert c["path"] == "fused"
     if "paths" in c:
         assert {"fused", "patched", "import_swap", "zero_diff"} <= set(c["paths"]) <= {
-            "fused", "patched", "import_swap", "zero_diff", "fused_mlp_bf16x3", "heavy_raster"}
-        ips = {k: v["iters_per_s"] for k, v in c["paths"].items() if k not in ("fused_mlp_bf16x3", "heavy_raster")}
+            "fused", "patched", "import_swap", "zero_diff", "fused_mlp_bf16x3", "fused_mlp_f32", "heavy_raster"}
+        ips = {k: v["iters_per_s"] for k, v in c["paths"].items() if k not in ("fused_mlp_bf16x3", "fused_mlp_f32", "heavy_raster")}
+        if "fused_mlp_f32" in c["paths"]:        # round 6: bf16x3 is the default, the exact chain is the leg
+            assert c["paths"]["fused_mlp_f32"].get("ms_per_step") and c["mlp_arithmetic"].startswith("bf16x3"), c["paths"]["fused_mlp_f32"]
         if "heavy_raster" in c["paths"]:     # round 6: the same step with ~8 x the (tile, Gaussian) instances
             hr = c["paths"]["heavy_raster"]
             assert hr.get("ms_per_step") and hr["arena_overflows"] == 0 and hr["instances_R_per_view"] > c["instances_R_per_view"], hr
