@@ -238,13 +238,18 @@ def cpu_baseline(P_full, width, height, seed=0):
     # BASELINE.md section 4 plans "all host cores"; whether torch's intra-op pools pay beyond ~64 threads for these element-wise /
     # gather ops is a property of the box, so it is MEASURED here: the same P/40 iteration at every candidate
     # thread count, the full-size iteration at the fastest; all timings go into the line
+    # -- ASCENDING, and stopping at the first count that is slower than its predecessor: on the 256-core host of this pool the same
+    # iteration took 0.76 s with 32 threads, 1.41 s with 64, 3.9 s with 128 and 157 s (!) with all 256 (profiles/r06_bench_line_thread_probe.json:
+    # oversubscribed intra-op pools on tensors this small), so probing downwards from "all cores" costs minutes.
     probe_P, probe = max(2000, P_full // 40), {}
     try:
-        torch.set_num_threads(cores)
+        torch.set_num_threads(min(cores, 16))
         _time_iteration(probe_P, width, height, seed, True, repeats=1, warm=False, ref=ref)       # allocator, lazy inits
-        for n in sorted({cores, min(cores, 128), min(cores, 64), min(cores, 32)}, reverse=True):
+        for n in sorted({min(cores, 16), min(cores, 32), min(cores, 64), min(cores, 128), cores}):
             torch.set_num_threads(n)
             probe[n] = _time_iteration(probe_P, width, height, seed, True, repeats=1, warm=True, ref=ref)
+            if len(probe) > 1 and probe[n] > sorted(probe.items())[-2][1]:
+                break
         threads = min(probe, key=probe.get)
         torch.set_num_threads(threads)
         t_full = _time_iteration(P_full, width, height, seed, True, repeats=1, warm=False, ref=ref)
@@ -259,7 +264,8 @@ def cpu_baseline(P_full, width, height, seed=0):
            "sample": f"measured, not extrapolated: ONE full iteration of the workload itself ({P_full} Gaussians, {width}x{height}) in "
                      f"{t_full:.2f} s -- {front}, rasterizer stubbed to a nearest-pixel "
                      f"point splat (torch threads {threads} of {cores} cores: the fastest of {sorted(probe)} on a {probe_P}-Gaussian "
-                     f"iteration, s/iter {[round(probe[k], 2) for k in sorted(probe)]})",
+                     f"iteration, s/iter {[round(probe[k], 2) for k in sorted(probe)]}; the probe goes up in thread count and stops at the "
+                     f"first count that is slower than the one before it)",
            "thread_probe_s_per_iter": {str(k): round(v, 3) for k, v in sorted(probe.items())}}
     try:
         sizes = (max(2000, P_full // 120), max(6000, P_full // 40), max(20000, P_full // 4))

@@ -53,6 +53,16 @@ int s3g_deform_mlp_backward(const s3g_mlp_params* w, int P, const float* feature
                             const float* g_dshs, const float* g_feat, float* g_features, const s3g_mlp_params* gw,
                             float* workspace, void* stream);
 
+/* The same with an ORDERED flush of the weight gradients (ABI 13).  s3g_deform_mlp_backward lets the up to 256 workgroups of the
+ * weight-gradient kernel add their partial [out][in] blocks onto `gw` with float atomics: the order of the additions, and with it
+ * the last bits of every weight gradient, differs from run to run.  Here each workgroup stores its partial blocks into
+ * `wgrad_partials` (device scratch of s3g_deform_mlp_wgrad_partial_bytes() bytes, uninitialised) and a second kernel adds them in
+ * workgroup order: the weight gradients are bit-reproducible (tests/test_mlp_gpu.py), for 38 MB of scratch traffic and one launch. */
+size_t s3g_deform_mlp_wgrad_partial_bytes(void);
+int s3g_deform_mlp_backward_ordered(const s3g_mlp_params* w, int P, const float* features, const float* stash, const float* g_dx,
+                                    const float* g_dshs, const float* g_feat, float* g_features, const s3g_mlp_params* gw,
+                                    float* workspace, float* wgrad_partials, void* stream);
+
 /* Arithmetic of the per-point GEMM chains of the two calls above (process-wide setting, default S3G_MLP_F32):
  *   S3G_MLP_F32     v_mfma_f32_32x32x2_f32, exact fp32 fma chains.
  *   S3G_MLP_BF16X3  v_mfma_f32_32x32x16_bf16 (the bf16 matrix pipe, 16 x the rate) with every fp32 operand -- weights, activations,

@@ -657,17 +657,26 @@ struct PackedTap {  // what the scatter needs of a Tap: 8 floats in LDS
 // An out-of-range corner has weight exactly 0 and takes the nw texel's value, like the per-point pass; a sample that is not safely
 // divisible contributes nothing here (the per-point pass scattered it exactly: same predicate, same bits).
 constexpr bool FOOT_SHIFT = true;
+// Round 6: the corners live in PAIRS (nw, ne) / (sw, se) so that the hit path -- which three calls in four take, and on which the
+// kernel is VALU-issue-bound (SQ_INSTS_VALU: 0.83 of its time in round 5) -- runs on packed fp32 instructions: the four products of
+// the sample as two v_pk_mul_f32, the four accumulations as two v_pk_fma_f32.  Same values bit for bit: the products are rounded
+// one by one and added in the order ((p00 + p01) + p10) + p11 exactly as before (the forward's order), an fma per corner as before.
 struct Foot1 {
-  int key;          // (texel index << 2 | corner flags), -1 = empty
-  float a[4], v[4]; // partial sums and texel values of the footprint's corners (nw, ne, sw, se)
+  int key;            // (texel index << 2 | corner flags), -1 = empty
+  f2v_ a01, a23;      // partial sums of the footprint's corners (nw, ne) (sw, se)
+  f2v_ v01, v23;      // texel values of the corners
 };
 __device__ __forceinline__ void foot1_init(Foot1& F) {
   F.key = -1;
-#pragma unroll
-  for (int k = 0; k < 4; k++) F.a[k] = 0.f;
+  F.a01 = f2v_{0.f, 0.f};
+  F.a23 = f2v_{0.f, 0.f};
 }
+struct PackedTap2 {   // one tap as the walker reads it back from LDS: 8 floats (32 bytes)
+  int key, flags;
+  f2v_ w01, w23;      // bilinear weights of (nw, ne) (sw, se)
+};
 template <bool ROW = false>
-__device__ __forceinline__ void foot1_add_t(Foot1& F, const PackedTap& t, float tv, float* __restrict__ gp,
+__device__ __forceinline__ void foot1_add_t(Foot1& F, const PackedTap2& t, float tv, float* __restrict__ gp,
                                             const float* __restrict__ pl /* plane values + channel */, int W, int c) {
   const int tkf = (t.key << 2) | (t.flags & 3);
   if (tkf != F.key) {  // miss (uniform inside the walker's lanes)
@@ -682,7 +691,7 @@ __device__ __forceinline__ void foot1_add_t(Foot1& F, const PackedTap& t, float 
     const bool down = FOOT_SHIFT && !ROW && KF >= 0 && t.key == K + W;
     const bool right = FOOT_SHIFT && KF >= 0 && t.key == K + 1 && (FL & 1);
     const bool shift = down || right;
-    const float A0 = F.a[0], A1 = F.a[1], A2 = ROW ? 0.f : F.a[2], A3 = ROW ? 0.f : F.a[3];
+    const float A0 = F.a01.x, A1 = F.a01.y, A2 = ROW ? 0.f : F.a23.x, A3 = ROW ? 0.f : F.a23.y;
     if (KF >= 0) {
       const uint32_t k = ((uint32_t)K * HEXC + (uint32_t)c) * 4u;
       const uint32_t dy = (uint32_t)W * (HEXC * 4u);
@@ -693,58 +702,59 @@ __device__ __forceinline__ void foot1_add_t(Foot1& F, const PackedTap& t, float 
       if (!ROW && (FL & 3) == 3 && !shift) vatomic(base, k + dy + HEXC * 4u, A3);
     }
     // new contents: shift down (nw, ne, sw, se) <- (sw, se, 0, 0); shift right <- (ne, 0, se, 0); evict <- 0
-    F.a[0] = down ? A2 : (right ? A1 : 0.f);
-    F.a[1] = down ? A3 : 0.f;
-    F.v[0] = n0; F.v[1] = n1;
+    F.a01 = f2v_{down ? A2 : (right ? A1 : 0.f), down ? A3 : 0.f};
+    F.v01 = f2v_{n0, n1};
     if (!ROW) {
-      F.a[2] = right ? A3 : 0.f;
-      F.a[3] = 0.f;
-      F.v[2] = n2; F.v[3] = n3;
+      F.a23 = f2v_{right ? A3 : 0.f, 0.f};
+      F.v23 = f2v_{n2, n3};
     }
     F.key = tkf;
   }
-  float sv = F.v[0] * t.w00;
-  sv = sv + F.v[1] * t.w01;
+  const f2v_ p01 = F.v01 * t.w01;
+  float sv = p01.x + p01.y;
   if (!ROW) {
-    sv = sv + F.v[2] * t.w10;
-    sv = sv + F.v[3] * t.w11;
+    const f2v_ p23 = F.v23 * t.w23;
+    sv = sv + p23.x;
+    sv = sv + p23.y;
   }
   const float g = tslab_divisible(sv) ? tv * __builtin_amdgcn_rcpf(sv) : 0.f;
-  F.a[0] = __builtin_fmaf(g, t.w00, F.a[0]); F.a[1] = __builtin_fmaf(g, t.w01, F.a[1]);
-  if (!ROW) {
-    F.a[2] = __builtin_fmaf(g, t.w10, F.a[2]); F.a[3] = __builtin_fmaf(g, t.w11, F.a[3]);
-  }
+  const f2v_ gg = f2v_{g, g};
+  F.a01 = __builtin_elementwise_fma(gg, t.w01, F.a01);
+  if (!ROW) F.a23 = __builtin_elementwise_fma(gg, t.w23, F.a23);
 }
 template <bool ROW = false>
 __device__ __forceinline__ void foot1_flush_all(const Foot1& F, float* __restrict__ gp, int W, int c) {
   if (F.key < 0) return;
-  foot_flush(Foot{F.key >> 2, ROW ? (F.key & 1) : (F.key & 3), F.a[0], F.a[1], ROW ? 0.f : F.a[2], ROW ? 0.f : F.a[3]}, gp, W, c);
+  foot_flush(Foot{F.key >> 2, ROW ? (F.key & 1) : (F.key & 3), F.a01.x, F.a01.y, ROW ? 0.f : F.a23.x, ROW ? 0.f : F.a23.y}, gp, W, c);
 }
 
 // A WALKER = 32 lanes (one per channel: a half-wave) walks seg_len consecutive points of ONE (orientation, level) order:
-// blockIdx.y = orientation * levels + level.  The kernel used to be VALU-bound on make_tap, which every lane repeated for each
-// tap of a point; the walker's lanes compute the taps of FOUR points at once (lane = point q x tap j), park them in LDS, and
-// every lane reads them back with broadcast loads while it accumulates its channel.  (Removed in round 5, measured slower in
-// rounds 2-4: two levels per walk, two channels per lane with v_pk_fma -- twice the flush atomics, 2.07 vs 1.14 ms --, the
-// two-entry footprint cache, 512- and 1024-point segments: DESIGN.md section 10.)
+// blockIdx.y = orientation * levels + level.  The taps are computed by the walker's lanes for a whole GROUP of points at once
+// (lane = point q x tap j), parked in LDS, and every lane reads them back with broadcast loads while it accumulates its channel.
+// Round 6: groups of SIXTEEN points (rounds 1-5: four).  make_tap + the coordinate / index loads are ~60 wave-instructions whoever
+// needs them; with 8 of a walker's 32 lanes busy they cost 15 per point, a quarter of everything the kernel issued -- with all 32
+// lanes busy they cost 4.  The T rows are still requested four points at a time, one batch ahead of their use (their addresses
+// come out of the same LDS records: the point's position in the processing order rides in the tap's spare slot).
+// (Removed in round 5, measured slower in rounds 2-4: two levels per walk, two channels per lane with v_pk_fma -- twice the flush
+// atomics, 2.07 vs 1.14 ms --, the two-entry footprint cache, 512- and 1024-point segments: DESIGN.md section 10.)
 #ifndef S3G_HEX_SCATTER_WAVES
 #define S3G_HEX_SCATTER_WAVES 6
 #endif
 constexpr int SCATTER_WG_PER_CU = S3G_HEX_SCATTER_WAVES;   // waves per SIMD the register budget is set for
-constexpr int TAPF = 8;  // floats per packed tap in LDS (6 used; 32-byte slots keep the 16-byte reads aligned)
+constexpr int TAPF = 8;   // floats per packed tap in LDS: key, flags, w00, w01 | w10, w11, position of the point's T rows, -
+constexpr int GRP = 16;   // points per tap group
 __device__ __forceinline__ float load_g(const float* p) { return G_NONTEMPORAL_LOAD ? __builtin_nontemporal_load(p) : *p; }
 template <bool UT>   // UT: uniform time -- the (axis, t) planes are height-1 row tables
 __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_CU - 1) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
                                                                const uint32_t* __restrict__ order_all, const uint32_t* __restrict__ comp_all) {
   constexpr int LANES = HEXC, WALKERS = 256 / LANES;
   constexpr int NTAP = 2;             // taps per point and walk: the orientation's spatial plane and its (major, t) plane
-  static_assert(LANES >= 4 * NTAP, "tap phase: one lane per (point of the group of four, tap)");
-  __shared__ __attribute__((aligned(16))) float tapbuf[WALKERS][2][4][NTAP][TAPF];  // [walker][double buffer][point][tap]
+  static_assert(LANES == GRP * NTAP, "tap phase: one lane per (point of the group, tap)");
+  __shared__ __attribute__((aligned(16))) float tapbuf[WALKERS][2][GRP][NTAP][TAPF];  // [walker][double buffer][point][tap]: 16 KiB
   const int oi = blockIdx.y;
   const int o = oi / a.d.levels, lv = oi % a.d.levels;
   const int c = threadIdx.x & (LANES - 1), hw = threadIdx.x / LANES;   // channel of this lane, walker of this half-wave
-  const int q = (c / NTAP) & 3, j = c % NTAP;  // tap-phase role: point q of the group of four, tap j (0 spatial, 1 time plane)
-  const bool tap_lane = c < 4 * NTAP;
+  const int q = c / NTAP, j = c % NTAP;  // tap-phase role: point q of the group, tap j (0 spatial, 1 time plane)
   const int seg = blockIdx.x * WALKERS + hw;
   const int k0 = seg * a.seg_len, k1 = min(a.P, k0 + a.seg_len);
   if (k0 >= a.P) return;  // whole walkers drop out; the LDS traffic below is private to a walker (wave-ordered)
@@ -758,73 +768,82 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   foot1_init(f1[0]);
   foot1_init(f1[1]);
   const int Wt = a.d.res[lv][axw], Ht = a.d.res[lv][axh];
-  // Three-stage software pipeline per lane role (point q of a group, tap j): the sorted index of group g+2, the
+  const float* Grow = G + (size_t)(lv * HEXC + c);    // this lane's column of every T row
+  // Software pipeline per lane role (point q of a group, tap j): the sorted index (and T-row position) of group g+2, the
   // coordinates of group g+1 and the taps of group g+1 are produced while group g is accumulated, so neither the
   // index -> position load chain nor the tap arithmetic sits between a group's T loads and their use.
-  auto load_index = [&](int kb) { return (int)order[min(kb + q, k1 - 1)]; };
-  auto load_coords = [&](int p, float* u) { point_coords(a, p, u); };
-  auto store_taps = [&](const float* u, int buf) {
+  auto slot_of = [&](int kb) { return min(kb + q, k1 - 1); };
+  auto store_taps = [&](const float* u, uint32_t cpos, int buf) {
     const Tap t = make_tap(u[axw], u[axh], Wt, Ht);
-    float4 lo;
-    lo.x = __int_as_float(t.o00);
-    lo.y = __int_as_float((t.o01 >= 0 ? 1 : 0) | (t.o10 >= 0 ? 2 : 0));
-    lo.z = t.w00;
-    lo.w = t.w01;
-    if (tap_lane) {
-      float* dst = &tapbuf[hw][buf][q][j][0];
-      *reinterpret_cast<float4*>(dst) = lo;
-      *reinterpret_cast<float2*>(dst + 4) = make_float2(t.w10, t.w11);
-    }
+    float* dst = &tapbuf[hw][buf][q][j][0];
+    *reinterpret_cast<float4*>(dst) = make_float4(__int_as_float(t.o00), __int_as_float((t.o01 >= 0 ? 1 : 0) | (t.o10 >= 0 ? 2 : 0)), t.w00, t.w01);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(t.w10, t.w11, __uint_as_float(cpos), 0.f);
   };
+  auto row_pos = [&](int buf, int qq) { return __float_as_uint(tapbuf[hw][buf][qq][0][6]); };
   float un[4];                       // coordinates of the NEXT group's point
+  uint32_t cn;                       // ... and the position of its T rows
   {
     float u0[4];
-    load_coords(load_index(k0), u0);
-    store_taps(u0, 0);
+    const int s0 = slot_of(k0);
+    point_coords(a, (int)order[s0], u0);
+    store_taps(u0, comp[s0], 0);
   }
-  load_coords(load_index(k0 + 4), un);
-  int pnn = load_index(k0 + 8);      // index of the group after next
-  // processing positions of this group's four points, fetched a group ahead (the T rows' addresses depend on them)
-  uint32_t cpos[4], cpos_n[4];
+  {
+    const int s1 = slot_of(k0 + GRP);
+    point_coords(a, (int)order[s1], un);
+    cn = comp[s1];
+  }
+  int snn = slot_of(k0 + 2 * GRP);
+  int pnn = (int)order[snn];         // index of the group after next
+  uint32_t cnn = comp[snn];
+  wave_lds_sync();
+  // the first batch of T rows (four points; ONE row per point and level: T = dL/dfeature * feature -- both planes of the walk
+  // divide it by their sample)
+  float g[4], gn[4];
 #pragma unroll
-  for (int qq = 0; qq < 4; qq++) cpos[qq] = comp[min(k0 + qq, k1 - 1)];
+  for (int qq = 0; qq < 4; qq++) g[qq] = load_g(Grow + (size_t)row_pos(0, qq) * GP);
   int buf = 0;
-  for (int kb = k0; kb < k1; kb += 4, buf ^= 1) {
+  for (int kb = k0; kb < k1; kb += GRP, buf ^= 1) {
+    // 1. the NEXT group's taps from coordinates loaded one iteration ago; then advance the two prefetch stages
+    store_taps(un, cn, buf ^ 1);
+    point_coords(a, pnn, un);
+    cn = cnn;
+    snn = slot_of(kb + 3 * GRP);
+    pnn = (int)order[snn];
+    cnn = comp[snn];
+    wave_lds_sync();
+    // 2. accumulate this group, four points at a time; each batch first requests the T rows of the batch after it
+#pragma unroll 1     // (rolled on purpose: every copy of the body carries eight inlined miss paths)
+    for (int sb = 0; sb < GRP / 4; sb++) {
 #pragma unroll
-    for (int qq = 0; qq < 4; qq++) cpos_n[qq] = comp[min(kb + 4 + qq, k1 - 1)];
-    // 1. this group's T rows (ONE row per point and level: T = dL/dfeature * feature; both planes of the walk divide it by their sample)
-    float g[4];
+      for (int qq = 0; qq < 4; qq++)
+        gn[qq] = load_g(Grow + (size_t)row_pos(sb == GRP / 4 - 1 ? buf ^ 1 : buf, (4 * (sb + 1) + qq) % GRP) * GP);
+      const int nq = k1 - kb - 4 * sb;       // points left from this batch on (<= 0: nothing)
 #pragma unroll
-    for (int qq = 0; qq < 4; qq++) g[qq] = load_g(G + (size_t)cpos[qq] * GP + (size_t)(lv * HEXC + c));
+      for (int qq = 0; qq < 4; qq++) {
+        if (qq >= nq) break;
 #pragma unroll
-    for (int qq = 0; qq < 4; qq++) cpos[qq] = cpos_n[qq];
-    // 2. the NEXT group's taps from coordinates loaded one iteration ago; then advance the two prefetch stages
-    store_taps(un, buf ^ 1);
-    load_coords(pnn, un);
-    pnn = load_index(kb + 12);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // 3. accumulate
-    const int nq = min(4, k1 - kb);
-#pragma unroll
-    for (int qq = 0; qq < 4; qq++) {
-      if (qq >= nq) break;
-#pragma unroll
-      for (int m = 0; m < 2; m++) {
-        float* gp = a.gplanes[lv][m ? i1 : i0];
-        if (gp == nullptr) continue;
-        const float* src = &tapbuf[hw][buf][qq][m][0];
-        const float4 lo = *reinterpret_cast<const float4*>(src);
-        const float2 hi = *reinterpret_cast<const float2*>(src + 4);
-        PackedTap t;
-        t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
-        t.w00 = lo.z; t.w01 = lo.w; t.w10 = hi.x; t.w11 = hi.y;
-        const float* pl = a.d.planes[lv][m ? i1 : i0] + c;
-        const int Wm = a.d.res[lv][PAIR0[m ? i1 : i0]];
-        if (UT && m == 1) foot1_add_t<true>(f1[m], t, g[qq], gp, pl, Wm, c);
-        else foot1_add_t<false>(f1[m], t, g[qq], gp, pl, Wm, c);
+        for (int m = 0; m < 2; m++) {
+          float* gp = a.gplanes[lv][m ? i1 : i0];
+          if (gp == nullptr) continue;
+          const float* src = &tapbuf[hw][buf][4 * sb + qq][m][0];
+          const float4 lo = *reinterpret_cast<const float4*>(src);
+          PackedTap2 t;
+          t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
+          t.w01 = f2v_{lo.z, lo.w};
+          const float* pl = a.d.planes[lv][m ? i1 : i0] + c;
+          const int Wm = a.d.res[lv][PAIR0[m ? i1 : i0]];
+          if (UT && m == 1) {
+            foot1_add_t<true>(f1[m], t, g[qq], gp, pl, Wm, c);
+          } else {
+            const float2 hi = *reinterpret_cast<const float2*>(src + 4);
+            t.w23 = f2v_{hi.x, hi.y};
+            foot1_add_t<false>(f1[m], t, g[qq], gp, pl, Wm, c);
+          }
+        }
       }
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) g[qq] = gn[qq];
     }
   }
 #pragma unroll

@@ -33,6 +33,9 @@ def _bind():
         L.s3g_deform_mlp_pack_bytes.restype = C.c_size_t
         L.s3g_deform_mlp_backward.restype = C.c_int
         L.s3g_deform_mlp_backward.argtypes = [C.POINTER(_Params), C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(_Params), vp, vp]
+        L.s3g_deform_mlp_backward_ordered.restype = C.c_int
+        L.s3g_deform_mlp_backward_ordered.argtypes = [C.POINTER(_Params), C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(_Params), vp, vp, vp]
+        L.s3g_deform_mlp_wgrad_partial_bytes.restype = C.c_size_t
         from .hexplane import _HexDesc
         L.s3g_deform_infer_workspace_bytes.restype = C.c_size_t
         L.s3g_deform_infer_workspace_bytes.argtypes = [C.POINTER(_HexDesc)]
@@ -56,6 +59,9 @@ _ARITHMETIC = {"f32": 0, "bf16x3": 1, "bf16x3_onthefly": 2}     # S3G_MLP_F32, S
 # 200 / 1000 launches with the staging-store guard asserted on the built ISA.  The results are fp32 results (distance from fp64 no larger
 # than the exact chain's); they are NOT bit-identical to the exact chain.  The C library's own default stays S3G_MLP_F32.
 DEFAULT_ARITHMETIC = "bf16x3"
+# S3G_MLP_ORDERED_WGRAD=0: the weight-gradient kernel's workgroups add their partial blocks with float atomics (rounds 1-5: the sum's
+# order, hence its last bits, differed between runs); default: partial blocks summed in workgroup order by a second kernel
+ORDERED_WGRAD_FLUSH = os.environ.get("S3G_MLP_ORDERED_WGRAD", "1") != "0"
 
 
 def set_mlp_arithmetic(mode: str) -> None:
@@ -127,9 +133,15 @@ class _DeformMLP(torch.autograd.Function):
         ws = torch.empty((5, P, 64), dtype=torch.float32, device=dev)
         w, gw = _pack([p.detach() for p in params]), _pack(grads)
         with torch.cuda.device(dev):
-            _lib.check(L.s3g_deform_mlp_backward(C.byref(w), P, x.data_ptr(), stash.data_ptr(), g_dx.data_ptr(),
-                                                 g_dshs.data_ptr(), None if no_feat else g_feat.data_ptr(), gx.data_ptr(),
-                                                 C.byref(gw), ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            if ORDERED_WGRAD_FLUSH:     # bit-reproducible weight gradients (include/s3g_mlp.h::s3g_deform_mlp_backward_ordered)
+                part = torch.empty(L.s3g_deform_mlp_wgrad_partial_bytes() // 4, dtype=torch.float32, device=dev)
+                _lib.check(L.s3g_deform_mlp_backward_ordered(C.byref(w), P, x.data_ptr(), stash.data_ptr(), g_dx.data_ptr(),
+                                                             g_dshs.data_ptr(), None if no_feat else g_feat.data_ptr(), gx.data_ptr(),
+                                                             C.byref(gw), ws.data_ptr(), part.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            else:
+                _lib.check(L.s3g_deform_mlp_backward(C.byref(w), P, x.data_ptr(), stash.data_ptr(), g_dx.data_ptr(),
+                                                     g_dshs.data_ptr(), None if no_feat else g_feat.data_ptr(), gx.data_ptr(),
+                                                     C.byref(gw), ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
         if no_feat:
             grads = [None if n.startswith(("D", "db")) else g for n, g in zip(_NAMES, grads)]
         return (gx, None, None, *grads)

@@ -23,7 +23,9 @@ def test_bench_py_prints_one_line_that_follows_the_contract(gpu_device):
     d = json.loads(lines[0])
     validate_bench_line(d, default_workload=False)
     assert d["steps"] == 4 and d["warmup"] == 2 and d["config"]["gaussians"] == 60000 and d["config"]["image"] == [320, 480]
-    assert d["roofline"]["traffic"] is None          # PMC traffic exists for the default workload only
+    # counters: collected by this very run when rocprofv3 is on the box (round 6), else absent for a non-default workload (the
+    # committed profiles/kernel_traffic.json describes the default workload only)
+    assert d["roofline"]["traffic"] is None or d["roofline"]["traffic_source"].startswith("collected IN THIS RUN")
 
 
 def test_plain_gpus_2_command_line_starts_two_ranks(gpu_device):

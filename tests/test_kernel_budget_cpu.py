@@ -45,7 +45,7 @@ def test_hexplane_kernels_keep_their_occupancy(built):
     vgpr, scratch = _one(res, "hexplane_backward_pointdiv_kernelILb1E")        # uniform time: four waves per SIMD, no spills
     assert vgpr <= 128 and scratch == 0, (vgpr, scratch)
     vgpr, scratch = _one(res, "hexplane_scatter_kernelILb1E")                 # single-entry footprint, one level per walk: eight waves
-    assert vgpr <= 64 and scratch == 0, (vgpr, scratch)
+    assert vgpr <= 72 and scratch == 0, (vgpr, scratch)          # round 6 (16-point tap groups, packed corner pairs): seven waves
     vgpr, scratch = _one(res, "hexplane_forward_kernelILb1E")
     assert vgpr <= 102 and scratch == 0, (vgpr, scratch)                       # five waves per SIMD
 

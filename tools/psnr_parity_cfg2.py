@@ -17,6 +17,8 @@ the wall time per iteration of both stacks (the first number in this repository 
 
     python tools/psnr_parity_cfg2.py                      # cfg2: 600 k Gaussians, 1066x1600, 1000 iterations  -> profiles/psnr_parity_cfg2.json
     python tools/psnr_parity_cfg2.py --P 60000 --width 480 --height 320 --iters 150      # what the -m gpu suite runs
+    python tools/psnr_parity_cfg2.py --P 1200000 --opacity-reset-at 600 --reference-twice --product-runs 3 --out gpurun_out/psnr_parity_cfg3.json
+                                                          # round 6: the headline configuration (cfg3), across an opacity reset
 """
 import argparse
 import json
@@ -38,7 +40,7 @@ def _psnr(a, b):
 
 
 def run(P=600_000, W=1600, H=1066, iters=1000, n_frames=6, seed=0, densify_at=None, prune_at=None, grad_threshold=0.0002,
-        opacity_threshold=0.005, verbose=True, reference_twice=False, eval_at=(), product_runs=1, reference=True):
+        opacity_threshold=0.005, verbose=True, reference_twice=False, eval_at=(), product_runs=1, reference=True, opacity_reset_at=None):
     """reference_twice: train the reference stack a second time from the same state and seeds -- its backward sums with float atomics
     (backward.cu:550-587), so two runs of the REFERENCE ITSELF are a chaotic pair too; their distance is the yardstick the
     product-vs-reference distance has to be read against.  eval_at: iterations at which every view is also rendered and scored
@@ -94,7 +96,9 @@ def run(P=600_000, W=1600, H=1066, iters=1000, n_frames=6, seed=0, densify_at=No
             # one densify and one prune event inside the run, by the reference's own schedule arithmetic (train.py:500-509)
             opt.densify_from_iter, opt.densification_interval = densify_at - 1, densify_at
             opt.pruning_from_iter, opt.pruning_interval = prune_at - 1, prune_at
-            opt.opacity_reset_interval = 10 ** 9
+            # opacity_reset_at = N: reset_opacity at iteration N (train.py:514-516; only multiples of N below the last iteration), and
+            # every densify / prune after N runs with size_threshold = 20 (train.py:502-508) -- VERDICT r5: "never across an opacity reset"
+            opt.opacity_reset_interval = opacity_reset_at if opacity_reset_at else 10 ** 9
             opt.densify_grad_threshold_fine_init = opt.densify_grad_threshold_after = grad_threshold
             opt.opacity_threshold_fine_init = opt.opacity_threshold_fine_after = opacity_threshold
             torch.manual_seed(seed)
@@ -157,7 +161,8 @@ def run(P=600_000, W=1600, H=1066, iters=1000, n_frames=6, seed=0, densify_at=No
     rec = dict(
         what=f"{iters} fine-stage iterations of the reference's own train.py::scene_reconstruction, {P} Gaussians, {H}x{W}, "
              f"{len(train_ids)} train + {len(test_ids)} held-out views, one densify event (iteration {densify_at}) and one prune event "
-             f"(iteration {prune_at}) by the reference's own rules, shared seeds: product (drop-in packages + patch_reference) vs the "
+             f"(iteration {prune_at})" + (f", reset_opacity at every multiple of {opacity_reset_at} (screen-size pruning on from there)" if opacity_reset_at else "") +
+             f" by the reference's own rules, shared seeds: product (drop-in packages + patch_reference) vs the "
              "whole reference on this GPU (its Python + its own kernels built for gfx950 + torch.optim.Adam)",
         mean_psnr_delta_db=mean_delta, max_abs_delta_db=float(max(abs(r["delta_db"]) for r in views)), views=views,
         mean_psnr_db={sp: {"product": float(np.mean([r["psnr_product"] for r in views if r["split"] == sp])),
@@ -206,9 +211,10 @@ def main():
     ap.add_argument("--eval-at", type=int, nargs="*", default=[], help="iterations at which every view is scored inside the run")
     ap.add_argument("--product-runs", type=int, default=1, help="train the product this many times (its own run-to-run spread)")
     ap.add_argument("--no-reference", action="store_true", help="product runs only (the reference stack costs 200 ms per iteration)")
+    ap.add_argument("--opacity-reset-at", type=int, default=None, help="opt.opacity_reset_interval (default: never inside the run)")
     a = ap.parse_args()
     rec = run(a.P, a.width, a.height, a.iters, a.frames, reference_twice=a.reference_twice, eval_at=tuple(a.eval_at),
-              product_runs=a.product_runs, reference=not a.no_reference)
+              product_runs=a.product_runs, reference=not a.no_reference, opacity_reset_at=a.opacity_reset_at)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(rec, open(a.out, "w"), indent=1)
     print(json.dumps({k: rec[k] for k in ("mean_psnr_delta_db", "max_abs_delta_db", "mean_psnr_db", "points", "ms_per_iteration",
