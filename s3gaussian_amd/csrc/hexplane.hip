@@ -672,24 +672,25 @@ __device__ __forceinline__ void foot1_init(Foot1& F) {
   F.a23 = f2v_{0.f, 0.f};
 }
 struct PackedTap2 {   // one tap as the walker reads it back from LDS: 8 floats (32 bytes)
-  int key, flags;
+  int kf;             // texel index of the nw corner << 2 | flags (bit 0: ne / se column in range, bit 1: sw / se row in range)
   f2v_ w01, w23;      // bilinear weights of (nw, ne) (sw, se)
 };
 template <bool ROW = false>
 __device__ __forceinline__ void foot1_add_t(Foot1& F, const PackedTap2& t, float tv, float* __restrict__ gp,
                                             const float* __restrict__ pl /* plane values + channel */, int W, int c) {
-  const int tkf = (t.key << 2) | (t.flags & 3);
+  const int tkf = t.kf;
   if (tkf != F.key) {  // miss (uniform inside the walker's lanes)
-    const float* px = pl + (size_t)t.key * HEXC;
-    const float n0 = px[0], n1 = px[(t.flags & 1) ? HEXC : 0];
+    const int tkey = tkf >> 2, tfl = tkf & 3;
+    const float* px = pl + (size_t)tkey * HEXC;
+    const float n0 = px[0], n1 = px[(tfl & 1) ? HEXC : 0];
     float n2 = 0.f, n3 = 0.f;
     if (!ROW) {
-      n2 = px[(t.flags & 2) ? (size_t)W * HEXC : 0];
-      n3 = px[((t.flags & 3) == 3) ? (size_t)W * HEXC + HEXC : 0];
+      n2 = px[(tfl & 2) ? (size_t)W * HEXC : 0];
+      n3 = px[(tfl == 3) ? (size_t)W * HEXC + HEXC : 0];
     }
     const int KF = F.key, K = KF >> 2, FL = KF & 3;
-    const bool down = FOOT_SHIFT && !ROW && KF >= 0 && t.key == K + W;
-    const bool right = FOOT_SHIFT && KF >= 0 && t.key == K + 1 && (FL & 1);
+    const bool down = FOOT_SHIFT && !ROW && KF >= 0 && tkey == K + W;
+    const bool right = FOOT_SHIFT && KF >= 0 && tkey == K + 1 && (FL & 1);
     const bool shift = down || right;
     const float A0 = F.a01.x, A1 = F.a01.y, A2 = ROW ? 0.f : F.a23.x, A3 = ROW ? 0.f : F.a23.y;
     if (KF >= 0) {
@@ -768,6 +769,13 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   foot1_init(f1[0]);
   foot1_init(f1[1]);
   const int Wt = a.d.res[lv][axw], Ht = a.d.res[lv][axh];
+  // uniform per workgroup; read ONCE (indexed kernel-argument reads inside the loop were an s_load + s_waitcnt lgkmcnt(0) per tap,
+  // i.e. every tap also waited for all of the wave's outstanding LDS reads)
+  float* const gp0 = a.gplanes[lv][i0];
+  float* const gp1 = a.gplanes[lv][i1];
+  const float* const pl0 = a.d.planes[lv][i0] + c;
+  const float* const pl1 = a.d.planes[lv][i1] + c;
+  const int W0 = a.d.res[lv][PAIR0[i0]], W1 = a.d.res[lv][PAIR0[i1]];
   const float* Grow = G + (size_t)(lv * HEXC + c);    // this lane's column of every T row
   // Software pipeline per lane role (point q of a group, tap j): the sorted index (and T-row position) of group g+2, the
   // coordinates of group g+1 and the taps of group g+1 are produced while group g is accumulated, so neither the
@@ -776,7 +784,8 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   auto store_taps = [&](const float* u, uint32_t cpos, int buf) {
     const Tap t = make_tap(u[axw], u[axh], Wt, Ht);
     float* dst = &tapbuf[hw][buf][q][j][0];
-    *reinterpret_cast<float4*>(dst) = make_float4(__int_as_float(t.o00), __int_as_float((t.o01 >= 0 ? 1 : 0) | (t.o10 >= 0 ? 2 : 0)), t.w00, t.w01);
+    // slot 0: (texel index << 2 | corner flags) -- the word the hit test compares; a plane has at most 2^24 texels (check_desc)
+    *reinterpret_cast<float4*>(dst) = make_float4(__int_as_float((t.o00 << 2) | (t.o01 >= 0 ? 1 : 0) | (t.o10 >= 0 ? 2 : 0)), 0.f, t.w00, t.w01);
     *reinterpret_cast<float4*>(dst + 4) = make_float4(t.w10, t.w11, __uint_as_float(cpos), 0.f);
   };
   auto row_pos = [&](int buf, int qq) { return __float_as_uint(tapbuf[hw][buf][qq][0][6]); };
@@ -824,21 +833,19 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
         if (qq >= nq) break;
 #pragma unroll
         for (int m = 0; m < 2; m++) {
-          float* gp = a.gplanes[lv][m ? i1 : i0];
+          float* gp = m ? gp1 : gp0;
           if (gp == nullptr) continue;
           const float* src = &tapbuf[hw][buf][4 * sb + qq][m][0];
           const float4 lo = *reinterpret_cast<const float4*>(src);
           PackedTap2 t;
-          t.key = __float_as_int(lo.x); t.flags = __float_as_int(lo.y);
+          t.kf = __float_as_int(lo.x);
           t.w01 = f2v_{lo.z, lo.w};
-          const float* pl = a.d.planes[lv][m ? i1 : i0] + c;
-          const int Wm = a.d.res[lv][PAIR0[m ? i1 : i0]];
           if (UT && m == 1) {
-            foot1_add_t<true>(f1[m], t, g[qq], gp, pl, Wm, c);
+            foot1_add_t<true>(f1[m], t, g[qq], gp, pl1, W1, c);
           } else {
             const float2 hi = *reinterpret_cast<const float2*>(src + 4);
             t.w23 = f2v_{hi.x, hi.y};
-            foot1_add_t<false>(f1[m], t, g[qq], gp, pl, Wm, c);
+            foot1_add_t<false>(f1[m], t, g[qq], gp, m ? pl1 : pl0, m ? W1 : W0, c);
           }
         }
       }
@@ -848,11 +855,10 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   }
 #pragma unroll
   for (int m = 0; m < 2; m++) {
-    float* gp = a.gplanes[lv][m ? i1 : i0];
+    float* gp = m ? gp1 : gp0;
     if (gp == nullptr) continue;
-    const int W = a.d.res[lv][PAIR0[m ? i1 : i0]];
-    if (UT && m == 1) foot1_flush_all<true>(f1[m], gp, W, c);
-    else foot1_flush_all<false>(f1[m], gp, W, c);
+    if (UT && m == 1) foot1_flush_all<true>(f1[m], gp, W1, c);
+    else foot1_flush_all<false>(f1[m], gp, m ? W1 : W0, c);
   }
 }
 
