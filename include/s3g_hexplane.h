@@ -53,6 +53,10 @@ int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const float* xyz, co
  * s3g_hexplane_backward_workspace_bytes(d, P, features != NULL) bytes (sort buffers, the row tables and their gradients when
  * uniform_time, + 128 B per point and level: one row T = dL/dfeature * feature; rounds 1-2: 3 KB per point), uninitialised. */
 int s3g_hexplane_backward_scratch_rows(int levels);   /* 128-byte rows of scratch per point the per-point pass writes */
+/* DIAGNOSTICS ONLY: which of the 3 * levels scatter walks of s3g_hexplane_backward run (bit orientation * levels + level; default all).
+ * With any other mask the plane gradients are incomplete -- for timing the walks one by one (tools/hex_probe.py walks,
+ * profiles/r06_hex_walks.txt).  Process-wide. */
+void s3g_hexplane_debug_walk_mask(uint32_t mask);
 /* 32-bit words per point of `sort_state` below: 2 x (walk orders) + 1.  Round 4: one walk order per orientation AND level,
  * 6 * levels + 1 words (25 at the reference's four levels); rounds 1-3 kept three orders (7 words). */
 int s3g_hexplane_sort_state_words(int levels);

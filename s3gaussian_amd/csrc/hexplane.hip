@@ -28,6 +28,8 @@
 //           drop to ~2 (rounds 1-3, every level in the finest order with a two-entry cache: ~5-6).  Taps are computed
 //           cooperatively (lane = point x tap) and shared through LDS; index, coordinate and tap computation run one to two groups
 //           ahead of the accumulation.
+#include <atomic>
+
 #include "hexplane_dev.hpp"
 
 namespace s3g {
@@ -753,6 +755,7 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   static_assert(LANES == GRP * NTAP, "tap phase: one lane per (point of the group, tap)");
   __shared__ __attribute__((aligned(16))) float tapbuf[WALKERS][2][GRP][NTAP][TAPF];  // [walker][double buffer][point][tap]: 16 KiB
   const int oi = blockIdx.y;
+  if (!((a.walk_mask >> oi) & 1u)) return;
   const int o = oi / a.d.levels, lv = oi % a.d.levels;
   const int c = threadIdx.x & (LANES - 1), hw = threadIdx.x / LANES;   // channel of this lane, walker of this half-wave
   const int q = c / NTAP, j = c % NTAP;  // tap-phase role: point q of the group, tap j (0 spatial, 1 time plane)
@@ -915,6 +918,11 @@ static void carve_backward(Carver& c, const s3g_hexplane_desc* d, int P, float**
 // 128-byte rows of scratch the default (slab) backward writes per point and level set: bench.py prices the implementation bytes
 extern "C" int s3g_hexplane_backward_scratch_rows(int levels) { return levels; }
 
+// Diagnostics only (tools/hex_probe.py walks): which of the 3 * levels scatter walks run -- bit orientation * levels + level.  With
+// anything but all ones the plane gradients are INCOMPLETE; the setting is process-wide and meant for timing the walks one by one.
+static std::atomic<uint32_t> g_walk_mask{0xffffffffu};
+extern "C" void s3g_hexplane_debug_walk_mask(uint32_t mask) { g_walk_mask.store(mask, std::memory_order_relaxed); }
+
 // 32-bit words per point of the caller-kept `sort_state`: the walk orders, their compositions with the processing order, and the
 // processing order itself (round 4: one walk order per orientation AND level, 6 * levels + 1; rounds 1-3: 7)
 extern "C" int s3g_hexplane_sort_state_words(int levels) { return 2 * n_walk_orders(levels) + 1; }
@@ -1008,6 +1016,7 @@ static int hexplane_backward_impl(const s3g_hexplane_desc* d, int P, const float
     use_time_rows(a, rows, tables, tables + nt, stream);
   }
   a.seg_len = segment_length(P);
+  a.walk_mask = g_walk_mask.load(std::memory_order_relaxed);
   const int nseg = (P + a.seg_len - 1) / a.seg_len;
   {
     // 2. per-point pass (dL/dxyz; ONE row T = dL/dfeature * feature per point and level -> G), then the scatter walks reading it back

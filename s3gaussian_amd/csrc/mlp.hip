@@ -1810,7 +1810,12 @@ __global__ void __launch_bounds__(WG_WAVES * 64) mlp_wgrad_all_kernel(const WAll
 // gradient element in block order 0 .. nb-1 -- a fixed summation order -- onto dW / db (which the caller zero-filled or holds a sum).
 // 256 x 37 440 floats = 38 MB of partials written and read once (~12 us of HBM time) + one launch.
 __global__ void __launch_bounds__(256) mlp_wgrad_reduce_kernel(const WAllArgs a, int nb, int njobs) {
-  const int j = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  // 64 gradient elements per workgroup (consecutive lanes = consecutive elements: coalesced 256-byte reads), the nb partials of
+  // each split over the four waves in CONTIGUOUS quarters; every wave adds its quarter in block order (eight independent loads in
+  // flight), wave 0 adds the four quarter sums in wave order: one fixed association of the nb addends, whatever the timing.
+  __shared__ float quarter[4][64];
+  const int j = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
   const WJobX jb = a.job[j];
   float* dst = nullptr;
   if (jb.kind == 0) {
@@ -1825,12 +1830,24 @@ __global__ void __launch_bounds__(256) mlp_wgrad_reduce_kernel(const WAllArgs a,
       else if (r >= WPART_HEAD_BIAS && r < WPART_HEAD_BIAS + 3 && db != nullptr) dst = db + (r - WPART_HEAD_BIAS);
     }
   }
-  if (dst == nullptr) return;
-  const float* src = a.part + (size_t)j * WPART + e;
-  const size_t stride = (size_t)njobs * WPART;
   float s = 0.f;
-  for (int b = 0; b < nb; b++) s += src[(size_t)b * stride];
-  *dst += s;
+  if (dst != nullptr && e < WPART) {
+    const size_t stride = (size_t)njobs * WPART;
+    const int per = (nb + 3) / 4, b0 = wv * per, b1 = min(nb, b0 + per);
+    const float* src = a.part + (size_t)j * WPART + e;
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = src[(size_t)(b + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; b < b1; b++) s += src[(size_t)b * stride];
+  }
+  quarter[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && dst != nullptr) *dst += ((quarter[0][lane] + quarter[1][lane]) + quarter[2][lane]) + quarter[3][lane];
 }
 
 static int launch_wgrad_all(const WJobX* jobs, int njobs, int P, hipStream_t stream, float* partials) {
@@ -1843,7 +1860,7 @@ static int launch_wgrad_all(const WJobX* jobs, int njobs, int P, hipStream_t str
   const int blocks = min(ntiles, WPART_MAX_BLOCKS);
   hipLaunchKernelGGL(mlp_wgrad_all_kernel, dim3(blocks), dim3(njobs * 64), (size_t)njobs * WM_RED * sizeof(float), stream, a);
   if (partials != nullptr)
-    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((WPART + 255) / 256, njobs), dim3(256), 0, stream, a, blocks, njobs);
+    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((WPART + 63) / 64, njobs), dim3(256), 0, stream, a, blocks, njobs);
   S3G_HIP_CHECK(hipGetLastError());
   return S3G_OK;
 }

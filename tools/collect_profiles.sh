@@ -33,6 +33,8 @@ timeout 200 rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d /tmp/hex_
 timeout 200 rocprofv3 --pmc $TCC --kernel-trace --output-format csv -d /tmp/hex_t -- python "$ROOT/tools/hex_probe.py" > /dev/null 2>&1
 ( echo "# rocprofv3 --pmc <SQ / TCC counters> --kernel-trace -- python tools/hex_probe.py  (three passes; tools/sq_table.py; 1.2 M points; tree of round ${TAG})"
   python "$ROOT/tools/sq_table.py" /tmp/hex_s1 /tmp/hex_s2 /tmp/hex_t ) > "$OUT/${TAG}_hexplane_sq_pmc.txt" 2>&1
+# 3b. the twelve scatter walks one by one (VERDICT r5 next #2 iii)
+timeout 300 python "$ROOT/tools/hex_probe.py" 1200000 walks > "$OUT/${TAG}_hex_walks.txt" 2>&1
 # 4. the bench line last, so that its `traffic` / VALU fields are the PMC data collected a minute earlier on this very box
 cp "$OUT/${TAG}_pmc/kernel_traffic.json" "$ROOT/profiles/kernel_traffic.json" 2>/dev/null
 cd /tmp

@@ -65,3 +65,32 @@ for i, name in ((2, "hexplane_forward"), (3, "hexplane_backward_point"), (4, "he
     print(f"{name}: {ms.value / max(n, 1):.4f} ms avg over {n}")
 L.s3g_profile_enable(0)
 print("S3G_HEX_BACKWARD =", os.environ.get("S3G_HEX_BACKWARD", "slab"))
+
+if "walks" in sys.argv[2:]:
+    # the twelve (orientation, level) scatter walks timed ONE BY ONE (include/s3g_hexplane.h::
+    # s3g_hexplane_debug_walk_mask; the gradients of such a run are incomplete -- timing only).  Level 0 has ~290 points per cell,
+    # level 3 ~4.6: is one serial-walker design right for both?
+    L.s3g_hexplane_debug_walk_mask.argtypes = [C.c_uint32]
+    L.s3g_hexplane_debug_walk_mask.restype = None
+    SC = 4   # S3G_PROFILE_HEXPLANE_SCATTER
+    L.s3g_profile_enable(1)
+    rows = []
+    for mask_name, mask in [("all", 0xffffffff)] + [(f"o{o} l{l}", 1 << (o * 4 + l)) for o in range(3) for l in range(4)] + \
+            [(f"level {l} (3 orientations)", sum(1 << (o * 4 + l) for o in range(3))) for l in range(4)]:
+        L.s3g_hexplane_debug_walk_mask(mask)
+        for i in range(10):
+            L.s3g_profile_read(i, None, None, None)
+        for it in range(6):
+            for p in f.parameters():
+                p.grad = None
+            out = f(xyz, t, uniform_time=True)
+            (out * w).sum().backward()
+        torch.cuda.synchronize()
+        ms = C.c_double()
+        n = L.s3g_profile_read(SC, C.byref(ms), None, None)
+        rows.append((mask_name, ms.value / max(n, 1)))
+    L.s3g_hexplane_debug_walk_mask(0xffffffff)
+    L.s3g_profile_enable(0)
+    print("scatter walks one by one (ms per launch; the launch always has the full grid, masked walks exit at once):")
+    for name, ms in rows:
+        print(f"  {name:28s} {ms:.4f}")
