@@ -1290,6 +1290,16 @@ def main(argv=None):
                 out["config"]["reference_stack_on_this_gpu_ms_per_iteration_cfg2"] = pj["ms_per_iteration"]["reference_stack_on_mi355x"]
             except Exception:
                 pass
+        cfg3_file = os.path.join(ROOT, "profiles", "psnr_parity_cfg3.json")
+        if os.path.exists(cfg3_file):   # round 6: the same experiment at the HEADLINE configuration (1.2 M Gaussians), across an opacity reset
+            try:
+                pj = json.load(open(cfg3_file))
+                out["config"]["psnr_cfg3_mean_delta_vs_reference_stack_db"] = pj["mean_psnr_delta_db"]
+                out["config"]["psnr_cfg3_reference_vs_itself_db"] = pj.get("reference_vs_reference_again", {}).get("mean_psnr_delta_db")
+                out["config"]["psnr_cfg3_source"] = "profiles/psnr_parity_cfg3.json (NOT collected in this run): " + pj.get("what", "")[:200]
+                out["config"]["reference_stack_on_this_gpu_ms_per_iteration_cfg3"] = pj["ms_per_iteration"]["reference_stack_on_mi355x"]
+            except Exception:
+                pass
         if world == 1 and not dist_on and not a.no_cpu_baseline:
             try:
                 import contextlib
