@@ -57,6 +57,18 @@ int s3g_hexplane_backward_scratch_rows(int levels);   /* 128-byte rows of scratc
  * With any other mask the plane gradients are incomplete -- for timing the walks one by one (tools/hex_probe.py walks,
  * profiles/r06_hex_walks.txt).  Process-wide. */
 void s3g_hexplane_debug_walk_mask(uint32_t mask);
+/* Deterministic mode of s3g_hexplane_backward (process-wide, default off; round 6).  The default backward adds the scatter walks' partial
+ * sums onto the plane gradients with float atomics, and its walk orders come from counting sorts whose placement step uses LDS atomics:
+ * the ORDER of the additions -- and with it the last bits of every plane gradient -- differs from run to run.  With the mode on
+ *   - the counting sorts place the points of a key in input order (ballot ranking instead of atomics: stable orders),
+ *   - a walker STORES the sums of every finished footprint ("run") as a record -- per cell, or per segment for a cell that straddles
+ *     segments -- instead of adding them with atomics,
+ *   - one stencil pass adds, for every texel, the records of the four cells around it in a fixed order.
+ * Plane gradients, dL/dxyz and the walk orders are then bit-identical between runs (tests/test_hexplane_gpu.py).  Requirements:
+ * desc.uniform_time != 0 and spatial resolutions <= 512; s3g_hexplane_backward_workspace_bytes follows the setting (+ 0.55 GB of run
+ * records at the reference's resolutions).  The exact fallback of (nearly) zero samples still uses atomics (a handful of addends). */
+void s3g_hexplane_set_deterministic(int on);
+int s3g_hexplane_get_deterministic(void);
 /* 32-bit words per point of `sort_state` below: 2 x (walk orders) + 1.  Round 4: one walk order per orientation AND level,
  * 6 * levels + 1 words (25 at the reference's four levels); rounds 1-3 kept three orders (7 words). */
 int s3g_hexplane_sort_state_words(int levels);

@@ -116,4 +116,4 @@ def check(code: int) -> None:
         raise RuntimeError(f"libs3g error {code}: {msg}")
 
 
-EXPORTED_SYMBOLS = ["s3g_raster_forward", "s3g_raster_forward_reuse", "s3g_raster_forward_decompose", "s3g_raster_forward2", "s3g_raster_forward_async", "s3g_raster_arena_bytes", "s3g_adam_step_guarded", "s3g_raster_backward", "s3g_raster_backward_workspace_bytes", "s3g_raster_backward2", "s3g_raster_backward2_workspace_bytes", "s3g_hexplane_forward_workspace_bytes", "s3g_knn_workspace_bytes", "s3g_knn_mean_dist2", "s3g_hexplane_forward", "s3g_hexplane_backward", "s3g_hexplane_backward_algo", "s3g_hexplane_backward_workspace_bytes", "s3g_hexplane_backward_scratch_rows", "s3g_hexplane_debug_walk_mask", "s3g_hexplane_sort_state_words", "s3g_profile_enable", "s3g_profile_read", "s3g_ssim_forward", "s3g_ssim_backward", "s3g_plane_regulation", "s3g_scale_unless_one", "s3g_pixel_losses_forward", "s3g_pixel_losses_combine", "s3g_pixel_losses_backward", "s3g_glue_forward", "s3g_glue_backward", "s3g_deform_mlp_forward", "s3g_deform_mlp_backward", "s3g_deform_mlp_backward_ordered", "s3g_deform_mlp_wgrad_partial_bytes", "s3g_deform_mlp_stash_bytes", "s3g_deform_mlp_pack_bytes", "s3g_deform_mlp_set_arithmetic", "s3g_deform_mlp_get_arithmetic", "s3g_deform_infer", "s3g_deform_infer_split", "s3g_deform_infer_workspace_bytes", "s3g_adam_step", "s3g_densify_stats", "s3g_densify_stats_guarded", "s3g_raster_backward_accum", "s3g_raster_backward2_accum", "s3g_mark_visible", "s3g_raster_set_exact_cull", "s3g_raster_get_exact_cull", "s3g_raster_set_bin_band", "s3g_last_error", "s3g_abi_version"]
+EXPORTED_SYMBOLS = ["s3g_raster_forward", "s3g_raster_forward_reuse", "s3g_raster_forward_decompose", "s3g_raster_forward2", "s3g_raster_forward_async", "s3g_raster_arena_bytes", "s3g_adam_step_guarded", "s3g_raster_backward", "s3g_raster_backward_workspace_bytes", "s3g_raster_backward2", "s3g_raster_backward2_workspace_bytes", "s3g_hexplane_forward_workspace_bytes", "s3g_knn_workspace_bytes", "s3g_knn_mean_dist2", "s3g_hexplane_forward", "s3g_hexplane_backward", "s3g_hexplane_backward_algo", "s3g_hexplane_backward_workspace_bytes", "s3g_hexplane_backward_scratch_rows", "s3g_hexplane_debug_walk_mask", "s3g_hexplane_set_deterministic", "s3g_hexplane_get_deterministic", "s3g_hexplane_sort_state_words", "s3g_profile_enable", "s3g_profile_read", "s3g_ssim_forward", "s3g_ssim_backward", "s3g_plane_regulation", "s3g_scale_unless_one", "s3g_pixel_losses_forward", "s3g_pixel_losses_combine", "s3g_pixel_losses_backward", "s3g_glue_forward", "s3g_glue_backward", "s3g_deform_mlp_forward", "s3g_deform_mlp_backward", "s3g_deform_mlp_backward_ordered", "s3g_deform_mlp_wgrad_partial_bytes", "s3g_deform_mlp_stash_bytes", "s3g_deform_mlp_pack_bytes", "s3g_deform_mlp_set_arithmetic", "s3g_deform_mlp_get_arithmetic", "s3g_deform_infer", "s3g_deform_infer_split", "s3g_deform_infer_workspace_bytes", "s3g_adam_step", "s3g_densify_stats", "s3g_densify_stats_guarded", "s3g_raster_backward_accum", "s3g_raster_backward2_accum", "s3g_mark_visible", "s3g_raster_set_exact_cull", "s3g_raster_get_exact_cull", "s3g_raster_set_bin_band", "s3g_last_error", "s3g_abi_version"]

@@ -525,14 +525,49 @@ struct SortWork {
 };
 __device__ __forceinline__ uint32_t* order_of(const SortWork& w, int o, int P) { return o < w.nw ? w.order + (size_t)o * P : w.proc; }
 
+// STABLE placement (round 6, deterministic mode): the position of an element among the elements of its key must not depend on the
+// order in which LDS atomics happen to execute.  One round = 256 consecutive elements; the four waves take turns (barriers), and inside
+// a wave the lanes of one key are ranked by lane number with a ballot per distinct key -- so the elements of a key keep their input
+// order.  Every thread of the workgroup calls this (barriers inside); inactive lanes pass active = false.
+__device__ __forceinline__ uint32_t stable_claim(uint32_t* __restrict__ cell, int key, bool active) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t pos = 0;
+  for (int w = 0; w < 4; w++) {
+    if (wave == w) {
+      uint64_t remaining = __ballot(active);
+      while (remaining) {   // uniform across the wave
+        const int leader = __ffsll((long long)remaining) - 1;
+        const int k = __shfl(key, leader);
+        const bool mine = active && key == k;
+        const uint64_t same = __ballot(mine);
+        const uint32_t base = cell[k];                                  // every lane reads it before the leader's store below (in-order LDS)
+        if (mine) pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (lane == leader) cell[k] = base + (uint32_t)__popcll(same);
+        remaining &= ~same;
+      }
+    }
+    __syncthreads();
+  }
+  return pos;
+}
+
 template <bool WRITE>
-__global__ void __launch_bounds__(256) hexsort_major_kernel(const HexArgs a, const SortWork w, int chunk) {
+__global__ void __launch_bounds__(256) hexsort_major_kernel(const HexArgs a, const SortWork w, int chunk, int stable) {
   __shared__ uint32_t cell[SORT_BINS];
   const int o = blockIdx.y;
   uint32_t* row = w.table + ((size_t)o * SORT_NB + blockIdx.x) * SORT_BINS;
   for (int i = threadIdx.x; i < SORT_BINS; i += 256) cell[i] = WRITE ? w.seg_start[o * (SORT_BINS + 1) + i] + row[i] : 0u;
   __syncthreads();
   const int g0 = blockIdx.x * chunk, g1 = min(a.P, g0 + chunk);
+  if (WRITE && stable) {
+    for (int gb = g0; gb < g1; gb += 256) {      // uniform trip count: stable_claim synchronises the workgroup
+      const int g = gb + threadIdx.x;
+      const bool act = g < g1;
+      const uint32_t pos = stable_claim(cell, act ? major_key(a, g, o) : 0, act);
+      if (act) w.tmp[(size_t)o * a.P + pos] = (uint32_t)g;
+    }
+    return;
+  }
   for (int g = g0 + threadIdx.x; g < g1; g += 256) {
     const uint32_t pos = atomicAdd(&cell[major_key(a, g, o)], 1u);
     if (WRITE) w.tmp[(size_t)o * a.P + pos] = (uint32_t)g;
@@ -567,7 +602,7 @@ __global__ void __launch_bounds__(512) hexsort_scan_kernel(const SortWork w, int
 }
 
 // one workgroup per (major bin, orientation): counting sort of the segment by minor cell
-__global__ void __launch_bounds__(256) hexsort_minor_kernel(const HexArgs a, const SortWork w) {
+__global__ void __launch_bounds__(256) hexsort_minor_kernel(const HexArgs a, const SortWork w, int stable) {
   __shared__ uint32_t cnt[SORT_BINS];
   __shared__ uint32_t wsum[4];
   const int o = blockIdx.y, bin = blockIdx.x, tid = threadIdx.x;
@@ -596,6 +631,16 @@ __global__ void __launch_bounds__(256) hexsort_minor_kernel(const HexArgs a, con
   cnt[2 * tid] = excl;
   cnt[2 * tid + 1] = excl + c0;
   __syncthreads();
+  if (stable) {
+    for (uint32_t kb = s0; kb < s1; kb += 256) {   // uniform trip count (stable_claim synchronises); tmp is index-ascending per major bin
+      const uint32_t k = kb + tid;
+      const bool act = k < s1;
+      const uint32_t g = act ? tmp[k] : 0u;
+      const uint32_t pos = stable_claim(cnt, act ? minor_key(a, (int)g, o) : 0, act);
+      if (act) order[pos] = g;
+    }
+    return;
+  }
   for (uint32_t k = s0 + tid; k < s1; k += 256) {
     const uint32_t g = tmp[k];
     order[atomicAdd(&cnt[minor_key(a, (int)g, o)], 1u)] = g;
@@ -677,6 +722,83 @@ struct PackedTap2 {   // one tap as the walker reads it back from LDS: 8 floats 
   int kf;             // texel index of the nw corner << 2 | flags (bit 0: ne / se column in range, bit 1: sw / se row in range)
   f2v_ w01, w23;      // bilinear weights of (nw, ne) (sw, se)
 };
+// ---- deterministic mode (round 6, opt-in: s3g_hexplane_set_deterministic) ---------------------------------------------------------
+// Plane gradients that are bit-identical from run to run need (1) walk orders that do not depend on the timing of LDS atomics (the
+// stable counting sorts above), (2) ONE writer per sum, and (3) a fixed order in which the sums of a texel are added.  The walk keeps
+// its structure -- segments of seg_len sorted points per walker, one remembered footprint -- but a finished footprint ("run": the
+// consecutive points of one cell inside one segment) is STORED, not added with atomics:
+//   CELL[cell][corner][32]   the run that contains the cell's first point (cells are contiguous in the order: exactly one such run),
+//   SEG[segment][corner][32] the first run of a segment when it continues a cell begun in an earlier segment (at most one per segment),
+// and hexplane_stencil_kernel adds, for every texel, the four cells around it (nw of its own cell, ne of the cell to the left, sw of
+// the cell above, se of the cell above-left), each as CELL + its SEG continuations in segment order.  Cell extents [start, end) in the
+// sorted order come from hexcell_ranges_kernel.  No shift reuse here: every cell keeps its own four sums.
+struct DetWalk {           // one (orientation, level) walk
+  uint32_t* cstart;        // [cells] first sorted position of the spatial cell (plane texel index of its nw corner); start >= end: empty
+  uint32_t* cend;
+  uint32_t* tstart;        // [Wmajor] the same for the 1-D cells of the (major, t) row table
+  uint32_t* tend;
+  float* cell;             // [cells][4][32]
+  float* seg;              // [segments][4][32]
+  float* tcell;            // [Wmajor][2][32]
+  float* tseg;             // [segments][2][32]
+};
+struct DetWork {
+  DetWalk walk[3 * S3G_HEX_MAX_LEVELS];
+};
+template <bool ROW>
+__device__ __forceinline__ void det_store_run(const Foot1& F, const DetWalk& dw, int seg, int k0, bool first_run, int c) {
+  if (F.key < 0) return;
+  const int cellid = F.key >> 2;
+  const uint32_t* cs = ROW ? dw.tstart : dw.cstart;
+  const bool continuation = first_run && cs[cellid] < (uint32_t)k0;      // the cell began in an earlier segment
+  constexpr int NC = ROW ? 2 : 4;
+  float* rec = continuation ? (ROW ? dw.tseg : dw.seg) + (size_t)seg * (NC * HEXC) : (ROW ? dw.tcell : dw.cell) + (size_t)cellid * (NC * HEXC);
+  rec[c] = F.a01.x;
+  rec[HEXC + c] = F.a01.y;
+  if (!ROW) {
+    rec[2 * HEXC + c] = F.a23.x;
+    rec[3 * HEXC + c] = F.a23.y;
+  }
+}
+// the deterministic walker's tap: like foot1_add_t, but a finished footprint is stored as a run record and nothing is shifted
+template <bool ROW>
+__device__ __forceinline__ void foot1_add_det(Foot1& F, bool& first_run, const PackedTap2& t, float tv, const DetWalk& dw, int seg, int k0,
+                                              const float* __restrict__ pl, int W, int c) {
+  const int tkf = t.kf;
+  if (tkf != F.key) {
+    const int tkey = tkf >> 2, tfl = tkf & 3;
+    const float* px = pl + (size_t)tkey * HEXC;
+    const float n0 = px[0], n1 = px[(tfl & 1) ? HEXC : 0];
+    float n2 = 0.f, n3 = 0.f;
+    if (!ROW) {
+      n2 = px[(tfl & 2) ? (size_t)W * HEXC : 0];
+      n3 = px[(tfl == 3) ? (size_t)W * HEXC + HEXC : 0];
+    }
+    if (F.key >= 0) {
+      det_store_run<ROW>(F, dw, seg, k0, first_run, c);
+      first_run = false;
+    }
+    F.a01 = f2v_{0.f, 0.f};
+    F.v01 = f2v_{n0, n1};
+    if (!ROW) {
+      F.a23 = f2v_{0.f, 0.f};
+      F.v23 = f2v_{n2, n3};
+    }
+    F.key = tkf;
+  }
+  const f2v_ p01 = F.v01 * t.w01;
+  float sv = p01.x + p01.y;
+  if (!ROW) {
+    const f2v_ p23 = F.v23 * t.w23;
+    sv = sv + p23.x;
+    sv = sv + p23.y;
+  }
+  const float g = tslab_divisible(sv) ? tv * __builtin_amdgcn_rcpf(sv) : 0.f;
+  const f2v_ gg = f2v_{g, g};
+  F.a01 = __builtin_elementwise_fma(gg, t.w01, F.a01);
+  if (!ROW) F.a23 = __builtin_elementwise_fma(gg, t.w23, F.a23);
+}
+
 template <bool ROW = false>
 __device__ __forceinline__ void foot1_add_t(Foot1& F, const PackedTap2& t, float tv, float* __restrict__ gp,
                                             const float* __restrict__ pl /* plane values + channel */, int W, int c) {
@@ -747,9 +869,10 @@ constexpr int SCATTER_WG_PER_CU = S3G_HEX_SCATTER_WAVES;   // waves per SIMD the
 constexpr int TAPF = 8;   // floats per packed tap in LDS: key, flags, w00, w01 | w10, w11, position of the point's T rows, -
 constexpr int GRP = 16;   // points per tap group
 __device__ __forceinline__ float load_g(const float* p) { return G_NONTEMPORAL_LOAD ? __builtin_nontemporal_load(p) : *p; }
-template <bool UT>   // UT: uniform time -- the (axis, t) planes are height-1 row tables
+template <bool UT, bool DET = false>   // UT: uniform time -- the (axis, t) planes are height-1 row tables; DET: deterministic mode (needs UT)
 __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_CU - 1) hexplane_scatter_kernel(const HexArgs a, const float* __restrict__ G,
-                                                               const uint32_t* __restrict__ order_all, const uint32_t* __restrict__ comp_all) {
+                                                               const uint32_t* __restrict__ order_all, const uint32_t* __restrict__ comp_all,
+                                                               const DetWork detw) {
   constexpr int LANES = HEXC, WALKERS = 256 / LANES;
   constexpr int NTAP = 2;             // taps per point and walk: the orientation's spatial plane and its (major, t) plane
   static_assert(LANES == GRP * NTAP, "tap phase: one lane per (point of the group, tap)");
@@ -771,6 +894,7 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   Foot1 f1[2];
   foot1_init(f1[0]);
   foot1_init(f1[1]);
+  bool first_run[2] = {true, true};   // deterministic mode: no run of this segment has been stored yet (per tap)
   const int Wt = a.d.res[lv][axw], Ht = a.d.res[lv][axh];
   // uniform per workgroup; read ONCE (indexed kernel-argument reads inside the loop were an s_load + s_waitcnt lgkmcnt(0) per tap,
   // i.e. every tap also waited for all of the wave's outstanding LDS reads)
@@ -843,7 +967,15 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
           PackedTap2 t;
           t.kf = __float_as_int(lo.x);
           t.w01 = f2v_{lo.z, lo.w};
-          if (UT && m == 1) {
+          if (DET) {
+            if (m == 1) {
+              foot1_add_det<true>(f1[1], first_run[1], t, g[qq], detw.walk[oi], seg, k0, pl1, W1, c);
+            } else {
+              const float2 hi = *reinterpret_cast<const float2*>(src + 4);
+              t.w23 = f2v_{hi.x, hi.y};
+              foot1_add_det<false>(f1[0], first_run[0], t, g[qq], detw.walk[oi], seg, k0, pl0, W0, c);
+            }
+          } else if (UT && m == 1) {
             foot1_add_t<true>(f1[m], t, g[qq], gp, pl1, W1, c);
           } else {
             const float2 hi = *reinterpret_cast<const float2*>(src + 4);
@@ -860,8 +992,85 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   for (int m = 0; m < 2; m++) {
     float* gp = m ? gp1 : gp0;
     if (gp == nullptr) continue;
-    if (UT && m == 1) foot1_flush_all<true>(f1[m], gp, W1, c);
+    if (DET) {
+      if (m == 1) det_store_run<true>(f1[1], detw.walk[oi], seg, k0, first_run[1], c);
+      else det_store_run<false>(f1[0], detw.walk[oi], seg, k0, first_run[0], c);
+    } else if (UT && m == 1) foot1_flush_all<true>(f1[m], gp, W1, c);
     else foot1_flush_all<false>(f1[m], gp, m ? W1 : W0, c);
+  }
+}
+
+// ---- deterministic mode: cell extents and the stencil gather ------------------------------------------------------------------------
+// extents of every cell of every walk in its sorted order: position k opens the cell of point order[k] when that cell differs from the
+// cell of order[k-1] (and closes that one).  Cells = texel cells of the walk's own level (sort_cell: floor of the clamped texel
+// coordinate, exactly make_tap's), spatial id = the plane texel index of the nw corner, row id = the major axis' texel.
+// The arrays are zero-filled before: an untouched cell reads start == end == 0, i.e. empty.
+__global__ void __launch_bounds__(256) hexcell_ranges_kernel(const HexArgs a, const uint32_t* __restrict__ order_all, const DetWork detw) {
+  const int oi = blockIdx.y, o = oi / a.d.levels, lv = oi % a.d.levels;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= a.P) return;
+  const uint32_t* order = order_all + (size_t)oi * a.P;
+  const DetWalk dw = detw.walk[oi];
+  const int ip = PLA[o], ax = PAIR0[ip], ay = PAIR1[ip], Wx = a.d.res[lv][ax];
+  const int p = (int)order[k];
+  const int cx = sort_cell(a, p, ax, lv), cy = sort_cell(a, p, ay, lv), cm = sort_cell(a, p, MAJ[o], lv);
+  const int cell = cy * Wx + cx;
+  int pcell = -1, pm = -1;
+  if (k > 0) {
+    const int q = (int)order[k - 1];
+    pcell = sort_cell(a, q, ay, lv) * Wx + sort_cell(a, q, ax, lv);
+    pm = sort_cell(a, q, MAJ[o], lv);
+  }
+  if (cell != pcell) {
+    dw.cstart[cell] = (uint32_t)k;
+    if (pcell >= 0) dw.cend[pcell] = (uint32_t)k;
+  }
+  if (cm != pm) {
+    dw.tstart[cm] = (uint32_t)k;
+    if (pm >= 0) dw.tend[pm] = (uint32_t)k;
+  }
+  if (k == a.P - 1) {
+    dw.cend[cell] = (uint32_t)a.P;
+    dw.tend[cm] = (uint32_t)a.P;
+  }
+}
+// sum of one cell's run records for corner `corner`, lane = channel: CELL first, then the SEG continuations in segment order
+template <int NC>
+__device__ __forceinline__ float det_cell_sum(const float* __restrict__ cellrec, const float* __restrict__ segrec, const uint32_t* __restrict__ cs,
+                                              const uint32_t* __restrict__ ce, int cellid, int corner, int seg_len, int c) {
+  const uint32_t s0 = cs[cellid], s1 = ce[cellid];
+  if (s1 <= s0) return 0.f;
+  float acc = cellrec[(size_t)cellid * (NC * HEXC) + corner * HEXC + c];
+  const uint32_t first = s0 / (uint32_t)seg_len + 1u, last = (s1 - 1u) / (uint32_t)seg_len;
+  for (uint32_t sg = first; sg <= last; sg++) acc += segrec[(size_t)sg * (NC * HEXC) + corner * HEXC + c];
+  return acc;
+}
+// grid = (texel groups, walks): a half-wave (lane = channel) per texel of the walk's spatial plane; the row tables' 1-D stencil rides in
+// the same launch (texels 0 .. Wmajor-1 of an extra "row" behind the plane).
+__global__ void __launch_bounds__(256) hexplane_stencil_kernel(const HexArgs a, const DetWork detw) {
+  const int oi = blockIdx.y, o = oi / a.d.levels, lv = oi % a.d.levels;
+  if (!((a.walk_mask >> oi) & 1u)) return;
+  const int c = threadIdx.x & (HEXC - 1);
+  const int ip = PLA[o], it = PLT[o];
+  const int Wx = a.d.res[lv][PAIR0[ip]], Wy = a.d.res[lv][PAIR1[ip]], Wm = a.d.res[lv][MAJ[o]];
+  const int t = blockIdx.x * (256 / HEXC) + threadIdx.x / HEXC;
+  const DetWalk dw = detw.walk[oi];
+  if (t < Wx * Wy) {
+    float* gp = a.gplanes[lv][ip];
+    if (gp == nullptr) return;
+    const int x = t % Wx, y = t / Wx;
+    float acc = det_cell_sum<4>(dw.cell, dw.seg, dw.cstart, dw.cend, t, 0, a.seg_len, c);                                   // nw of its own cell
+    if (x > 0) acc += det_cell_sum<4>(dw.cell, dw.seg, dw.cstart, dw.cend, t - 1, 1, a.seg_len, c);                       // ne of the cell to the left
+    if (y > 0) acc += det_cell_sum<4>(dw.cell, dw.seg, dw.cstart, dw.cend, t - Wx, 2, a.seg_len, c);                      // sw of the cell above
+    if (x > 0 && y > 0) acc += det_cell_sum<4>(dw.cell, dw.seg, dw.cstart, dw.cend, t - Wx - 1, 3, a.seg_len, c);         // se of the cell above-left
+    gp[(size_t)t * HEXC + c] += acc;
+  } else if (t < Wx * Wy + Wm) {
+    float* gt = a.gplanes[lv][it];       // (uniform time: the row table's gradient, folded back into the plane rows afterwards)
+    if (gt == nullptr) return;
+    const int x = t - Wx * Wy;
+    float acc = det_cell_sum<2>(dw.tcell, dw.tseg, dw.tstart, dw.tend, x, 0, a.seg_len, c);
+    if (x > 0) acc += det_cell_sum<2>(dw.tcell, dw.tseg, dw.tstart, dw.tend, x - 1, 1, a.seg_len, c);
+    gt[(size_t)x * HEXC + c] += acc;
   }
 }
 
@@ -897,6 +1106,33 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
   return S3G_OK;
 }
 
+static std::atomic<int> g_hex_deterministic{0};
+static void carve_det(Carver& c, const s3g_hexplane_desc* d, int P, DetWork* dw, void** index_begin, size_t* index_bytes) {
+  // deterministic mode: per-walk cell extents (zero-filled every backward: they come first, contiguous) and run records
+  const int nseg = (P + segment_length(P) - 1) / segment_length(P);
+  DetWork w;
+  memset(&w, 0, sizeof w);
+  const size_t b0 = (c.off + 127) & ~size_t(127);
+  size_t b1 = b0;
+  for (int pass = 0; pass < 2; pass++)
+    for (int o = 0; o < 3; o++)
+      for (int l = 0; l < d->levels; l++) {
+        const int oi = o * d->levels + l;
+        static const int PLA_H[3] = {0, 3, 1}, MAJ_H[3] = {0, 1, 2};
+        const size_t cells = (size_t)d->res[l][PAIR0_HOST[PLA_H[o]]] * d->res[l][PAIR1_HOST[PLA_H[o]]], wm = (size_t)d->res[l][MAJ_H[o]];
+        if (pass == 0) {
+          w.walk[oi].cstart = c.take<uint32_t>(cells); w.walk[oi].cend = c.take<uint32_t>(cells);
+          w.walk[oi].tstart = c.take<uint32_t>(wm); w.walk[oi].tend = c.take<uint32_t>(wm);
+          b1 = c.off;
+        } else {
+          w.walk[oi].cell = c.take<float>(cells * 4 * HEXC); w.walk[oi].seg = c.take<float>((size_t)nseg * 4 * HEXC);
+          w.walk[oi].tcell = c.take<float>(wm * 2 * HEXC); w.walk[oi].tseg = c.take<float>((size_t)nseg * 2 * HEXC);
+        }
+      }
+  if (dw) *dw = w;
+  if (index_begin) *index_begin = c.base ? c.base + b0 : nullptr;
+  if (index_bytes) *index_bytes = b1 - b0;
+}
 static void carve_backward(Carver& c, const s3g_hexplane_desc* d, int P, float** G, float** tables, SortWork* w) {
   const size_t n = (size_t)P;
   float* g = c.take<float>((size_t)d->levels * n * HEXC);   // the T rows: one 128-byte row per point and level
@@ -923,6 +1159,12 @@ extern "C" int s3g_hexplane_backward_scratch_rows(int levels) { return levels; }
 static std::atomic<uint32_t> g_walk_mask{0xffffffffu};
 extern "C" void s3g_hexplane_debug_walk_mask(uint32_t mask) { g_walk_mask.store(mask, std::memory_order_relaxed); }
 
+// Deterministic mode of the backward (process-wide; include/s3g_hexplane.h): stable walk orders, run records instead of atomics, a
+// stencil gather in fixed order -- plane gradients bit-identical from run to run.  Needs uniform_time and resolutions <= 512; the
+// workspace grows (s3g_hexplane_backward_workspace_bytes follows the setting).
+extern "C" void s3g_hexplane_set_deterministic(int on) { g_hex_deterministic.store(on ? 1 : 0, std::memory_order_relaxed); }
+extern "C" int s3g_hexplane_get_deterministic(void) { return g_hex_deterministic.load(std::memory_order_relaxed); }
+
 // 32-bit words per point of the caller-kept `sort_state`: the walk orders, their compositions with the processing order, and the
 // processing order itself (round 4: one walk order per orientation AND level, 6 * levels + 1; rounds 1-3: 7)
 extern "C" int s3g_hexplane_sort_state_words(int levels) { return 2 * n_walk_orders(levels) + 1; }
@@ -932,6 +1174,7 @@ extern "C" size_t s3g_hexplane_backward_workspace_bytes(const s3g_hexplane_desc*
   Carver c(nullptr);
   (void)have_features;   // (until round 5 the slab-free "walk" algorithm had a different, smaller layout)
   carve_backward(c, d, P, nullptr, nullptr, nullptr);
+  if (g_hex_deterministic.load(std::memory_order_relaxed)) carve_det(c, d, P, nullptr, nullptr, nullptr);
   return c.bytes();
 }
 
@@ -990,6 +1233,24 @@ static int hexplane_backward_impl(const s3g_hexplane_desc* d, int P, const float
   SortWork w;
   carve_backward(c, d, P, &G, &tables, &w);
   const int NO = n_orders(d->levels), NW = n_walk_orders(d->levels);
+  const int det = g_hex_deterministic.load(std::memory_order_relaxed);
+  DetWork detw;
+  memset(&detw, 0, sizeof detw);
+  void* det_index = nullptr;
+  size_t det_index_bytes = 0;
+  if (det) {
+    if (!d->uniform_time) {
+      set_error("s3g_hexplane_backward: the deterministic mode needs desc.uniform_time (the (axis, t) planes as row tables)");
+      return S3G_ERR_INVALID_ARG;
+    }
+    for (int l = 0; l < d->levels; l++)
+      for (int k = 0; k < 3; k++)
+        if (d->res[l][k] > SORT_BINS) {
+          set_error("s3g_hexplane_backward: the deterministic mode needs spatial resolutions <= %d (sort cells = texel cells)", SORT_BINS);
+          return S3G_ERR_INVALID_ARG;
+        }
+    carve_det(c, d, P, &detw, &det_index, &det_index_bytes);
+  }
   if (sort_state) {  // caller-owned, persistent: s3g_hexplane_sort_state_words(levels) * P words
     w.order = sort_state;
     w.comp = sort_state + (size_t)NW * P;
@@ -999,10 +1260,10 @@ static int hexplane_backward_impl(const s3g_hexplane_desc* d, int P, const float
   // 1. three spatial orders (2-level LDS counting sorts); the legacy path also needs their inverse permutations
   if (!sort_reuse) {
     const int chunk = (((P + SORT_NB - 1) / SORT_NB + 255) / 256) * 256;
-    hipLaunchKernelGGL(hexsort_major_kernel<false>, dim3(SORT_NB, NO), dim3(256), 0, stream, a, w, chunk);
+    hipLaunchKernelGGL(hexsort_major_kernel<false>, dim3(SORT_NB, NO), dim3(256), 0, stream, a, w, chunk, det);
     hipLaunchKernelGGL(hexsort_scan_kernel, dim3(NO), dim3(512), 0, stream, w, P);
-    hipLaunchKernelGGL(hexsort_major_kernel<true>, dim3(SORT_NB, NO), dim3(256), 0, stream, a, w, chunk);
-    hipLaunchKernelGGL(hexsort_minor_kernel, dim3(SORT_BINS, NO), dim3(256), 0, stream, a, w);
+    hipLaunchKernelGGL(hexsort_major_kernel<true>, dim3(SORT_NB, NO), dim3(256), 0, stream, a, w, chunk, det);
+    hipLaunchKernelGGL(hexsort_minor_kernel, dim3(SORT_BINS, NO), dim3(256), 0, stream, a, w, det);
     // comp[oi][k]; the inverse of the processing order goes through w.tmp (free after the sorts)
     hipLaunchKernelGGL(hexsort_rank_kernel, dim3((P + 255) / 256, 1), dim3(256), 0, stream, P, w.proc, w.tmp);
     hipLaunchKernelGGL(hexsort_compose_kernel, dim3((P + 255) / 256, NW), dim3(256), 0, stream, P, w.order, w.tmp, w.comp);
@@ -1037,10 +1298,22 @@ static int hexplane_backward_impl(const s3g_hexplane_desc* d, int P, const float
     S3G_HIP_CHECK(hipGetLastError());
     profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
     constexpr int walkers = 256 / HEXC;
-    if (d->uniform_time)
-      hipLaunchKernelGGL((hexplane_scatter_kernel<true>), dim3((nseg + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, G, w.order, w.comp);
+    if (det) {
+      // extents of every cell in its walk's order, run records by the walk (no atomics), one stencil gather per texel
+      S3G_HIP_CHECK(hipMemsetAsync(det_index, 0, det_index_bytes, stream));
+      hipLaunchKernelGGL(hexcell_ranges_kernel, dim3((P + 255) / 256, NW), dim3(256), 0, stream, a, w.order, detw);
+      hipLaunchKernelGGL((hexplane_scatter_kernel<true, true>), dim3((nseg + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, G, w.order, w.comp, detw);
+      int maxt = 0;
+      for (int l = 0; l < d->levels; l++)
+        for (int o = 0; o < 3; o++) {
+          static const int PLA_H[3] = {0, 3, 1}, MAJ_H[3] = {0, 1, 2};
+          maxt = max(maxt, d->res[l][PAIR0_HOST[PLA_H[o]]] * d->res[l][PAIR1_HOST[PLA_H[o]]] + d->res[l][MAJ_H[o]]);
+        }
+      hipLaunchKernelGGL(hexplane_stencil_kernel, dim3((maxt + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, detw);
+    } else if (d->uniform_time)
+      hipLaunchKernelGGL((hexplane_scatter_kernel<true>), dim3((nseg + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, G, w.order, w.comp, detw);
     else
-      hipLaunchKernelGGL((hexplane_scatter_kernel<false>), dim3((nseg + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, G, w.order, w.comp);
+      hipLaunchKernelGGL((hexplane_scatter_kernel<false>), dim3((nseg + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, G, w.order, w.comp, detw);
     profile_end(S3G_PROFILE_HEXPLANE_SCATTER, stream, (double)P, (double)d->levels);
   }
   if (d->uniform_time) {
