@@ -730,13 +730,16 @@ struct PackedTap2 {   // one tap as the walker reads it back from LDS: 8 floats 
 //   CELL[cell][corner][32]   the run that contains the cell's first point (cells are contiguous in the order: exactly one such run),
 //   SEG[segment][corner][32] the first run of a segment when it continues a cell begun in an earlier segment (at most one per segment),
 // and hexplane_stencil_kernel adds, for every texel, the four cells around it (nw of its own cell, ne of the cell to the left, sw of
-// the cell above, se of the cell above-left), each as CELL + its SEG continuations in segment order.  Cell extents [start, end) in the
-// sorted order come from hexcell_ranges_kernel.  No shift reuse here: every cell keeps its own four sums.
+// the cell above, se of the cell above-left), each as CELL + its SEG continuations in segment order.  The walkers also leave the index
+// the stencil needs: cstart[cell] (written by whoever meets the cell's first point) and segcell[segment] (which cell a segment's first
+// run continues: the walker compares its first point's cell with the cell of the point just before its segment).  No shift reuse here:
+// every cell keeps its own four sums.  (A first version derived the cell extents in a kernel of its own -- two sort_cell evaluations
+// per sorted position and walk through the order's indirection: 0.62 ms; the walk knows them for free.)
 struct DetWalk {           // one (orientation, level) walk
-  uint32_t* cstart;        // [cells] first sorted position of the spatial cell (plane texel index of its nw corner); start >= end: empty
-  uint32_t* cend;
+  uint32_t* cstart;        // [cells] sorted position of the spatial cell's first point (cell id = plane texel index of its nw corner); ~0u: empty
   uint32_t* tstart;        // [Wmajor] the same for the 1-D cells of the (major, t) row table
-  uint32_t* tend;
+  int* segcell;            // [segments] the cell the segment's FIRST run continues from an earlier segment, -1 if it opens its cell itself
+  int* tsegcell;
   float* cell;             // [cells][4][32]
   float* seg;              // [segments][4][32]
   float* tcell;            // [Wmajor][2][32]
@@ -746,11 +749,9 @@ struct DetWork {
   DetWalk walk[3 * S3G_HEX_MAX_LEVELS];
 };
 template <bool ROW>
-__device__ __forceinline__ void det_store_run(const Foot1& F, const DetWalk& dw, int seg, int k0, bool first_run, int c) {
+__device__ __forceinline__ void det_store_run(const Foot1& F, const DetWalk& dw, int seg, bool continuation, int c) {
   if (F.key < 0) return;
   const int cellid = F.key >> 2;
-  const uint32_t* cs = ROW ? dw.tstart : dw.cstart;
-  const bool continuation = first_run && cs[cellid] < (uint32_t)k0;      // the cell began in an earlier segment
   constexpr int NC = ROW ? 2 : 4;
   float* rec = continuation ? (ROW ? dw.tseg : dw.seg) + (size_t)seg * (NC * HEXC) : (ROW ? dw.tcell : dw.cell) + (size_t)cellid * (NC * HEXC);
   rec[c] = F.a01.x;
@@ -760,9 +761,11 @@ __device__ __forceinline__ void det_store_run(const Foot1& F, const DetWalk& dw,
     rec[3 * HEXC + c] = F.a23.y;
   }
 }
-// the deterministic walker's tap: like foot1_add_t, but a finished footprint is stored as a run record and nothing is shifted
+// the deterministic walker's tap: like foot1_add_t, but a finished footprint is stored as a run record and nothing is shifted.
+// cont: the run being accumulated is the segment's first AND continues the cell of the point before the segment (prev_kf);
+// kpos: sorted position of this point.
 template <bool ROW>
-__device__ __forceinline__ void foot1_add_det(Foot1& F, bool& first_run, const PackedTap2& t, float tv, const DetWalk& dw, int seg, int k0,
+__device__ __forceinline__ void foot1_add_det(Foot1& F, bool& cont, int prev_kf, int kpos, const PackedTap2& t, float tv, const DetWalk& dw, int seg,
                                               const float* __restrict__ pl, int W, int c) {
   const int tkf = t.kf;
   if (tkf != F.key) {
@@ -774,9 +777,12 @@ __device__ __forceinline__ void foot1_add_det(Foot1& F, bool& first_run, const P
       n2 = px[(tfl & 2) ? (size_t)W * HEXC : 0];
       n3 = px[(tfl == 3) ? (size_t)W * HEXC + HEXC : 0];
     }
-    if (F.key >= 0) {
-      det_store_run<ROW>(F, dw, seg, k0, first_run, c);
-      first_run = false;
+    const bool opening = F.key < 0;                 // the segment's first footprint
+    if (!opening) det_store_run<ROW>(F, dw, seg, cont, c);
+    cont = opening && tkf == prev_kf;
+    if (c == 0) {
+      if (opening) (ROW ? dw.tsegcell : dw.segcell)[seg] = cont ? tkey : -1;
+      if (!cont) (ROW ? dw.tstart : dw.cstart)[tkey] = (uint32_t)kpos;       // this point is the first of its cell
     }
     F.a01 = f2v_{0.f, 0.f};
     F.v01 = f2v_{n0, n1};
@@ -894,7 +900,8 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
   Foot1 f1[2];
   foot1_init(f1[0]);
   foot1_init(f1[1]);
-  bool first_run[2] = {true, true};   // deterministic mode: no run of this segment has been stored yet (per tap)
+  bool cont[2] = {false, false};      // deterministic mode: the open run is the segment's first and continues an earlier segment's cell
+  int prev_kf[2] = {-2, -2};          // deterministic mode: hit key (texel << 2 | flags) of the point just before the segment, per tap
   const int Wt = a.d.res[lv][axw], Ht = a.d.res[lv][axh];
   // uniform per workgroup; read ONCE (indexed kernel-argument reads inside the loop were an s_load + s_waitcnt lgkmcnt(0) per tap,
   // i.e. every tap also waited for all of the wave's outstanding LDS reads)
@@ -916,6 +923,14 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
     *reinterpret_cast<float4*>(dst + 4) = make_float4(t.w10, t.w11, __uint_as_float(cpos), 0.f);
   };
   auto row_pos = [&](int buf, int qq) { return __float_as_uint(tapbuf[hw][buf][qq][0][6]); };
+  if (DET && k0 > 0) {               // lane j of the walker (q == 0) evaluates tap j of the previous point; broadcast inside the half-wave
+    float up[4];
+    point_coords(a, (int)order[k0 - 1], up);
+    const Tap tp = make_tap(up[axw], up[axh], Wt, Ht);
+    const int kfp = (tp.o00 << 2) | (tp.o01 >= 0 ? 1 : 0) | (tp.o10 >= 0 ? 2 : 0);
+    prev_kf[0] = __shfl(kfp, (int)(threadIdx.x & 32u));
+    prev_kf[1] = __shfl(kfp, (int)(threadIdx.x & 32u) + 1);
+  }
   float un[4];                       // coordinates of the NEXT group's point
   uint32_t cn;                       // ... and the position of its T rows
   {
@@ -968,12 +983,13 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
           t.kf = __float_as_int(lo.x);
           t.w01 = f2v_{lo.z, lo.w};
           if (DET) {
+            const int kpos = kb + 4 * sb + qq;
             if (m == 1) {
-              foot1_add_det<true>(f1[1], first_run[1], t, g[qq], detw.walk[oi], seg, k0, pl1, W1, c);
+              foot1_add_det<true>(f1[1], cont[1], prev_kf[1], kpos, t, g[qq], detw.walk[oi], seg, pl1, W1, c);
             } else {
               const float2 hi = *reinterpret_cast<const float2*>(src + 4);
               t.w23 = f2v_{hi.x, hi.y};
-              foot1_add_det<false>(f1[0], first_run[0], t, g[qq], detw.walk[oi], seg, k0, pl0, W0, c);
+              foot1_add_det<false>(f1[0], cont[0], prev_kf[0], kpos, t, g[qq], detw.walk[oi], seg, pl0, W0, c);
             }
           } else if (UT && m == 1) {
             foot1_add_t<true>(f1[m], t, g[qq], gp, pl1, W1, c);
@@ -993,56 +1009,23 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
     float* gp = m ? gp1 : gp0;
     if (gp == nullptr) continue;
     if (DET) {
-      if (m == 1) det_store_run<true>(f1[1], detw.walk[oi], seg, k0, first_run[1], c);
-      else det_store_run<false>(f1[0], detw.walk[oi], seg, k0, first_run[0], c);
+      if (m == 1) det_store_run<true>(f1[1], detw.walk[oi], seg, cont[1], c);
+      else det_store_run<false>(f1[0], detw.walk[oi], seg, cont[0], c);
     } else if (UT && m == 1) foot1_flush_all<true>(f1[m], gp, W1, c);
     else foot1_flush_all<false>(f1[m], gp, m ? W1 : W0, c);
   }
 }
 
-// ---- deterministic mode: cell extents and the stencil gather ------------------------------------------------------------------------
-// extents of every cell of every walk in its sorted order: position k opens the cell of point order[k] when that cell differs from the
-// cell of order[k-1] (and closes that one).  Cells = texel cells of the walk's own level (sort_cell: floor of the clamped texel
-// coordinate, exactly make_tap's), spatial id = the plane texel index of the nw corner, row id = the major axis' texel.
-// The arrays are zero-filled before: an untouched cell reads start == end == 0, i.e. empty.
-__global__ void __launch_bounds__(256) hexcell_ranges_kernel(const HexArgs a, const uint32_t* __restrict__ order_all, const DetWork detw) {
-  const int oi = blockIdx.y, o = oi / a.d.levels, lv = oi % a.d.levels;
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= a.P) return;
-  const uint32_t* order = order_all + (size_t)oi * a.P;
-  const DetWalk dw = detw.walk[oi];
-  const int ip = PLA[o], ax = PAIR0[ip], ay = PAIR1[ip], Wx = a.d.res[lv][ax];
-  const int p = (int)order[k];
-  const int cx = sort_cell(a, p, ax, lv), cy = sort_cell(a, p, ay, lv), cm = sort_cell(a, p, MAJ[o], lv);
-  const int cell = cy * Wx + cx;
-  int pcell = -1, pm = -1;
-  if (k > 0) {
-    const int q = (int)order[k - 1];
-    pcell = sort_cell(a, q, ay, lv) * Wx + sort_cell(a, q, ax, lv);
-    pm = sort_cell(a, q, MAJ[o], lv);
-  }
-  if (cell != pcell) {
-    dw.cstart[cell] = (uint32_t)k;
-    if (pcell >= 0) dw.cend[pcell] = (uint32_t)k;
-  }
-  if (cm != pm) {
-    dw.tstart[cm] = (uint32_t)k;
-    if (pm >= 0) dw.tend[pm] = (uint32_t)k;
-  }
-  if (k == a.P - 1) {
-    dw.cend[cell] = (uint32_t)a.P;
-    dw.tend[cm] = (uint32_t)a.P;
-  }
-}
+// ---- deterministic mode: the stencil gather ---------------------------------------------------------------------------------------
 // sum of one cell's run records for corner `corner`, lane = channel: CELL first, then the SEG continuations in segment order
 template <int NC>
 __device__ __forceinline__ float det_cell_sum(const float* __restrict__ cellrec, const float* __restrict__ segrec, const uint32_t* __restrict__ cs,
-                                              const uint32_t* __restrict__ ce, int cellid, int corner, int seg_len, int c) {
-  const uint32_t s0 = cs[cellid], s1 = ce[cellid];
-  if (s1 <= s0) return 0.f;
+                                              const int* __restrict__ segcell, int cellid, int corner, int seg_len, int nseg, int c) {
+  const uint32_t s0 = cs[cellid];
+  if (s0 == 0xffffffffu) return 0.f;
   float acc = cellrec[(size_t)cellid * (NC * HEXC) + corner * HEXC + c];
-  const uint32_t first = s0 / (uint32_t)seg_len + 1u, last = (s1 - 1u) / (uint32_t)seg_len;
-  for (uint32_t sg = first; sg <= last; sg++) acc += segrec[(size_t)sg * (NC * HEXC) + corner * HEXC + c];
+  for (int sg = (int)(s0 / (uint32_t)seg_len) + 1; sg < nseg && segcell[sg] == cellid; sg++)
+    acc += segrec[(size_t)sg * (NC * HEXC) + corner * HEXC + c];
   return acc;
 }
 // grid = (texel groups, walks): a half-wave (lane = channel) per texel of the walk's spatial plane; the row tables' 1-D stencil rides in
@@ -1054,22 +1037,48 @@ __global__ void __launch_bounds__(256) hexplane_stencil_kernel(const HexArgs a, 
   const int ip = PLA[o], it = PLT[o];
   const int Wx = a.d.res[lv][PAIR0[ip]], Wy = a.d.res[lv][PAIR1[ip]], Wm = a.d.res[lv][MAJ[o]];
   const int t = blockIdx.x * (256 / HEXC) + threadIdx.x / HEXC;
+  const int sl = a.seg_len, nseg = (a.P + sl - 1) / sl;
   const DetWalk dw = detw.walk[oi];
   if (t < Wx * Wy) {
     float* gp = a.gplanes[lv][ip];
     if (gp == nullptr) return;
     const int x = t % Wx, y = t / Wx;
-    float acc = det_cell_sum<4>(dw.cell, dw.seg, dw.cstart, dw.cend, t, 0, a.seg_len, c);                                   // nw of its own cell
-    if (x > 0) acc += det_cell_sum<4>(dw.cell, dw.seg, dw.cstart, dw.cend, t - 1, 1, a.seg_len, c);                       // ne of the cell to the left
-    if (y > 0) acc += det_cell_sum<4>(dw.cell, dw.seg, dw.cstart, dw.cend, t - Wx, 2, a.seg_len, c);                      // sw of the cell above
-    if (x > 0 && y > 0) acc += det_cell_sum<4>(dw.cell, dw.seg, dw.cstart, dw.cend, t - Wx - 1, 3, a.seg_len, c);         // se of the cell above-left
+    // the four cells around the texel, in the fixed order nw (own cell), ne (left), sw (above), se (above-left).  Three rounds of
+    // independent loads -- starts, then records + the next segment's link, then (rarely) continuation records -- instead of four
+    // dependent chains one after the other: the pass is latency-bound (0.65 -> see profiles/r06_hex_deterministic.txt)
+    const int cid[4] = {t, t - 1, t - Wx, t - Wx - 1};
+    const bool ok[4] = {true, x > 0, y > 0, x > 0 && y > 0};
+    uint32_t s0[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) s0[k] = ok[k] ? dw.cstart[cid[k]] : 0xffffffffu;
+    float v[4];
+    int nxt[4], link[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool have = s0[k] != 0xffffffffu;
+      v[k] = have ? dw.cell[(size_t)cid[k] * (4 * HEXC) + k * HEXC + c] : 0.f;
+      nxt[k] = have ? (int)(s0[k] / (uint32_t)sl) + 1 : nseg;
+      link[k] = nxt[k] < nseg ? dw.segcell[nxt[k]] : -1;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float part = v[k];
+      int sg = nxt[k], lk = link[k];
+      while (sg < nseg && lk == cid[k]) {          // the cell straddles segments: its continuation records, in segment order
+        part += dw.seg[(size_t)sg * (4 * HEXC) + k * HEXC + c];
+        sg++;
+        lk = sg < nseg ? dw.segcell[sg] : -1;
+      }
+      acc += part;
+    }
     gp[(size_t)t * HEXC + c] += acc;
   } else if (t < Wx * Wy + Wm) {
     float* gt = a.gplanes[lv][it];       // (uniform time: the row table's gradient, folded back into the plane rows afterwards)
     if (gt == nullptr) return;
     const int x = t - Wx * Wy;
-    float acc = det_cell_sum<2>(dw.tcell, dw.tseg, dw.tstart, dw.tend, x, 0, a.seg_len, c);
-    if (x > 0) acc += det_cell_sum<2>(dw.tcell, dw.tseg, dw.tstart, dw.tend, x - 1, 1, a.seg_len, c);
+    float acc = det_cell_sum<2>(dw.tcell, dw.tseg, dw.tstart, dw.tsegcell, x, 0, sl, nseg, c);
+    if (x > 0) acc += det_cell_sum<2>(dw.tcell, dw.tseg, dw.tstart, dw.tsegcell, x - 1, 1, sl, nseg, c);
     gt[(size_t)x * HEXC + c] += acc;
   }
 }
@@ -1108,7 +1117,7 @@ extern "C" int s3g_hexplane_forward(const s3g_hexplane_desc* d, int P, const flo
 
 static std::atomic<int> g_hex_deterministic{0};
 static void carve_det(Carver& c, const s3g_hexplane_desc* d, int P, DetWork* dw, void** index_begin, size_t* index_bytes) {
-  // deterministic mode: per-walk cell extents (zero-filled every backward: they come first, contiguous) and run records
+  // deterministic mode: per-walk cell starts (0xff-filled every backward: they come first, contiguous), segment links and run records
   const int nseg = (P + segment_length(P) - 1) / segment_length(P);
   DetWork w;
   memset(&w, 0, sizeof w);
@@ -1121,10 +1130,11 @@ static void carve_det(Carver& c, const s3g_hexplane_desc* d, int P, DetWork* dw,
         static const int PLA_H[3] = {0, 3, 1}, MAJ_H[3] = {0, 1, 2};
         const size_t cells = (size_t)d->res[l][PAIR0_HOST[PLA_H[o]]] * d->res[l][PAIR1_HOST[PLA_H[o]]], wm = (size_t)d->res[l][MAJ_H[o]];
         if (pass == 0) {
-          w.walk[oi].cstart = c.take<uint32_t>(cells); w.walk[oi].cend = c.take<uint32_t>(cells);
-          w.walk[oi].tstart = c.take<uint32_t>(wm); w.walk[oi].tend = c.take<uint32_t>(wm);
+          w.walk[oi].cstart = c.take<uint32_t>(cells);
+          w.walk[oi].tstart = c.take<uint32_t>(wm);
           b1 = c.off;
         } else {
+          w.walk[oi].segcell = c.take<int>((size_t)nseg); w.walk[oi].tsegcell = c.take<int>((size_t)nseg);
           w.walk[oi].cell = c.take<float>(cells * 4 * HEXC); w.walk[oi].seg = c.take<float>((size_t)nseg * 4 * HEXC);
           w.walk[oi].tcell = c.take<float>(wm * 2 * HEXC); w.walk[oi].tseg = c.take<float>((size_t)nseg * 2 * HEXC);
         }
@@ -1299,9 +1309,8 @@ static int hexplane_backward_impl(const s3g_hexplane_desc* d, int P, const float
     profile_begin(S3G_PROFILE_HEXPLANE_SCATTER, stream);
     constexpr int walkers = 256 / HEXC;
     if (det) {
-      // extents of every cell in its walk's order, run records by the walk (no atomics), one stencil gather per texel
-      S3G_HIP_CHECK(hipMemsetAsync(det_index, 0, det_index_bytes, stream));
-      hipLaunchKernelGGL(hexcell_ranges_kernel, dim3((P + 255) / 256, NW), dim3(256), 0, stream, a, w.order, detw);
+      // run records + cell index by the walk (no atomics), then one stencil gather per texel
+      S3G_HIP_CHECK(hipMemsetAsync(det_index, 0xff, det_index_bytes, stream));     // cstart / tstart: ~0u = empty cell
       hipLaunchKernelGGL((hexplane_scatter_kernel<true, true>), dim3((nseg + walkers - 1) / walkers, NW), dim3(256), 0, stream, a, G, w.order, w.comp, detw);
       int maxt = 0;
       for (int l = 0; l < d->levels; l++)
