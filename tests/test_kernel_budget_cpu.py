@@ -44,8 +44,10 @@ def test_hexplane_kernels_keep_their_occupancy(built):
     assert res, "tools/kernel_resources.sh found no kernels (llvm-objcopy / clang-offload-bundler / llvm-readelf)"
     vgpr, scratch = _one(res, "hexplane_backward_pointdiv_kernelILb1E")        # uniform time: four waves per SIMD, no spills
     assert vgpr <= 128 and scratch == 0, (vgpr, scratch)
-    vgpr, scratch = _one(res, "hexplane_scatter_kernelILb1E")                 # single-entry footprint, one level per walk: eight waves
+    vgpr, scratch = _one(res, "hexplane_scatter_kernelILb1ELb0E")             # single-entry footprint, one level per walk
     assert vgpr <= 72 and scratch == 0, (vgpr, scratch)          # round 6 (16-point tap groups, packed corner pairs): seven waves
+    vgpr, scratch = _one(res, "hexplane_scatter_kernelILb1ELb1E")             # the deterministic mode's walk (run records, no atomics)
+    assert vgpr <= 80 and scratch == 0, (vgpr, scratch)                        # six waves per SIMD
     vgpr, scratch = _one(res, "hexplane_forward_kernelILb1E")
     assert vgpr <= 102 and scratch == 0, (vgpr, scratch)                       # five waves per SIMD
 
