@@ -412,3 +412,35 @@ def test_deterministic_mode_refuses_what_it_cannot_do(gpu_device, deterministic_
     t = torch.rand(500, 1, device=gpu_device)                             # per-point time: the (axis, t) planes are not row tables
     with pytest.raises(Exception, match="uniform_time"):      # (S3G_ERR_INVALID_ARG: the reference's plain Exception for bad argument combinations)
         f(xyz, t, uniform_time=False).sum().backward()
+
+
+def test_deterministic_mode_re_sorts_for_every_backward(gpu_device, deterministic_mode):
+    """The run records of the deterministic mode rely on every cell being CONTIGUOUS in the walk order: that only holds for an order
+    sorted on the current coordinates, so the mode must not reuse cached orders (the default walk sums with atomics and is indifferent
+    to a stale order: test_stale_spatial_order_is_only_a_performance_matter).  Three different point sets through ONE field."""
+    from oracle import hexplane_ref as hr
+    from s3gaussian_amd.hexplane import HexPlaneField
+    torch.manual_seed(5)
+    cfg = dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32, resolution=[16, 16, 16, 7])
+    ref = hr.HexPlaneField(1.6, cfg, [1, 2, 4])
+    with torch.no_grad():
+        for p in ref.grids.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    mine = HexPlaneField(1.6, cfg, [1, 2, 4])
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(gpu_device)
+    P = 5000
+    for it in range(3):
+        xyz = torch.rand(P, 3) * 3.0 - 1.5
+        time = torch.full((P, 1), 0.1 * it)
+        w = torch.randn(P, 96)
+        for m in (ref, mine):
+            for p in m.parameters():
+                p.grad = None
+        xr = xyz.clone().requires_grad_(True)
+        (ref(xr, time) * w).sum().backward()
+        xg = xyz.to(gpu_device).requires_grad_(True)
+        (mine(xg, time.to(gpu_device), uniform_time=True) * w.to(gpu_device)).sum().backward()
+        assert rel_l2(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1e-4
+        for (k, pr), (_, pg) in zip(ref.grids.named_parameters(), mine.grids.named_parameters()):
+            assert rel_l2(pg.grad.cpu().numpy(), pr.grad.numpy()) < 1e-5, (it, k)
