@@ -83,7 +83,8 @@ def _bind():
 def set_deterministic(on: bool) -> bool:
     """Deterministic mode of the HexPlane backward (include/s3g_hexplane.h::s3g_hexplane_set_deterministic; environment
     S3G_HEX_DETERMINISTIC=1): stable walk orders, run records instead of float atomics, a stencil gather in fixed order -- plane
-    gradients bit-identical from run to run, for ~0.3 ms per backward at 1.2 M points.  Process-wide; returns the previous
+    gradients bit-identical from run to run, for +2.0 ms per backward at 1.2 M points (the walk orders are then re-sorted, stably,
+    on every backward).  Process-wide; returns the previous
     setting.  Cached walk orders of existing fields were sorted under the old setting: clear `field._order_cache` (or let them age
     out) before relying on bit-identity."""
     L = _bind()
