@@ -57,12 +57,6 @@ int s3g_hexplane_backward_scratch_rows(int levels);   /* 128-byte rows of scratc
  * With any other mask the plane gradients are incomplete -- for timing the walks one by one (tools/hex_probe.py walks,
  * profiles/r06_hex_walks.txt).  Process-wide. */
 void s3g_hexplane_debug_walk_mask(uint32_t mask);
-/* DIAGNOSTICS ONLY: the scatter walks' stray bypass on / off (default on; round 6).  The walk orders are re-sorted every 16th backward;
- * a point that has crossed a cell boundary since then sits among the points of its OLD cell.  With the bypass, a point whose successor
- * in the walk is back in the footprint being accumulated sends its own four (two) contributions out directly and leaves the open
- * footprint alone (instead of flushing it, being flushed itself one point later, and the old footprint's texels being fetched again).
- * Same sums either way (tests/test_hexplane_gpu.py); off only to measure it (tools/scatter_context_probe.py).  Process-wide. */
-void s3g_hexplane_debug_stray_bypass(int on);
 /* Deterministic mode of s3g_hexplane_backward (process-wide, default off; round 6).  The default backward adds the scatter walks' partial
  * sums onto the plane gradients with float atomics, and its walk orders come from counting sorts whose placement step uses LDS atomics:
  * the ORDER of the additions -- and with it the last bits of every plane gradient -- differs from run to run.  With the mode on

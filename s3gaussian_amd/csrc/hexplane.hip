@@ -827,8 +827,7 @@ __device__ __forceinline__ void foot1_add_det(Foot1& F, bool& cont, int prev_kf,
 
 template <bool ROW = false>
 __device__ __forceinline__ void foot1_add_t(Foot1& F, const PackedTap2& t, float tv, float* __restrict__ gp,
-                                            const float* __restrict__ pl /* plane values + channel */, int W, int c,
-                                            const float* next_rec = nullptr /* LDS record of the walk's next point (same tap), or null */) {
+                                            const float* __restrict__ pl /* plane values + channel */, int W, int c) {
   const int tkf = t.kf;
   if (tkf != F.key) {  // miss (uniform inside the walker's lanes)
     const int tkey = tkf >> 2, tfl = tkf & 3;
@@ -838,28 +837,6 @@ __device__ __forceinline__ void foot1_add_t(Foot1& F, const PackedTap2& t, float
     if (!ROW) {
       n2 = px[(tfl & 2) ? (size_t)W * HEXC : 0];
       n3 = px[(tfl == 3) ? (size_t)W * HEXC + HEXC : 0];
-    }
-    // A STRAY: the walk's next point is back in the footprint being accumulated.  The walk orders are re-sorted every 16th backward
-    // only; a point that has crossed a cell boundary since then sits among the points of its old cell.  Evicting for it costs the open
-    // footprint's flush (2-4 atomics), this point's own flush one step later (4 more) and the old footprint's texels a second time --
-    // instead its four (two) contributions go out directly and the open footprint stays.
-    if (next_rec != nullptr && F.key >= 0 && __float_as_int(*next_rec) == F.key) {
-      const f2v_ q01 = f2v_{n0, n1} * t.w01;
-      float ss = q01.x + q01.y;
-      if (!ROW) {
-        const f2v_ q23 = f2v_{n2, n3} * t.w23;
-        ss = ss + q23.x;
-        ss = ss + q23.y;
-      }
-      const float gs = tslab_divisible(ss) ? tv * __builtin_amdgcn_rcpf(ss) : 0.f;
-      const uint32_t k = ((uint32_t)tkey * HEXC + (uint32_t)c) * 4u;
-      const uint32_t dy = (uint32_t)W * (HEXC * 4u);
-      char* base = reinterpret_cast<char*>(gp);
-      vatomic(base, k, gs * t.w01.x);
-      if (tfl & 1) vatomic(base, k + HEXC * 4u, gs * t.w01.y);
-      if (!ROW && (tfl & 2)) vatomic(base, k + dy, gs * t.w23.x);
-      if (!ROW && tfl == 3) vatomic(base, k + dy + HEXC * 4u, gs * t.w23.y);
-      return;
     }
     const int KF = F.key, K = KF >> 2, FL = KF & 3;
     const bool down = FOOT_SHIFT && !ROW && KF >= 0 && tkey == K + W;
@@ -997,14 +974,6 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
 #pragma unroll
   for (int qq = 0; qq < 4; qq++) g[qq] = load_g(Grow + (size_t)row_pos(0, qq) * GP);
   int buf = 0;
-  const bool stray_bypass = !DET && a.stray_bypass != 0;
-  // the record of the walk's NEXT point (same tap): the following slot of this group, or slot 0 of the next group's buffer (its taps
-  // are stored before this group is accumulated); null at the segment's last point
-  auto next_rec = [&](int sb, int qq, int m, int nq) -> const float* {
-    if (!stray_bypass || qq + 1 >= nq) return nullptr;
-    const int idx = 4 * sb + qq + 1;
-    return idx < GRP ? &tapbuf[hw][buf][idx][m][0] : &tapbuf[hw][buf ^ 1][0][m][0];
-  };
   for (int kb = k0; kb < k1; kb += GRP, buf ^= 1) {
     // 1. the NEXT group's taps from coordinates loaded one iteration ago; then advance the two prefetch stages
     store_taps(un, cn, buf ^ 1);
@@ -1043,11 +1012,11 @@ __global__ void __launch_bounds__(256, UT ? SCATTER_WG_PER_CU : SCATTER_WG_PER_C
               foot1_add_det<false>(f1[0], cont[0], prev_kf[0], kpos, t, g[qq], detw.walk[oi], seg, pl0, W0, c);
             }
           } else if (UT && m == 1) {
-            foot1_add_t<true>(f1[m], t, g[qq], gp, pl1, W1, c, next_rec(sb, qq, m, nq));
+            foot1_add_t<true>(f1[m], t, g[qq], gp, pl1, W1, c);
           } else {
             const float2 hi = *reinterpret_cast<const float2*>(src + 4);
             t.w23 = f2v_{hi.x, hi.y};
-            foot1_add_t<false>(f1[m], t, g[qq], gp, m ? pl1 : pl0, m ? W1 : W0, c, next_rec(sb, qq, m, nq));
+            foot1_add_t<false>(f1[m], t, g[qq], gp, m ? pl1 : pl0, m ? W1 : W0, c);
           }
         }
       }
@@ -1219,10 +1188,6 @@ extern "C" int s3g_hexplane_backward_scratch_rows(int levels) { return levels; }
 // anything but all ones the plane gradients are INCOMPLETE; the setting is process-wide and meant for timing the walks one by one.
 static std::atomic<uint32_t> g_walk_mask{0xffffffffu};
 extern "C" void s3g_hexplane_debug_walk_mask(uint32_t mask) { g_walk_mask.store(mask, std::memory_order_relaxed); }
-// Diagnostics only (tools/scatter_context_probe.py): the scatter walk's stray bypass (foot1_add_t) on / off; the result is the same sum
-// either way.  Process-wide, default on.
-static std::atomic<int> g_hex_stray_bypass{1};
-extern "C" void s3g_hexplane_debug_stray_bypass(int on) { g_hex_stray_bypass.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 // Deterministic mode of the backward (process-wide; include/s3g_hexplane.h): stable walk orders, run records instead of atomics, a
 // stencil gather in fixed order -- plane gradients bit-identical from run to run.  Needs uniform_time and resolutions <= 512; the
@@ -1345,7 +1310,6 @@ static int hexplane_backward_impl(const s3g_hexplane_desc* d, int P, const float
   }
   a.seg_len = segment_length(P);
   a.walk_mask = g_walk_mask.load(std::memory_order_relaxed);
-  a.stray_bypass = g_hex_stray_bypass.load(std::memory_order_relaxed);
   const int nseg = (P + a.seg_len - 1) / a.seg_len;
   {
     // 2. per-point pass (dL/dxyz; ONE row T = dL/dfeature * feature per point and level -> G), then the scatter walks reading it back

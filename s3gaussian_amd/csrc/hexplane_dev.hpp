@@ -36,7 +36,6 @@ struct HexArgs {
   const uint32_t* proc_order;  // optional: process point proc_order[i] at step i (spatially sorted -> texel reuse in L1/L2)
   int seg_len;                 // scatter walks: sorted points per half-wave
   uint32_t walk_mask;          // scatter walks: bit oi = walk (orientation * levels + level) runs (diagnostics: time the walks one by one)
-  int stray_bypass;            // scatter walks: a point whose successor is back in the open footprint goes out directly (foot1_add_t)
 };
 
 struct Tap {         // one bilinear footprint

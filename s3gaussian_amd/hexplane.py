@@ -77,10 +77,6 @@ def _bind():
         _bound = True
         if os.environ.get("S3G_HEX_DETERMINISTIC", "0") == "1":
             L.s3g_hexplane_set_deterministic(1)
-        if os.environ.get("S3G_HEX_STRAY_BYPASS", "1") == "0":   # diagnostics: the scatter walk without its stray bypass
-            L.s3g_hexplane_debug_stray_bypass.restype = None
-            L.s3g_hexplane_debug_stray_bypass.argtypes = [C.c_int]
-            L.s3g_hexplane_debug_stray_bypass(0)
     return L
 
 

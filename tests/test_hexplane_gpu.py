@@ -123,54 +123,6 @@ def test_stale_spatial_order_is_only_a_performance_matter(gpu_device):
                 assert rel_l2(pg.grad.cpu().numpy(), pr.grad.numpy()) < 1e-5, (it, k)
 
 
-@pytest.mark.parametrize("uniform_time", [True, False])
-def test_points_that_drift_out_of_their_cells_take_the_stray_bypass(gpu_device, uniform_time):
-    """Round 6: between two re-sorts the points move (Adam), and a point that has crossed a cell boundary sits among the points of
-    its OLD cell in the cached walk order.  The walk recognises it (its successor is back in the open footprint) and sends its
-    contributions out directly (csrc/hexplane.hip::foot1_add_t).  Many points per cell, a tenth of them pushed over a boundary after
-    the orders were sorted: gradients against the reference's arithmetic, with the bypass and without it."""
-    import ctypes as C
-    from oracle import hexplane_ref as hr
-    from s3gaussian_amd import _lib
-    from s3gaussian_amd.hexplane import HexPlaneField
-    torch.manual_seed(11)
-    cfg = dict(grid_dimensions=2, input_coordinate_dim=4, output_coordinate_dim=32, resolution=[8, 8, 8, 5])
-    ref = hr.HexPlaneField(1.6, cfg, [1, 2, 4])
-    with torch.no_grad():
-        for p in ref.grids.parameters():
-            p.add_(0.3 * torch.randn_like(p))
-    mine = HexPlaneField(1.6, cfg, [1, 2, 4])
-    mine.load_state_dict(ref.state_dict())
-    mine = mine.to(gpu_device)
-    L = _lib.lib()
-    L.s3g_hexplane_debug_stray_bypass.restype = None
-    L.s3g_hexplane_debug_stray_bypass.argtypes = [C.c_int]
-    P = 40000
-    xyz0 = torch.rand(P, 3) * 3.0 - 1.5
-    time = torch.full((P, 1), 0.3) if uniform_time else torch.rand(P, 1)
-    w = torch.randn(P, 96)
-    try:
-        for it, bypass in enumerate((1, 1, 0, 1)):
-            L.s3g_hexplane_debug_stray_bypass(bypass)
-            xyz = xyz0.clone()
-            if it > 0:      # pass 0 sorts the orders on xyz0; afterwards every tenth point sits up to a coarse cell away
-                moved = torch.arange(it, P, 10)
-                xyz[moved] += (torch.rand(len(moved), 3) - 0.5) * (3.2 / 8)
-            for m in (ref, mine):
-                for p in m.parameters():
-                    p.grad = None
-            xr = xyz.clone().requires_grad_(True)
-            (ref(xr, time) * w).sum().backward()
-            xg = xyz.to(gpu_device).requires_grad_(True)
-            (mine(xg, time.to(gpu_device), uniform_time=uniform_time) * w.to(gpu_device)).sum().backward()
-            assert mine._order_cache["sort_age"] == it          # sorted on pass 0, reused afterwards
-            assert rel_l2(xg.grad.cpu().numpy(), xr.grad.numpy()) < 1e-4
-            for (k, pr), (_, pg) in zip(ref.grids.named_parameters(), mine.grids.named_parameters()):
-                assert rel_l2(pg.grad.cpu().numpy(), pr.grad.numpy()) < 1e-5, (it, bypass, k)
-    finally:
-        L.s3g_hexplane_debug_stray_bypass(1)
-
-
 @pytest.mark.parametrize("use", ["both", "features_only", "reg_only"])
 def test_regulariser_on_the_sampler_node_matches_separate_nodes(gpu_device, use):
     """field(xyz, t, reg_weights=...) -> (features, compute_regulation value) as ONE autograd node (the regulariser's

@@ -23,9 +23,17 @@ P = int(sys.argv[1]) if len(sys.argv) > 1 else 1_200_000
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 NV = int(sys.argv[3]) if len(sys.argv) > 3 else 6      # distinct views the training steps cycle through (the bench line: steps + warm-up)
 pc, cams, hyper, opt, bg = bench.build_scene(P, 1600, 1066, 50, dev)
-targets = {v: bench.make_targets(pc, cams[v], bg, hyper, seed=1000 + v) for v in range(6)}
 L = _lib.lib()
 L.s3g_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+L.s3g_profile_enable(1)
+for i in range(10):
+    L.s3g_profile_read(i, None, None, None)
+targets = {v: bench.make_targets(pc, cams[v], bg, hyper, seed=1000 + v) for v in range(6)}
+torch.cuda.synchronize()
+_ms = C.c_double()
+_n = L.s3g_profile_read(2, C.byref(_ms), None, None)
+print(f"0. the bench's make_targets renders (no backward has run yet: no processing order cached)   hexplane_forward {_ms.value / max(_n, 1):.4f} ({_n})", flush=True)
+L.s3g_profile_enable(0)
 NAMES = ((2, "hexplane_forward"), (3, "hexplane_backward_point"), (4, "hexplane_scatter"))
 
 
