@@ -29,9 +29,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # > 65 536 points: every MLP wave loops over more than one tile; V < P.  The oracle side costs ~2.2 s per iteration on the GPU box's
-# host cores: the routine suite runs 80 iterations (~3 min; 120 and 200 were run and recorded this round: same bars, deltas of
-# 0.004-0.006 dB); S3G_PSNR_ITERS=200 reproduces the committed profiles/psnr_parity.json
-P, W, H, K = 100_000, 480, 320, int(os.environ.get("S3G_PSNR_ITERS", "80"))
+# host cores: the routine suite runs 40 iterations (~1.5 min; round 6: the whole suite has to stay inside the driver's window, and the
+# PSNR evidence proper now comes from the WHOLE reference on the GPU at cfg2 / cfg3 size -- test_psnr_parity_cfg2_gpu.py,
+# profiles/psnr_parity_cfg3*.json; 80, 120 and 200 were run and recorded in earlier rounds: same bars, deltas of 0.004-0.006 dB);
+# S3G_PSNR_ITERS=200 reproduces the committed profiles/psnr_parity.json
+P, W, H, K = 100_000, 480, 320, int(os.environ.get("S3G_PSNR_ITERS", "40"))
 
 
 def _psnr(a, b):
