@@ -191,22 +191,13 @@ __device__ __forceinline__ void glue_backward_point(const GlueArgs& a, int p, fl
     a.g_opacity_logit[p] = a.g_opacity ? a.g_opacity[p] * o * (1.f - o) : 0.f;
   }
   // SH backward (same derivation as backward.cu:20-139, coefficients split over f_dc / f_rest / dshs)
+  float sh[16][3];
+  load_sh(a, p, sh);
   float dRGB[3];
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     const float g = a.g_colors ? a.g_colors[3 * (size_t)p + c] : 0.f;
     dRGB[c] = a.colors[3 * (size_t)p + c] > 0.f ? g : 0.f;  // clamp_min(., 0): zero gradient where the clamp is active
-  }
-  // The coefficient rows (2 x 192 B per Gaussian, read as per-lane rows) are only needed for dRGB/d(direction) -- and that is multiplied
-  // by dRGB: a Gaussian no pixel saw (82 % of them in the cfg3 bench scene) or whose colour is clamped leaves them alone (round 6).
-  float sh[16][3];
-  if (dRGB[0] != 0.f || dRGB[1] != 0.f || dRGB[2] != 0.f) {
-    load_sh(a, p, sh);
-  } else {
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) sh[k][c] = 0.f;
   }
   const float ox = a.xyz[3 * (size_t)p] - a.campos[0], oy = a.xyz[3 * (size_t)p + 1] - a.campos[1], oz = a.xyz[3 * (size_t)p + 2] - a.campos[2];
   const float len = sqrtf(ox * ox + oy * oy + oz * oz);
