@@ -25,9 +25,13 @@ def test_glue_matches_reference_golden(gpu_device):
     np.testing.assert_allclose(cols.cpu().numpy(), gl["colors"], rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("live", [1.0, 0.3, 0.15])
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
 @pytest.mark.parametrize("with_dshs", [True, False])
-def test_glue_forward_backward_vs_restatement(gpu_device, deg, with_dshs):
+def test_glue_forward_backward_vs_restatement(gpu_device, deg, with_dshs, live):
+    """live: fraction of the Gaussians whose colour receives a gradient (a view sees ~18 % of them).  The backward stages the
+    coefficient rows of up to 64 live Gaussians per workgroup through LDS (csrc/glue.hip, round 6): 0.15 = every live row staged,
+    0.3 = staged rows and per-lane rows in one workgroup, 1.0 = mostly per-lane rows."""
     from oracle import hexplane_ref as hr
     from s3gaussian_amd.glue import activations_and_colors
     g = torch.Generator().manual_seed(10 * deg + int(with_dshs))
@@ -36,6 +40,8 @@ def test_glue_forward_backward_vs_restatement(gpu_device, deg, with_dshs):
     f_dc, f_rest, dshs, xyz = mk(P, 1, 3), 0.3 * mk(P, 15, 3), 0.1 * mk(P, 16, 3), 3 * mk(P, 3)
     ls, rr, ol, campos = 0.5 * mk(P, 3), mk(P, 4), mk(P, 1), torch.tensor([0.3, -0.2, 1.1])
     ws = [mk(P, 3), mk(P, 3), mk(P, 4), mk(P, 1)]
+    if live < 1.0:
+        ws[0] = ws[0] * (torch.rand(P, 1, generator=g) < live).float()
     leaf = lambda t, dev: t.clone().to(dev).requires_grad_(True)
 
     def run(dev, fused):
