@@ -928,6 +928,30 @@ def main(argv=None):
         n = L.s3g_profile_read(i, C.byref(ms), C.byref(x), C.byref(y))
         prof[i] = (n, ms.value / n, x.value / n, y.value / n) if n else (0, 0.0, 0.0, 0.0)
 
+    # ---- 2b. the scatter walk on FRESH walk orders: a few more instrumented steps with the orders re-sorted on every backward.  The
+    #          walk orders are refreshed every 16th backward only (a re-sort costs ~0.9 ms) and the points move under Adam in between: the
+    #          difference to the bracket above is what the age of the orders costs (profiles/r06_scatter_context*.txt) ----
+    scatter_fresh_ms = None
+    if world == 1 and not dist_on:
+        import s3gaussian_amd.hexplane as _hx
+        keep_refresh = _hx.SORT_REFRESH
+        try:
+            _hx.SORT_REFRESH = 1
+            step(headline_idx[0])
+            clear_profile_slots()
+            L.s3g_profile_enable(1)
+            for i in headline_idx[:8]:
+                step(i)
+            torch.cuda.synchronize()
+            L.s3g_profile_enable(0)
+            ms_ = C.c_double()
+            n_ = L.s3g_profile_read(4, C.byref(ms_), None, None)
+            scatter_fresh_ms = round(ms_.value / n_, 4) if n_ else None
+        finally:
+            _hx.SORT_REFRESH = keep_refresh
+            L.s3g_profile_enable(0)
+            clear_profile_slots()
+
     # ---- 3. render ms/frame (the second half of BASELINE's metric): one render(stage="fine") under no_grad, SURVEY.md 3.5 ----
     from types import SimpleNamespace
     from s3gaussian_amd.pipeline import render as render_fn
@@ -1180,7 +1204,11 @@ def main(argv=None):
             tr = [k.get("traffic") for k in hb]
             roof["hexplane_backward_pair"] = {"ms": round(ms, 4), "algorithmic_bytes": nb, "hbm_GBps": round(nb / (ms * 1e-3) / 1e9, 1),
                                               "frac": round(nb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                              "traffic": sum(tr) if all(t is not None for t in tr) else None}
+                                              "traffic": sum(tr) if all(t is not None for t in tr) else None,
+                                              "scatter_ms_on_fresh_walk_orders": scatter_fresh_ms,
+                                              "scatter_note": "avg_launch_ms of the scatter kernel is taken with walk orders up to 16 iterations old "
+                                                              "(re-sorted every 16th backward: a re-sort costs ~0.9 ms); scatter_ms_on_fresh_walk_orders "
+                                                              "is the same kernel over 8 more steps with the orders re-sorted on every backward"}
         fwd = next((k for k in kernels if k["kernel"] == "s3g::blend_forward_kernel"), None)
         srt = sorted(per_step)
         out = {
