@@ -540,7 +540,149 @@ __device__ __forceinline__ void bitonic_network(KeyPtr a, uint32_t n, uint32_t t
   }
 }
 
-// Tiles with lo < n <= hi are handled by this launch; lds_keys = capacity of the dynamic LDS buffer in keys.
+// ---- long lists (round 6): one bucket pass, then small sorts ---------------------------------------------------------------------
+// The bitonic network moves every key through LDS log2(n) (log2(n) + 1) / 2 times: 78 steps at 4096 keys -- on a scene whose mean tile
+// list is 1800 instances (bench.py's heavy_raster leg: R = 12 M) the per-tile sort was the most expensive kernel of the step (2 x 0.67
+// ms).  A list longer than BUCKET_MIN keys is first split into SORT_BINS buckets by the leading bits of (depth bits - smallest depth bits
+// of the list) -- monotone in the key, so the buckets are in order and only have to be sorted inside: LDS histogram, one scan, one
+// scatter into a second LDS buffer (each an integer atomic per key: WHERE a key lands inside its bucket depends on their order, the
+// sorted result does not -- the 64-bit keys of a list are all different) -- and then every key counts the smaller keys of its own
+// bucket (<= BUCKET_RANK keys; a bucket holds one or two on average) and goes to bucket start + rank; the rare larger buckets take the
+// network, by one wave (<= BUCKET_WAVE keys) or the workgroup.  About ten LDS operations per key instead of a hundred and fifty;
+// the result is the same ascending list.
+constexpr int SORT_BIN_BITS = 11;
+constexpr uint32_t SORT_BINS = 1u << SORT_BIN_BITS, BUCKET_MIN = 1024, BUCKET_RANK = 48, BUCKET_WAVE = 512, BUCKET_LIST = 256;
+constexpr uint32_t BUCKET_LDS_EXTRA = SORT_BINS * 4 + BUCKET_LIST * 2 * 2;   // bytes behind the two key buffers: cursors, two bucket lists
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// the network of bitonic_network run by ONE wave on a short list (no workgroup barrier: the list belongs to this wave)
+__device__ __forceinline__ void bitonic_network_wave(uint64_t* a, uint32_t n, uint32_t lane) {
+  uint32_t lN = 0;
+  while ((1u << lN) < n) lN++;
+  const uint32_t half = (1u << lN) >> 1;
+  for (uint32_t lk = 1; lk <= lN; lk++) {
+    {
+      const uint32_t k = 1u << lk, lhk = lk - 1, hk = 1u << lhk;
+      for (uint32_t c = lane; c < half; c += 64) {
+        const uint32_t b = c >> lhk, o = c & (hk - 1);
+        const uint32_t i = (b << lk) + o, l = (b << lk) + (k - 1 - o);
+        if (l < n) {
+          const uint64_t x = a[i], y = a[l];
+          if (x > y) { a[i] = y; a[l] = x; }
+        }
+      }
+      wave_lds_fence();
+    }
+    for (int lj = (int)lk - 2; lj >= 0; lj--) {
+      const uint32_t j = 1u << lj;
+      for (uint32_t c = lane; c < half; c += 64) {
+        const uint32_t b = c >> lj, o = c & (j - 1);
+        const uint32_t i = (b << (lj + 1)) + o, l = i + j;
+        if (l < n) {
+          const uint64_t x = a[i], y = a[l];
+          if (x > y) { a[i] = y; a[l] = x; }
+        }
+      }
+      wave_lds_fence();
+    }
+  }
+}
+// A[0, n) holds the list; returns with A[0, n) sorted (B: scratch of n keys).  cur: SORT_BINS words, lists: 2 x BUCKET_LIST uint16.
+// 256 threads.  (n <= 7424 keys: at most n / (BUCKET_RANK + 1) < BUCKET_LIST buckets can be listed.)
+__device__ __forceinline__ void bucket_sort_lds(uint64_t* __restrict__ A, uint64_t* __restrict__ B, uint32_t* __restrict__ cur,
+                                                uint16_t* __restrict__ lists, uint32_t n, uint32_t tid) {
+  __shared__ uint32_t red[8];
+  __shared__ uint32_t nlist[2];
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  uint32_t mn = 0xffffffffu, mx = 0u;
+  for (uint32_t i = tid; i < n; i += 256) {
+    const uint32_t h = (uint32_t)(A[i] >> 32);
+    mn = min(mn, h); mx = max(mx, h);
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+  }
+  if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+  if (tid < 2) nlist[tid] = 0u;
+  for (uint32_t b = tid; b < SORT_BINS; b += 256) cur[b] = 0u;
+  __syncthreads();
+  mn = min(min(red[0], red[1]), min(red[2], red[3]));
+  mx = max(max(red[4], red[5]), max(red[6], red[7]));
+  const uint32_t range = mx - mn;
+  const int sh = range ? max(0, 32 - (int)__clz(range) - SORT_BIN_BITS) : 0;     // (range >> sh) < SORT_BINS
+  for (uint32_t i = tid; i < n; i += 256) atomicAdd(&cur[((uint32_t)(A[i] >> 32) - mn) >> sh], 1u);
+  __syncthreads();
+  {  // exclusive scan of the SORT_BINS counters: thread t owns PER consecutive bins
+    constexpr int PER = SORT_BINS / 256;
+    uint32_t c[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { c[k] = cur[PER * tid + k]; sum += c[k]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= (uint32_t)off) incl += t;
+    }
+    __syncthreads();               // red[] is read above
+    if (lane == 63) red[wave] = incl;
+    __syncthreads();
+    uint32_t excl = incl - sum;
+    for (uint32_t w = 0; w < wave; w++) excl += red[w];
+#pragma unroll
+    for (int k = 0; k < PER; k++) { cur[PER * tid + k] = excl; excl += c[k]; }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += 256) {
+    const uint64_t k = A[i];
+    B[atomicAdd(&cur[((uint32_t)(k >> 32) - mn) >> sh], 1u)] = k;
+  }
+  __syncthreads();
+  // cur[b] is now the END of bucket b; it starts where bucket b - 1 ends.  Buckets of more than BUCKET_RANK keys (rare: > 30 x the mean)
+  // are listed for a network sort; every other key finds its place by COUNTING the smaller keys of its own bucket -- one thread per
+  // key, no thread waits for another, ~(2 + bucket size) LDS reads per key -- and goes back into A at bucket start + rank.
+  for (uint32_t b = tid; b < SORT_BINS; b += 256) {
+    const uint32_t s0 = b ? cur[b - 1] : 0u, m = cur[b] - s0;
+    if (m > BUCKET_RANK) {
+      const uint32_t which = m <= BUCKET_WAVE ? 0u : 1u;
+      const uint32_t slot = atomicAdd(&nlist[which], 1u);
+      if (slot < BUCKET_LIST) lists[which * BUCKET_LIST + slot] = (uint16_t)b;
+    }
+  }
+  for (uint32_t i = tid; i < n; i += 256) {
+    const uint64_t k = B[i];
+    const uint32_t b = ((uint32_t)(k >> 32) - mn) >> sh;
+    const uint32_t s0 = b ? cur[b - 1] : 0u, e0 = cur[b];
+    if (e0 - s0 > BUCKET_RANK) continue;
+    uint32_t rank = 0;
+    for (uint32_t j = s0; j < e0; j++) rank += B[j] < k ? 1u : 0u;
+    A[s0 + rank] = k;
+  }
+  __syncthreads();
+  const uint32_t nw = nlist[0], ng = nlist[1];
+  for (uint32_t q = wave; q < nw; q += 4) {      // one wave per medium bucket: sorted in B, copied to A
+    const uint32_t b = lists[q];
+    const uint32_t s0 = b ? cur[b - 1] : 0u, m = cur[b] - s0;
+    bitonic_network_wave(B + s0, m, lane);
+    for (uint32_t i = lane; i < m; i += 64) A[s0 + i] = B[s0 + i];
+  }
+  __syncthreads();
+  for (uint32_t q = 0; q < ng; q++) {            // the workgroup on every large bucket (uniform loop; bitonic_network ends on a barrier)
+    const uint32_t b = lists[BUCKET_LIST + q];
+    const uint32_t s0 = b ? cur[b - 1] : 0u, m = cur[b] - s0;
+    bitonic_network(B + s0, m, tid, 256u);
+    for (uint32_t i = tid; i < m; i += 256) A[s0 + i] = B[s0 + i];
+  }
+  __syncthreads();
+}
+
+// Tiles with lo < n <= hi are handled by this launch; lds_keys = capacity of the dynamic LDS buffer in keys; bucket_keys != 0: the
+// buffer is laid out for bucket_sort_lds (two key buffers of bucket_keys keys + BUCKET_LDS_EXTRA bytes) and lists of more than
+// BUCKET_MIN and at most bucket_keys keys take it.
 // After sorting, slot_pos[gauss_off[g] + (tile's index inside g's rect)] = position of the instance in point_list:
 // the instance -> position map that lets the backward gather per-instance gradients without atomics.
 __device__ __forceinline__ void emit_instance(uint32_t pos, uint32_t g, int tx, int ty, const ushort4* __restrict__ rect,
@@ -558,7 +700,7 @@ __global__ void __launch_bounds__(256) sort_tiles_kernel(int tiles, int gx, cons
                                                          const ushort4* __restrict__ rect,
                                                          const uint32_t* __restrict__ gauss_off,
                                                          uint32_t* __restrict__ slot_pos,
-                                                         uint32_t lo, uint32_t hi, uint32_t lds_keys) {
+                                                         uint32_t lo, uint32_t hi, uint32_t lds_keys, uint32_t bucket_keys) {
   extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
   const uint32_t t = xcd_swizzle(blockIdx.x, gridDim.x);
   if (t >= (uint32_t)tiles) return;
@@ -568,7 +710,15 @@ __global__ void __launch_bounds__(256) sort_tiles_kernel(int tiles, int gx, cons
   uint64_t* gk = keys + rg.x;
   const uint32_t tid = threadIdx.x;
   const int tx = (int)(t % (uint32_t)gx), ty = (int)(t / (uint32_t)gx);
-  if (n <= lds_keys) {
+  if (n > BUCKET_MIN && n <= bucket_keys) {
+    uint64_t* B = skeys + bucket_keys;
+    uint32_t* cur = reinterpret_cast<uint32_t*>(B + bucket_keys);
+    for (uint32_t i = tid; i < n; i += 256) skeys[i] = gk[i];
+    __syncthreads();
+    bucket_sort_lds(skeys, B, cur, reinterpret_cast<uint16_t*>(cur + SORT_BINS), n, tid);
+    for (uint32_t i = tid; i < n; i += 256)
+      emit_instance(rg.x + i, (uint32_t)skeys[i], tx, ty, rect, gauss_off, point_list, slot_pos);
+  } else if (n <= lds_keys) {
     for (uint32_t i = tid; i < n; i += 256) skeys[i] = gk[i];
     __syncthreads();
     if (n > 1) bitonic_network(skeys, n, tid, 256u);
@@ -970,22 +1120,33 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
     // short lists: <= 32 KiB of LDS per workgroup (5 workgroups/CU); long lists: up to 128 KiB, beyond that in global
     // (asynchronous: max_tile is the caller's estimate; a list longer than the LDS buffer is sorted in global memory)
     const uint32_t small_cap = max_tile < SMALL ? max_tile : SMALL;
+    static std::atomic<uint64_t> attr_set{0};
+    if (device_needs_setup(attr_set)) {
+      S3G_HIP_CHECK(hipFuncSetAttribute((const void*)sort_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LARGE * 8));
+      device_setup_done(attr_set);
+    }
     // (a separate launch with a 2-8 KiB buffer for the lists of <= 256 / 512 / 1024 keys -- eight workgroups per CU instead of
     // five -- changes nothing: 136 / 127 / 122 us per frame against 123 with one launch, profiles/r04_sort.txt; the network's
     // LDS traffic bounds the kernel, not the workgroups in flight)
-    hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)small_cap * 8, stream, tiles, gx,
-                       im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, slot_map, 0u, SMALL, small_cap);
+    // round 6: lists of (BUCKET_MIN, SMALL] keys in a launch of their own with the LDS layout of bucket_sort_lds (two key buffers +
+    // cursors: <= 74 KiB, two workgroups per CU); the short lists keep their small buffer and their occupancy
+    const uint32_t short_cap = small_cap < BUCKET_MIN ? small_cap : BUCKET_MIN;
+    hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)short_cap * 8, stream, tiles, gx,
+                       im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, slot_map, 0u, BUCKET_MIN, short_cap, 0u);
     S3G_KERNEL_CHECK(stream, debug);
+    if (small_cap > BUCKET_MIN) {
+      hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)small_cap * 16 + BUCKET_LDS_EXTRA, stream, tiles, gx,
+                         im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, slot_map, BUCKET_MIN, SMALL, 2 * small_cap, small_cap);
+      S3G_KERNEL_CHECK(stream, debug);
+    }
     if (as ? as->long_lists != 0 : max_tile > SMALL) {
+      // up to LARGE keys in 128 KiB: lists that fit twice (+ the cursors) take the bucket pass too, longer ones the network in LDS,
+      // still longer ones the network in global memory
       const uint32_t large_cap = as ? LARGE : (max_tile < LARGE ? max_tile : LARGE);
-      static std::atomic<uint64_t> attr_set{0};
-      if (device_needs_setup(attr_set)) {
-        S3G_HIP_CHECK(hipFuncSetAttribute((const void*)sort_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          LARGE * 8));
-        device_setup_done(attr_set);
-      }
-      hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)large_cap * 8, stream, tiles, gx,
-                         im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, slot_map, SMALL, 0xffffffffu, large_cap);
+      const uint32_t lds_bytes = large_cap * 8 > 2 * SMALL * 8 + BUCKET_LDS_EXTRA ? large_cap * 8 : 2 * SMALL * 8 + BUCKET_LDS_EXTRA;
+      const uint32_t bucket_cap = (lds_bytes - BUCKET_LDS_EXTRA) / 16;
+      hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)lds_bytes, stream, tiles, gx,
+                         im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, slot_map, SMALL, 0xffffffffu, lds_bytes / 8, bucket_cap);
       S3G_KERNEL_CHECK(stream, debug);
     }
   }

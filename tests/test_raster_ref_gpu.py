@@ -97,6 +97,23 @@ def _long_lists():
     return s
 
 
+def _bucket_lists(P, seed):
+    """Round 6: lists of (1024, 4096] keys take the bucket pass of the per-tile sort in a launch of their own, lists of (4096, 7424]
+    keys in the long-list launch (csrc/raster_forward.hip::bucket_sort_lds); two tiles share P Gaussians here."""
+    s = tiny_scene(P=P, W=32, H=16, seed=seed, scale=0.02, spread=0.25)
+    s["opacities"] = s["opacities"] * 0.05
+    return s
+
+
+def _bucket_ties():
+    """Thousands of instances at ONE depth: the bucket pass finds a single bucket and the index decides the order."""
+    s = tiny_scene(P=3000, W=32, H=16, seed=17, scale=0.02, spread=0.25)
+    s["means3D"][:, 2] = 4.0
+    s["means3D"][::3, 2] = 4.5
+    s["opacities"] = s["opacities"] * 0.05
+    return s
+
+
 def _huge():
     s = tiny_scene(P=3, W=80, H=48)
     s["means3D"][:] = torch.tensor([[0.0, 0.0, 2.0], [0.3, -0.2, 2.5], [-0.4, 0.1, 3.0]])
@@ -117,6 +134,9 @@ SCENES = {
     "state_2000": (lambda: tiny_scene(P=2000, W=96, H=80, seed=3, scale=0.06), "precomp"),
     "depth_ties": (_ties, "precomp"),
     "long_lists": (_long_lists, "precomp"),
+    "bucket_lists_mid": (lambda: _bucket_lists(5000, 19), "precomp"),
+    "bucket_lists_long": (lambda: _bucket_lists(11000, 23), "precomp"),
+    "bucket_ties": (_bucket_ties, "precomp"),
     "huge": (_huge, "precomp"),
     "near_plane": (_near_plane, "sh"),
     "cov3d_precomp": (lambda: tiny_scene(P=300, W=48, H=48, seed=2), "cov3d"),

@@ -14,13 +14,14 @@ ap.add_argument("--P", type=int, default=1_200_000)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--cam", type=int, default=0)
 ap.add_argument("--stats", action="store_true")
+ap.add_argument("--scale-mult", type=float, default=1.0, help="every Gaussian's scale multiplied (bench.py --scale-mult: 3.5 = the heavy-raster leg)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 sc = synth.street_scene(P=a.P, n_frames=4)
 gs = sc["gaussians"]
 cam = sc["cameras"][a.cam]
 xyz = gs["xyz"].to(dev).requires_grad_(True)
-scales = torch.exp(gs["log_scales"]).to(dev).requires_grad_(True)
+scales = (torch.exp(gs["log_scales"]) * a.scale_mult).to(dev).requires_grad_(True)
 rot = gs["rotations_raw"].to(dev).requires_grad_(True)
 op = torch.sigmoid(gs["opacity_logit"]).to(dev).requires_grad_(True)
 col = torch.rand(a.P, 3, device=dev).requires_grad_(True)
@@ -50,6 +51,10 @@ if a.stats:
     nc = im["n_contrib"].float()
     print(f"P={a.P} visible={(radii > 0).sum().item()} R={R} tiles={cnt.numel()} mean_list={cnt.mean().item():.1f} max_list={cnt.max().item():.0f} "
           f"mean_n_contrib={nc.mean().item():.1f} max_n_contrib={nc.max().item():.0f} mean_final_T={im['final_T'].mean().item():.3f}")
+    edges = [0, 1, 256, 1024, 4096, 7424, 16384, 1 << 30]       # the per-tile sort's launches: <= 1024 | <= 4096 | bucket pass <= 7424 | LDS <= 16384 | global
+    for lo_, hi_ in zip(edges[:-1], edges[1:]):
+        m = (cnt >= lo_) & (cnt < hi_)
+        print(f"  lists of [{lo_}, {hi_}): {int(m.sum())} tiles, {int(cnt[m].sum())} instances")
 
 for _ in range(3):
     c, r, d = step()
