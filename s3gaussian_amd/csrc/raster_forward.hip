@@ -551,7 +551,7 @@ __device__ __forceinline__ void bitonic_network(KeyPtr a, uint32_t n, uint32_t t
 // network, by one wave (<= BUCKET_WAVE keys) or the workgroup.  About ten LDS operations per key instead of a hundred and fifty;
 // the result is the same ascending list.
 constexpr int SORT_BIN_BITS = 11;
-constexpr uint32_t SORT_BINS = 1u << SORT_BIN_BITS, BUCKET_MIN = 1024, BUCKET_RANK = 48, BUCKET_WAVE = 512, BUCKET_LIST = 256;
+constexpr uint32_t SORT_BINS = 1u << SORT_BIN_BITS, BUCKET_MIN = 512, BUCKET_RANK = 48, BUCKET_WAVE = 512, BUCKET_LIST = 256;
 constexpr uint32_t BUCKET_LDS_EXTRA = SORT_BINS * 4 + BUCKET_LIST * 2 * 2;   // bytes behind the two key buffers: cursors, two bucket lists
 
 __device__ __forceinline__ void wave_lds_fence() {
