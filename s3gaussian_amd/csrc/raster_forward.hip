@@ -552,6 +552,13 @@ __device__ __forceinline__ void bitonic_network(KeyPtr a, uint32_t n, uint32_t t
 // the result is the same ascending list.
 constexpr int SORT_BIN_BITS = 11;
 constexpr uint32_t SORT_BINS = 1u << SORT_BIN_BITS, BUCKET_MIN = 512, BUCKET_RANK = 48, BUCKET_WAVE = 512, BUCKET_LIST = 256;
+#ifndef S3G_SORT_THREADS_MID
+#define S3G_SORT_THREADS_MID 512
+#endif
+#ifndef S3G_SORT_THREADS_LONG
+#define S3G_SORT_THREADS_LONG 1024
+#endif
+constexpr uint32_t SORT_THREADS_MID = S3G_SORT_THREADS_MID, SORT_THREADS_LONG = S3G_SORT_THREADS_LONG;   // workgroup sizes of the two long-list launches
 constexpr uint32_t BUCKET_LDS_EXTRA = SORT_BINS * 4 + BUCKET_LIST * 2 * 2;   // bytes behind the two key buffers: cursors, two bucket lists
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -592,14 +599,15 @@ __device__ __forceinline__ void bitonic_network_wave(uint64_t* a, uint32_t n, ui
   }
 }
 // A[0, n) holds the list; returns with A[0, n) sorted (B: scratch of n keys).  cur: SORT_BINS words, lists: 2 x BUCKET_LIST uint16.
-// 256 threads.  (n <= 7424 keys: at most n / (BUCKET_RANK + 1) < BUCKET_LIST buckets can be listed.)
+// nt = 256 ... 1024 threads (the long-list launches bring more waves: the passes below are chains of dependent LDS operations, and a
+// workgroup that fills most of a CU's LDS is alone on it).  (n <= 7424 keys: at most n / (BUCKET_RANK + 1) < BUCKET_LIST buckets can be listed.)
 __device__ __forceinline__ void bucket_sort_lds(uint64_t* __restrict__ A, uint64_t* __restrict__ B, uint32_t* __restrict__ cur,
-                                                uint16_t* __restrict__ lists, uint32_t n, uint32_t tid) {
-  __shared__ uint32_t red[8];
+                                                uint16_t* __restrict__ lists, uint32_t n, uint32_t tid, uint32_t nt) {
+  __shared__ uint32_t red[32];
   __shared__ uint32_t nlist[2];
-  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  const uint32_t lane = tid & 63u, wave = tid >> 6, nwaves = nt >> 6;
   uint32_t mn = 0xffffffffu, mx = 0u;
-  for (uint32_t i = tid; i < n; i += 256) {
+  for (uint32_t i = tid; i < n; i += nt) {
     const uint32_t h = (uint32_t)(A[i] >> 32);
     mn = min(mn, h); mx = max(mx, h);
   }
@@ -607,21 +615,23 @@ __device__ __forceinline__ void bucket_sort_lds(uint64_t* __restrict__ A, uint64
     mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
     mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
   }
-  if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+  if (lane == 0) { red[wave] = mn; red[16 + wave] = mx; }
   if (tid < 2) nlist[tid] = 0u;
-  for (uint32_t b = tid; b < SORT_BINS; b += 256) cur[b] = 0u;
+  for (uint32_t b = tid; b < SORT_BINS; b += nt) cur[b] = 0u;
   __syncthreads();
-  mn = min(min(red[0], red[1]), min(red[2], red[3]));
-  mx = max(max(red[4], red[5]), max(red[6], red[7]));
+  mn = red[0]; mx = red[16];
+  for (uint32_t w = 1; w < nwaves; w++) { mn = min(mn, red[w]); mx = max(mx, red[16 + w]); }
   const uint32_t range = mx - mn;
   const int sh = range ? max(0, 32 - (int)__clz(range) - SORT_BIN_BITS) : 0;     // (range >> sh) < SORT_BINS
-  for (uint32_t i = tid; i < n; i += 256) atomicAdd(&cur[((uint32_t)(A[i] >> 32) - mn) >> sh], 1u);
+  for (uint32_t i = tid; i < n; i += nt) atomicAdd(&cur[((uint32_t)(A[i] >> 32) - mn) >> sh], 1u);
   __syncthreads();
-  {  // exclusive scan of the SORT_BINS counters: thread t owns PER consecutive bins
+  {  // exclusive scan of the SORT_BINS counters: thread t < 256 owns PER consecutive bins (the other waves only keep the barriers company)
     constexpr int PER = SORT_BINS / 256;
     uint32_t c[PER], sum = 0;
+    if (tid < 256) {
 #pragma unroll
-    for (int k = 0; k < PER; k++) { c[k] = cur[PER * tid + k]; sum += c[k]; }
+      for (int k = 0; k < PER; k++) { c[k] = cur[PER * tid + k]; sum += c[k]; }
+    }
     uint32_t incl = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -629,15 +639,17 @@ __device__ __forceinline__ void bucket_sort_lds(uint64_t* __restrict__ A, uint64
       if (lane >= (uint32_t)off) incl += t;
     }
     __syncthreads();               // red[] is read above
-    if (lane == 63) red[wave] = incl;
+    if (lane == 63 && wave < 4) red[wave] = incl;
     __syncthreads();
-    uint32_t excl = incl - sum;
-    for (uint32_t w = 0; w < wave; w++) excl += red[w];
+    if (tid < 256) {
+      uint32_t excl = incl - sum;
+      for (uint32_t w = 0; w < wave; w++) excl += red[w];
 #pragma unroll
-    for (int k = 0; k < PER; k++) { cur[PER * tid + k] = excl; excl += c[k]; }
+      for (int k = 0; k < PER; k++) { cur[PER * tid + k] = excl; excl += c[k]; }
+    }
   }
   __syncthreads();
-  for (uint32_t i = tid; i < n; i += 256) {
+  for (uint32_t i = tid; i < n; i += nt) {
     const uint64_t k = A[i];
     B[atomicAdd(&cur[((uint32_t)(k >> 32) - mn) >> sh], 1u)] = k;
   }
@@ -645,7 +657,7 @@ __device__ __forceinline__ void bucket_sort_lds(uint64_t* __restrict__ A, uint64
   // cur[b] is now the END of bucket b; it starts where bucket b - 1 ends.  Buckets of more than BUCKET_RANK keys (rare: > 30 x the mean)
   // are listed for a network sort; every other key finds its place by COUNTING the smaller keys of its own bucket -- one thread per
   // key, no thread waits for another, ~(2 + bucket size) LDS reads per key -- and goes back into A at bucket start + rank.
-  for (uint32_t b = tid; b < SORT_BINS; b += 256) {
+  for (uint32_t b = tid; b < SORT_BINS; b += nt) {
     const uint32_t s0 = b ? cur[b - 1] : 0u, m = cur[b] - s0;
     if (m > BUCKET_RANK) {
       const uint32_t which = m <= BUCKET_WAVE ? 0u : 1u;
@@ -653,7 +665,7 @@ __device__ __forceinline__ void bucket_sort_lds(uint64_t* __restrict__ A, uint64
       if (slot < BUCKET_LIST) lists[which * BUCKET_LIST + slot] = (uint16_t)b;
     }
   }
-  for (uint32_t i = tid; i < n; i += 256) {
+  for (uint32_t i = tid; i < n; i += nt) {
     const uint64_t k = B[i];
     const uint32_t b = ((uint32_t)(k >> 32) - mn) >> sh;
     const uint32_t s0 = b ? cur[b - 1] : 0u, e0 = cur[b];
@@ -664,7 +676,7 @@ __device__ __forceinline__ void bucket_sort_lds(uint64_t* __restrict__ A, uint64
   }
   __syncthreads();
   const uint32_t nw = nlist[0], ng = nlist[1];
-  for (uint32_t q = wave; q < nw; q += 4) {      // one wave per medium bucket: sorted in B, copied to A
+  for (uint32_t q = wave; q < nw; q += nwaves) {      // one wave per medium bucket: sorted in B, copied to A
     const uint32_t b = lists[q];
     const uint32_t s0 = b ? cur[b - 1] : 0u, m = cur[b] - s0;
     bitonic_network_wave(B + s0, m, lane);
@@ -674,8 +686,8 @@ __device__ __forceinline__ void bucket_sort_lds(uint64_t* __restrict__ A, uint64
   for (uint32_t q = 0; q < ng; q++) {            // the workgroup on every large bucket (uniform loop; bitonic_network ends on a barrier)
     const uint32_t b = lists[BUCKET_LIST + q];
     const uint32_t s0 = b ? cur[b - 1] : 0u, m = cur[b] - s0;
-    bitonic_network(B + s0, m, tid, 256u);
-    for (uint32_t i = tid; i < m; i += 256) A[s0 + i] = B[s0 + i];
+    bitonic_network(B + s0, m, tid, nt);
+    for (uint32_t i = tid; i < m; i += nt) A[s0 + i] = B[s0 + i];
   }
   __syncthreads();
 }
@@ -695,7 +707,7 @@ __device__ __forceinline__ void emit_instance(uint32_t pos, uint32_t g, int tx, 
   slot_pos[gauss_off[g] + local] = pos;
 }
 
-__global__ void __launch_bounds__(256) sort_tiles_kernel(int tiles, int gx, const uint2* __restrict__ ranges,
+__global__ void __launch_bounds__(1024) sort_tiles_kernel(int tiles, int gx, const uint2* __restrict__ ranges,
                                                          uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list,
                                                          const ushort4* __restrict__ rect,
                                                          const uint32_t* __restrict__ gauss_off,
@@ -708,25 +720,25 @@ __global__ void __launch_bounds__(256) sort_tiles_kernel(int tiles, int gx, cons
   const uint32_t n = rg.y - rg.x;
   if (n <= lo || n > hi) return;
   uint64_t* gk = keys + rg.x;
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;     // 256 threads for the short lists, 512 / 1024 for the launches of the long ones
   const int tx = (int)(t % (uint32_t)gx), ty = (int)(t / (uint32_t)gx);
   if (n > BUCKET_MIN && n <= bucket_keys) {
     uint64_t* B = skeys + bucket_keys;
     uint32_t* cur = reinterpret_cast<uint32_t*>(B + bucket_keys);
-    for (uint32_t i = tid; i < n; i += 256) skeys[i] = gk[i];
+    for (uint32_t i = tid; i < n; i += nt) skeys[i] = gk[i];
     __syncthreads();
-    bucket_sort_lds(skeys, B, cur, reinterpret_cast<uint16_t*>(cur + SORT_BINS), n, tid);
-    for (uint32_t i = tid; i < n; i += 256)
+    bucket_sort_lds(skeys, B, cur, reinterpret_cast<uint16_t*>(cur + SORT_BINS), n, tid, nt);
+    for (uint32_t i = tid; i < n; i += nt)
       emit_instance(rg.x + i, (uint32_t)skeys[i], tx, ty, rect, gauss_off, point_list, slot_pos);
   } else if (n <= lds_keys) {
-    for (uint32_t i = tid; i < n; i += 256) skeys[i] = gk[i];
+    for (uint32_t i = tid; i < n; i += nt) skeys[i] = gk[i];
     __syncthreads();
-    if (n > 1) bitonic_network(skeys, n, tid, 256u);
-    for (uint32_t i = tid; i < n; i += 256)
+    if (n > 1) bitonic_network(skeys, n, tid, nt);
+    for (uint32_t i = tid; i < n; i += nt)
       emit_instance(rg.x + i, (uint32_t)skeys[i], tx, ty, rect, gauss_off, point_list, slot_pos);
   } else {
-    bitonic_network((volatile uint64_t*)gk, n, tid, 256u);  // same workgroup: coherent through its own L1 after barriers
-    for (uint32_t i = tid; i < n; i += 256)
+    bitonic_network((volatile uint64_t*)gk, n, tid, nt);  // same workgroup: coherent through its own L1 after barriers
+    for (uint32_t i = tid; i < n; i += nt)
       emit_instance(rg.x + i, (uint32_t)gk[i], tx, ty, rect, gauss_off, point_list, slot_pos);
   }
 }
@@ -1135,7 +1147,7 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
                        im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, slot_map, 0u, BUCKET_MIN, short_cap, 0u);
     S3G_KERNEL_CHECK(stream, debug);
     if (small_cap > BUCKET_MIN) {
-      hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)small_cap * 16 + BUCKET_LDS_EXTRA, stream, tiles, gx,
+      hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(SORT_THREADS_MID), (size_t)small_cap * 16 + BUCKET_LDS_EXTRA, stream, tiles, gx,
                          im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, slot_map, BUCKET_MIN, SMALL, 2 * small_cap, small_cap);
       S3G_KERNEL_CHECK(stream, debug);
     }
@@ -1145,7 +1157,7 @@ static int raster_forward_impl(const s3g_raster_inputs* in, const float* colors2
       const uint32_t large_cap = as ? LARGE : (max_tile < LARGE ? max_tile : LARGE);
       const uint32_t lds_bytes = large_cap * 8 > 2 * SMALL * 8 + BUCKET_LDS_EXTRA ? large_cap * 8 : 2 * SMALL * 8 + BUCKET_LDS_EXTRA;
       const uint32_t bucket_cap = (lds_bytes - BUCKET_LDS_EXTRA) / 16;
-      hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(256), (size_t)lds_bytes, stream, tiles, gx,
+      hipLaunchKernelGGL(sort_tiles_kernel, dim3(tile_blocks), dim3(SORT_THREADS_LONG), (size_t)lds_bytes, stream, tiles, gx,
                          im.ranges, b.keys, b.point_list, g.rect, g.gauss_off, slot_map, SMALL, 0xffffffffu, lds_bytes / 8, bucket_cap);
       S3G_KERNEL_CHECK(stream, debug);
     }
