@@ -46,10 +46,10 @@ class _Glue(torch.autograd.Function):
         asked_l1 = bool(want_dshs_l1)
         want_dshs_l1 = asked_l1 and dshs is not None and P > 0
         abs_sum = torch.zeros(64 * 16, dtype=torch.float64, device=dev) if want_dshs_l1 else None   # S3G_SUM_DOUBLES
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.s3g_glue_forward(P, int(deg), _p(f_dc), _p(f_rest), _p(dshs), _p(xyz_c), _p(campos_c), _p(ls), _p(rr),
                                           _p(ol), _p(colors), _p(scales), _p(rot), _p(opac), _p(abs_sum),
-                                          torch.cuda.current_stream().cuda_stream))
+                                          _lib.stream_ptr()))
         ctx.deg = int(deg)
         ctx.has_dshs = dshs is not None
         ctx.save_for_backward(f_dc, f_rest, dshs if dshs is not None else torch.empty(0, device=dev), xyz_c, campos_c, rr,
@@ -75,11 +75,11 @@ class _Glue(torch.autograd.Function):
         g_f_dc, g_f_rest, g_xyz, g_ls, g_rr, g_ol = e(P, 1, 3), e(P, 15, 3), e(P, 3), e(P, 3), e(P, 4), e(P, 1)
         g_dshs = e(P, 16, 3) if ctx.has_dshs else None
         g_l1 = g_l1.contiguous().float() if (ctx.want_dshs_l1 and g_l1 is not None) else None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.s3g_glue_backward(P, ctx.deg, _p(f_dc), _p(f_rest), _p(dshs), _p(xyz), _p(campos), _p(rr), _p(colors),
                                            _p(scales), _p(rot), _p(opac), _p(g_colors), _p(g_scales), _p(g_rot), _p(g_opac),
                                            _p(g_f_dc), _p(g_f_rest), _p(g_dshs), _p(g_xyz), _p(g_ls), _p(g_rr), _p(g_ol), _p(g_l1),
-                                           torch.cuda.current_stream().cuda_stream))
+                                           _lib.stream_ptr()))
         return None, g_f_dc, g_f_rest, g_dshs, g_xyz, None, g_ls, g_rr, g_ol, None
 
 

@@ -138,11 +138,11 @@ class _HexPlaneSample(torch.autograd.Function):
         order = cache.get("order") if cache is not None else None
         if order is not None and (order.numel() != P or order.device != xyz.device):
             order = None  # stale (densification changed P): fall back to identity order
-        with torch.cuda.device(xyz.device):
+        with _lib.on_device(xyz.device):
             _lib.check(L.s3g_hexplane_forward(C.byref(d), P, xyz_c.data_ptr(), t_c.data_ptr(), feat.data_ptr(),
                                               order.data_ptr() if order is not None else None,
                                               ws.data_ptr() if ws is not None else None,
-                                              torch.cuda.current_stream().cuda_stream))
+                                              _lib.stream_ptr()))
         ctx.meta = (resolutions, aabb_host, cache, uniform_time)
         # the output is saved too: the backward divides dL/dfeature * feature by one re-derived sample instead of storing
         # dL/d(sample) for every plane-level (it stays alive anyway as the MLP's input)
@@ -172,8 +172,8 @@ class _HexPlaneSample(torch.autograd.Function):
             if g_reg is not None:
                 flat = ctx.reg_flat
                 g32 = g_reg.detach().reshape(-1)[:1].contiguous().float()
-                with torch.cuda.device(flat.device):    # in place; a no-op decided on the device when the upstream gradient is 1
-                    _lib.check(L.s3g_scale_unless_one(flat.data_ptr(), flat.numel(), g32.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                with _lib.on_device(flat.device):    # in place; a no-op decided on the device when the upstream gradient is 1
+                    _lib.check(L.s3g_scale_unless_one(flat.data_ptr(), flat.numel(), g32.data_ptr(), _lib.stream_ptr()))
             else:
                 flat = ctx.reg_flat.zero_()
             ctx.reg_flat = None
@@ -211,12 +211,12 @@ class _HexPlaneSample(torch.autograd.Function):
                     cache["sort_age"] = 0
                 else:
                     reuse = 1
-        with torch.cuda.device(xyz_c.device):
+        with _lib.on_device(xyz_c.device):
             _lib.check(L.s3g_hexplane_backward_algo(C.byref(d), P, xyz_c.data_ptr(), t_c.data_ptr(), gfeat.data_ptr(),
                                                     None if algorithm == 0 else feat.data_ptr(), algorithm,
                                                     gxyz.data_ptr(), C.byref(ptrs), work.data_ptr(),
                                                     state.data_ptr() if state is not None else None, reuse,
-                                                    torch.cuda.current_stream().cuda_stream))
+                                                    _lib.stream_ptr()))
         if cache is not None:
             cache["order"] = state[(words - 1) * P:words * P]  # 3-D blocked processing order for the forwards
         return (gxyz if ctx.needs_input_grad[0] else None, None, None, *gplanes)
@@ -306,7 +306,9 @@ class HexPlaneField(nn.Module):
         return self._aabb_host[1]
 
     def _planes(self):
-        return [p for planes in self.grids for p in planes]
+        # (straight from the containers' dicts: iterating nn.ModuleList / nn.ParameterList goes through string indices -- 67 us for the 24
+        #  planes, three times per training iteration; this is 3 us)
+        return [p for planes in self.grids._modules.values() for p in planes._parameters.values()]
 
     def get_density(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None, uniform_time=None, reg_weights=None):
         pts = pts.reshape(-1, pts.shape[-1])

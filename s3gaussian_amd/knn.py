@@ -25,8 +25,8 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     L.s3g_knn_mean_dist2.restype = C.c_int
     L.s3g_knn_mean_dist2.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     work = torch.empty(L.s3g_knn_workspace_bytes(P), dtype=torch.uint8, device=points.device)
-    with torch.cuda.device(points.device):
+    with _lib.on_device(points.device):
         code = L.s3g_knn_mean_dist2(P, pts.data_ptr(), means.data_ptr(), work.data_ptr(),
-                                    torch.cuda.current_stream().cuda_stream)
+                                    _lib.stream_ptr())
     _lib.check(code)
     return means

@@ -46,9 +46,9 @@ class _SSIM(torch.autograd.Function):
         Cn, H, W = a.shape
         total = torch.zeros(SUM_DOUBLES, dtype=torch.float64, device=a.device)
         maps = torch.empty((3, Cn, H, W), dtype=torch.float32, device=a.device)
-        with torch.cuda.device(a.device):
+        with _lib.on_device(a.device):
             _lib.check(L.s3g_ssim_forward(Cn, H, W, a.data_ptr(), b.data_ptr(), total.data_ptr(), maps[0].data_ptr(),
-                                          maps[1].data_ptr(), maps[2].data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                          maps[1].data_ptr(), maps[2].data_ptr(), _lib.stream_ptr()))
         ctx.save_for_backward(a, b, maps)
         ctx.shape = img1.shape
         return (total.sum() / float(Cn * H * W)).float()
@@ -60,10 +60,10 @@ class _SSIM(torch.autograd.Function):
         Cn, H, W = a.shape
         g = g.detach().reshape(1).contiguous().float()
         out = torch.empty_like(a)
-        with torch.cuda.device(a.device):
+        with _lib.on_device(a.device):
             _lib.check(L.s3g_ssim_backward(Cn, H, W, a.data_ptr(), b.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(),
                                            maps[2].data_ptr(), g.data_ptr(), out.data_ptr(),
-                                           torch.cuda.current_stream().cuda_stream))
+                                           _lib.stream_ptr()))
         return out.view(ctx.shape), None
 
 
@@ -99,8 +99,8 @@ class _PhotometricLoss(torch.autograd.Function):
         maps = torch.empty((3, 3, H, W), dtype=torch.float32, device=dev) if w_ssim != 0.0 else None
         loss = torch.empty((), dtype=torch.float32, device=dev)
         p = lambda t: None if t is None else t.data_ptr()
-        with torch.cuda.device(dev):
-            st = torch.cuda.current_stream().cuda_stream
+        with _lib.on_device(dev):
+            st = _lib.stream_ptr()
             if maps is not None:
                 _lib.check(L.s3g_ssim_forward(3, H, W, p(img), p(gt), p(sums), p(maps[0]), p(maps[1]), p(maps[2]), st))
             _lib.check(L.s3g_pixel_losses_forward(H, W, p(img), p(gt), p(dep), p(gdep), p(ft), p(gft), float(max_depth),
@@ -136,8 +136,8 @@ class _PhotometricLoss(torch.autograd.Function):
         g_dep = torch.empty_like(dep) if has_d else None
         g_ft = torch.empty_like(ft) if has_f else None
         p = lambda t: None if t is None else t.data_ptr()
-        with torch.cuda.device(dev):
-            st = torch.cuda.current_stream().cuda_stream
+        with _lib.on_device(dev):
+            st = _lib.stream_ptr()
             if has_s:
                 gs = g * (-w_ssim)
                 _lib.check(L.s3g_ssim_backward(3, H, W, p(img), p(gt), p(maps[0]), p(maps[1]), p(maps[2]), p(gs), p(g_img), st))
@@ -182,8 +182,8 @@ class _PixelTerms(torch.autograd.Function):
         p = lambda t: None if t is None else t.data_ptr()
         wl, wd, wf = (float(w_l1) if img is not None else 0.0, float(w_depth) if dep is not None else 0.0,
                       float(w_feat) if ft is not None else 0.0)
-        with torch.cuda.device(dev):
-            st = torch.cuda.current_stream().cuda_stream
+        with _lib.on_device(dev):
+            st = _lib.stream_ptr()
             _lib.check(L.s3g_pixel_losses_forward(H, W, p(img), p(gt), p(dep), p(gdep), p(ft), p(gft), float(max_depth), p(sums), st))
             _lib.check(L.s3g_pixel_losses_combine(H, W, p(sums), p(totals), wl, wd, 0.0, wf, p(loss), st))
         ctx.save_for_backward(*(t for t in (img, gt, dep, gdep, ft, gft) if t is not None), totals)
@@ -214,9 +214,9 @@ class _PixelTerms(torch.autograd.Function):
         g_dep = torch.empty_like(dep) if (has_d and need[2]) else None
         g_ft = torch.empty_like(ft) if (has_f and need[4]) else None
         p = lambda t: None if t is None else t.data_ptr()
-        with torch.cuda.device(totals.device):
+        with _lib.on_device(totals.device):
             _lib.check(L.s3g_pixel_losses_backward(H, W, p(img), p(gt), p(dep), p(gdep), p(ft), p(gft), max_depth, p(totals), p(g),
-                                                   wl, wd, wf, p(g_img), 0, p(g_dep), p(g_ft), torch.cuda.current_stream().cuda_stream))
+                                                   wl, wd, wf, p(g_img), 0, p(g_dep), p(g_ft), _lib.stream_ptr()))
         return (None if g_img is None else g_img.view(ishape), None, None if g_dep is None else g_dep.view(dshape), None,
                 None if g_ft is None else g_ft.view(fshape), None, None, None, None, None)
 
@@ -252,8 +252,8 @@ class _PlaneRegulation(torch.autograd.Function):
                 raise RuntimeError("plane regulation expects [1,32,H,W] channels_last planes")
             descs[i] = _PlaneRegDesc(p.data_ptr(), g.data_ptr(), p.shape[2], p.shape[3], ws, wl)
         value = torch.zeros(SUM_DOUBLES, dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
-            _lib.check(L.s3g_plane_regulation(len(planes), descs, value.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        with _lib.on_device(dev):
+            _lib.check(L.s3g_plane_regulation(len(planes), descs, value.data_ptr(), _lib.stream_ptr()))
         ctx.grads = grads
         return value.sum().float()
 
@@ -286,8 +286,8 @@ def plane_regulation_into(planes, reg_weights, grad_views):
             raise RuntimeError("plane regulation: gradient views must be channels_last")
         descs[i] = _PlaneRegDesc(p.data_ptr(), g.data_ptr(), p.shape[2], p.shape[3], ws, wl)
     value = torch.zeros(SUM_DOUBLES, dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(L.s3g_plane_regulation(len(planes), descs, value.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    with _lib.on_device(dev):
+        _lib.check(L.s3g_plane_regulation(len(planes), descs, value.data_ptr(), _lib.stream_ptr()))
     return value.sum().float()
 
 

@@ -105,9 +105,9 @@ class _DeformMLP(torch.autograd.Function):
         nbytes = L.s3g_deform_mlp_stash_bytes(P) if need_bwd else L.s3g_deform_mlp_pack_bytes()
         stash = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         w = _pack([p.detach() for p in params])
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(L.s3g_deform_mlp_forward(C.byref(w), P, x.data_ptr(), dx.data_ptr(), dshs.data_ptr(), feat.data_ptr() if feat is not None else None,
-                                                stash.data_ptr(), int(need_bwd), torch.cuda.current_stream().cuda_stream))
+                                                stash.data_ptr(), int(need_bwd), _lib.stream_ptr()))
         if need_bwd:
             ctx.save_for_backward(x, stash, *params)
             ctx.set_materialize_grads(False)   # an output the loss never touched must arrive as None, not as zeros
@@ -132,16 +132,16 @@ class _DeformMLP(torch.autograd.Function):
             off += p.numel()
         ws = torch.empty((5, P, 64), dtype=torch.float32, device=dev)
         w, gw = _pack([p.detach() for p in params]), _pack(grads)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             if ORDERED_WGRAD_FLUSH:     # bit-reproducible weight gradients (include/s3g_mlp.h::s3g_deform_mlp_backward_ordered)
                 part = torch.empty(L.s3g_deform_mlp_wgrad_partial_bytes() // 4, dtype=torch.float32, device=dev)
                 _lib.check(L.s3g_deform_mlp_backward_ordered(C.byref(w), P, x.data_ptr(), stash.data_ptr(), g_dx.data_ptr(),
                                                              g_dshs.data_ptr(), None if no_feat else g_feat.data_ptr(), gx.data_ptr(),
-                                                             C.byref(gw), ws.data_ptr(), part.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                                             C.byref(gw), ws.data_ptr(), part.data_ptr(), _lib.stream_ptr()))
             else:
                 _lib.check(L.s3g_deform_mlp_backward(C.byref(w), P, x.data_ptr(), stash.data_ptr(), g_dx.data_ptr(),
                                                      g_dshs.data_ptr(), None if no_feat else g_feat.data_ptr(), gx.data_ptr(),
-                                                     C.byref(gw), ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                                     C.byref(gw), ws.data_ptr(), _lib.stream_ptr()))
         if no_feat:
             grads = [None if n.startswith(("D", "db")) else g for n, g in zip(_NAMES, grads)]
         return (gx, None, None, *grads)
@@ -182,10 +182,10 @@ def deform_infer(grid, xyz, time, feature_out, pos_deform, shs_deform, dino_head
     dshs = torch.empty((P, 48), dtype=torch.float32, device=dev)
     ws = torch.empty(max(L.s3g_deform_infer_workspace_bytes(C.byref(d)), 4) // 4, dtype=torch.float32, device=dev)
     w = _pack([p.detach() for p in _head_params(feature_out, pos_deform, shs_deform, dino_head)])
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         fn = L.s3g_deform_infer_split if arithmetic == "bf16x3" else L.s3g_deform_infer
         _lib.check(fn(C.byref(d), C.byref(w), P, xyz_c.data_ptr(), t_c.data_ptr(), order.data_ptr() if order is not None else None,
-                      dx.data_ptr(), dshs.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                      dx.data_ptr(), dshs.data_ptr(), ws.data_ptr(), _lib.stream_ptr()))
     return dx, dshs
 
 

@@ -160,8 +160,8 @@ class Adam(torch.optim.Adam):
             # before the next one (a two-phase data-parallel step calls step() twice per iteration).  A process that trains two
             # independent models on one device with interleaved forwards should switch the mechanism off (S3G_RASTER_ASYNC=0).
             flag = raster_C.async_skip_flag(dev)   # data parallel: dp.reduce_skip_flag() has all-reduced it in place
-            with torch.cuda.device(dev):
-                stream = torch.cuda.current_stream().cuda_stream
+            with _lib.on_device(dev):
+                stream = _lib.stream_ptr()
                 for k in range(0, len(items), MAX_TENSORS):
                     chunk = items[k:k + MAX_TENSORS]
                     arr = (_AdamTensor * len(chunk))(*chunk)
@@ -217,10 +217,10 @@ def densify_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_rad
         v = visible.to(torch.uint8).contiguous()
     from . import raster_C
     flag = raster_C.async_skip_flag(radii.device)     # the view's asynchronous forward overflowed -> no statistics
-    with torch.cuda.device(radii.device):
+    with _lib.on_device(radii.device):
         _lib.check(L.s3g_densify_stats_guarded(P, g.data_ptr(), int(g.stride(0)), r.data_ptr(), v.data_ptr() if v is not None else None,
                                                xyz_gradient_accum.data_ptr(), denom.data_ptr(), max_radii2D.data_ptr(),
                                                flag.data_ptr() if flag is not None else None,
-                                               torch.cuda.current_stream().cuda_stream))
+                                               _lib.stream_ptr()))
     for t_ in (xyz_gradient_accum, denom, max_radii2D):
         torch.autograd.graph.increment_version(t_)

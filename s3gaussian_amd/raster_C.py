@@ -300,7 +300,7 @@ def async_acknowledge(device=None) -> None:
     st = _state_of(device)
     if st is None:
         return
-    with torch.cuda.device(st.device):
+    with _lib.on_device(st.device):
         st.sticky_dev.zero_()
     st.replay_from = None
     st.ack_seq = st.seq
@@ -372,7 +372,7 @@ def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_
         slot = st.seq % _ASYNC_RING
         if st.events[slot] is not None and any(s == slot for s, _, _ in st.pending):
             st.drain(block=True)            # the host is a whole ring ahead of the device: let the oldest rows land
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             ev = st.events[slot]
             if ev is None:
                 ev = st.events[slot] = torch.cuda.Event()
@@ -380,7 +380,7 @@ def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_
             desc = _lib.RasterAsync(cap_r, cap_s, lds, long_lists, geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
                                     st.status_dev.data_ptr() + 4 * slot, st.status_host.data_ptr() + 32 * slot, 1 if forward_only else 0,
                                     sticky.data_ptr() if sticky is not None else None, ev.cuda_event)
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _lib.stream_ptr()
             code = L.s3g_raster_forward_async(C.byref(inp), col2_.data_ptr() if col2_ is not None else None, C.byref(desc),
                                               out_color.data_ptr(), out_depth.data_ptr(),
                                               out_color2.data_ptr() if out_color2 is not None else None, radii.data_ptr(), stream)
@@ -402,7 +402,7 @@ def _forward_async(L, st: _AsyncState, inp, col2_, P, W, H, dev, out_color, out_
             st.train_forwards -= 1
         if sticky is not None:              # the overflow set the sticky word; every earlier row has landed (blocking drain): unless an
             if st.replay_from is None:      # EARLIER forward is waiting to be replayed, nothing else is frozen -- thaw
-                with torch.cuda.device(dev):
+                with _lib.on_device(dev):
                     st.sticky_dev.zero_()
         caps = st.caps(key)
         caps = (max(caps[0], cap_r), max(caps[1], cap_s), caps[2], caps[3])
@@ -471,10 +471,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             keep = [_f32(background, "bg"), _f32(colors, "colors_precomp")]
             inp = _inputs(P, degree, 0, W, H, keep[0], None, None, keep[1], None, None, scale_modifier, None, None, None,
                           None, tan_fovx, tan_fovy, None, prefiltered, debug)
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 code = L.s3g_raster_forward_reuse(C.byref(inp), int(R), _ptr(geom_c), _ptr(binning_c), _ptr(img_c),
                                                   out_color.data_ptr(), out_depth.data_ptr(),
-                                                  torch.cuda.current_stream().cuda_stream)
+                                                  _lib.stream_ptr())
             _lib.check(code)
             return R, out_color, out_depth, radii_c, geom_c, binning_c, img_c
     # the library writes every pixel (background included) and every radius; only the P == 0 early-out needs zeros
@@ -514,7 +514,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                         # the model is frozen on the device and this forward is not: its backward would do real bookkeeping inside a
                         # window that is about to be re-issued.  Stop here; pipeline.run_training_steps rewinds.
                         raise ReplayNeeded(st.replay_from)
-                with torch.cuda.device(dev):
+                with _lib.on_device(dev):
                     st.fallback_word.fill_(1 if frozen else 0)      # data parallel: MAX-reduced with the other ranks' words like any other
                 st.last_slot, st.flag_override = None, st.fallback_word
                 st.train_forwards += 1
@@ -526,8 +526,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             if colors2 is not None:
                 return R_cap, out_color, out_depth, radii, geom_t, binning_t, img_t, out_color2
             return R_cap, out_color, out_depth, radii, geom_t, binning_t, img_t
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream().cuda_stream
+        with _lib.on_device(dev):
+            stream = _lib.stream_ptr()
             if col2_ is not None:
                 code = L.s3g_raster_forward2(C.byref(inp), col2_.data_ptr(), geom.cb, None, binning.cb, None, img.cb, None,
                                              out_color.data_ptr(), out_depth.data_ptr(), out_color2.data_ptr(),
@@ -565,10 +565,10 @@ def rasterize_decomposition(background, colors, is_dynamic, tan_fovx, tan_fovy, 
         raise RuntimeError("is_dynamic must be a GPU mask with one entry per Gaussian")
     inp = _inputs(P, 0, 0, W, H, keep[0], None, None, keep[1], None, None, 1.0, None, None, None, None, tan_fovx, tan_fovy,
                   None, False, debug)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = L.s3g_raster_forward_decompose(C.byref(inp), int(R), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
                                               keep[2].data_ptr(), counts.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
-                                              out[3].data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                              out[3].data_ptr(), _lib.stream_ptr())
     _lib.check(code)
     return tuple(out)
 
@@ -608,8 +608,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         inp = _inputs(P, degree, M, W, H, bg_, m3_, sh_, col_, None, sc_, scale_modifier, rot_, cov_, view_, proj_,
                       tan_fovx, tan_fovy, cam_, False, debug)
         work = torch.empty(L.s3g_raster_backward_workspace_bytes(P, int(R)), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream().cuda_stream
+        with _lib.on_device(dev):
+            stream = _lib.stream_ptr()
             args = (C.byref(inp), int(R), radii_.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer),
                     _ptr(imageBuffer), _ptr(work), gcol_.data_ptr(), gdep_.data_ptr(),
                     v["means2D"].data_ptr(), _ptr(v["conic"]), v["opacity"].data_ptr(),
@@ -652,8 +652,8 @@ def rasterize_gaussians_backward2(background, means3D, radii, colors, colors2, s
         inp = _inputs(P, 0, 0, W, H, bg_, m3_, None, col_, None, sc_, scale_modifier, rot_, cov_, view_, proj_,
                       tan_fovx, tan_fovy, cam_, False, debug)
         work = torch.empty(L.s3g_raster_backward2_workspace_bytes(P, int(R)), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream().cuda_stream
+        with _lib.on_device(dev):
+            stream = _lib.stream_ptr()
             args = (C.byref(inp), col2_.data_ptr(), int(R), radii_.data_ptr(), _ptr(geomBuffer),
                     _ptr(binningBuffer), _ptr(imageBuffer), _ptr(work), gcol_.data_ptr(),
                     gdep_.data_ptr(), gcol2_.data_ptr(), v["means2D"].data_ptr(), None,
@@ -698,8 +698,8 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     if P != 0:
         _require_gpu(means3D, "means3D")
         m3, view, proj = _f32(means3D, "means3D"), _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix")
-        with torch.cuda.device(means3D.device):
-            stream = torch.cuda.current_stream().cuda_stream
+        with _lib.on_device(means3D.device):
+            stream = _lib.stream_ptr()
             code = L.s3g_mark_visible(P, m3.data_ptr(), view.data_ptr(), proj.data_ptr(), present.data_ptr(), stream)
         _lib.check(code)
     return present
