@@ -151,7 +151,7 @@ def on_device(dev):
     global _torch, _raw_stream, _cur_device
     if _torch is None:
         _torch, _raw_stream, _cur_device = _bind_fast_paths()
-    if _cur_device is not None and dev.index is not None and _cur_device() == dev.index:
+    if _cur_device is not None and getattr(dev, "index", None) is not None and _cur_device() == dev.index:
         return _NULL
     return _torch.cuda.device(dev)
 
