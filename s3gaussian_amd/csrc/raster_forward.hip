@@ -558,6 +558,10 @@ constexpr uint32_t SORT_BINS = 1u << SORT_BIN_BITS, BUCKET_MIN = 512, BUCKET_RAN
 #ifndef S3G_SORT_THREADS_LONG
 #define S3G_SORT_THREADS_LONG 1024
 #endif
+#ifndef S3G_SORT_RANK_DIRECT
+#define S3G_SORT_RANK_DIRECT 256
+#endif
+constexpr uint32_t RANK_DIRECT = S3G_SORT_RANK_DIRECT;   // lists of at most this many keys: one thread per key, rank by counting
 constexpr uint32_t SORT_THREADS_MID = S3G_SORT_THREADS_MID, SORT_THREADS_LONG = S3G_SORT_THREADS_LONG;   // workgroup sizes of the two long-list launches
 constexpr uint32_t BUCKET_LDS_EXTRA = SORT_BINS * 4 + BUCKET_LIST * 2 * 2;   // bytes behind the two key buffers: cursors, two bucket lists
 
@@ -730,6 +734,18 @@ __global__ void __launch_bounds__(1024) sort_tiles_kernel(int tiles, int gx, con
     bucket_sort_lds(skeys, B, cur, reinterpret_cast<uint16_t*>(cur + SORT_BINS), n, tid, nt);
     for (uint32_t i = tid; i < n; i += nt)
       emit_instance(rg.x + i, (uint32_t)skeys[i], tx, ty, rect, gauss_off, point_list, slot_pos);
+  } else if (n <= RANK_DIRECT && n <= lds_keys && nt >= RANK_DIRECT) {
+    // a short list: every thread counts the keys smaller than its own (all lanes read the same LDS address: a broadcast) and emits at
+    // that rank -- one barrier, no network (36 steps at 256 keys).  Two keys per thread up to 512 keys: slower than the network
+    // (profiles/r06_tile_sort_ab.txt).
+    const uint64_t k = tid < n ? gk[tid] : ~0ull;
+    if (tid < n) skeys[tid] = k;
+    __syncthreads();
+    if (tid < n) {
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < n; j++) rank += skeys[j] < k ? 1u : 0u;
+      emit_instance(rg.x + rank, (uint32_t)k, tx, ty, rect, gauss_off, point_list, slot_pos);
+    }
   } else if (n <= lds_keys) {
     for (uint32_t i = tid; i < n; i += nt) skeys[i] = gk[i];
     __syncthreads();
